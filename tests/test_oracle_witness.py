@@ -1,0 +1,78 @@
+"""Oracle vs the independent torch-autograd witness (CPU, float64)."""
+import numpy as np
+import pytest
+
+import oracle
+from sketchformer_amd import synthetic
+import witness_torch
+
+
+def _tiny(continuous=False, attn_version=1, blind=True):
+    return oracle.Config(num_layers=2, d_model=16, dff=32, num_heads=4, dropout_rate=0.1, lowerdim=8,
+                         attn_version=attn_version, vocab_size=24, n_classes=5, seq_len=12,
+                         continuous=continuous, blind_decoder_mask=blind, max_pos=32)
+
+
+def _drops(cfg, B, seed=1):
+    rng = np.random.RandomState(seed)
+    out = {}
+    for name, tag in oracle.dropout_sites(cfg):
+        L = cfg.seq_len if tag == "enc" else cfg.seq_len - 1
+        out[name] = rng.rand(B, L, cfg.d_model) >= cfg.dropout_rate
+    return out
+
+
+@pytest.mark.parametrize("continuous,attn_version,blind", [(False, 1, True), (False, 2, False), (True, 1, True)])
+def test_oracle_matches_autograd(continuous, attn_version, blind):
+    cfg = _tiny(continuous, attn_version, blind)
+    B = 3
+    if continuous:
+        x, y = synthetic.continuous_batch(B, cfg.seq_len, cfg.n_classes, seed=3)
+        x = x.astype(np.float64)
+    else:
+        x, y = synthetic.token_batch(B, cfg.seq_len, cfg.vocab_size, cfg.n_classes, seed=3)
+    x[0, 6:] = 0 if not continuous else x[0, 6:]
+    if continuous:
+        x[0, 6:, :] = [0, 0, 0, 0, 1]
+    P = oracle.init_params(cfg, seed=0)
+    # make biases / LN params non-trivial so their gradients are exercised
+    rng = np.random.RandomState(5)
+    for k in P:
+        if k.endswith(("bias", "beta", "b_attn")):
+            P[k] = rng.normal(0, 0.1, P[k].shape)
+        if k.endswith("gamma"):
+            P[k] = 1 + rng.normal(0, 0.1, P[k].shape)
+    drops = _drops(cfg, B)
+    losses, out, G = oracle.loss_and_grads(P, cfg, x, x, y, drops)
+    wl, wo, WG = witness_torch.loss_and_grads(P, cfg, x, x, y, drops)
+    for k in ("recon_loss", "class_loss", "total_loss"):
+        assert abs(losses[k] - wl[k]) < 1e-12
+    np.testing.assert_allclose(out["recon"], wo["recon"], rtol=0, atol=1e-11)
+    assert set(G) == set(P)
+    for k in P:
+        assert WG[k] is not None, k
+        np.testing.assert_allclose(G[k], WG[k], rtol=0, atol=1e-11, err_msg=k)
+
+
+def test_finite_difference_spot():
+    cfg = _tiny()
+    cfg.dropout_rate = 0.0
+    B = 2
+    x, y = synthetic.token_batch(B, cfg.seq_len, cfg.vocab_size, cfg.n_classes, seed=7)
+    P = oracle.init_params(cfg, seed=2)
+    _, _, G = oracle.loss_and_grads(P, cfg, x, x, y)
+    rng = np.random.RandomState(0)
+    for name in ["encoder/layer0/mha/wk/kernel", "decoder/layer1/mha2/wv/kernel", "expand/kernel",
+                 "bottleneck/V_attn", "decoder/layer0/layernorm2/gamma", "encoder/embedding"]:
+        idx = tuple(rng.randint(0, s) for s in P[name].shape)
+        if name == "encoder/embedding":
+            idx = (int(x[0, 1]), 3)
+        eps = 1e-6
+        old = P[name][idx]
+        P[name][idx] = old + eps
+        lp = oracle.loss_and_grads(P, cfg, x, x, y, want_grads=False)[0]["total_loss"]
+        P[name][idx] = old - eps
+        lm = oracle.loss_and_grads(P, cfg, x, x, y, want_grads=False)[0]["total_loss"]
+        P[name][idx] = old
+        fd = (lp - lm) / (2 * eps)
+        assert abs(fd - G[name][idx]) < 1e-7 * max(1.0, abs(fd)), (name, fd, G[name][idx])
