@@ -1,0 +1,185 @@
+/* skf.h - C ABI of libskf.so, the MI355X (gfx950) implementation of the
+ * sketch-transformer-tf2 training hot path of leosampaio/sketchformer.
+ *
+ * The reference has no native layer: every entry point below replaces arithmetic
+ * that the reference delegates to TensorFlow 2.1 / Keras from the cited Python call
+ * site (paths relative to the reference repository).  A reference-side binding
+ * (ctypes) is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; all pointers are DEVICE pointers unless the
+ *    parameter name ends in _host.  Activations are row-major (B, L, features).
+ *  - the caller owns every buffer; kernels never allocate.  Scratch is passed as
+ *    (workspace, workspace_bytes); sizes come from the *_workspace_bytes queries.
+ *  - launches are asynchronous on `stream` (a hipStream_t cast to void*), re-entrant,
+ *    and keep no global state besides a thread-local error string.
+ *  - return 0 on success, negative on error (never throws across the ABI);
+ *    skf_last_error() describes the last failure on the calling thread.
+ */
+#ifndef SKF_H_
+#define SKF_H_
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* skf_stream_t; /* hipStream_t */
+
+#define SKF_OK 0
+#define SKF_EINVAL (-1)       /* bad argument */
+#define SKF_EUNSUPPORTED (-2) /* valid in the reference, not implemented here */
+#define SKF_EHIP (-3)         /* HIP runtime / launch failure */
+
+const char* skf_last_error(void);
+int skf_version(void);
+/* name of the device the library will launch on + number of visible devices (host query) */
+int skf_device_info(char* name_host, size_t name_len, int* n_devices_host);
+
+/* ------------------------------------------------------------------ Dense
+ * tf.keras.layers.Dense forward / dgrad / wgrad (+bias grad).
+ * builders/layers/transformer.py:154-158,196-197; models/sketchformer.py:85-104.
+ *   C[M,N] (+)= opA(A)[M,K] . opB(B)[K,N] (+bias) (act) (relu mask)
+ *   a_kcontig: 1 = A stored [M][K] (lda = row stride), 0 = A stored [K][M]
+ *   b_kcontig: 0 = B stored [K][N] (ldb = row stride), 1 = B stored [N][K]
+ *   act: 0 none, 1 relu, 2 tanh;  relu_src (optional, ld_relu): C = 0 where relu_src <= 0
+ *   splits > 1 (or bias_grad != NULL): split-K through `workspace`; bias_grad[n] = sum_k B[k][n]
+ *   (the bias gradient of a wgrad call, B stored [K][N]); no fused epilogue on that path. */
+size_t skf_gemm_workspace_bytes(int M, int N, int K, int splits, int with_bias_grad);
+int skf_gemm_default_splits(int M, int N, int K);
+int skf_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                 float* C, int ldc, const float* bias, int act, const float* relu_src, int ld_relu, int accumulate,
+                 int splits, float* bias_grad, int bias_grad_accumulate, void* workspace, size_t workspace_bytes,
+                 skf_stream_t stream);
+
+/* ------------------------------------------------------------------ attention
+ * builders/utils.py:71-105 scaled_dot_product_attention + the head split / merge of
+ * builders/layers/transformer.py:160-186 + the masks of builders/utils.py:35-68.
+ * Q (B,Lq,ldq) K,V (B,Lk,ld*) O (B,Lq,ldo); head h = columns [h*dh,(h+1)*dh).
+ * key_mask: (B, key_mask_ld) bytes, 1 = padded key (create_padding_mask), may be NULL.
+ * causal: add the look-ahead mask (needs Lq == Lk).  stats: (B,H,Lq,2) row max and
+ * 1/row-sum, kept for the backward.  dh in {16,32,64}. */
+int skf_attention_fwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
+                      const unsigned char* key_mask, int key_mask_ld, int causal, int B, int H, int Lq, int Lk, int dh,
+                      float* O, int ldo, float* stats, skf_stream_t stream);
+int skf_attention_bwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* O, int ldo,
+                      const float* dO, int lddo, const float* stats, const unsigned char* key_mask, int key_mask_ld,
+                      int causal, int B, int H, int Lq, int Lk, int dh, float* dQ, int lddq, float* dK, int lddk,
+                      float* dV, int lddv, skf_stream_t stream);
+
+/* ------------------------------------------------------------------ embedding stage
+ * Encoder.call / Decoder.call head, builders/layers/transformer.py:288-296, 325-334:
+ * out = Dropout(Embedding(tok) * sqrt(d) + pos[:L]).  tokens (B, tok_ld) int64 (first L used). */
+int skf_embed_fwd(const long long* tokens, int tok_ld, int B, int L, const float* table, int vocab, int d,
+                  const float* pos, float* out, float rate, unsigned site, const void* step_state, skf_stream_t stream);
+/* dtable (vocab,d) must be zeroed by the caller; receives the dense embedding gradient. */
+int skf_embed_bwd(const long long* tokens, int tok_ld, int B, int L, const float* dx, int vocab, int d, float* dtable,
+                  float rate, unsigned site, const void* step_state, skf_stream_t stream);
+/* key padding mask bytes (create_padding_mask, builders/utils.py:35-43): out[b][t] = tokens[b][t]==0 */
+int skf_padding_mask(const long long* tokens, int tok_ld, int B, int L, unsigned char* out, skf_stream_t stream);
+
+/* ------------------------------------------------------------------ residual + LayerNorm
+ * out = LayerNormalization(eps=1e-6)(x + Dropout(y)); builders/layers/transformer.py:217-222,247-260.
+ * y is overwritten with z = x + Dropout(y); stats (rows,2) = mean, rstd. */
+int skf_layernorm_residual_fwd(const float* x, float* y_inout_z, const float* gamma, const float* beta, float* out,
+                               float* stats, int rows, int d, float rate, unsigned site, const void* step_state,
+                               skf_stream_t stream);
+size_t skf_layernorm_bwd_workspace_bytes(int rows, int d);
+/* dz = d(x + drop(y)); dy = dz * dropout mask (only written when rate > 0; with rate == 0 dy == dz). */
+int skf_layernorm_residual_bwd(const float* dout, const float* z, const float* stats, const float* gamma, float* dz,
+                               float* dy, float* dgamma, float* dbeta, int rows, int d, float rate, unsigned site,
+                               const void* step_state, void* workspace, size_t workspace_bytes, skf_stream_t stream);
+int skf_colsum(const float* in, int nrows, int ld, int ncols, float* out, int accumulate, skf_stream_t stream);
+
+/* ------------------------------------------------------------------ loss heads + metrics
+ * Sparse softmax CE from logits, fused accuracy + in-place gradient.
+ * builders/losses.py:26-41 (mask_pad=1: loss*(target!=0), mean over ALL rows -> scale = weight/rows),
+ * builders/losses.py:21-24 (mask_pad=0), builders/keras_metrics.py:25 (first-index argmax == target).
+ * target element for row r: target[(r / tgt_cols) * tgt_ld + (r % tgt_cols) + tgt_off].
+ * probs_out (rows,ncls) optional (classify_layer's softmax output, models/sketchformer.py:99). */
+int skf_softmax_ce(float* logits, int ld, int rows, int ncls, const long long* target, int tgt_ld, int tgt_cols,
+                   int tgt_off, int mask_pad, float scale, float* row_loss, float* row_hit, float* probs_out,
+                   int write_grad, skf_stream_t stream);
+/* metrics (32 floats): [0..4] this step recon_loss, recon_acc, class_loss, class_acc, total_loss;
+ * [8..12] running totals, [16..20] running counts (Keras Mean / SparseCategoricalAccuracy). */
+int skf_metrics_update(const float* recon_loss, const float* recon_hit, int recon_rows, float recon_weight,
+                       const float* class_loss, const float* class_hit, int class_rows, float class_weight,
+                       float* metrics, skf_stream_t stream);
+
+/* ------------------------------------------------------------------ bottleneck + expander
+ * SelfAttnV1.call after u = tanh(xW+b): builders/layers/transformer.py:70-73. */
+int skf_pool_fwd(const float* u, const float* Vw, const float* x, int B, int L, int U, int d, float* a_out, float* emb,
+                 skf_stream_t stream);
+/* u is overwritten with d(pre-tanh); dx receives a[t]*demb[c]; workspace >= B*U floats */
+int skf_pool_bwd(float* u_inout_dpre, const float* Vw, const float* x, const float* a, const float* demb, int B, int L,
+                 int U, int d, float* dx, float* dV, void* workspace, size_t workspace_bytes, skf_stream_t stream);
+/* DenseExpander.call: builders/layers/transformer.py:370-376. workspace >= 2*B*L floats */
+int skf_expander_fwd(const float* emb, const float* w, const float* bias, int B, int L, int d, float* pre,
+                     skf_stream_t stream);
+int skf_expander_bwd(const float* dpre, const float* emb, const float* w, int B, int L, int d, float* demb,
+                     int demb_accumulate, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
+                     skf_stream_t stream);
+
+/* ------------------------------------------------------------------ optimizer
+ * builders/schedulers.py:13-46 + tf.keras.optimizers.Adam (models/sketchformer.py:112-124,348).
+ * step_state is skf_step_state_bytes() of device memory {int64 iterations; float lr, alpha; u32 drop_key}.
+ * schedule 0: WarmupDecay p0=d_model, p1=warmup^-1.5; 1: StepDecay p0=init_lr p1=rate p2=steps p3=min_ratio; 2: const p0 */
+size_t skf_step_state_bytes(void);
+int skf_step_prologue(void* step_state, int schedule, float p0, float p1, float p2, float p3, float beta1, float beta2,
+                      unsigned seed, skf_stream_t stream);
+int skf_step_epilogue(void* step_state, skf_stream_t stream);
+int skf_adam_step(float* w, const float* g, float* m, float* v, size_t n, const void* step_state, float grad_scale,
+                  float beta1, float beta2, float eps, skf_stream_t stream);
+/* host helper for parity tests: the keep-mask the kernels derive for (drop_key, site) */
+int skf_dropout_keep_mask(unsigned drop_key, unsigned site, float rate, size_t n, unsigned char* out_host);
+
+/* ------------------------------------------------------------------ the train step
+ * Transformer.build_model / call / model_trainer, models/sketchformer.py:63-147, 313-349. */
+typedef struct SkfConfig {
+  int32_t batch, seq_len, d_model, num_heads, dff, num_layers;
+  int32_t vocab_size, n_classes, lowerdim, attn_version;
+  int32_t continuous, blind_decoder_mask, max_pos;
+  float dropout_rate, recon_weight, class_weight;
+  int32_t schedule;
+  float sched_p0, sched_p1, sched_p2, sched_p3;
+  float beta1, beta2, eps;
+  uint32_t seed;
+  int32_t use_graph; /* capture the step into hipGraphs and replay them */
+} SkfConfig;
+
+typedef struct SkfParamEntry {
+  char name[96];
+  int64_t offset;      /* in floats, into the flat parameter / gradient / moment buffers */
+  int32_t rows, cols;  /* logical 2-D shape (1-D variables: rows = 1) */
+  int32_t row_stride;  /* floats between rows (fused wq|wk|wv blocks are strided views) */
+} SkfParamEntry;
+
+typedef struct SkfModel SkfModel;
+
+int skf_config_validate(const SkfConfig* cfg);
+size_t skf_model_param_floats(const SkfConfig* cfg);            /* length of the flat buffers */
+int skf_model_param_entries(const SkfConfig* cfg, SkfParamEntry* out_host, int max_entries); /* returns count */
+size_t skf_model_workspace_bytes(const SkfConfig* cfg);
+
+int skf_model_create(const SkfConfig* cfg, SkfModel** out);
+void skf_model_destroy(SkfModel* m);
+/* params/grads/adam_m/adam_v: skf_model_param_floats floats each; pos: (max_pos, d_model) table
+ * (builders/utils.py:17-32, computed by the host in float64 like the reference);
+ * metrics: 32 floats; step_state: skf_step_state_bytes bytes.  All device memory owned by the caller. */
+int skf_model_bind(SkfModel* m, float* params, float* grads, float* adam_m, float* adam_v, const float* pos,
+                   void* workspace, size_t workspace_bytes, float* metrics, void* step_state);
+/* forward only (Transformer.call); training != 0 enables dropout.  inp (B,L) tar_inp (B,L-1 used, row stride tar_ld). */
+int skf_model_forward(SkfModel* m, const long long* inp, const long long* tar, int tar_ld, int training,
+                      skf_stream_t stream);
+/* model_trainer minus apply_gradients: forward, losses, metrics, backward into `grads`. labels (B,1) int64. */
+int skf_model_forward_backward(SkfModel* m, const long long* inp, const long long* tar, int tar_ld,
+                               const long long* labels, skf_stream_t stream);
+/* optimizer.apply_gradients with grads pre-multiplied by grad_scale (1/world_size under data parallelism) */
+int skf_model_apply_gradients(SkfModel* m, float grad_scale, skf_stream_t stream);
+/* look up an internal activation by name ("logits", "class_probs", "embedding", "enc_output", ...) */
+int skf_model_buffer(SkfModel* m, const char* name, float** ptr, int* rows, int* cols);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SKF_H_ */

@@ -1,0 +1,119 @@
+"""ctypes binding of libskf.so (the C ABI declared in include/skf.h).
+
+There is no CPU fallback: if the HIP library is missing or a call fails this
+module raises.  PyTorch is used by callers only to own device memory/streams;
+nothing here takes a torch type - pointers go through ``tensor.data_ptr()``.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libskf.so")
+
+SKF_OK = 0
+
+
+class SkfError(RuntimeError):
+    pass
+
+
+class SkfConfig(C.Structure):
+    _fields_ = [
+        ("batch", C.c_int32), ("seq_len", C.c_int32), ("d_model", C.c_int32), ("num_heads", C.c_int32),
+        ("dff", C.c_int32), ("num_layers", C.c_int32),
+        ("vocab_size", C.c_int32), ("n_classes", C.c_int32), ("lowerdim", C.c_int32), ("attn_version", C.c_int32),
+        ("continuous", C.c_int32), ("blind_decoder_mask", C.c_int32), ("max_pos", C.c_int32),
+        ("dropout_rate", C.c_float), ("recon_weight", C.c_float), ("class_weight", C.c_float),
+        ("schedule", C.c_int32),
+        ("sched_p0", C.c_float), ("sched_p1", C.c_float), ("sched_p2", C.c_float), ("sched_p3", C.c_float),
+        ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+        ("seed", C.c_uint32),
+        ("use_graph", C.c_int32),
+    ]
+
+
+class SkfParamEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 96), ("offset", C.c_int64), ("rows", C.c_int32), ("cols", C.c_int32),
+                ("row_stride", C.c_int32)]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_F = C.c_float
+_Z = C.c_size_t
+_U = C.c_uint
+
+# name -> (restype, argtypes).  Mirrors include/skf.h one to one (tests check this).
+SIGNATURES = {
+    "skf_last_error": (C.c_char_p, []),
+    "skf_version": (_I, []),
+    "skf_device_info": (_I, [C.c_char_p, _Z, C.POINTER(_I)]),
+    "skf_gemm_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
+    "skf_gemm_default_splits": (_I, [_I, _I, _I]),
+    "skf_gemm_f32": (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _I, _P, _Z, _P]),
+    "skf_attention_fwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P]),
+    "skf_attention_bwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I,
+                               _P, _I, _P, _I, _P, _I, _P]),
+    "skf_embed_fwd": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _P, _F, _U, _P, _P]),
+    "skf_embed_bwd": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _F, _U, _P, _P]),
+    "skf_padding_mask": (_I, [_P, _I, _I, _I, _P, _P]),
+    "skf_layernorm_residual_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _U, _P, _P]),
+    "skf_layernorm_bwd_workspace_bytes": (_Z, [_I, _I]),
+    "skf_layernorm_residual_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U, _P, _P, _Z, _P]),
+    "skf_colsum": (_I, [_P, _I, _I, _I, _P, _I, _P]),
+    "skf_softmax_ce": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _I, _F, _P, _P, _P, _I, _P]),
+    "skf_metrics_update": (_I, [_P, _P, _I, _F, _P, _P, _I, _F, _P, _P]),
+    "skf_pool_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "skf_pool_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _Z, _P]),
+    "skf_expander_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
+    "skf_expander_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _Z, _P]),
+    "skf_step_state_bytes": (_Z, []),
+    "skf_step_prologue": (_I, [_P, _I, _F, _F, _F, _F, _F, _F, _U, _P]),
+    "skf_step_epilogue": (_I, [_P, _P]),
+    "skf_adam_step": (_I, [_P, _P, _P, _P, _Z, _P, _F, _F, _F, _F, _P]),
+    "skf_dropout_keep_mask": (_I, [_U, _U, _F, _Z, _P]),
+    "skf_config_validate": (_I, [C.POINTER(SkfConfig)]),
+    "skf_model_param_floats": (_Z, [C.POINTER(SkfConfig)]),
+    "skf_model_param_entries": (_I, [C.POINTER(SkfConfig), C.POINTER(SkfParamEntry), _I]),
+    "skf_model_workspace_bytes": (_Z, [C.POINTER(SkfConfig)]),
+    "skf_model_create": (_I, [C.POINTER(SkfConfig), C.POINTER(_P)]),
+    "skf_model_destroy": (None, [_P]),
+    "skf_model_bind": (_I, [_P, _P, _P, _P, _P, _P, _P, _Z, _P, _P]),
+    "skf_model_forward": (_I, [_P, _P, _P, _I, _I, _P]),
+    "skf_model_forward_backward": (_I, [_P, _P, _P, _I, _P, _P]),
+    "skf_model_apply_gradients": (_I, [_P, _F, _P]),
+    "skf_model_buffer": (_I, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(_I), C.POINTER(_I)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libskf.so; raises SkfError (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SkfError("libskf.so not found at %s - run `python -m sketchformer_amd.build` "
+                       "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != SKF_OK:
+        lib = load()
+        msg = lib.skf_last_error()
+        raise SkfError("%s failed (rc=%d): %s" % (what or "libskf call", rc, msg.decode() if msg else ""))
+    return rc
+
+
+def call(name, *args):
+    """Call an int-returning entry point and raise SkfError on a non-zero code."""
+    lib = load()
+    return check(getattr(lib, name)(*args), name)

@@ -1,0 +1,61 @@
+"""Builds libskf.so (the C-ABI HIP library) in-tree with hipcc for gfx950."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libskf.so")
+SOURCES = ["skf_model.hip", "skf_gemm.hip", "skf_attention.hip", "skf_rowops.hip", "skf_optimizer.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "skf.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force=False, verbose=True):
+    """Compile every HIP source for gfx950 and link libskf.so next to this file."""
+    if not force and not needs_build():
+        return LIB
+    objs = []
+    procs = []
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    for src in SOURCES:
+        obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
+        cmd = [_hipcc()] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(obj)
+    failed = False
+    for src, p in procs:
+        out, _ = p.communicate()
+        if out and verbose:
+            sys.stdout.write(out.decode(errors="replace"))
+        if p.returncode != 0:
+            failed = True
+            sys.stderr.write("hipcc failed on %s\n%s\n" % (src, out.decode(errors="replace")))
+    if failed:
+        raise RuntimeError("libskf.so build failed")
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build_library(force="--force" in sys.argv)
+    print(LIB)

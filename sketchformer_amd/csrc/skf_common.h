@@ -1,0 +1,82 @@
+// Shared device/host helpers for the sketchformer_amd HIP kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/skf.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define SKF_WAVE 64
+
+void skf_set_error(const char* fmt, ...);
+
+#define SKF_CHECK_ARG(cond, msg)                                   \
+  do {                                                             \
+    if (!(cond)) {                                                 \
+      skf_set_error("%s: %s (%s)", __func__, msg, #cond);          \
+      return SKF_EINVAL;                                           \
+    }                                                              \
+  } while (0)
+
+#define SKF_LAUNCH_CHECK()                                          \
+  do {                                                              \
+    hipError_t e__ = hipGetLastError();                             \
+    if (e__ != hipSuccess) {                                        \
+      skf_set_error("%s: launch failed: %s", __func__, hipGetErrorString(e__)); \
+      return SKF_EHIP;                                              \
+    }                                                               \
+  } while (0)
+
+#define SKF_HIP(call)                                               \
+  do {                                                              \
+    hipError_t e__ = (call);                                        \
+    if (e__ != hipSuccess) {                                        \
+      skf_set_error("%s: %s failed: %s", __func__, #call, hipGetErrorString(e__)); \
+      return SKF_EHIP;                                              \
+    }                                                               \
+  } while (0)
+
+static inline int skf_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------- device
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Counter-based dropout RNG: one 32-bit hash per element, keyed on
+// (key = f(seed, step), site, flat element index).  Deterministic, stateless,
+// identical on host (skf_dropout_keep_mask) and device.
+__host__ __device__ __forceinline__ uint32_t skf_hash32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__host__ __device__ __forceinline__ uint32_t skf_site_key(uint32_t key, uint32_t site) {
+  return skf_hash32(key ^ (0x9e3779b9U * (site + 1)));
+}
+__host__ __device__ __forceinline__ bool skf_keep(uint32_t site_key, uint32_t idx, uint32_t thresh) {
+  // keep iff u >= rate  (tf.nn.dropout: random_uniform >= rate)
+  return skf_hash32(idx * 0x9e3779b1U + site_key) >= thresh;
+}
+__host__ __device__ __forceinline__ uint32_t skf_drop_thresh(float rate) {
+  double t = (double)rate * 4294967296.0;
+  return t >= 4294967295.0 ? 0xffffffffU : (uint32_t)t;
+}
+
+// Per-step scalars that live in device memory so a captured hipGraph can be
+// replayed: written by the step-prologue kernel, read by dropout sites / Adam.
+struct SkfStepState {
+  long long iterations;   // optimizer.iterations (pre-increment value used this step)
+  float lr;               // schedule(iterations)
+  float alpha;            // lr * sqrt(1-b2^t)/(1-b1^t)
+  uint32_t drop_key;      // hash(seed, iterations)
+  uint32_t pad;
+};

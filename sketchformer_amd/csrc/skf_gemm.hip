@@ -1,0 +1,337 @@
+// fp32 GEMM family on v_mfma_f32_32x32x2_f32 (exact fp32, 157 TF peak on gfx950).
+//
+// Replaces the tf.keras.layers.Dense forward (x.W+b, optional relu/tanh) and the
+// dgrad / wgrad+bias-grad that tf.GradientTape derives for it
+// (reference: builders/layers/transformer.py:154-158,196-197, models/sketchformer.py:85-104,347).
+//
+//   C[M,N] (+)= opA(A)[M,K] . opB(B)[K,N]  (+ bias[N]) (act) (relu-grad mask)
+//
+//   a_kcontig=1 : A is [M][K], K contiguous   (forward x, dgrad dY)
+//   a_kcontig=0 : A is [K][M], M contiguous   (wgrad: X viewed as X^T)
+//   b_kcontig=0 : B is [K][N], N contiguous   (forward W, wgrad dY)
+//   b_kcontig=1 : B is [N][K], K contiguous   (dgrad: W viewed as W^T)
+//
+// Work decomposition: 256-thread workgroups (4 waves, one per SIMD), BMxBN output
+// tile, BK=32 k-slab double-buffered in LDS with register-staged prefetch (global
+// loads for slab t+1 are issued before the MFMAs of slab t and written to LDS
+// after them).  Both operands are stored k-major in LDS (S[k][mn]) so each MFMA
+// fragment read is one conflict-free ds_read_b32 per lane; k-contiguous operands
+// are transposed on the LDS store with a +1 pad that makes the 4 scalar stores
+// conflict-free.  blockIdx is remapped so that consecutive logical tiles (which
+// share an A row-panel) land on the same XCD / L2.
+#include "skf_common.h"
+
+namespace {
+
+constexpr int BK = 32;
+
+struct GemmParams {
+  const float* A; const float* B; float* C;
+  int M, N, K;
+  int lda, ldb, ldc;
+  const float* bias;
+  int act;                 // 0 none, 1 relu, 2 tanh
+  const float* relu_src;   // optional: C *= (relu_src > 0)
+  int ld_relu;
+  int accumulate;          // C += result
+  int a_vec, b_vec;        // 16-byte vector loads legal
+  // split-K
+  int k_chunk;             // k range per blockIdx.z (multiple of BK)
+  float* slab;             // [splits][M][N] raw partial tiles (split-K only)
+  float* colsum_slab;      // [splits][N] partial column sums of B (bias grad), or null
+  int tiles_m, tiles_n;
+};
+
+template <int BX, bool KC>
+struct TileLD { static constexpr int value = KC ? BX + 1 : BX + 4; };
+
+// ---- global -> register staging of one BX x BK operand slab
+template <int BX, bool KC>
+__device__ __forceinline__ void load_slab(const float* __restrict__ P, int ld, int mn0, int mn_max,
+                                          int k0, int k_end, bool vec, float4 (&r)[BX * BK / 1024]) {
+  const int t = threadIdx.x;
+  constexpr int NV = BX * BK / 1024;
+#pragma unroll
+  for (int p = 0; p < NV; ++p) {
+    int mn, k;
+    if (KC) { mn = mn0 + (t >> 3) + p * 32; k = k0 + (t & 7) * 4; }
+    else    { k = k0 + t / (BX / 4) + p * (1024 / BX); mn = mn0 + (t % (BX / 4)) * 4; }
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (KC) {
+      if (mn < mn_max) {
+        const float* src = P + (size_t)mn * ld + k;
+        if (vec && k + 3 < k_end) v = *reinterpret_cast<const float4*>(src);
+        else {
+          if (k + 0 < k_end) v.x = src[0];
+          if (k + 1 < k_end) v.y = src[1];
+          if (k + 2 < k_end) v.z = src[2];
+          if (k + 3 < k_end) v.w = src[3];
+        }
+      }
+    } else {
+      if (k < k_end) {
+        const float* src = P + (size_t)k * ld + mn;
+        if (vec && mn + 3 < mn_max) v = *reinterpret_cast<const float4*>(src);
+        else {
+          if (mn + 0 < mn_max) v.x = src[0];
+          if (mn + 1 < mn_max) v.y = src[1];
+          if (mn + 2 < mn_max) v.z = src[2];
+          if (mn + 3 < mn_max) v.w = src[3];
+        }
+      }
+    }
+    r[p] = v;
+  }
+}
+
+// ---- register -> LDS (k-major image S[k][mn])
+template <int BX, bool KC>
+__device__ __forceinline__ void store_slab(float* __restrict__ S, const float4 (&r)[BX * BK / 1024]) {
+  const int t = threadIdx.x;
+  constexpr int LD = TileLD<BX, KC>::value;
+  constexpr int NV = BX * BK / 1024;
+#pragma unroll
+  for (int p = 0; p < NV; ++p) {
+    if (KC) {
+      const int row = (t >> 3) + p * 32, kq = (t & 7) * 4;
+      S[(kq + 0) * LD + row] = r[p].x;
+      S[(kq + 1) * LD + row] = r[p].y;
+      S[(kq + 2) * LD + row] = r[p].z;
+      S[(kq + 3) * LD + row] = r[p].w;
+    } else {
+      const int kr = t / (BX / 4) + p * (1024 / BX), c = (t % (BX / 4)) * 4;
+      *reinterpret_cast<float4*>(&S[kr * LD + c]) = r[p];
+    }
+  }
+}
+
+template <int BM, int BN, int WGM, bool A_KC, bool B_KC, bool SPLITK>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
+  constexpr int WGN = 4 / WGM;
+  constexpr int WM = BM / WGM, WN = BN / WGN;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int LDA_S = TileLD<BM, A_KC>::value, LDB_S = TileLD<BN, B_KC>::value;
+  constexpr int A_SZ = BK * LDA_S, B_SZ = BK * LDB_S;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                  // [2][BK][LDA_S]
+  float* Bs = smem + 2 * A_SZ;       // [2][BK][LDB_S]
+
+  // XCD-aware bijective remap of the 1-D grid (block b runs on XCD b%8).
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int orig = blockIdx.x;
+  const int xcd = orig & 7, q = nwg >> 3, rr = nwg & 7;
+  const int logical = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (orig >> 3);
+  const int tile_m = logical / p.tiles_n, tile_n = logical % p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  int kb = 0, ke = p.K;
+  if (SPLITK) { kb = blockIdx.z * p.k_chunk; ke = min(p.K, kb + p.k_chunk); }
+  const int nk = (ke - kb + BK - 1) / BK;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[BM * BK / 1024], rb[BN * BK / 1024];
+  float colsum = 0.f;
+  const bool do_colsum = SPLITK && p.colsum_slab != nullptr && tile_m == 0;
+
+  if (nk > 0) {
+    load_slab<BM, A_KC>(p.A, p.lda, m0, p.M, kb, ke, p.a_vec, ra);
+    load_slab<BN, B_KC>(p.B, p.ldb, n0, p.N, kb, ke, p.b_vec, rb);
+    store_slab<BM, A_KC>(As, ra);
+    store_slab<BN, B_KC>(Bs, rb);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nk;
+    if (more) {
+      load_slab<BM, A_KC>(p.A, p.lda, m0, p.M, kb + (kt + 1) * BK, ke, p.a_vec, ra);
+      load_slab<BN, B_KC>(p.B, p.ldb, n0, p.N, kb + (kt + 1) * BK, ke, p.b_vec, rb);
+    }
+    const float* Ac = As + cur * A_SZ;
+    const float* Bc = Bs + cur * B_SZ;
+#pragma unroll
+    for (int kp = 0; kp < BK / 2; ++kp) {
+      const int k = 2 * kp + lhi;
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = Ac[k * LDA_S + wm0 + i * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = Bc[k * LDB_S + wn0 + j * 32 + l31];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (do_colsum && threadIdx.x < BN) {
+#pragma unroll 8
+      for (int k = 0; k < BK; ++k) colsum += Bc[k * LDB_S + threadIdx.x];
+    }
+    if (more) {
+      store_slab<BM, A_KC>(As + (cur ^ 1) * A_SZ, ra);
+      store_slab<BN, B_KC>(Bs + (cur ^ 1) * B_SZ, rb);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  if (SPLITK) {
+    float* slab = p.slab + (size_t)blockIdx.z * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn0 + j * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          if (row < p.M && col < p.N) slab[(size_t)row * p.N + col] = acc[i][j][r];
+        }
+      }
+    if (do_colsum && threadIdx.x < BN && n0 + (int)threadIdx.x < p.N)
+      p.colsum_slab[(size_t)blockIdx.z * p.N + n0 + threadIdx.x] = colsum;
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn0 + j * 32 + l31;
+      if (col >= p.N) continue;
+      const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (row >= p.M) continue;
+        float v = acc[i][j][r] + bv;
+        if (p.act == 1) v = fmaxf(v, 0.f);
+        else if (p.act == 2) v = tanhf(v);
+        if (p.relu_src && !(p.relu_src[(size_t)row * p.ld_relu + col] > 0.f)) v = 0.f;
+        float* dst = p.C + (size_t)row * p.ldc + col;
+        if (p.accumulate) v += *dst;
+        *dst = v;
+      }
+    }
+}
+
+// C[m][n] (=|+=) sum_z slab[z][m][n];  bias_grad[n] = sum_z colsum_slab[z][n]
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, int splits, int M, int N,
+                                                            float* __restrict__ C, int ldc, int accumulate,
+                                                            const float* __restrict__ colsum_slab,
+                                                            float* __restrict__ bias_grad, int bias_accumulate) {
+  const size_t total = (size_t)M * N;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total + N; i += stride) {
+    if (i < total) {
+      float s = 0.f;
+      for (int z = 0; z < splits; ++z) s += slab[(size_t)z * total + i];
+      const int m = (int)(i / N), n = (int)(i % N);
+      float* dst = C + (size_t)m * ldc + n;
+      *dst = accumulate ? *dst + s : s;
+    } else if (colsum_slab) {
+      const int n = (int)(i - total);
+      float s = 0.f;
+      for (int z = 0; z < splits; ++z) s += colsum_slab[(size_t)z * N + n];
+      bias_grad[n] = bias_accumulate ? bias_grad[n] + s : s;
+    }
+  }
+}
+
+template <int BM, int BN, int WGM, bool SPLITK>
+int launch_variant(const GemmParams& p, int a_kc, int b_kc, int splits, hipStream_t st) {
+  dim3 grid(p.tiles_m * p.tiles_n, 1, splits), block(256);
+#define SKF_GEMM_GO(AK, BKC)                                                                                   \
+  {                                                                                                            \
+    constexpr size_t smem = 2 * BK * (TileLD<BM, AK>::value + TileLD<BN, BKC>::value) * sizeof(float);         \
+    auto kfn = gemm_kernel<BM, BN, WGM, AK, BKC, SPLITK>;                                                      \
+    static bool attr_done = false;                                                                             \
+    if (!attr_done) {                                                                                          \
+      SKF_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));   \
+      attr_done = true;                                                                                        \
+    }                                                                                                          \
+    hipLaunchKernelGGL(kfn, grid, block, smem, st, p);                                                         \
+  }
+  if (a_kc && !b_kc) SKF_GEMM_GO(true, false)
+  else if (a_kc && b_kc) SKF_GEMM_GO(true, true)
+  else if (!a_kc && !b_kc) SKF_GEMM_GO(false, false)
+  else SKF_GEMM_GO(false, true)
+#undef SKF_GEMM_GO
+  SKF_LAUNCH_CHECK();
+  return SKF_OK;
+}
+
+}  // namespace
+
+extern "C" size_t skf_gemm_workspace_bytes(int M, int N, int K, int splits, int with_bias_grad) {
+  (void)K;
+  if (splits <= 1 && !with_bias_grad) return 0;
+  if (splits < 1) splits = 1;
+  return ((size_t)M * N + N) * (size_t)splits * sizeof(float);
+}
+
+extern "C" int skf_gemm_default_splits(int M, int N, int K) {
+  // wgrad-shaped problems: small output, long contraction.  Aim at ~2 workgroups per CU.
+  const int tiles = skf_cdiv(M, 128) * skf_cdiv(N, 128);
+  if (tiles >= 256 || K <= 512) return 1;
+  int splits = 512 / tiles;
+  const int max_splits = skf_cdiv(K, 4 * BK);   // at least 4 slabs per split
+  if (splits > max_splits) splits = max_splits;
+  return splits < 1 ? 1 : splits;
+}
+
+extern "C" int skf_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K,
+                            const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                            const float* bias, int act, const float* relu_src, int ld_relu, int accumulate,
+                            int splits, float* bias_grad, int bias_grad_accumulate,
+                            void* workspace, size_t workspace_bytes, skf_stream_t stream) {
+  SKF_CHECK_ARG(M > 0 && N > 0 && K > 0, "empty problem");
+  SKF_CHECK_ARG(A && B && C, "null operand");
+  SKF_CHECK_ARG(act >= 0 && act <= 2, "bad activation");
+  hipStream_t st = (hipStream_t)stream;
+  GemmParams p{};
+  p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.bias = bias; p.act = act; p.relu_src = relu_src; p.ld_relu = ld_relu; p.accumulate = accumulate;
+  p.a_vec = ((lda & 3) == 0) && (((uintptr_t)A & 15) == 0);
+  p.b_vec = ((ldb & 3) == 0) && (((uintptr_t)B & 15) == 0);
+  p.tiles_m = skf_cdiv(M, 128); p.tiles_n = skf_cdiv(N, 128);
+  if (splits <= 1 && !bias_grad) {
+    // 64-row tiles when 128-row tiles would leave most CUs idle
+    if (p.tiles_m * p.tiles_n < 400 && M > 64) {
+      p.tiles_m = skf_cdiv(M, 64);
+      return launch_variant<64, 128, 1, false>(p, a_kcontig, b_kcontig, 1, st);
+    }
+    return launch_variant<128, 128, 2, false>(p, a_kcontig, b_kcontig, 1, st);
+  }
+  SKF_CHECK_ARG(!bias && act == 0 && !relu_src, "split-K supports no fused epilogue");
+  if (splits < 1) splits = 1;
+  SKF_CHECK_ARG(workspace && workspace_bytes >= skf_gemm_workspace_bytes(M, N, K, splits, 1), "workspace too small");
+  SKF_CHECK_ARG(!bias_grad || !b_kcontig, "bias_grad needs B as [K][N]");
+  int chunk = skf_cdiv(K, splits);
+  chunk = skf_cdiv(chunk, BK) * BK;
+  splits = skf_cdiv(K, chunk);
+  p.k_chunk = chunk;
+  p.slab = (float*)workspace;
+  p.colsum_slab = bias_grad ? p.slab + (size_t)splits * M * N : nullptr;
+  int rc = launch_variant<128, 128, 2, true>(p, a_kcontig, b_kcontig, splits, st);
+  if (rc != SKF_OK) return rc;
+  const size_t total = (size_t)M * N + N;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.slab, splits, M, N, C, ldc, accumulate,
+                     p.colsum_slab, bias_grad, bias_grad_accumulate);
+  SKF_LAUNCH_CHECK();
+  return SKF_OK;
+}

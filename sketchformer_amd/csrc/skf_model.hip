@@ -1,0 +1,642 @@
+// Train-step orchestrator: the fixed launch sequence of Transformer.call +
+// model_trainer (models/sketchformer.py:131-181, 325-349) over caller-owned flat
+// device buffers, optionally captured into hipGraphs (one for forward+backward,
+// one for the optimizer, so a data-parallel caller can all-reduce the flat
+// gradient buffer in between).  No autograd: the backward sequence is explicit.
+#include <stdarg.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <map>
+#include "skf_common.h"
+
+// ------------------------------------------------------------------ error plumbing
+static thread_local char g_err[512] = "";
+void skf_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* skf_last_error(void) { return g_err; }
+extern "C" int skf_version(void) { return 100; }
+extern "C" int skf_device_info(char* name_host, size_t name_len, int* n_devices_host) {
+  int n = 0;
+  SKF_HIP(hipGetDeviceCount(&n));
+  if (n_devices_host) *n_devices_host = n;
+  if (name_host && name_len) {
+    int dev = 0;
+    SKF_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    SKF_HIP(hipGetDeviceProperties(&prop, dev));
+    snprintf(name_host, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+  }
+  return SKF_OK;
+}
+
+namespace {
+
+inline size_t pad4(size_t n) { return (n + 3) & ~(size_t)3; }
+
+struct DenseP { size_t w, b; int in, out, ld; };     // offsets into the flat buffer
+struct LnP { size_t g, b; };
+struct SelfMhaP { DenseP qkv, o; };
+struct CrossMhaP { DenseP q, kv, o; };
+struct EncLayerP { SelfMhaP mha; DenseP f1, f2; LnP ln1, ln2; };
+struct DecLayerP { SelfMhaP mha1; CrossMhaP mha2; DenseP f1, f2; LnP ln1, ln2, ln3; };
+
+struct Layout {
+  size_t total = 0;
+  size_t enc_emb = 0, dec_emb = 0;
+  std::vector<EncLayerP> enc;
+  std::vector<DecLayerP> dec;
+  DenseP bott_w{};      // W_attn + b_attn
+  size_t bott_v = 0;    // V_attn
+  DenseP cls{}, out{};
+  size_t exp_w = 0, exp_b = 0;
+  std::vector<SkfParamEntry> entries;
+};
+
+void add_entry(Layout& L, const std::string& name, size_t off, int rows, int cols, int stride) {
+  SkfParamEntry e;
+  memset(&e, 0, sizeof(e));
+  snprintf(e.name, sizeof(e.name), "%s", name.c_str());
+  e.offset = (int64_t)off; e.rows = rows; e.cols = cols; e.row_stride = stride;
+  L.entries.push_back(e);
+}
+
+size_t alloc(Layout& L, size_t n) { size_t o = L.total; L.total += pad4(n); return o; }
+
+DenseP dense(Layout& L, const std::string& name, int in, int out) {
+  DenseP d; d.in = in; d.out = out; d.ld = out;
+  d.w = alloc(L, (size_t)in * out); d.b = alloc(L, out);
+  add_entry(L, name + "/kernel", d.w, in, out, out);
+  add_entry(L, name + "/bias", d.b, 1, out, out);
+  return d;
+}
+
+// fused [in][nparts*out] block exposed as nparts strided (in,out) kernels
+DenseP fused_dense(Layout& L, const std::string& prefix, const char* const* names, int nparts, int in, int out) {
+  DenseP d; d.in = in; d.out = nparts * out; d.ld = nparts * out;
+  d.w = alloc(L, (size_t)in * d.out); d.b = alloc(L, d.out);
+  for (int i = 0; i < nparts; ++i) {
+    add_entry(L, prefix + "/" + names[i] + "/kernel", d.w + (size_t)i * out, in, out, d.ld);
+    add_entry(L, prefix + "/" + names[i] + "/bias", d.b + (size_t)i * out, 1, out, out);
+  }
+  return d;
+}
+
+LnP lnp(Layout& L, const std::string& name, int d) {
+  LnP p; p.g = alloc(L, d); p.b = alloc(L, d);
+  add_entry(L, name + "/gamma", p.g, 1, d, d);
+  add_entry(L, name + "/beta", p.b, 1, d, d);
+  return p;
+}
+
+Layout build_layout(const SkfConfig& c) {
+  Layout L;
+  const int d = c.d_model, E = d;   // attn_version 1: embedding width = d_model
+  static const char* const qkv_names[3] = {"wq", "wk", "wv"};
+  static const char* const kv_names[2] = {"wk", "wv"};
+  L.enc_emb = alloc(L, (size_t)c.vocab_size * d);
+  add_entry(L, "encoder/embedding", L.enc_emb, c.vocab_size, d, d);
+  for (int i = 0; i < c.num_layers; ++i) {
+    const std::string p = "encoder/layer" + std::to_string(i);
+    EncLayerP e;
+    e.mha.qkv = fused_dense(L, p + "/mha", qkv_names, 3, d, d);
+    e.mha.o = dense(L, p + "/mha/dense", d, d);
+    e.f1 = dense(L, p + "/ffn/dense1", d, c.dff);
+    e.f2 = dense(L, p + "/ffn/dense2", c.dff, d);
+    e.ln1 = lnp(L, p + "/layernorm1", d);
+    e.ln2 = lnp(L, p + "/layernorm2", d);
+    L.enc.push_back(e);
+  }
+  L.bott_w.in = d; L.bott_w.out = c.lowerdim; L.bott_w.ld = c.lowerdim;
+  L.bott_w.w = alloc(L, (size_t)d * c.lowerdim); L.bott_w.b = alloc(L, c.lowerdim);
+  L.bott_v = alloc(L, c.lowerdim);
+  add_entry(L, "bottleneck/W_attn", L.bott_w.w, d, c.lowerdim, c.lowerdim);
+  add_entry(L, "bottleneck/b_attn", L.bott_w.b, 1, c.lowerdim, c.lowerdim);
+  add_entry(L, "bottleneck/V_attn", L.bott_v, c.lowerdim, 1, 1);
+  L.cls = dense(L, "classify", E, c.n_classes);
+  L.exp_w = alloc(L, c.seq_len); L.exp_b = alloc(L, c.seq_len);
+  add_entry(L, "expand/kernel", L.exp_w, 1, c.seq_len, c.seq_len);
+  add_entry(L, "expand/bias", L.exp_b, 1, c.seq_len, c.seq_len);
+  L.dec_emb = alloc(L, (size_t)c.vocab_size * d);
+  add_entry(L, "decoder/embedding", L.dec_emb, c.vocab_size, d, d);
+  for (int i = 0; i < c.num_layers; ++i) {
+    const std::string p = "decoder/layer" + std::to_string(i);
+    DecLayerP e;
+    e.mha1.qkv = fused_dense(L, p + "/mha1", qkv_names, 3, d, d);
+    e.mha1.o = dense(L, p + "/mha1/dense", d, d);
+    e.mha2.q = dense(L, p + "/mha2/wq", d, d);
+    e.mha2.kv = fused_dense(L, p + "/mha2", kv_names, 2, E, d);
+    e.mha2.o = dense(L, p + "/mha2/dense", d, d);
+    e.f1 = dense(L, p + "/ffn/dense1", d, c.dff);
+    e.f2 = dense(L, p + "/ffn/dense2", c.dff, d);
+    e.ln1 = lnp(L, p + "/layernorm1", d);
+    e.ln2 = lnp(L, p + "/layernorm2", d);
+    e.ln3 = lnp(L, p + "/layernorm3", d);
+    L.dec.push_back(e);
+  }
+  L.out = dense(L, "output", d, c.vocab_size);
+  return L;
+}
+
+// ------------------------------------------------------------------ workspace plan
+struct Bump {
+  size_t off = 0;
+  size_t take(size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; }
+};
+
+struct EncAct { size_t x_in, qkv, o, z1, st1, astats, x1, h, z2, st2, x2; };
+struct DecAct { size_t x_in, qkv, o1, z1, st1, astats1, out1, q2, kv2, o2, astats2, z2, st2, out2, h, z3, st3, out3; };
+
+struct Plan {
+  size_t bytes = 0;
+  size_t inp, tar, labels, enc_mask, dec_mask;
+  std::vector<EncAct> enc;
+  std::vector<DecAct> dec;
+  size_t u, pool_a, emb, cls_logits, cls_probs, pre, logits;
+  size_t recon_loss, recon_hit, cls_loss, cls_hit;
+  size_t gA, gB, gC, dqkv, dh, do_, dpre, dkv2, dq2, demb;
+  size_t gemm_ws, gemm_ws_bytes, small_ws, small_ws_bytes;
+};
+
+size_t wgrad_ws(int in, int out, int rows) {
+  return skf_gemm_workspace_bytes(in, out, rows, skf_gemm_default_splits(in, out, rows), 1);
+}
+
+Plan build_plan(const SkfConfig& c) {
+  Plan P;
+  Bump b;
+  const size_t B = c.batch, L = c.seq_len, Ld = c.seq_len - 1, d = c.d_model, F = c.dff, U = c.lowerdim;
+  const size_t Me = B * L, Md = B * Ld, H = c.num_heads, f = sizeof(float);
+  P.inp = b.take(B * L * 8); P.tar = b.take(B * L * 8); P.labels = b.take(B * 8);
+  P.enc_mask = b.take(B * L); P.dec_mask = b.take(B * L);
+  for (int i = 0; i < c.num_layers; ++i) {
+    EncAct a;
+    a.x_in = b.take(Me * d * f); a.qkv = b.take(Me * 3 * d * f); a.o = b.take(Me * d * f); a.z1 = b.take(Me * d * f);
+    a.st1 = b.take(Me * 2 * f); a.astats = b.take(B * H * L * 2 * f); a.x1 = b.take(Me * d * f);
+    a.h = b.take(Me * F * f); a.z2 = b.take(Me * d * f); a.st2 = b.take(Me * 2 * f);
+    a.x2 = 0;
+    P.enc.push_back(a);
+  }
+  const size_t enc_out = b.take(Me * d * f);
+  for (int i = 0; i < c.num_layers; ++i) P.enc[i].x2 = (i + 1 < c.num_layers) ? P.enc[i + 1].x_in : enc_out;
+  P.u = b.take(Me * U * f); P.pool_a = b.take(B * L * f); P.emb = b.take(B * d * f);
+  P.cls_logits = b.take(B * c.n_classes * f); P.cls_probs = b.take(B * c.n_classes * f);
+  P.pre = b.take(Me * d * f);
+  for (int i = 0; i < c.num_layers; ++i) {
+    DecAct a;
+    a.x_in = b.take(Md * d * f); a.qkv = b.take(Md * 3 * d * f); a.o1 = b.take(Md * d * f); a.z1 = b.take(Md * d * f);
+    a.st1 = b.take(Md * 2 * f); a.astats1 = b.take(B * H * Ld * 2 * f); a.out1 = b.take(Md * d * f);
+    a.q2 = b.take(Md * d * f); a.kv2 = b.take(Me * 2 * d * f); a.o2 = b.take(Md * d * f);
+    a.astats2 = b.take(B * H * Ld * 2 * f); a.z2 = b.take(Md * d * f); a.st2 = b.take(Md * 2 * f);
+    a.out2 = b.take(Md * d * f); a.h = b.take(Md * F * f); a.z3 = b.take(Md * d * f); a.st3 = b.take(Md * 2 * f);
+    a.out3 = 0;
+    P.dec.push_back(a);
+  }
+  const size_t dec_out = b.take(Md * d * f);
+  for (int i = 0; i < c.num_layers; ++i) P.dec[i].out3 = (i + 1 < c.num_layers) ? P.dec[i + 1].x_in : dec_out;
+  P.logits = b.take(Md * (size_t)c.vocab_size * f);
+  P.recon_loss = b.take(Md * f); P.recon_hit = b.take(Md * f); P.cls_loss = b.take(B * f); P.cls_hit = b.take(B * f);
+  P.gA = b.take(Me * d * f); P.gB = b.take(Me * d * f); P.gC = b.take(Me * d * f);
+  P.dqkv = b.take(Me * 3 * d * f); P.dh = b.take(Me * F * f); P.do_ = b.take(Me * d * f);
+  P.dpre = b.take(Me * d * f); P.dkv2 = b.take(Me * 2 * d * f); P.dq2 = b.take(Md * d * f); P.demb = b.take(B * d * f);
+  size_t g = 0;
+  auto mx = [&](size_t v) { if (v > g) g = v; };
+  mx(wgrad_ws(d, 3 * d, Me)); mx(wgrad_ws(d, d, Me)); mx(wgrad_ws(d, F, Me)); mx(wgrad_ws(F, d, Me));
+  mx(wgrad_ws(d, 2 * d, Me)); mx(wgrad_ws(d, c.vocab_size, Md)); mx(wgrad_ws(d, U, Me)); mx(wgrad_ws(d, c.n_classes, B));
+  P.gemm_ws_bytes = g; P.gemm_ws = b.take(g);
+  size_t s = skf_layernorm_bwd_workspace_bytes((int)Me, (int)d);
+  if (B * U * f > s) s = B * U * f;
+  if (2 * B * L * f > s) s = 2 * B * L * f;
+  P.small_ws_bytes = s; P.small_ws = b.take(s);
+  P.bytes = b.off;
+  return P;
+}
+
+}  // namespace
+
+struct SkfModel {
+  SkfConfig cfg;
+  Layout lay;
+  Plan plan;
+  float *params = nullptr, *grads = nullptr, *m = nullptr, *v = nullptr, *metrics = nullptr;
+  const float* pos = nullptr;
+  char* ws = nullptr;
+  void* state = nullptr;
+  hipGraphExec_t g_fb = nullptr, g_opt = nullptr;
+  float g_opt_scale = 0.f;
+  std::map<std::string, std::pair<size_t, std::pair<int, int>>> named;
+
+  template <typename T> T* at(size_t off) const { return reinterpret_cast<T*>(ws + off); }
+  float* P(size_t off) const { return params + off; }
+  float* G(size_t off) const { return grads + off; }
+};
+
+#define SKF_TRY(call)            \
+  do {                           \
+    int rc__ = (call);           \
+    if (rc__ != SKF_OK) return rc__; \
+  } while (0)
+
+namespace {
+
+int dense_fwd(SkfModel* M, const DenseP& w, const float* x, int rows, float* y, int act, hipStream_t s) {
+  return skf_gemm_f32(1, 0, rows, w.out, w.in, x, w.in, M->P(w.w), w.ld, y, w.out, M->P(w.b), act, nullptr, 0, 0, 1,
+                      nullptr, 0, nullptr, 0, s);
+}
+// strided-input variant (x has row stride ldx)
+int dense_fwd_ld(SkfModel* M, const DenseP& w, const float* x, int ldx, int rows, float* y, int ldy, int act, hipStream_t s) {
+  return skf_gemm_f32(1, 0, rows, w.out, w.in, x, ldx, M->P(w.w), w.ld, y, ldy, M->P(w.b), act, nullptr, 0, 0, 1,
+                      nullptr, 0, nullptr, 0, s);
+}
+int dense_wgrad(SkfModel* M, const DenseP& w, const float* x, int ldx, const float* dy, int lddy, int rows, hipStream_t s) {
+  const int splits = skf_gemm_default_splits(w.in, w.out, rows);
+  return skf_gemm_f32(0, 0, w.in, w.out, rows, x, ldx, dy, lddy, M->G(w.w), w.ld, nullptr, 0, nullptr, 0, 0, splits,
+                      M->G(w.b), 0, M->at<char>(M->plan.gemm_ws), M->plan.gemm_ws_bytes, s);
+}
+int dense_dgrad(SkfModel* M, const DenseP& w, const float* dy, int lddy, int rows, float* dx, int lddx, int accumulate,
+                const float* relu_src, int ld_relu, hipStream_t s) {
+  return skf_gemm_f32(1, 1, rows, w.in, w.out, dy, lddy, M->P(w.w), w.ld, dx, lddx, nullptr, 0, relu_src, ld_relu,
+                      accumulate, 1, nullptr, 0, nullptr, 0, s);
+}
+
+// site ids follow oracle.dropout_sites()
+inline unsigned site_enc_embed() { return 0; }
+inline unsigned site_enc(int layer, int j) { return 1 + 2 * layer + j; }
+inline unsigned site_dec_embed(int N) { return 1 + 2 * N; }
+inline unsigned site_dec(int N, int layer, int j) { return 2 + 2 * N + 3 * layer + j; }
+
+int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s) {
+  const SkfConfig& c = M->cfg;
+  const Layout& L = M->lay;
+  const Plan& P = M->plan;
+  const int B = c.batch, Le = c.seq_len, Ld = c.seq_len - 1, d = c.d_model, H = c.num_heads, dh = d / H;
+  const int Me = B * Le, Md = B * Ld, N = c.num_layers;
+  const float rate = training ? c.dropout_rate : 0.f;
+  const long long* inp = M->at<long long>(P.inp);
+  const long long* tar = M->at<long long>(P.tar);
+  unsigned char* emask = M->at<unsigned char>(P.enc_mask);
+  unsigned char* dmask = M->at<unsigned char>(P.dec_mask);
+
+  SKF_TRY(skf_padding_mask(inp, Le, B, Le, emask, s));
+  SKF_TRY(skf_padding_mask(tar, Le, B, Ld, dmask, s));
+
+  // ---------------- encoder (builders/layers/transformer.py:288-301)
+  SKF_TRY(skf_embed_fwd(inp, Le, B, Le, M->P(L.enc_emb), c.vocab_size, d, M->pos, M->at<float>(P.enc[0].x_in), rate,
+                        site_enc_embed(), M->state, s));
+  for (int i = 0; i < N; ++i) {
+    const EncLayerP& w = L.enc[i];
+    const EncAct& a = P.enc[i];
+    float* x = M->at<float>(a.x_in);
+    float* qkv = M->at<float>(a.qkv);
+    SKF_TRY(dense_fwd(M, w.mha.qkv, x, Me, qkv, 0, s));
+    SKF_TRY(skf_attention_fwd(qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, emask, Le, 0, B, H, Le, Le, dh,
+                              M->at<float>(a.o), d, M->at<float>(a.astats), s));
+    SKF_TRY(dense_fwd(M, w.mha.o, M->at<float>(a.o), Me, M->at<float>(a.z1), 0, s));
+    SKF_TRY(skf_layernorm_residual_fwd(x, M->at<float>(a.z1), M->P(w.ln1.g), M->P(w.ln1.b), M->at<float>(a.x1),
+                                       M->at<float>(a.st1), Me, d, rate, site_enc(i, 0), M->state, s));
+    SKF_TRY(dense_fwd(M, w.f1, M->at<float>(a.x1), Me, M->at<float>(a.h), 1, s));
+    SKF_TRY(dense_fwd(M, w.f2, M->at<float>(a.h), Me, M->at<float>(a.z2), 0, s));
+    SKF_TRY(skf_layernorm_residual_fwd(M->at<float>(a.x1), M->at<float>(a.z2), M->P(w.ln2.g), M->P(w.ln2.b),
+                                       M->at<float>(a.x2), M->at<float>(a.st2), Me, d, rate, site_enc(i, 1), M->state, s));
+  }
+  float* enc_out = M->at<float>(P.enc[N - 1].x2);
+  // ---------------- bottleneck + classifier + expander (models/sketchformer.py:149-160,183-199,170-176)
+  SKF_TRY(dense_fwd(M, L.bott_w, enc_out, Me, M->at<float>(P.u), 2, s));
+  SKF_TRY(skf_pool_fwd(M->at<float>(P.u), M->P(L.bott_v), enc_out, B, Le, c.lowerdim, d, M->at<float>(P.pool_a),
+                       M->at<float>(P.emb), s));
+  SKF_TRY(dense_fwd(M, L.cls, M->at<float>(P.emb), B, M->at<float>(P.cls_logits), 0, s));
+  SKF_TRY(skf_expander_fwd(M->at<float>(P.emb), M->P(L.exp_w), M->P(L.exp_b), B, Le, d, M->at<float>(P.pre), s));
+
+  // ---------------- decoder (builders/layers/transformer.py:325-344)
+  SKF_TRY(skf_embed_fwd(tar, Le, B, Ld, M->P(L.dec_emb), c.vocab_size, d, M->pos, M->at<float>(P.dec[0].x_in), rate,
+                        site_dec_embed(N), M->state, s));
+  const unsigned char* cross_mask = c.blind_decoder_mask ? nullptr : emask;
+  for (int i = 0; i < N; ++i) {
+    const DecLayerP& w = L.dec[i];
+    const DecAct& a = P.dec[i];
+    float* x = M->at<float>(a.x_in);
+    float* qkv = M->at<float>(a.qkv);
+    SKF_TRY(dense_fwd(M, w.mha1.qkv, x, Md, qkv, 0, s));
+    SKF_TRY(skf_attention_fwd(qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, dmask, Ld, 1, B, H, Ld, Ld, dh,
+                              M->at<float>(a.o1), d, M->at<float>(a.astats1), s));
+    SKF_TRY(dense_fwd(M, w.mha1.o, M->at<float>(a.o1), Md, M->at<float>(a.z1), 0, s));
+    SKF_TRY(skf_layernorm_residual_fwd(x, M->at<float>(a.z1), M->P(w.ln1.g), M->P(w.ln1.b), M->at<float>(a.out1),
+                                       M->at<float>(a.st1), Md, d, rate, site_dec(N, i, 0), M->state, s));
+    float* kv2 = M->at<float>(a.kv2);
+    SKF_TRY(dense_fwd(M, w.mha2.q, M->at<float>(a.out1), Md, M->at<float>(a.q2), 0, s));
+    SKF_TRY(dense_fwd(M, w.mha2.kv, M->at<float>(P.pre), Me, kv2, 0, s));
+    SKF_TRY(skf_attention_fwd(M->at<float>(a.q2), d, kv2, 2 * d, kv2 + d, 2 * d, cross_mask, Le, 0, B, H, Ld, Le, dh,
+                              M->at<float>(a.o2), d, M->at<float>(a.astats2), s));
+    SKF_TRY(dense_fwd(M, w.mha2.o, M->at<float>(a.o2), Md, M->at<float>(a.z2), 0, s));
+    SKF_TRY(skf_layernorm_residual_fwd(M->at<float>(a.out1), M->at<float>(a.z2), M->P(w.ln2.g), M->P(w.ln2.b),
+                                       M->at<float>(a.out2), M->at<float>(a.st2), Md, d, rate, site_dec(N, i, 1), M->state, s));
+    SKF_TRY(dense_fwd(M, w.f1, M->at<float>(a.out2), Md, M->at<float>(a.h), 1, s));
+    SKF_TRY(dense_fwd(M, w.f2, M->at<float>(a.h), Md, M->at<float>(a.z3), 0, s));
+    SKF_TRY(skf_layernorm_residual_fwd(M->at<float>(a.out2), M->at<float>(a.z3), M->P(w.ln3.g), M->P(w.ln3.b),
+                                       M->at<float>(a.out3), M->at<float>(a.st3), Md, d, rate, site_dec(N, i, 2), M->state, s));
+  }
+  SKF_TRY(dense_fwd(M, L.out, M->at<float>(P.dec[N - 1].out3), Md, M->at<float>(P.logits), 0, s));
+
+  // ---------------- losses + metrics (models/sketchformer.py:334-346)
+  const long long* labels = M->at<long long>(P.labels);
+  if (with_loss) {
+    // tar_real = tar[:, 1:]  -> target offset 1 within rows of stride L
+    SKF_TRY(skf_softmax_ce(M->at<float>(P.logits), c.vocab_size, Md, c.vocab_size, tar, Le, Ld, 1, 1,
+                           c.recon_weight / (float)Md, M->at<float>(P.recon_loss), M->at<float>(P.recon_hit), nullptr, 1, s));
+    SKF_TRY(skf_softmax_ce(M->at<float>(P.cls_logits), c.n_classes, B, c.n_classes, labels, 1, 1, 0, 0,
+                           c.class_weight / (float)B, M->at<float>(P.cls_loss), M->at<float>(P.cls_hit),
+                           M->at<float>(P.cls_probs), 1, s));
+    SKF_TRY(skf_metrics_update(M->at<float>(P.recon_loss), M->at<float>(P.recon_hit), Md, c.recon_weight,
+                               M->at<float>(P.cls_loss), M->at<float>(P.cls_hit), B, c.class_weight, M->metrics, s));
+  } else {
+    SKF_TRY(skf_softmax_ce(M->at<float>(P.cls_logits), c.n_classes, B, c.n_classes, labels, 1, 1, 0, 0, 0.f,
+                           M->at<float>(P.cls_loss), M->at<float>(P.cls_hit), M->at<float>(P.cls_probs), 0, s));
+  }
+  return SKF_OK;
+}
+
+int ffn_bwd(SkfModel* M, const DenseP& f1, const DenseP& f2, const float* x_in, const float* h, const float* dy,
+            float* dx_acc, int rows, hipStream_t s) {
+  const Plan& P = M->plan;
+  float* dh = M->at<float>(P.dh);
+  SKF_TRY(dense_wgrad(M, f2, h, f2.in, dy, f2.out, rows, s));
+  SKF_TRY(dense_dgrad(M, f2, dy, f2.out, rows, dh, f2.in, 0, h, f2.in, s));
+  SKF_TRY(dense_wgrad(M, f1, x_in, f1.in, dh, f1.out, rows, s));
+  SKF_TRY(dense_dgrad(M, f1, dh, f1.out, rows, dx_acc, f1.in, 1, nullptr, 0, s));
+  return SKF_OK;
+}
+
+int ln_bwd(SkfModel* M, const LnP& ln, const float* dout, const float* z, const float* st, float* dz, float* dy,
+           int rows, float rate, unsigned site, hipStream_t s) {
+  const Plan& P = M->plan;
+  return skf_layernorm_residual_bwd(dout, z, st, M->P(ln.g), dz, dy, M->G(ln.g), M->G(ln.b), rows, M->cfg.d_model, rate,
+                                    site, M->state, M->at<char>(P.small_ws), P.small_ws_bytes, s);
+}
+
+int run_backward(SkfModel* M, hipStream_t s) {
+  const SkfConfig& c = M->cfg;
+  const Layout& L = M->lay;
+  const Plan& P = M->plan;
+  const int B = c.batch, Le = c.seq_len, Ld = c.seq_len - 1, d = c.d_model, H = c.num_heads, dh = d / H;
+  const int Me = B * Le, Md = B * Ld, N = c.num_layers;
+  const float rate = c.dropout_rate;
+  const long long* inp = M->at<long long>(P.inp);
+  const long long* tar = M->at<long long>(P.tar);
+  const unsigned char* emask = M->at<unsigned char>(P.enc_mask);
+  const unsigned char* dmask = M->at<unsigned char>(P.dec_mask);
+  float* G = M->at<float>(P.gA);
+  float* G2 = M->at<float>(P.gB);
+  float* G3 = M->at<float>(P.gC);
+  float* dqkv = M->at<float>(P.dqkv);
+  float* dO = M->at<float>(P.do_);
+  float* dpre = M->at<float>(P.dpre);
+  float* dkv2 = M->at<float>(P.dkv2);
+  float* dq2 = M->at<float>(P.dq2);
+  float* demb = M->at<float>(P.demb);
+  auto dybuf = [&](float* dz) { return rate > 0.f ? G3 : dz; };
+
+  // output layer: logits buffer now holds dlogits
+  const float* dlog = M->at<float>(P.logits);
+  SKF_TRY(dense_wgrad(M, L.out, M->at<float>(P.dec[N - 1].out3), d, dlog, c.vocab_size, Md, s));
+  SKF_TRY(dense_dgrad(M, L.out, dlog, c.vocab_size, Md, G, d, 0, nullptr, 0, s));
+
+  const unsigned char* cross_mask = c.blind_decoder_mask ? nullptr : emask;
+  for (int i = N - 1; i >= 0; --i) {
+    const DecLayerP& w = L.dec[i];
+    const DecAct& a = P.dec[i];
+    // out3 = LN3(out2 + drop(ffn(out2)))
+    SKF_TRY(ln_bwd(M, w.ln3, G, M->at<float>(a.z3), M->at<float>(a.st3), G2, dybuf(G2), Md, rate, site_dec(N, i, 2), s));
+    SKF_TRY(ffn_bwd(M, w.f1, w.f2, M->at<float>(a.out2), M->at<float>(a.h), dybuf(G2), G2, Md, s));
+    // out2 = LN2(out1 + drop(mha2(pre, pre, out1)))
+    SKF_TRY(ln_bwd(M, w.ln2, G2, M->at<float>(a.z2), M->at<float>(a.st2), G, dybuf(G), Md, rate, site_dec(N, i, 1), s));
+    SKF_TRY(dense_wgrad(M, w.mha2.o, M->at<float>(a.o2), d, dybuf(G), d, Md, s));
+    SKF_TRY(dense_dgrad(M, w.mha2.o, dybuf(G), d, Md, dO, d, 0, nullptr, 0, s));
+    const float* kv2 = M->at<float>(a.kv2);
+    SKF_TRY(skf_attention_bwd(M->at<float>(a.q2), d, kv2, 2 * d, kv2 + d, 2 * d, M->at<float>(a.o2), d, dO, d,
+                              M->at<float>(a.astats2), cross_mask, Le, 0, B, H, Ld, Le, dh, dq2, d, dkv2, 2 * d,
+                              dkv2 + d, 2 * d, s));
+    SKF_TRY(dense_wgrad(M, w.mha2.q, M->at<float>(a.out1), d, dq2, d, Md, s));
+    SKF_TRY(dense_dgrad(M, w.mha2.q, dq2, d, Md, G, d, 1, nullptr, 0, s));
+    SKF_TRY(dense_wgrad(M, w.mha2.kv, M->at<float>(P.pre), d, dkv2, 2 * d, Me, s));
+    SKF_TRY(dense_dgrad(M, w.mha2.kv, dkv2, 2 * d, Me, dpre, d, i != N - 1, nullptr, 0, s));
+    // out1 = LN1(x + drop(mha1(x,x,x)))
+    SKF_TRY(ln_bwd(M, w.ln1, G, M->at<float>(a.z1), M->at<float>(a.st1), G2, dybuf(G2), Md, rate, site_dec(N, i, 0), s));
+    SKF_TRY(dense_wgrad(M, w.mha1.o, M->at<float>(a.o1), d, dybuf(G2), d, Md, s));
+    SKF_TRY(dense_dgrad(M, w.mha1.o, dybuf(G2), d, Md, dO, d, 0, nullptr, 0, s));
+    const float* qkv = M->at<float>(a.qkv);
+    SKF_TRY(skf_attention_bwd(qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, M->at<float>(a.o1), d, dO, d,
+                              M->at<float>(a.astats1), dmask, Ld, 1, B, H, Ld, Ld, dh, dqkv, 3 * d, dqkv + d, 3 * d,
+                              dqkv + 2 * d, 3 * d, s));
+    SKF_TRY(dense_wgrad(M, w.mha1.qkv, M->at<float>(a.x_in), d, dqkv, 3 * d, Md, s));
+    SKF_TRY(dense_dgrad(M, w.mha1.qkv, dqkv, 3 * d, Md, G2, d, 1, nullptr, 0, s));
+    float* t = G; G = G2; G2 = t;
+  }
+  // decoder embedding
+  SKF_HIP(hipMemsetAsync(M->G(L.dec_emb), 0, (size_t)c.vocab_size * d * sizeof(float), s));
+  SKF_TRY(skf_embed_bwd(tar, Le, B, Ld, G, c.vocab_size, d, M->G(L.dec_emb), rate, site_dec_embed(N), M->state, s));
+  // expander, classifier
+  SKF_TRY(skf_expander_bwd(dpre, M->at<float>(P.emb), M->P(L.exp_w), B, Le, d, demb, 0, M->G(L.exp_w), M->G(L.exp_b),
+                           M->at<char>(P.small_ws), P.small_ws_bytes, s));
+  const float* dcls = M->at<float>(P.cls_logits);
+  SKF_TRY(dense_wgrad(M, L.cls, M->at<float>(P.emb), d, dcls, c.n_classes, B, s));
+  SKF_TRY(dense_dgrad(M, L.cls, dcls, c.n_classes, B, demb, d, 1, nullptr, 0, s));
+  // bottleneck
+  float* enc_out = M->at<float>(P.enc[N - 1].x2);
+  SKF_TRY(skf_pool_bwd(M->at<float>(P.u), M->P(L.bott_v), enc_out, M->at<float>(P.pool_a), demb, B, Le, c.lowerdim, d,
+                       G, M->G(L.bott_v), M->at<char>(P.small_ws), P.small_ws_bytes, s));
+  SKF_TRY(dense_wgrad(M, L.bott_w, enc_out, d, M->at<float>(P.u), c.lowerdim, Me, s));
+  SKF_TRY(dense_dgrad(M, L.bott_w, M->at<float>(P.u), c.lowerdim, Me, G, d, 1, nullptr, 0, s));
+  for (int i = N - 1; i >= 0; --i) {
+    const EncLayerP& w = L.enc[i];
+    const EncAct& a = P.enc[i];
+    SKF_TRY(ln_bwd(M, w.ln2, G, M->at<float>(a.z2), M->at<float>(a.st2), G2, dybuf(G2), Me, rate, site_enc(i, 1), s));
+    SKF_TRY(ffn_bwd(M, w.f1, w.f2, M->at<float>(a.x1), M->at<float>(a.h), dybuf(G2), G2, Me, s));
+    SKF_TRY(ln_bwd(M, w.ln1, G2, M->at<float>(a.z1), M->at<float>(a.st1), G, dybuf(G), Me, rate, site_enc(i, 0), s));
+    SKF_TRY(dense_wgrad(M, w.mha.o, M->at<float>(a.o), d, dybuf(G), d, Me, s));
+    SKF_TRY(dense_dgrad(M, w.mha.o, dybuf(G), d, Me, dO, d, 0, nullptr, 0, s));
+    const float* qkv = M->at<float>(a.qkv);
+    SKF_TRY(skf_attention_bwd(qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, M->at<float>(a.o), d, dO, d,
+                              M->at<float>(a.astats), emask, Le, 0, B, H, Le, Le, dh, dqkv, 3 * d, dqkv + d, 3 * d,
+                              dqkv + 2 * d, 3 * d, s));
+    SKF_TRY(dense_wgrad(M, w.mha.qkv, M->at<float>(a.x_in), d, dqkv, 3 * d, Me, s));
+    SKF_TRY(dense_dgrad(M, w.mha.qkv, dqkv, 3 * d, Me, G, d, 1, nullptr, 0, s));
+  }
+  SKF_HIP(hipMemsetAsync(M->G(L.enc_emb), 0, (size_t)c.vocab_size * d * sizeof(float), s));
+  SKF_TRY(skf_embed_bwd(inp, Le, B, Le, G, c.vocab_size, d, M->G(L.enc_emb), rate, site_enc_embed(), M->state, s));
+  return SKF_OK;
+}
+
+int prologue(SkfModel* M, hipStream_t s) {
+  const SkfConfig& c = M->cfg;
+  return skf_step_prologue(M->state, c.schedule, c.sched_p0, c.sched_p1, c.sched_p2, c.sched_p3, c.beta1, c.beta2,
+                           c.seed, s);
+}
+
+int stage_inputs(SkfModel* M, const long long* inp, const long long* tar, int tar_ld, const long long* labels, hipStream_t s) {
+  const SkfConfig& c = M->cfg;
+  const Plan& P = M->plan;
+  SKF_CHECK_ARG(inp && tar, "null input");
+  SKF_HIP(hipMemcpyAsync(M->at<char>(P.inp), inp, (size_t)c.batch * c.seq_len * 8, hipMemcpyDeviceToDevice, s));
+  if (tar_ld == c.seq_len) {
+    SKF_HIP(hipMemcpyAsync(M->at<char>(P.tar), tar, (size_t)c.batch * c.seq_len * 8, hipMemcpyDeviceToDevice, s));
+  } else {
+    SKF_HIP(hipMemcpy2DAsync(M->at<char>(P.tar), (size_t)c.seq_len * 8, tar, (size_t)tar_ld * 8, (size_t)c.seq_len * 8,
+                             c.batch, hipMemcpyDeviceToDevice, s));
+  }
+  if (labels) SKF_HIP(hipMemcpyAsync(M->at<char>(P.labels), labels, (size_t)c.batch * 8, hipMemcpyDeviceToDevice, s));
+  else SKF_HIP(hipMemsetAsync(M->at<char>(P.labels), 0, (size_t)c.batch * 8, s));
+  return SKF_OK;
+}
+
+template <typename F>
+int capture_or_run(SkfModel* M, hipGraphExec_t* exec, hipStream_t s, F body) {
+  if (!M->cfg.use_graph) return body();
+  if (!*exec) {
+    hipGraph_t graph = nullptr;
+    SKF_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    int rc = body();
+    hipError_t e = hipStreamEndCapture(s, &graph);
+    if (rc != SKF_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) { skf_set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return SKF_EHIP; }
+    e = hipGraphInstantiate(exec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (e != hipSuccess) { skf_set_error("hipGraphInstantiate: %s", hipGetErrorString(e)); *exec = nullptr; return SKF_EHIP; }
+  }
+  SKF_HIP(hipGraphLaunch(*exec, s));
+  return SKF_OK;
+}
+
+}  // namespace
+
+// =========================================================================== C ABI
+extern "C" int skf_config_validate(const SkfConfig* c) {
+  SKF_CHECK_ARG(c, "null config");
+  SKF_CHECK_ARG(c->batch > 0 && c->seq_len > 1 && c->num_layers > 0, "bad sizes");
+  SKF_CHECK_ARG(c->d_model % c->num_heads == 0, "d_model must be divisible by num_heads");
+  const int dh = c->d_model / c->num_heads;
+  if (!(dh == 16 || dh == 32 || dh == 64)) { skf_set_error("head dim %d not in {16,32,64}", dh); return SKF_EUNSUPPORTED; }
+  if (!(c->d_model == 64 || c->d_model == 128 || c->d_model == 256 || c->d_model == 512)) {
+    skf_set_error("d_model %d not in {64,128,256,512}", c->d_model); return SKF_EUNSUPPORTED; }
+  if (c->continuous) { skf_set_error("use_continuous_data=True is not implemented yet"); return SKF_EUNSUPPORTED; }
+  if (c->attn_version != 1) { skf_set_error("attn_version=%d: only SelfAttnV1 is implemented", c->attn_version); return SKF_EUNSUPPORTED; }
+  if (c->lowerdim <= 0) { skf_set_error("lowerdim=0 is not implemented"); return SKF_EUNSUPPORTED; }
+  SKF_CHECK_ARG(c->vocab_size > 0 && c->n_classes > 0, "bad vocab / classes");
+  SKF_CHECK_ARG(c->vocab_size % 4 == 0, "vocab_size must be a multiple of 4");
+  SKF_CHECK_ARG(c->dff % 4 == 0 && c->lowerdim % 4 == 0, "dff and lowerdim must be multiples of 4");
+  SKF_CHECK_ARG(c->max_pos >= c->seq_len, "max_pos < seq_len");
+  SKF_CHECK_ARG(c->dropout_rate >= 0.f && c->dropout_rate < 1.f, "dropout_rate out of range");
+  SKF_CHECK_ARG(c->seq_len <= 512, "seq_len > 512 not supported");
+  return SKF_OK;
+}
+
+extern "C" size_t skf_model_param_floats(const SkfConfig* cfg) {
+  if (skf_config_validate(cfg) != SKF_OK) return 0;
+  return build_layout(*cfg).total;
+}
+
+extern "C" int skf_model_param_entries(const SkfConfig* cfg, SkfParamEntry* out_host, int max_entries) {
+  int rc = skf_config_validate(cfg);
+  if (rc != SKF_OK) return rc;
+  Layout L = build_layout(*cfg);
+  const int n = (int)L.entries.size();
+  if (out_host) for (int i = 0; i < n && i < max_entries; ++i) out_host[i] = L.entries[i];
+  return n;
+}
+
+extern "C" size_t skf_model_workspace_bytes(const SkfConfig* cfg) {
+  if (skf_config_validate(cfg) != SKF_OK) return 0;
+  return build_plan(*cfg).bytes;
+}
+
+extern "C" int skf_model_create(const SkfConfig* cfg, SkfModel** out) {
+  SKF_CHECK_ARG(out, "null out");
+  int rc = skf_config_validate(cfg);
+  if (rc != SKF_OK) return rc;
+  SkfModel* M = new SkfModel();
+  M->cfg = *cfg;
+  M->lay = build_layout(*cfg);
+  M->plan = build_plan(*cfg);
+  const Plan& P = M->plan;
+  const int B = cfg->batch, L = cfg->seq_len, Ld = L - 1, d = cfg->d_model, N = cfg->num_layers;
+  auto reg = [&](const char* n, size_t off, int r, int c) { M->named[n] = {off, {r, c}}; };
+  reg("logits", P.logits, B * Ld, cfg->vocab_size);
+  reg("class_probs", P.cls_probs, B, cfg->n_classes);
+  reg("class_logits", P.cls_logits, B, cfg->n_classes);
+  reg("embedding", P.emb, B, d);
+  reg("enc_output", P.enc[N - 1].x2, B * L, d);
+  reg("dec_output", P.dec[N - 1].out3, B * Ld, d);
+  reg("pre_decoder", P.pre, B * L, d);
+  reg("bottleneck_attn", P.pool_a, B, L);
+  reg("enc_embed_out", P.enc[0].x_in, B * L, d);
+  reg("dec_embed_out", P.dec[0].x_in, B * Ld, d);
+  *out = M;
+  return SKF_OK;
+}
+
+extern "C" void skf_model_destroy(SkfModel* m) {
+  if (!m) return;
+  if (m->g_fb) hipGraphExecDestroy(m->g_fb);
+  if (m->g_opt) hipGraphExecDestroy(m->g_opt);
+  delete m;
+}
+
+extern "C" int skf_model_bind(SkfModel* m, float* params, float* grads, float* adam_m, float* adam_v, const float* pos,
+                              void* workspace, size_t workspace_bytes, float* metrics, void* step_state) {
+  SKF_CHECK_ARG(m && params && grads && adam_m && adam_v && pos && workspace && metrics && step_state, "null buffer");
+  SKF_CHECK_ARG(workspace_bytes >= m->plan.bytes, "workspace too small");
+  SKF_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
+  SKF_CHECK_ARG((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)adam_m | (uintptr_t)adam_v) & 15) == 0, "flat buffers must be 16-byte aligned");
+  m->params = params; m->grads = grads; m->m = adam_m; m->v = adam_v; m->pos = pos;
+  m->ws = (char*)workspace; m->metrics = metrics; m->state = step_state;
+  if (m->g_fb) { hipGraphExecDestroy(m->g_fb); m->g_fb = nullptr; }
+  if (m->g_opt) { hipGraphExecDestroy(m->g_opt); m->g_opt = nullptr; }
+  return SKF_OK;
+}
+
+extern "C" int skf_model_forward(SkfModel* m, const long long* inp, const long long* tar, int tar_ld, int training,
+                                 skf_stream_t stream) {
+  SKF_CHECK_ARG(m && m->ws, "model not bound");
+  hipStream_t s = (hipStream_t)stream;
+  SKF_TRY(stage_inputs(m, inp, tar, tar_ld, nullptr, s));
+  if (training) SKF_TRY(prologue(m, s));
+  return run_forward(m, training != 0, false, s);
+}
+
+extern "C" int skf_model_forward_backward(SkfModel* m, const long long* inp, const long long* tar, int tar_ld,
+                                          const long long* labels, skf_stream_t stream) {
+  SKF_CHECK_ARG(m && m->ws, "model not bound");
+  SKF_CHECK_ARG(labels, "null labels");
+  hipStream_t s = (hipStream_t)stream;
+  SKF_TRY(stage_inputs(m, inp, tar, tar_ld, labels, s));
+  return capture_or_run(m, &m->g_fb, s, [&]() -> int {
+    SKF_TRY(prologue(m, s));
+    SKF_TRY(run_forward(m, true, true, s));
+    return run_backward(m, s);
+  });
+}
+
+extern "C" int skf_model_apply_gradients(SkfModel* m, float grad_scale, skf_stream_t stream) {
+  SKF_CHECK_ARG(m && m->ws, "model not bound");
+  hipStream_t s = (hipStream_t)stream;
+  if (m->g_opt && m->g_opt_scale != grad_scale) { hipGraphExecDestroy(m->g_opt); m->g_opt = nullptr; }
+  m->g_opt_scale = grad_scale;
+  return capture_or_run(m, &m->g_opt, s, [&]() -> int {
+    SKF_TRY(skf_adam_step(m->params, m->grads, m->m, m->v, m->lay.total, m->state, grad_scale, m->cfg.beta1,
+                          m->cfg.beta2, m->cfg.eps, s));
+    return skf_step_epilogue(m->state, s);
+  });
+}
+
+extern "C" int skf_model_buffer(SkfModel* m, const char* name, float** ptr, int* rows, int* cols) {
+  SKF_CHECK_ARG(m && m->ws && name && ptr, "bad argument");
+  auto it = m->named.find(name);
+  if (it == m->named.end()) { skf_set_error("skf_model_buffer: unknown buffer '%s'", name); return SKF_EINVAL; }
+  *ptr = m->at<float>(it->second.first);
+  if (rows) *rows = it->second.second.first;
+  if (cols) *cols = it->second.second.second;
+  return SKF_OK;
+}

@@ -1,0 +1,571 @@
+// HBM-bound row kernels: embedding (+scale +positional encoding +dropout),
+// residual + dropout + LayerNorm (fwd / bwd), softmax cross-entropy heads, the
+// SelfAttnV1 bottleneck pool, the DenseExpander, column reductions.
+// One 64-lane wave owns one (B*L) row; rows are read/written once, fully coalesced
+// (a 128-float row = one 512-byte wave access).
+#include "skf_common.h"
+
+namespace {
+
+constexpr int kMaxGrid = 2048;
+
+__global__ void padding_mask_kernel(const long long* __restrict__ tok, int tok_ld, int B, int L,
+                                    unsigned char* __restrict__ out) {
+  const int n = B * L;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256)
+    out[e] = tok[(size_t)(e / L) * tok_ld + (e % L)] == 0 ? 1 : 0;
+}
+
+// ------------------------------------------------------------------ embedding
+// builders/layers/transformer.py:288-296 / 325-334:
+//   x = Embedding(tok); x *= sqrt(d_model); x += pos[:, :L]; x = Dropout(x)
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restrict__ tok, int tok_ld, int Lrows,
+                                                        int rows, const float* __restrict__ table, int vocab, int d,
+                                                        const float* __restrict__ pos, float* __restrict__ out,
+                                                        float rate, uint32_t site, const SkfStepState* st) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float sq = sqrtf((float)d);
+  const uint32_t thresh = skf_drop_thresh(rate);
+  const float inv_keep = 1.0f / (1.0f - rate);
+  const uint32_t sk = rate > 0.f ? skf_site_key(st->drop_key, site) : 0u;
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const int b = row / Lrows, t = row % Lrows;
+    long long tk = tok[(size_t)b * tok_ld + t];
+    if (tk < 0 || tk >= vocab) tk = 0;   // tf.gather on GPU yields zeros for OOB; ids are validated on the host
+    const float* e = table + (size_t)tk * d;
+    const float* pe = pos + (size_t)t * d;
+    float* o = out + (size_t)row * d;
+    for (int c = lane * 2; c < d; c += 128) {
+      float2 v = *reinterpret_cast<const float2*>(e + c);
+      const float2 pp = *reinterpret_cast<const float2*>(pe + c);
+      v.x = v.x * sq + pp.x; v.y = v.y * sq + pp.y;
+      if (rate > 0.f) {
+        const uint32_t idx = (uint32_t)row * (uint32_t)d + c;
+        v.x *= skf_keep(sk, idx, thresh) ? inv_keep : 0.f;
+        v.y *= skf_keep(sk, idx + 1, thresh) ? inv_keep : 0.f;
+      }
+      *reinterpret_cast<float2*>(o + c) = v;
+    }
+  }
+}
+
+// Embedding gradient (dense (V,d) buffer, pre-zeroed): scatter-add of
+// dx * dropout * sqrt(d).  A wave takes 64 consecutive rows, groups equal token
+// ids with ballots and issues one atomic row-add per distinct id (PAD rows, ~60 %
+// of a QuickDraw batch, collapse to one add per wave).
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* __restrict__ tok, int tok_ld, int Lrows,
+                                                        int rows, const float* __restrict__ dx, int vocab, int d,
+                                                        float* __restrict__ dtable, float rate, uint32_t site,
+                                                        const SkfStepState* st) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float sq = sqrtf((float)d);
+  const uint32_t thresh = skf_drop_thresh(rate);
+  const float inv_keep = 1.0f / (1.0f - rate);
+  const uint32_t sk = rate > 0.f ? skf_site_key(st->drop_key, site) : 0u;
+  for (int base = (blockIdx.x * 4 + wave) * 64; base < rows; base += gridDim.x * 4 * 64) {
+    const int row = base + lane;
+    long long tk = -1;
+    if (row < rows) {
+      tk = tok[(size_t)(row / Lrows) * tok_ld + (row % Lrows)];
+      if (tk < 0 || tk >= vocab) tk = -1;
+    }
+    unsigned long long todo = __ballot(tk >= 0);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const long long ltk = __shfl(tk, leader, 64);
+      unsigned long long grp = __ballot(tk == ltk) & todo;
+      todo &= ~grp;
+      for (int c = lane * 2; c < d; c += 128) {
+        float2 acc = make_float2(0.f, 0.f);
+        unsigned long long m = grp;
+        while (m) {
+          const int src = __ffsll((long long)m) - 1;
+          m &= m - 1;
+          const int r = base + src;
+          float2 v = *reinterpret_cast<const float2*>(dx + (size_t)r * d + c);
+          if (rate > 0.f) {
+            const uint32_t idx = (uint32_t)r * (uint32_t)d + c;
+            v.x *= skf_keep(sk, idx, thresh) ? inv_keep : 0.f;
+            v.y *= skf_keep(sk, idx + 1, thresh) ? inv_keep : 0.f;
+          }
+          acc.x += v.x; acc.y += v.y;
+        }
+        atomicAdd(dtable + (size_t)ltk * d + c, acc.x * sq);
+        atomicAdd(dtable + (size_t)ltk * d + c + 1, acc.y * sq);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ layernorm
+// out = LayerNorm(x + Dropout(y)), eps=1e-6, biased variance
+// (builders/layers/transformer.py:217-222, 247-260).  z = x + drop(y) is written
+// over y (it is what the backward needs); stats = (mean, rstd) per row.
+template <int VPL>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float* __restrict__ out, float* __restrict__ stats, int rows,
+                                                     float rate, uint32_t site, const SkfStepState* st) {
+  constexpr int D = VPL * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t thresh = skf_drop_thresh(rate);
+  const float inv_keep = 1.0f / (1.0f - rate);
+  const uint32_t sk = rate > 0.f ? skf_site_key(st->drop_key, site) : 0u;
+  float gm[VPL], bt[VPL];
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) { gm[v] = gamma[lane * VPL + v]; bt[v] = beta[lane * VPL + v]; }
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const size_t off = (size_t)row * D + lane * VPL;
+    float z[VPL];
+    float sum = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      float yv = y[off + v];
+      if (rate > 0.f) yv *= skf_keep(sk, (uint32_t)off + v, thresh) ? inv_keep : 0.f;
+      z[v] = x[off + v] + yv;
+      sum += z[v];
+    }
+    const float mean = wave_sum(sum) * (1.0f / D);
+    float sq = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) { const float c = z[v] - mean; sq += c * c; }
+    const float rstd = rsqrtf(wave_sum(sq) * (1.0f / D) + 1e-6f);
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      y[off + v] = z[v];
+      out[off + v] = (z[v] - mean) * rstd * gm[v] + bt[v];
+    }
+    if (lane == 0) { stats[2 * (size_t)row] = mean; stats[2 * (size_t)row + 1] = rstd; }
+  }
+}
+
+// dz = LN'(dout); dy = dz * dropmask (written to dy when dy != null, i.e. rate > 0);
+// partial dgamma/dbeta per workgroup -> part[block][2][D].
+template <int VPL>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ z,
+                                                     const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                     float* __restrict__ dz, float* __restrict__ dy,
+                                                     float* __restrict__ part, int rows, float rate, uint32_t site,
+                                                     const SkfStepState* st) {
+  constexpr int D = VPL * 64;
+  __shared__ float red[4][2][D];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t thresh = skf_drop_thresh(rate);
+  const float inv_keep = 1.0f / (1.0f - rate);
+  const uint32_t sk = rate > 0.f ? skf_site_key(st->drop_key, site) : 0u;
+  float gm[VPL], dg[VPL], db[VPL];
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) { gm[v] = gamma[lane * VPL + v]; dg[v] = 0.f; db[v] = 0.f; }
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const size_t off = (size_t)row * D + lane * VPL;
+    const float mean = stats[2 * (size_t)row], rstd = stats[2 * (size_t)row + 1];
+    float xh[VPL], gg[VPL];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const float d = dout[off + v];
+      xh[v] = (z[off + v] - mean) * rstd;
+      gg[v] = d * gm[v];
+      dg[v] += d * xh[v];
+      db[v] += d;
+      s1 += gg[v];
+      s2 += gg[v] * xh[v];
+    }
+    s1 = wave_sum(s1) * (1.0f / D);
+    s2 = wave_sum(s2) * (1.0f / D);
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const float g = rstd * (gg[v] - s1 - xh[v] * s2);
+      dz[off + v] = g;
+      if (dy) dy[off + v] = g * (skf_keep(sk, (uint32_t)off + v, thresh) ? inv_keep : 0.f);
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) { red[wave][0][lane * VPL + v] = dg[v]; red[wave][1][lane * VPL + v] = db[v]; }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 2 * D; e += 256) {
+    const int w = e / D, c = e % D;
+    part[(size_t)blockIdx.x * 2 * D + e] = red[0][w][c] + red[1][w][c] + red[2][w][c] + red[3][w][c];
+  }
+}
+
+// out[j] (=|+=) sum_i in[i*ld + j]
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, int nrows, int ld, int ncols,
+                                                     float* __restrict__ out, int accumulate) {
+  __shared__ float red[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+  float s = 0.f;
+  if (col < ncols)
+    for (int i = rg; i < nrows; i += 4) s += in[(size_t)i * ld + col];
+  red[rg][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rg == 0 && col < ncols) {
+    const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    out[col] = accumulate ? out[col] + t : t;
+  }
+}
+
+// ------------------------------------------------------------------ softmax CE
+// Sparse softmax cross-entropy from logits for one row per wave, fused with the
+// accuracy test (first-index argmax == target) and the gradient, written in place:
+//   g = (softmax - onehot) * mask * scale,  mask = (target != 0) when mask_pad.
+// builders/losses.py:26-41 (recon), :21-24 (class), builders/keras_metrics.py:25.
+__global__ __launch_bounds__(256) void softmax_ce_kernel(float* __restrict__ logits, int ld, int rows, int ncls,
+                                                         const long long* __restrict__ target, int tgt_ld, int tgt_cols,
+                                                         int tgt_off, int mask_pad, float scale,
+                                                         float* __restrict__ row_loss, float* __restrict__ row_hit,
+                                                         float* __restrict__ probs_out, int write_grad) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    float* x = logits + (size_t)row * ld;
+    const long long tg = target[(size_t)(row / tgt_cols) * tgt_ld + (row % tgt_cols) + tgt_off];
+    float mx = -INFINITY; int am = 0x7fffffff;
+    for (int j = lane; j < ncls; j += 64) {
+      const float v = x[j];
+      if (v > mx) { mx = v; am = j; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float om = __shfl_xor(mx, o, 64); const int oa = __shfl_xor(am, o, 64);
+      if (om > mx || (om == mx && oa < am)) { mx = om; am = oa; }
+    }
+    float se = 0.f;
+    for (int j = lane; j < ncls; j += 64) se += __expf(x[j] - mx);
+    se = wave_sum(se);
+    const float lse = mx + __logf(se);
+    const bool valid = tg >= 0 && tg < ncls;
+    const float m = (mask_pad && tg == 0) ? 0.f : 1.f;
+    if (lane == 0) {
+      row_loss[row] = valid ? (lse - x[tg]) * m : 0.f;
+      row_hit[row] = (am == (int)tg) ? 1.f : 0.f;
+    }
+    const float gs = m * scale, rse = 1.0f / se;
+    for (int j = lane; j < ncls; j += 64) {
+      const float pj = __expf(x[j] - mx) * rse;
+      if (probs_out) probs_out[(size_t)row * ncls + j] = pj;
+      if (write_grad) x[j] = (pj - ((long long)j == tg ? 1.f : 0.f)) * gs;
+    }
+  }
+}
+
+// Step metrics + running Keras metrics (builders/keras_metrics.py:19-42).
+// metrics layout (floats): [0..4]  this step: recon_loss, recon_acc, class_loss, class_acc, total_loss
+//                          [8..12] running totals, [16..20] running counts
+__global__ __launch_bounds__(256) void metrics_kernel(const float* __restrict__ recon_loss, const float* __restrict__ recon_hit,
+                                                      int recon_rows, float recon_weight,
+                                                      const float* __restrict__ class_loss, const float* __restrict__ class_hit,
+                                                      int class_rows, float class_weight, float* __restrict__ metrics) {
+  __shared__ float red[4][256];
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < recon_rows; i += 256) { s[0] += recon_loss[i]; s[1] += recon_hit[i]; }
+  for (int i = threadIdx.x; i < class_rows; i += 256) { s[2] += class_loss[i]; s[3] += class_hit[i]; }
+  for (int k = 0; k < 4; ++k) red[k][threadIdx.x] = s[k];
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o)
+      for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float rl = recon_rows ? recon_weight * red[0][0] / recon_rows : 0.f;
+    const float cl = class_rows ? class_weight * red[2][0] / class_rows : 0.f;
+    metrics[0] = rl; metrics[1] = recon_rows ? red[1][0] / recon_rows : 0.f;
+    metrics[2] = cl; metrics[3] = class_rows ? red[3][0] / class_rows : 0.f;
+    metrics[4] = rl + cl;
+    metrics[8] += rl;  metrics[16] += 1.f;
+    metrics[9] += red[1][0]; metrics[17] += (float)recon_rows;
+    metrics[10] += cl; metrics[18] += 1.f;
+    metrics[11] += red[3][0]; metrics[19] += (float)class_rows;
+    metrics[12] += rl + cl; metrics[20] += 1.f;
+  }
+}
+
+// ------------------------------------------------------------------ SelfAttnV1 pool
+// builders/layers/transformer.py:70-73 after u = tanh(xW+b) (a GEMM):
+//   s[t] = u[b,t,:].V ; a = softmax_t(s) (no padding mask) ; emb[b,:] = sum_t a[t] x[b,t,:]
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__ u, const float* __restrict__ Vw,
+                                                       const float* __restrict__ x, int L, int U, int d,
+                                                       float* __restrict__ a_out, float* __restrict__ emb) {
+  extern __shared__ float sm[];   // [L] scores
+  __shared__ float red[4];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int t = wave; t < L; t += 4) {
+    const float* ur = u + ((size_t)b * L + t) * U;
+    float s = 0.f;
+    for (int j = lane; j < U; j += 64) s += ur[j] * Vw[j];
+    s = wave_sum(s);
+    if (lane == 0) sm[t] = s;
+  }
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int t = threadIdx.x; t < L; t += 256) mx = fmaxf(mx, sm[t]);
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float se = 0.f;
+  for (int t = threadIdx.x; t < L; t += 256) { const float e = __expf(sm[t] - mx); sm[t] = e; se += e; }
+  se = wave_sum(se);
+  if (lane == 0) red[wave] = se;
+  __syncthreads();
+  se = red[0] + red[1] + red[2] + red[3];
+  const float rinv = 1.0f / se;
+  for (int t = threadIdx.x; t < L; t += 256) { const float a = sm[t] * rinv; sm[t] = a; a_out[(size_t)b * L + t] = a; }
+  __syncthreads();
+  for (int c = threadIdx.x; c < d; c += 256) {
+    float acc = 0.f;
+    for (int t = 0; t < L; ++t) acc += sm[t] * x[((size_t)b * L + t) * d + c];
+    emb[(size_t)b * d + c] = acc;
+  }
+}
+
+// backward of the pool: dx_direct[b,t,c] = a[t] demb[c]; da[t] = demb . x[b,t,:];
+// ds = a (da - sum a da); dpre[b,t,j] = ds[t] V[j] (1 - u^2) (in place over u);
+// dV partial[b][j] = sum_t ds[t] u[b,t,j]
+__global__ __launch_bounds__(256) void pool_bwd_kernel(float* __restrict__ u, const float* __restrict__ Vw,
+                                                       const float* __restrict__ x, const float* __restrict__ a_in,
+                                                       const float* __restrict__ demb, int L, int U, int d,
+                                                       float* __restrict__ dx, float* __restrict__ dV_part) {
+  extern __shared__ float sm[];   // [L] ds, then [L] a
+  __shared__ float red[4];
+  float* ds = sm;
+  float* av = sm + L;
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int t = threadIdx.x; t < L; t += 256) av[t] = a_in[(size_t)b * L + t];
+  __syncthreads();
+  float part = 0.f;
+  for (int t = wave; t < L; t += 4) {
+    const float* xr = x + ((size_t)b * L + t) * d;
+    float* dxr = dx + ((size_t)b * L + t) * d;
+    float s = 0.f;
+    const float at = av[t];
+    for (int c = lane; c < d; c += 64) { const float de = demb[(size_t)b * d + c]; s += de * xr[c]; dxr[c] = at * de; }
+    s = wave_sum(s);
+    if (lane == 0) { ds[t] = s; }
+    part += (lane == 0) ? at * s : 0.f;
+  }
+  part = wave_sum(part);
+  if (lane == 0) red[wave] = part;
+  __syncthreads();
+  const float dot = red[0] + red[1] + red[2] + red[3];
+  for (int t = threadIdx.x; t < L; t += 256) ds[t] = av[t] * (ds[t] - dot);
+  __syncthreads();
+  for (int j = threadIdx.x; j < U; j += 256) {
+    const float vj = Vw[j];
+    float acc = 0.f;
+    for (int t = 0; t < L; ++t) {
+      float* up = u + ((size_t)b * L + t) * U + j;
+      const float uv = *up;
+      acc += ds[t] * uv;
+      *up = ds[t] * vj * (1.f - uv * uv);
+    }
+    dV_part[(size_t)b * U + j] = acc;
+  }
+}
+
+// ------------------------------------------------------------------ DenseExpander
+// builders/layers/transformer.py:370-376: pre[b,t,c] = emb[b,c]*w[t] + bias[t]
+__global__ __launch_bounds__(256) void expander_fwd_kernel(const float* __restrict__ emb, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, int B, int L, int d,
+                                                           float* __restrict__ pre) {
+  const size_t total = (size_t)B * L * d;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int c = (int)(e % d);
+    const size_t bt = e / d;
+    const int t = (int)(bt % L), b = (int)(bt / L);
+    pre[e] = emb[(size_t)b * d + c] * w[t] + bias[t];
+  }
+}
+
+// demb[b,c] = sum_t dpre[b,t,c] w[t]; per-b partials dw[b][t] = sum_c dpre*emb, dbias[b][t] = sum_c dpre
+__global__ __launch_bounds__(256) void expander_bwd_kernel(const float* __restrict__ dpre, const float* __restrict__ emb,
+                                                           const float* __restrict__ w, int L, int d,
+                                                           float* __restrict__ demb, int demb_accumulate,
+                                                           float* __restrict__ dw_part, float* __restrict__ db_part) {
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c = threadIdx.x; c < d; c += 256) {
+    float acc = 0.f;
+    for (int t = 0; t < L; ++t) acc += dpre[((size_t)b * L + t) * d + c] * w[t];
+    float* dst = demb + (size_t)b * d + c;
+    *dst = demb_accumulate ? *dst + acc : acc;
+  }
+  for (int t = wave; t < L; t += 4) {
+    const float* r = dpre + ((size_t)b * L + t) * d;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane; c < d; c += 64) { const float v = r[c]; s1 += v * emb[(size_t)b * d + c]; s2 += v; }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane == 0) { dw_part[(size_t)b * L + t] = s1; db_part[(size_t)b * L + t] = s2; }
+  }
+}
+
+int grid_for_rows(int rows) { int g = skf_cdiv(rows, 4); return g > kMaxGrid ? kMaxGrid : g; }
+
+}  // namespace
+
+// =========================================================================== C ABI
+extern "C" int skf_embed_fwd(const long long* tokens, int tok_ld, int B, int L, const float* table, int vocab, int d,
+                             const float* pos, float* out, float rate, unsigned site, const void* step_state,
+                             skf_stream_t stream) {
+  SKF_CHECK_ARG(tokens && table && pos && out, "null operand");
+  SKF_CHECK_ARG((d & 1) == 0, "d_model must be even");
+  SKF_CHECK_ARG(rate == 0.f || step_state, "dropout needs the step state");
+  const int rows = B * L;
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid_for_rows(rows)), dim3(256), 0, (hipStream_t)stream, tokens, tok_ld, L,
+                     rows, table, vocab, d, pos, out, rate, site, (const SkfStepState*)step_state);
+  SKF_LAUNCH_CHECK();
+  return SKF_OK;
+}
+
+extern "C" int skf_padding_mask(const long long* tokens, int tok_ld, int B, int L, unsigned char* out,
+                                skf_stream_t stream) {
+  SKF_CHECK_ARG(tokens && out && B > 0 && L > 0, "bad argument");
+  int grid = skf_cdiv(B * L, 256); if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(padding_mask_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, tokens, tok_ld, B, L, out);
+  SKF_LAUNCH_CHECK();
+  return SKF_OK;
+}
+
+extern "C" int skf_embed_bwd(const long long* tokens, int tok_ld, int B, int L, const float* dx, int vocab, int d,
+                             float* dtable, float rate, unsigned site, const void* step_state, skf_stream_t stream) {
+  SKF_CHECK_ARG(tokens && dx && dtable, "null operand");
+  SKF_CHECK_ARG((d & 1) == 0, "d_model must be even");
+  const int rows = B * L;
+  int grid = skf_cdiv(rows, 256);
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, tokens, tok_ld, L, rows, dx, vocab,
+                     d, dtable, rate, site, (const SkfStepState*)step_state);
+  SKF_LAUNCH_CHECK();
+  return SKF_OK;
+}
+
+extern "C" int skf_layernorm_residual_fwd(const float* x, float* y_inout_z, const float* gamma, const float* beta,
+                                          float* out, float* stats, int rows, int d, float rate, unsigned site,
+                                          const void* step_state, skf_stream_t stream) {
+  SKF_CHECK_ARG(x && y_inout_z && gamma && beta && out && stats, "null operand");
+  SKF_CHECK_ARG(rate == 0.f || step_state, "dropout needs the step state");
+  const SkfStepState* st = (const SkfStepState*)step_state;
+  dim3 grid(grid_for_rows(rows)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  switch (d) {
+    case 128: hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, block, 0, s, x, y_inout_z, gamma, beta, out, stats, rows, rate, site, st); break;
+    case 256: hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, block, 0, s, x, y_inout_z, gamma, beta, out, stats, rows, rate, site, st); break;
+    case 512: hipLaunchKernelGGL(ln_fwd_kernel<8>, grid, block, 0, s, x, y_inout_z, gamma, beta, out, stats, rows, rate, site, st); break;
+    case 64:  hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, block, 0, s, x, y_inout_z, gamma, beta, out, stats, rows, rate, site, st); break;
+    default: skf_set_error("skf_layernorm_residual_fwd: d_model %d not in {64,128,256,512}", d); return SKF_EUNSUPPORTED;
+  }
+  SKF_LAUNCH_CHECK();
+  return SKF_OK;
+}
+
+extern "C" size_t skf_layernorm_bwd_workspace_bytes(int rows, int d) {
+  return (size_t)(grid_for_rows(rows) > 512 ? 512 : grid_for_rows(rows)) * 2 * d * sizeof(float);
+}
+
+extern "C" int skf_layernorm_residual_bwd(const float* dout, const float* z, const float* stats, const float* gamma,
+                                          float* dz, float* dy, float* dgamma, float* dbeta, int rows, int d, float rate,
+                                          unsigned site, const void* step_state, void* workspace, size_t workspace_bytes,
+                                          skf_stream_t stream) {
+  SKF_CHECK_ARG(dout && z && stats && gamma && dz && dgamma && dbeta, "null operand");
+  SKF_CHECK_ARG(workspace && workspace_bytes >= skf_layernorm_bwd_workspace_bytes(rows, d), "workspace too small");
+  SKF_CHECK_ARG(rate == 0.f || (step_state && dy), "dropout needs the step state and a dy buffer");
+  const SkfStepState* st = (const SkfStepState*)step_state;
+  int g = grid_for_rows(rows); if (g > 512) g = 512;
+  dim3 grid(g), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  float* dyp = rate > 0.f ? dy : nullptr;
+  switch (d) {
+    case 128: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, 0, s, dout, z, stats, gamma, dz, dyp, part, rows, rate, site, st); break;
+    case 256: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, s, dout, z, stats, gamma, dz, dyp, part, rows, rate, site, st); break;
+    case 512: hipLaunchKernelGGL(ln_bwd_kernel<8>, grid, block, 0, s, dout, z, stats, gamma, dz, dyp, part, rows, rate, site, st); break;
+    case 64:  hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, 0, s, dout, z, stats, gamma, dz, dyp, part, rows, rate, site, st); break;
+    default: skf_set_error("skf_layernorm_residual_bwd: d_model %d not in {64,128,256,512}", d); return SKF_EUNSUPPORTED;
+  }
+  SKF_LAUNCH_CHECK();
+  // part is [g][2][d] : columns 0..d-1 = dgamma, d..2d-1 = dbeta
+  hipLaunchKernelGGL(colsum_kernel, dim3(skf_cdiv(d, 64)), block, 0, s, part, g, 2 * d, d, dgamma, 0);
+  hipLaunchKernelGGL(colsum_kernel, dim3(skf_cdiv(d, 64)), block, 0, s, part + d, g, 2 * d, d, dbeta, 0);
+  SKF_LAUNCH_CHECK();
+  return SKF_OK;
+}
+
+extern "C" int skf_colsum(const float* in, int nrows, int ld, int ncols, float* out, int accumulate, skf_stream_t stream) {
+  SKF_CHECK_ARG(in && out && nrows > 0 && ncols > 0, "bad argument");
+  hipLaunchKernelGGL(colsum_kernel, dim3(skf_cdiv(ncols, 64)), dim3(256), 0, (hipStream_t)stream, in, nrows, ld, ncols, out, accumulate);
+  SKF_LAUNCH_CHECK();
+  return SKF_OK;
+}
+
+extern "C" int skf_softmax_ce(float* logits, int ld, int rows, int ncls, const long long* target, int tgt_ld,
+                              int tgt_cols, int tgt_off, int mask_pad, float scale, float* row_loss, float* row_hit,
+                              float* probs_out, int write_grad, skf_stream_t stream) {
+  SKF_CHECK_ARG(logits && target && row_loss && row_hit, "null operand");
+  SKF_CHECK_ARG(rows > 0 && ncls > 0 && tgt_cols > 0, "empty problem");
+  hipLaunchKernelGGL(softmax_ce_kernel, dim3(grid_for_rows(rows)), dim3(256), 0, (hipStream_t)stream, logits, ld, rows, ncls,
+                     target, tgt_ld, tgt_cols, tgt_off, mask_pad, scale, row_loss, row_hit, probs_out, write_grad);
+  SKF_LAUNCH_CHECK();
+  return SKF_OK;
+}
+
+extern "C" int skf_metrics_update(const float* recon_loss, const float* recon_hit, int recon_rows, float recon_weight,
+                                  const float* class_loss, const float* class_hit, int class_rows, float class_weight,
+                                  float* metrics, skf_stream_t stream) {
+  SKF_CHECK_ARG(metrics, "null metrics");
+  hipLaunchKernelGGL(metrics_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, recon_loss, recon_hit, recon_rows,
+                     recon_weight, class_loss, class_hit, class_rows, class_weight, metrics);
+  SKF_LAUNCH_CHECK();
+  return SKF_OK;
+}
+
+extern "C" int skf_pool_fwd(const float* u, const float* Vw, const float* x, int B, int L, int U, int d, float* a_out,
+                            float* emb, skf_stream_t stream) {
+  SKF_CHECK_ARG(u && Vw && x && a_out && emb, "null operand");
+  hipLaunchKernelGGL(pool_fwd_kernel, dim3(B), dim3(256), L * sizeof(float), (hipStream_t)stream, u, Vw, x, L, U, d, a_out, emb);
+  SKF_LAUNCH_CHECK();
+  return SKF_OK;
+}
+
+extern "C" int skf_pool_bwd(float* u_inout_dpre, const float* Vw, const float* x, const float* a, const float* demb,
+                            int B, int L, int U, int d, float* dx, float* dV, void* workspace, size_t workspace_bytes,
+                            skf_stream_t stream) {
+  SKF_CHECK_ARG(u_inout_dpre && Vw && x && a && demb && dx && dV, "null operand");
+  SKF_CHECK_ARG(workspace && workspace_bytes >= (size_t)B * U * sizeof(float), "workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  hipLaunchKernelGGL(pool_bwd_kernel, dim3(B), dim3(256), 2 * L * sizeof(float), s, u_inout_dpre, Vw, x, a, demb, L, U, d, dx, part);
+  hipLaunchKernelGGL(colsum_kernel, dim3(skf_cdiv(U, 64)), dim3(256), 0, s, part, B, U, U, dV, 0);
+  SKF_LAUNCH_CHECK();
+  return SKF_OK;
+}
+
+extern "C" int skf_expander_fwd(const float* emb, const float* w, const float* bias, int B, int L, int d, float* pre,
+                                skf_stream_t stream) {
+  SKF_CHECK_ARG(emb && w && bias && pre, "null operand");
+  const size_t total = (size_t)B * L * d;
+  int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(expander_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, emb, w, bias, B, L, d, pre);
+  SKF_LAUNCH_CHECK();
+  return SKF_OK;
+}
+
+extern "C" int skf_expander_bwd(const float* dpre, const float* emb, const float* w, int B, int L, int d, float* demb,
+                                int demb_accumulate, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
+                                skf_stream_t stream) {
+  SKF_CHECK_ARG(dpre && emb && w && demb && dw && dbias, "null operand");
+  SKF_CHECK_ARG(workspace && workspace_bytes >= (size_t)2 * B * L * sizeof(float), "workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  float* p1 = (float*)workspace;
+  float* p2 = p1 + (size_t)B * L;
+  hipLaunchKernelGGL(expander_bwd_kernel, dim3(B), dim3(256), 0, s, dpre, emb, w, L, d, demb, demb_accumulate, p1, p2);
+  hipLaunchKernelGGL(colsum_kernel, dim3(skf_cdiv(L, 64)), dim3(256), 0, s, p1, B, L, L, dw, 0);
+  hipLaunchKernelGGL(colsum_kernel, dim3(skf_cdiv(L, 64)), dim3(256), 0, s, p2, B, L, L, dbias, 0);
+  SKF_LAUNCH_CHECK();
+  return SKF_OK;
+}
+
+extern "C" int skf_dropout_keep_mask(unsigned drop_key, unsigned site, float rate, size_t n, unsigned char* out_host) {
+  SKF_CHECK_ARG(out_host, "null output");
+  const uint32_t sk = skf_site_key(drop_key, site), th = skf_drop_thresh(rate);
+  for (size_t i = 0; i < n; ++i) out_host[i] = skf_keep(sk, (uint32_t)i, th) ? 1 : 0;
+  return SKF_OK;
+}

@@ -1,0 +1,230 @@
+"""TrainEngine: owns the flat device buffers of one replica and drives the
+C-ABI train step (skf_model_*).  Host-side mirror of what
+``Transformer.build_model`` + ``prepare_model_trainer`` + ``train_on_batch`` set up
+in the reference (models/sketchformer.py:63-129, 313-359).
+
+Data parallelism (new functionality): one process per
+GPU; every rank runs forward+backward on its shard of the global batch, the flat
+fp32 gradient buffer is summed with ONE all-reduce (RCCL over xGMI on GPUs) and
+the 1/world_size scale is fused into the Adam sweep.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import SkfConfig, SkfParamEntry
+
+METRIC_NAMES = ("recon_loss", "recon_acc", "class_loss", "class_acc", "total_loss")
+
+
+def positional_encoding(position, d_model):
+    """builders/utils.py:12-32: float64 numpy angles with an np.float32(d_model)
+    divisor, sin on even / cos on odd columns, cast to float32.  -> (position, d_model)."""
+    pos = np.arange(position)[:, np.newaxis]
+    i = np.arange(d_model)[np.newaxis, :]
+    rates = 1 / np.power(10000, (2 * (i // 2)) / np.float32(d_model))
+    ang = pos * rates
+    ang[:, 0::2] = np.sin(ang[:, 0::2])
+    ang[:, 1::2] = np.cos(ang[:, 1::2])
+    return ang.astype(np.float32)
+
+
+def make_config(batch, seq_len=200, d_model=128, num_heads=8, dff=512, num_layers=4, vocab_size=1004, n_classes=345,
+                lowerdim=256, attn_version=1, continuous=False, blind_decoder_mask=True, dropout_rate=0.1,
+                recon_weight=1.0, class_weight=1.0, lr_scheduler="WarmupDecay", lr=0.01, seed=0, use_graph=True,
+                max_pos=1000):
+    cfg = SkfConfig()
+    cfg.batch, cfg.seq_len, cfg.d_model, cfg.num_heads, cfg.dff, cfg.num_layers = batch, seq_len, d_model, num_heads, dff, num_layers
+    cfg.vocab_size, cfg.n_classes, cfg.lowerdim, cfg.attn_version = vocab_size or 0, n_classes, lowerdim, attn_version
+    cfg.continuous, cfg.blind_decoder_mask, cfg.max_pos = int(continuous), int(blind_decoder_mask), max_pos
+    cfg.dropout_rate, cfg.recon_weight, cfg.class_weight = dropout_rate, recon_weight, class_weight
+    name = lr_scheduler.lower()
+    if name in ("warmupdecay", "warmup-decay"):
+        # models/sketchformer.py:113-114: warmup_steps=5000 hard-coded (hparams warmup_steps / lr ignored)
+        cfg.schedule, cfg.sched_p0, cfg.sched_p1 = 0, float(d_model), float(5000 ** -1.5)
+    elif name == "step-decay":
+        # models/sketchformer.py:116-118 passes the non-existent kwarg min_lr= -> TypeError in the reference
+        raise TypeError("__init__() got an unexpected keyword argument 'min_lr'")
+    else:
+        raise ValueError("unknown lr_scheduler %r" % lr_scheduler)
+    cfg.beta1, cfg.beta2, cfg.eps = 0.9, 0.98, 1e-9   # models/sketchformer.py:122-124
+    cfg.seed, cfg.use_graph = seed, int(use_graph)
+    return cfg
+
+
+def keras_init(entries, total, seed=0):
+    """Keras default initialisers into a flat float32 numpy buffer
+    (glorot_uniform Dense kernels, zeros biases, uniform(+-0.05) embeddings,
+    ones/zeros LayerNorm, RandomNormal(0.05)/uniform(+-0.05) SelfAttnV1)."""
+    rng = np.random.RandomState(seed)
+    flat = np.zeros(total, dtype=np.float32)
+    for e in entries:
+        name = e["name"]
+        r, c = e["rows"], e["cols"]
+        view = strided_view(flat, e)
+        if name.endswith("/kernel"):
+            lim = math.sqrt(6.0 / (r + c))
+            view[...] = rng.uniform(-lim, lim, size=(r, c))
+        elif name.endswith("embedding") or name.endswith("V_attn"):
+            view[...] = rng.uniform(-0.05, 0.05, size=(r, c))
+        elif name.endswith("W_attn"):
+            view[...] = rng.normal(0.0, 0.05, size=(r, c))
+        elif name.endswith("/gamma"):
+            view[...] = 1.0
+    return flat
+
+
+def strided_view(flat, e):
+    """2-D numpy view of one variable inside a flat numpy buffer."""
+    return np.lib.stride_tricks.as_strided(flat[e["offset"]:], shape=(e["rows"], e["cols"]),
+                                           strides=(e["row_stride"] * flat.itemsize, flat.itemsize))
+
+
+def param_entries(cfg):
+    lib = _lib.load()
+    n = lib.skf_model_param_entries(C.byref(cfg), None, 0)
+    if n < 0:
+        _lib.check(n, "skf_model_param_entries")
+    arr = (SkfParamEntry * n)()
+    lib.skf_model_param_entries(C.byref(cfg), arr, n)
+    return [{"name": a.name.decode(), "offset": int(a.offset), "rows": int(a.rows), "cols": int(a.cols),
+             "row_stride": int(a.row_stride)} for a in arr]
+
+
+# shapes as the reference's trainable variables report them (1-D variables, (U,1) V_attn, (1,L) expand kernel)
+def logical_shape(e):
+    n = e["name"]
+    if n.endswith(("/bias", "/gamma", "/beta", "b_attn")):
+        return (e["cols"],)
+    return (e["rows"], e["cols"])
+
+
+class TrainEngine:
+    """One replica of the sketch-transformer-tf2 train step on one GPU."""
+
+    def __init__(self, cfg, device=None, init_seed=0, process_group=None):
+        if not torch.cuda.is_available():
+            raise _lib.SkfError("TrainEngine needs a HIP device: torch.cuda.is_available() is False (no CPU fallback)")
+        self.lib = _lib.load()
+        self.cfg = cfg
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        _lib.call("skf_config_validate", C.byref(cfg))
+        self.entries = param_entries(cfg)
+        self.by_name = {e["name"]: e for e in self.entries}
+        self.n_floats = int(self.lib.skf_model_param_floats(C.byref(cfg)))
+        flat = keras_init(self.entries, self.n_floats, init_seed)
+        dev = self.device
+        self.params = torch.from_numpy(flat).to(dev)
+        self.grads = torch.zeros(self.n_floats, dtype=torch.float32, device=dev)
+        self.adam_m = torch.zeros_like(self.grads)
+        self.adam_v = torch.zeros_like(self.grads)
+        self.pos = torch.from_numpy(positional_encoding(cfg.max_pos, cfg.d_model)).to(dev)
+        self.metrics = torch.zeros(32, dtype=torch.float32, device=dev)
+        self.state = torch.zeros(int(self.lib.skf_step_state_bytes()) // 8 + 1, dtype=torch.int64, device=dev)
+        ws_bytes = int(self.lib.skf_model_workspace_bytes(C.byref(cfg)))
+        self.workspace = torch.empty(ws_bytes + 256, dtype=torch.uint8, device=dev)
+        off = (-self.workspace.data_ptr()) % 256
+        self._ws_ptr = self.workspace.data_ptr() + off
+        self._ws_bytes = ws_bytes
+        handle = C.c_void_p()
+        _lib.call("skf_model_create", C.byref(cfg), C.byref(handle))
+        self.handle = handle
+        _lib.call("skf_model_bind", handle, self._p(self.params), self._p(self.grads), self._p(self.adam_m),
+                  self._p(self.adam_v), self._p(self.pos), C.c_void_p(self._ws_ptr), ws_bytes, self._p(self.metrics),
+                  self._p(self.state))
+        self.pg = process_group
+        self.world_size = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h is not None and h.value:
+            try:
+                self.lib.skf_model_destroy(h)
+            except Exception:
+                pass
+
+    @staticmethod
+    def _p(t):
+        return C.c_void_p(t.data_ptr())
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- parameters by (Keras-style) name
+    def _view(self, flat, name):
+        e = self.by_name[name]
+        return torch.as_strided(flat, (e["rows"], e["cols"]), (e["row_stride"], 1), e["offset"])
+
+    def get(self, name, which="params"):
+        e = self.by_name[name]
+        return self._view(getattr(self, which), name).detach().cpu().numpy().reshape(logical_shape(e)).copy()
+
+    def set(self, name, value, which="params"):
+        v = self._view(getattr(self, which), name)
+        v.copy_(torch.as_tensor(np.asarray(value, dtype=np.float32).reshape(v.shape)).to(self.device))
+
+    def state_dict_numpy(self, which="params"):
+        return {e["name"]: self.get(e["name"], which) for e in self.entries}
+
+    def load_numpy(self, params, which="params"):
+        for k, v in params.items():
+            self.set(k, v, which)
+
+    # ---- steps
+    def _dev_tokens(self, x):
+        t = torch.as_tensor(x)
+        if t.dtype != torch.int64:
+            t = t.to(torch.int64)
+        return t.to(self.device, non_blocking=True).contiguous()
+
+    def forward(self, inp, tar=None, training=False):
+        """Transformer.call: fills the internal buffers (see ``buffer``)."""
+        inp = self._dev_tokens(inp)
+        tar = inp if tar is None else self._dev_tokens(tar)
+        _lib.call("skf_model_forward", self.handle, self._p(inp), self._p(tar), tar.stride(0), int(training), self._stream())
+
+    def forward_backward(self, inp, tar, labels):
+        inp = self._dev_tokens(inp)
+        tar = inp if tar is None else self._dev_tokens(tar)
+        labels = self._dev_tokens(labels)
+        _lib.call("skf_model_forward_backward", self.handle, self._p(inp), self._p(tar), tar.stride(0), self._p(labels),
+                  self._stream())
+
+    def apply_gradients(self):
+        if self.world_size > 1:
+            torch.distributed.all_reduce(self.grads, group=self.pg)
+        _lib.call("skf_model_apply_gradients", self.handle, 1.0 / self.world_size, self._stream())
+
+    def train_step(self, inp, labels, tar=None):
+        """model_trainer(inp, tar, lab) (models/sketchformer.py:325-349); no host sync."""
+        self.forward_backward(inp, tar, labels)
+        self.apply_gradients()
+
+    def buffer(self, name):
+        ptr, rows, cols = C.c_void_p(), C.c_int(), C.c_int()
+        _lib.call("skf_model_buffer", self.handle, name.encode(), C.byref(ptr), C.byref(rows), C.byref(cols))
+        base = self._ws_ptr
+        off = (ptr.value - base) // 4
+        lo = self._ws_ptr - self.workspace.data_ptr()
+        ws_f = self.workspace[lo:lo + self._ws_bytes].view(torch.float32)
+        return ws_f[off:off + rows.value * cols.value].view(rows.value, cols.value)
+
+    def step_metrics(self):
+        """This step's five scalars (host sync)."""
+        m = self.metrics[:5].cpu().numpy()
+        return dict(zip(METRIC_NAMES, (float(x) for x in m)))
+
+    def running_metrics(self):
+        """Keras running metrics (never reset during train(), core/models.py:183-197)."""
+        m = self.metrics.cpu().numpy()
+        return {n: float(m[8 + i] / m[16 + i]) if m[16 + i] else 0.0 for i, n in enumerate(METRIC_NAMES)}
+
+    def reset_metrics(self):
+        self.metrics.zero_()
+
+    @property
+    def iterations(self):
+        return int(self.state[0].item())

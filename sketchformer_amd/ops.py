@@ -1,0 +1,220 @@
+"""Thin torch-tensor front-ends over the C ABI (one function per kernel family).
+
+PyTorch only owns the device memory and the stream; every function checks
+dtype / device / contiguity, passes raw pointers to libskf.so and raises
+``SkfError`` on failure.  No CPU path exists.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.SkfError("sketchformer_amd ops need CUDA(HIP) tensors; got a CPU tensor (no CPU fallback)")
+    return C.c_void_p(t.data_ptr())
+
+
+def _f32(t, name):
+    if t.dtype != torch.float32:
+        raise TypeError("%s must be float32" % name)
+    if t.stride(-1) != 1:
+        raise ValueError("%s must have a unit innermost stride" % name)
+    return t
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def new_step_state(device, iterations=0):
+    """Device-resident per-step scalars {int64 iterations; f32 lr, alpha; u32 drop_key, pad}."""
+    n = _lib.load().skf_step_state_bytes()
+    st = torch.zeros(n // 8 + 1, dtype=torch.int64, device=device)
+    st[0] = iterations
+    return st
+
+
+def step_prologue(state, schedule=0, p0=128.0, p1=5000 ** -1.5, p2=0.0, p3=0.0, beta1=0.9, beta2=0.98, seed=0):
+    _lib.call("skf_step_prologue", _p(state), schedule, p0, p1, p2, p3, beta1, beta2, seed, _stream())
+
+
+def step_epilogue(state):
+    _lib.call("skf_step_epilogue", _p(state), _stream())
+
+
+def read_step_state(state):
+    """-> dict(iterations, lr, alpha, drop_key) (host sync)."""
+    raw = state.cpu().numpy().tobytes()
+    import struct
+    it, lr, alpha, key, _ = struct.unpack("<qffII", raw[:24])
+    return {"iterations": it, "lr": lr, "alpha": alpha, "drop_key": key}
+
+
+def gemm(a, b, a_kcontig=True, b_kcontig=False, bias=None, act=0, relu_src=None, out=None, accumulate=False,
+         splits=1, bias_grad=None):
+    """C[M,N] (+)= opA(a) . opB(b).  a: [M,K] (a_kcontig) or [K,M]; b: [K,N] or [N,K] (b_kcontig)."""
+    _f32(a, "a"); _f32(b, "b")
+    M, K = (a.shape[0], a.shape[1]) if a_kcontig else (a.shape[1], a.shape[0])
+    N = b.shape[0] if b_kcontig else b.shape[1]
+    assert (b.shape[1] if b_kcontig else b.shape[0]) == K, "inner dimensions differ"
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    ws = None
+    wsb = 0
+    if splits > 1 or bias_grad is not None:
+        wsb = _lib.load().skf_gemm_workspace_bytes(M, N, K, splits, 1)
+        ws = _ws(wsb, a.device)
+    _lib.call("skf_gemm_f32", int(a_kcontig), int(b_kcontig), M, N, K, _p(a), a.stride(0), _p(b), b.stride(0),
+              _p(out), out.stride(0), _p(bias), act, _p(relu_src), relu_src.stride(0) if relu_src is not None else 0,
+              int(accumulate), splits, _p(bias_grad), 0, _p(ws), wsb, _stream())
+    return out
+
+
+def attention_fwd(q, k, v, num_heads, key_mask=None, causal=False):
+    """q (B,Lq,d) k,v (B,Lk,d) views with unit inner stride -> o (B,Lq,d), stats (B,H,Lq,2)."""
+    B, Lq, d = q.shape
+    Lk = k.shape[1]
+    o = torch.empty(B, Lq, d, dtype=torch.float32, device=q.device)
+    stats = torch.empty(B, num_heads, Lq, 2, dtype=torch.float32, device=q.device)
+    _lib.call("skf_attention_fwd", _p(q), q.stride(1), _p(k), k.stride(1), _p(v), v.stride(1), _p(key_mask),
+              key_mask.stride(0) if key_mask is not None else 0, int(causal), B, num_heads, Lq, Lk, d // num_heads,
+              _p(o), o.stride(1), _p(stats), _stream())
+    return o, stats
+
+
+def attention_bwd(q, k, v, o, do, stats, num_heads, key_mask=None, causal=False):
+    B, Lq, d = q.shape
+    Lk = k.shape[1]
+    dq = torch.empty(B, Lq, d, dtype=torch.float32, device=q.device)
+    dk = torch.empty(B, Lk, d, dtype=torch.float32, device=q.device)
+    dv = torch.empty(B, Lk, d, dtype=torch.float32, device=q.device)
+    _lib.call("skf_attention_bwd", _p(q), q.stride(1), _p(k), k.stride(1), _p(v), v.stride(1), _p(o), o.stride(1),
+              _p(do), do.stride(1), _p(stats), _p(key_mask), key_mask.stride(0) if key_mask is not None else 0,
+              int(causal), B, num_heads, Lq, Lk, d // num_heads, _p(dq), dq.stride(1), _p(dk), dk.stride(1),
+              _p(dv), dv.stride(1), _stream())
+    return dq, dk, dv
+
+
+def padding_mask(tokens, L=None):
+    B, ld = tokens.shape
+    L = L or ld
+    out = torch.empty(B, L, dtype=torch.uint8, device=tokens.device)
+    _lib.call("skf_padding_mask", _p(tokens), ld, B, L, _p(out), _stream())
+    return out
+
+
+def embed_fwd(tokens, table, pos, L=None, rate=0.0, site=0, state=None):
+    B, ld = tokens.shape
+    L = L or ld
+    V, d = table.shape
+    out = torch.empty(B, L, d, dtype=torch.float32, device=table.device)
+    _lib.call("skf_embed_fwd", _p(tokens), ld, B, L, _p(table), V, d, _p(pos), _p(out), rate, site, _p(state), _stream())
+    return out
+
+
+def embed_bwd(tokens, dx, vocab, L=None, rate=0.0, site=0, state=None):
+    B, ld = tokens.shape
+    L = L or ld
+    d = dx.shape[-1]
+    dtable = torch.zeros(vocab, d, dtype=torch.float32, device=dx.device)
+    _lib.call("skf_embed_bwd", _p(tokens), ld, B, L, _p(dx), vocab, d, _p(dtable), rate, site, _p(state), _stream())
+    return dtable
+
+
+def layernorm_residual_fwd(x, y, gamma, beta, rate=0.0, site=0, state=None):
+    """-> out, z (= x + drop(y), written over a copy of y), stats."""
+    d = x.shape[-1]
+    rows = x.numel() // d
+    z = y.clone()
+    out = torch.empty_like(x)
+    stats = torch.empty(rows, 2, dtype=torch.float32, device=x.device)
+    _lib.call("skf_layernorm_residual_fwd", _p(x), _p(z), _p(gamma), _p(beta), _p(out), _p(stats), rows, d, rate, site,
+              _p(state), _stream())
+    return out, z, stats
+
+
+def layernorm_residual_bwd(dout, z, stats, gamma, rate=0.0, site=0, state=None):
+    d = dout.shape[-1]
+    rows = dout.numel() // d
+    dz = torch.empty_like(dout)
+    dy = torch.empty_like(dout) if rate > 0 else None
+    dg = torch.empty(d, dtype=torch.float32, device=dout.device)
+    db = torch.empty(d, dtype=torch.float32, device=dout.device)
+    wsb = _lib.load().skf_layernorm_bwd_workspace_bytes(rows, d)
+    ws = _ws(wsb, dout.device)
+    _lib.call("skf_layernorm_residual_bwd", _p(dout), _p(z), _p(stats), _p(gamma), _p(dz), _p(dy), _p(dg), _p(db), rows,
+              d, rate, site, _p(state), _p(ws), wsb, _stream())
+    return dz, (dy if dy is not None else dz), dg, db
+
+
+def softmax_ce(logits, target, tgt_cols, tgt_off=0, mask_pad=False, scale=1.0, want_probs=False, write_grad=True):
+    """In place: logits (rows, ncls) become the gradient.  target: int64 (B, tgt_ld)."""
+    rows, ncls = logits.shape
+    row_loss = torch.empty(rows, dtype=torch.float32, device=logits.device)
+    row_hit = torch.empty(rows, dtype=torch.float32, device=logits.device)
+    probs = torch.empty(rows, ncls, dtype=torch.float32, device=logits.device) if want_probs else None
+    _lib.call("skf_softmax_ce", _p(logits), logits.stride(0), rows, ncls, _p(target), target.stride(0), tgt_cols, tgt_off,
+              int(mask_pad), scale, _p(row_loss), _p(row_hit), _p(probs), int(write_grad), _stream())
+    return row_loss, row_hit, probs
+
+
+def pool_fwd(u, Vw, x):
+    B, L, U = u.shape
+    d = x.shape[-1]
+    a = torch.empty(B, L, dtype=torch.float32, device=x.device)
+    emb = torch.empty(B, d, dtype=torch.float32, device=x.device)
+    _lib.call("skf_pool_fwd", _p(u), _p(Vw), _p(x), B, L, U, d, _p(a), _p(emb), _stream())
+    return a, emb
+
+
+def pool_bwd(u, Vw, x, a, demb):
+    """-> dpre (overwrites a copy of u), dx_direct, dV."""
+    B, L, U = u.shape
+    d = x.shape[-1]
+    dpre = u.clone()
+    dx = torch.empty_like(x)
+    dV = torch.empty(U, dtype=torch.float32, device=x.device)
+    ws = _ws(B * U * 4, x.device)
+    _lib.call("skf_pool_bwd", _p(dpre), _p(Vw), _p(x), _p(a), _p(demb), B, L, U, d, _p(dx), _p(dV), _p(ws), B * U * 4,
+              _stream())
+    return dpre, dx, dV
+
+
+def expander_fwd(emb, w, bias):
+    B, d = emb.shape
+    L = w.numel()
+    pre = torch.empty(B, L, d, dtype=torch.float32, device=emb.device)
+    _lib.call("skf_expander_fwd", _p(emb), _p(w), _p(bias), B, L, d, _p(pre), _stream())
+    return pre
+
+
+def expander_bwd(dpre, emb, w):
+    B, L, d = dpre.shape
+    demb = torch.empty(B, d, dtype=torch.float32, device=emb.device)
+    dw = torch.empty(L, dtype=torch.float32, device=emb.device)
+    db = torch.empty(L, dtype=torch.float32, device=emb.device)
+    ws = _ws(2 * B * L * 4, emb.device)
+    _lib.call("skf_expander_bwd", _p(dpre), _p(emb), _p(w), B, L, d, _p(demb), 0, _p(dw), _p(db), _p(ws), 2 * B * L * 4,
+              _stream())
+    return demb, dw, db
+
+
+def adam_step(w, g, m, v, state, grad_scale=1.0, beta1=0.9, beta2=0.98, eps=1e-9):
+    _lib.call("skf_adam_step", _p(w), _p(g), _p(m), _p(v), w.numel(), _p(state), grad_scale, beta1, beta2, eps, _stream())
+
+
+def dropout_keep_mask(drop_key, site, rate, n):
+    """Host replica of the kernels' counter-based keep mask (for parity tests)."""
+    import numpy as np
+    out = np.empty(n, dtype=np.uint8)
+    _lib.call("skf_dropout_keep_mask", drop_key, site, rate, n, out.ctypes.data_as(C.c_void_p))
+    return out.astype(bool)

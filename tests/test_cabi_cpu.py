@@ -1,0 +1,89 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads and
+exports every symbol include/skf.h declares (no compute calls without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from sketchformer_amd import build, _lib
+    build.build_library(verbose=False)
+    return _lib.load()
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "skf.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(skf_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = _declared()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), "libskf.so does not export %s" % n
+
+
+def test_binding_table_matches_header(lib):
+    from sketchformer_amd import _lib
+    assert sorted(_lib.SIGNATURES) == _declared()
+
+
+def test_host_only_entry_points(lib):
+    from sketchformer_amd import _lib, engine
+    assert lib.skf_version() >= 100
+    cfg = engine.make_config(batch=4, seq_len=24, d_model=64, num_heads=4, dff=128, num_layers=2, vocab_size=52,
+                             n_classes=7, lowerdim=32)
+    assert lib.skf_config_validate(C.byref(cfg)) == 0
+    entries = engine.param_entries(cfg)
+    n = lib.skf_model_param_floats(C.byref(cfg))
+    assert n > 0 and lib.skf_model_workspace_bytes(C.byref(cfg)) > 0
+    # layout is a partition: no overlap, inside the buffer
+    import numpy as np
+    used = np.zeros(n, dtype=np.int32)
+    for e in entries:
+        for r in range(e["rows"]):
+            used[e["offset"] + r * e["row_stride"]: e["offset"] + r * e["row_stride"] + e["cols"]] += 1
+    assert used.max() == 1
+
+
+def test_layout_names_match_oracle(lib):
+    import oracle
+    from sketchformer_amd import engine
+    ocfg = oracle.Config(num_layers=2, d_model=64, dff=128, num_heads=4, lowerdim=32, vocab_size=52, n_classes=7, seq_len=24)
+    cfg = engine.make_config(batch=4, seq_len=24, d_model=64, num_heads=4, dff=128, num_layers=2, vocab_size=52,
+                             n_classes=7, lowerdim=32)
+    want = {n: s for n, s, _ in oracle.param_specs(ocfg)}
+    got = {e["name"]: engine.logical_shape(e) for e in engine.param_entries(cfg)}
+    assert got == want
+
+
+def test_unsupported_configs_fail_loudly(lib):
+    from sketchformer_amd import engine
+    cfg = engine.make_config(batch=4, continuous=True)
+    assert lib.skf_config_validate(C.byref(cfg)) == -2
+    assert b"continuous" in lib.skf_last_error()
+    with pytest.raises(TypeError):
+        engine.make_config(batch=4, lr_scheduler="step-decay")
+
+
+def test_param_count_matches_survey(lib):
+    """P = 2,316,117 for cfg 2 (C=345), 2,271,741 for cfg 1 (C=1)."""
+    from sketchformer_amd import engine
+    for C_, want in ((345, 2316117), (1, 2271741)):
+        cfg = engine.make_config(batch=128, n_classes=C_)
+        assert sum(e["rows"] * e["cols"] for e in engine.param_entries(cfg)) == want
+
+
+def test_no_cpu_fallback():
+    import torch
+    from sketchformer_amd import engine, _lib
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.SkfError):
+        engine.TrainEngine(engine.make_config(batch=4))

@@ -1,0 +1,188 @@
+"""Train-step parity: the HIP path (C ABI, skf_model_*) against the CPU oracle on
+identical parameters and inputs - forward logits, argmax, losses, every gradient,
+and a short Adam trajectory; plus the analytic known-answer tests of SURVEY 8(c)
+at the full BASELINE size."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from sketchformer_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(batch, rate=0.0, use_graph=False, blind=True, **kw):
+    from sketchformer_amd import engine
+    small = dict(seq_len=24, d_model=64, num_heads=4, dff=128, num_layers=2, vocab_size=52, n_classes=7, lowerdim=32)
+    small.update(kw)
+    cfg = engine.make_config(batch=batch, dropout_rate=rate, use_graph=use_graph, blind_decoder_mask=blind, seed=11, **small)
+    ocfg = oracle.Config(num_layers=small["num_layers"], d_model=small["d_model"], dff=small["dff"],
+                         num_heads=small["num_heads"], dropout_rate=rate, lowerdim=small["lowerdim"],
+                         vocab_size=small["vocab_size"], n_classes=small["n_classes"], seq_len=small["seq_len"],
+                         blind_decoder_mask=blind)
+    eng = engine.TrainEngine(cfg, init_seed=1)
+    # make biases / LN parameters non-trivial
+    rng = np.random.RandomState(9)
+    for e in eng.entries:
+        n = e["name"]
+        if n.endswith(("/bias", "/beta", "b_attn")):
+            eng.set(n, rng.normal(0, 0.1, engine.logical_shape(e)))
+        elif n.endswith("/gamma"):
+            eng.set(n, 1 + rng.normal(0, 0.1, engine.logical_shape(e)))
+    return eng, ocfg
+
+
+def _rel(got, want):
+    return np.abs(np.asarray(got, np.float64) - want).max() / max(np.abs(want).max(), 1e-30)
+
+
+def _drops_from_engine(eng, ocfg, B):
+    from sketchformer_amd import ops
+    key = ops.read_step_state(eng.state)["drop_key"]
+    drops = {}
+    for site, (name, tag) in enumerate(oracle.dropout_sites(ocfg)):
+        L = ocfg.seq_len if tag == "enc" else ocfg.seq_len - 1
+        drops[name] = ops.dropout_keep_mask(key, site, ocfg.dropout_rate, B * L * ocfg.d_model).reshape(B, L, ocfg.d_model)
+    return drops
+
+
+@pytest.mark.parametrize("blind", [True, False])
+def test_forward_logits_and_argmax(blind):
+    B = 5
+    eng, ocfg = _mk(B, blind=blind)
+    x, y = synthetic.token_batch(B, ocfg.seq_len, ocfg.vocab_size, ocfg.n_classes, seed=2)
+    x[0, 9:] = 0
+    P = {k: v.astype(np.float64) for k, v in eng.state_dict_numpy().items()}
+    out, _ = oracle.forward(P, ocfg, x, x[:, :-1], training=False)
+    eng.forward(x, training=False)
+    torch.cuda.synchronize()
+    logits = eng.buffer("logits").cpu().numpy().reshape(B, ocfg.seq_len - 1, -1)
+    assert _rel(logits, out["recon"]) < 1e-4          # north star: 1e-3 rel
+    assert _rel(eng.buffer("embedding").cpu().numpy(), out["embedding"]) < 1e-4
+    assert _rel(eng.buffer("class_probs").cpu().numpy(), out["class"]) < 1e-4
+    # token argmax: identical wherever the oracle's top-2 margin exceeds 1e-4
+    srt = np.sort(out["recon"], -1)
+    safe = (srt[..., -1] - srt[..., -2]) > 1e-4
+    assert safe.mean() > 0.9
+    assert np.array_equal(logits.argmax(-1)[safe], out["recon"].argmax(-1)[safe])
+
+
+@pytest.mark.parametrize("rate,use_graph", [(0.0, False), (0.1, False), (0.1, True)])
+def test_losses_and_all_gradients(rate, use_graph):
+    B = 6
+    eng, ocfg = _mk(B, rate=rate, use_graph=use_graph)
+    x, y = synthetic.token_batch(B, ocfg.seq_len, ocfg.vocab_size, ocfg.n_classes, seed=3)
+    x[1, 7:] = 0
+    P = {k: v.astype(np.float64) for k, v in eng.state_dict_numpy().items()}
+    eng.forward_backward(x, None, y)
+    torch.cuda.synchronize()
+    drops = _drops_from_engine(eng, ocfg, B) if rate > 0 else None
+    losses, out, G = oracle.loss_and_grads(P, ocfg, x, x, y, drops)
+    m = eng.step_metrics()
+    for k in ("recon_loss", "class_loss", "total_loss"):
+        assert abs(m[k] - losses[k]) < 1e-5 * max(1.0, abs(losses[k])), (k, m[k], losses[k])
+    acc = (out["recon"].argmax(-1) == x[:, 1:]).mean()
+    assert abs(m["recon_acc"] - acc) < 1e-6
+    got = eng.state_dict_numpy("grads")
+    worst = max((_rel(got[k], G[k]), k) for k in G)
+    assert worst[0] < 1e-3, worst                 # acceptance bar; typically ~1e-5
+    assert np.median([_rel(got[k], G[k]) for k in G]) < 5e-5
+
+
+def test_adam_trajectory_matches_oracle():
+    B = 4
+    eng, ocfg = _mk(B, rate=0.0, use_graph=True)
+    P = {k: v.astype(np.float64) for k, v in eng.state_dict_numpy().items()}
+    st = oracle.TrainState.create(P)
+    st.iterations = 3000           # lr ~ 1e-3, so parameters really move
+    eng.state[0] = 3000
+    for step in range(4):
+        x, y = synthetic.token_batch(B, ocfg.seq_len, ocfg.vocab_size, ocfg.n_classes, seed=20 + step)
+        res, losses, _, _ = oracle.train_step(st, ocfg, x, x, y)
+        eng.train_step(x, y)
+        torch.cuda.synchronize()
+        m = eng.step_metrics()
+        assert abs(m["total_loss"] - losses["total_loss"]) < 1e-3 * abs(losses["total_loss"]), (step, m, losses)
+    assert eng.iterations == 3004
+    run = eng.running_metrics()
+    for k, v in res.items():
+        assert abs(run[k] - v) < 1e-3 * max(1.0, abs(v)), (k, run[k], v)
+    got = eng.state_dict_numpy()
+    worst = max((np.abs(got[k] - st.params[k]).max(), k) for k in got)
+    assert worst[0] < 5e-4, worst
+
+
+def test_first_update_has_zero_lr_k7():
+    """K7: Keras evaluates the schedule on iterations=0 -> weights unchanged, m=(1-b1)g, v=(1-b2)g^2."""
+    eng, ocfg = _mk(3)
+    x, y = synthetic.token_batch(3, ocfg.seq_len, ocfg.vocab_size, ocfg.n_classes, seed=1)
+    before = eng.params.clone()
+    eng.train_step(x, y)
+    torch.cuda.synchronize()
+    assert torch.equal(before, eng.params)
+    g = eng.grads
+    assert torch.allclose(eng.adam_m, g * (1 - 0.9), rtol=1e-5, atol=1e-12)
+    assert torch.allclose(eng.adam_v, g * g * (1 - 0.98), rtol=1e-4, atol=1e-14)
+
+
+# ------------------------------------------------------------------ full BASELINE size (cfg 2): properties
+@pytest.fixture(scope="module")
+def full():
+    from sketchformer_amd import engine
+    cfg = engine.make_config(batch=128, dropout_rate=0.0, use_graph=True)
+    return engine.TrainEngine(cfg, init_seed=0)
+
+
+def test_full_size_k2_zero_output_layer(full):
+    """K2: output W=0,b=0 -> recon_loss = ln(V) * (#non-pad targets)/(B*L'), recon_acc = fraction of targets == 0."""
+    x, y = synthetic.token_batch(128, 200, 1004, 345, seed=0)
+    full.set("output/kernel", np.zeros((128, 1004)))
+    full.set("output/bias", np.zeros(1004))
+    full.forward_backward(x, None, y)
+    torch.cuda.synchronize()
+    m = full.step_metrics()
+    tgt = x[:, 1:]
+    assert abs(m["recon_loss"] - np.log(1004.0) * (tgt != 0).mean()) < 1e-4
+    assert abs(m["recon_acc"] - (tgt == 0).mean()) < 1e-6
+    assert np.isfinite(full.grads.cpu().numpy()).all()
+
+
+def test_full_size_k4a_causality(full):
+    """K4a: with inp fixed, decoder logits at position t do not depend on tar_inp[:, t+1:]."""
+    x, _ = synthetic.token_batch(128, 200, 1004, 345, seed=1)
+    rng = np.random.RandomState(0)
+    full.load_numpy({"output/kernel": rng.uniform(-0.07, 0.07, (128, 1004))})
+    full.forward(x, tar=x, training=False)
+    a = full.buffer("logits").clone().view(128, 199, 1004)
+    tar2 = x.copy()
+    t0 = 60
+    tar2[:, t0 + 1:] = rng.randint(0, 1004, size=tar2[:, t0 + 1:].shape)
+    full.forward(x, tar=tar2, training=False)
+    b = full.buffer("logits").view(128, 199, 1004)
+    torch.cuda.synchronize()
+    assert torch.equal(a[:, :t0 + 1], b[:, :t0 + 1])
+    assert not torch.equal(a[:, t0 + 1:], b[:, t0 + 1:])
+
+
+def test_full_size_k5_pre_decoder_rank_one(full):
+    """K5: pre_decoder[b,t,:] - pre_decoder[b,t',:] = (w[t]-w[t']) * emb[b,:] + const."""
+    pre = full.buffer("pre_decoder").view(128, 200, 128).cpu().numpy().astype(np.float64)
+    emb = full.buffer("embedding").cpu().numpy().astype(np.float64)
+    w = full.get("expand/kernel")[0].astype(np.float64)
+    bias = full.get("expand/bias").astype(np.float64)
+    want = emb[:, None, :] * w[None, :, None] + bias[None, :, None]
+    assert np.abs(pre - want).max() < 1e-5 * max(1.0, np.abs(want).max())
+
+
+def test_full_size_c1_class_head_k3():
+    """K3 / cfg 1: one class -> class loss 0, class_acc 1 and zero gradient from that head."""
+    from sketchformer_amd import engine
+    eng = engine.TrainEngine(engine.make_config(batch=8, n_classes=1, dropout_rate=0.0, use_graph=False), init_seed=0)
+    x, _ = synthetic.token_batch(8, 200, 1004, 1, seed=2)
+    y = np.zeros((8, 1), np.int64)
+    eng.forward_backward(x, None, y)
+    torch.cuda.synchronize()
+    m = eng.step_metrics()
+    assert m["class_loss"] == 0.0 and m["class_acc"] == 1.0
+    assert np.abs(eng.get("classify/kernel", "grads")).max() == 0.0

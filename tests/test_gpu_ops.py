@@ -1,0 +1,293 @@
+"""Kernel-level parity: every HIP kernel family, called through the C ABI, against
+the CPU oracle (float64) on the same seeded inputs.  Tolerances are fp32
+accumulation-order tolerances (north star: logits within 1e-3 rel)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 2e-5   # relative to the max |reference| of the tensor
+
+
+def _dev(a, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(a)).to(dtype).cuda()
+
+
+def _close(got, want, rtol=RTOL, name=""):
+    got = got.detach().cpu().numpy().astype(np.float64) if torch.is_tensor(got) else np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    assert np.isfinite(got).all(), name + ": non-finite output"
+    scale = max(np.abs(want).max(), 1e-30)
+    err = np.abs(got - want).max() / scale
+    assert err <= rtol, "%s: max err %.3e of scale %.3e (rel %.3e > %.1e)" % (name, np.abs(got - want).max(), scale, err, rtol)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from sketchformer_amd import ops
+    return ops
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(256, 128, 128), (200, 384, 128), (331, 1004, 128), (128, 345, 128), (77, 52, 36),
+                                   (1000, 128, 512), (25472, 128, 128)])
+def test_gemm_forward_bias_act(ops, M, N, K):
+    rng = np.random.RandomState(M + N + K)
+    x, w, b = rng.randn(M, K), rng.randn(K, N) / np.sqrt(K), rng.randn(N)
+    for act, fn in ((0, lambda v: v), (1, lambda v: np.maximum(v, 0)), (2, np.tanh)):
+        y = ops.gemm(_dev(x), _dev(w), bias=_dev(b), act=act)
+        _close(y, fn(x @ w + b), name="fwd act=%d" % act)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 512), (199, 128, 1004), (300, 128, 384), (128, 128, 345), (64, 36, 52)])
+def test_gemm_dgrad_relu_mask_accumulate(ops, M, N, K):
+    rng = np.random.RandomState(M * 3 + N + K)
+    dy, w, h, c0 = rng.randn(M, K), rng.randn(N, K) / np.sqrt(K), rng.randn(M, N), rng.randn(M, N)
+    got = ops.gemm(_dev(dy), _dev(w), a_kcontig=True, b_kcontig=True, relu_src=_dev(h))
+    _close(got, (dy @ w.T) * (h > 0), name="dgrad+relu mask")
+    out = _dev(c0)
+    ops.gemm(_dev(dy), _dev(w), a_kcontig=True, b_kcontig=True, out=out, accumulate=True)
+    _close(out, c0 + dy @ w.T, name="dgrad accumulate")
+
+
+@pytest.mark.parametrize("rows,inf,outf", [(25600, 128, 128), (25472, 128, 1004), (5000, 512, 128), (3000, 128, 384),
+                                           (128, 128, 345), (999, 36, 52)])
+def test_gemm_wgrad_splitk_bias_grad(ops, rows, inf, outf):
+    from sketchformer_amd import _lib
+    rng = np.random.RandomState(rows + inf + outf)
+    x, dy = rng.randn(rows, inf), rng.randn(rows, outf)
+    splits = _lib.load().skf_gemm_default_splits(inf, outf, rows)
+    bg = torch.empty(outf, dtype=torch.float32, device="cuda")
+    dw = ops.gemm(_dev(x), _dev(dy), a_kcontig=False, b_kcontig=False, splits=splits, bias_grad=bg)
+    _close(dw, x.T @ dy, rtol=5e-5, name="wgrad splits=%d" % splits)
+    _close(bg, dy.sum(0), rtol=5e-5, name="bias grad")
+
+
+def test_gemm_strided_views(ops):
+    """fused QKV layout: W stored [d][3d]; outputs written into a (rows, 3d) buffer at a column offset."""
+    rng = np.random.RandomState(5)
+    rows, d = 300, 128
+    x, w = rng.randn(rows, d), rng.randn(d, 3 * d) / np.sqrt(d)
+    W = _dev(w)
+    out = torch.zeros(rows, 3 * d, dtype=torch.float32, device="cuda")
+    ops.gemm(_dev(x), W[:, d:2 * d], out=out[:, d:2 * d])
+    want = np.zeros((rows, 3 * d)); want[:, d:2 * d] = x @ w[:, d:2 * d]
+    _close(out, want, name="strided")
+
+
+# ------------------------------------------------------------------ attention
+def _attn_case(B, H, Lq, Lk, dh, causal, with_mask, seed, all_pad_row=False):
+    rng = np.random.RandomState(seed)
+    d = H * dh
+    q, k, v = rng.randn(B, Lq, d), rng.randn(B, Lk, d), rng.randn(B, Lk, d)
+    do = rng.randn(B, Lq, d)
+    km = None
+    if with_mask:
+        lens = rng.randint(1, Lk + 1, size=B)
+        lens[0] = Lk
+        km = (np.arange(Lk)[None, :] >= lens[:, None])
+        if all_pad_row:
+            km[-1, :] = True
+    mask = np.zeros((B, 1, Lq, Lk), np.float32)
+    if km is not None:
+        mask = np.maximum(mask, km[:, None, None, :].astype(np.float32))
+    if causal:
+        mask = np.maximum(mask, oracle.create_look_ahead_mask(Lq)[None, None])
+    return q, k, v, do, km, mask
+
+
+def _split(x, H):
+    B, L, d = x.shape
+    return x.reshape(B, L, H, d // H).transpose(0, 2, 1, 3)
+
+
+def _merge(x):
+    B, H, L, dh = x.shape
+    return x.transpose(0, 2, 1, 3).reshape(B, L, H * dh)
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,dh,causal,with_mask", [
+    (3, 8, 200, 200, 16, False, True),     # encoder self-attention, padding mask
+    (3, 8, 199, 199, 16, True, True),      # decoder self-attention, combined mask
+    (3, 8, 199, 200, 16, False, False),    # blind cross-attention
+    (2, 4, 37, 53, 16, False, True),       # ragged tiles
+    (2, 8, 200, 200, 32, False, True),     # cfg 3 head dim
+    (2, 4, 64, 64, 64, True, False),       # head dim 64
+    (2, 2, 16, 16, 16, True, True),
+    (1, 1, 1, 1, 16, False, False),        # degenerate
+])
+def test_attention_fwd_bwd(ops, B, H, Lq, Lk, dh, causal, with_mask):
+    q, k, v, do, km, mask = _attn_case(B, H, Lq, Lk, dh, causal, with_mask, seed=B * 1000 + Lq + dh)
+    want_o, _, cache = oracle.sdpa_fwd(_split(q, H), _split(k, H), _split(v, H), mask.astype(np.float64))
+    kmd = _dev(km, torch.uint8) if km is not None else None
+    o, stats = ops.attention_fwd(_dev(q), _dev(k), _dev(v), H, key_mask=kmd, causal=causal)
+    _close(o, _merge(want_o), name="attn fwd")
+    dq, dk, dv = oracle.sdpa_bwd(_split(do, H), cache)
+    gq, gk, gv = ops.attention_bwd(_dev(q), _dev(k), _dev(v), o, _dev(do), stats, H, key_mask=kmd, causal=causal)
+    _close(gq, _merge(dq), rtol=5e-5, name="attn dQ")
+    _close(gk, _merge(dk), rtol=5e-5, name="attn dK")
+    _close(gv, _merge(dv), rtol=5e-5, name="attn dV")
+
+
+def test_attention_fully_padded_sequence_matches_fp32_reference_semantics(ops):
+    """A row whose keys are ALL masked: x + (-1e9) rounds to -1e9 in fp32, so the
+    reference yields a uniform distribution over every key (incl. look-ahead ones)."""
+    B, H, L, dh = 2, 2, 40, 16
+    q, k, v, do, km, mask = _attn_case(B, H, L, L, dh, True, True, seed=11, all_pad_row=True)
+    f32 = np.float32
+    want_o, _, _ = oracle.sdpa_fwd(_split(q, H).astype(f32), _split(k, H).astype(f32), _split(v, H).astype(f32), mask)
+    o, _ = ops.attention_fwd(_dev(q), _dev(k), _dev(v), H, key_mask=_dev(km, torch.uint8), causal=True)
+    _close(o, _merge(want_o), rtol=1e-4, name="all-pad row")
+
+
+def test_attention_strided_qkv(ops):
+    """q/k/v as column slices of one (B,L,3d) projection buffer, as the train step uses them."""
+    B, H, L, dh = 2, 8, 50, 16
+    d = H * dh
+    rng = np.random.RandomState(3)
+    qkv = rng.randn(B, L, 3 * d)
+    t = _dev(qkv)
+    o, _ = ops.attention_fwd(t[..., :d], t[..., d:2 * d], t[..., 2 * d:], H)
+    want, _, _ = oracle.sdpa_fwd(_split(qkv[..., :d], H), _split(qkv[..., d:2 * d], H), _split(qkv[..., 2 * d:], H), None)
+    _close(o, _merge(want), name="strided qkv")
+
+
+# ------------------------------------------------------------------ embedding / layernorm / dropout
+def test_embed_fwd_bwd_with_dropout(ops):
+    from sketchformer_amd import engine
+    B, L, V, d, rate, site = 5, 33, 52, 128, 0.1, 3
+    rng = np.random.RandomState(0)
+    tok = rng.randint(0, V, size=(B, L + 1)); tok[:, 20:] = 0
+    table = rng.uniform(-0.05, 0.05, (V, d))
+    pos = engine.positional_encoding(64, d)
+    st = ops.new_step_state("cuda", iterations=7)
+    ops.step_prologue(st, seed=123)
+    key = ops.read_step_state(st)["drop_key"]
+    keep = ops.dropout_keep_mask(key, site, rate, B * L * d).reshape(B, L, d)
+    assert 0.85 < keep.mean() < 0.95
+    x = table[tok[:, :L]] * np.sqrt(np.float64(d)) + pos[None, :L]
+    out = ops.embed_fwd(_dev(tok, torch.int64), _dev(table), _dev(pos), L=L, rate=rate, site=site, state=st)
+    _close(out, x * keep / (1 - rate), name="embed fwd")
+    dx = rng.randn(B, L, d)
+    want = np.zeros((V, d))
+    np.add.at(want, tok[:, :L].reshape(-1), (dx * keep / (1 - rate) * np.sqrt(np.float64(d))).reshape(-1, d))
+    got = ops.embed_bwd(_dev(tok, torch.int64), _dev(dx), V, L=L, rate=rate, site=site, state=st)
+    _close(got, want, rtol=5e-5, name="embed bwd")
+
+
+@pytest.mark.parametrize("d,rate", [(128, 0.0), (128, 0.1), (256, 0.1), (64, 0.0), (512, 0.0)])
+def test_layernorm_residual_fwd_bwd(ops, d, rate):
+    rows = 1031
+    rng = np.random.RandomState(d)
+    x, y, dout = rng.randn(rows, d), rng.randn(rows, d), rng.randn(rows, d)
+    gamma, beta = 1 + 0.1 * rng.randn(d), 0.1 * rng.randn(d)
+    st = ops.new_step_state("cuda", iterations=3)
+    ops.step_prologue(st, seed=5)
+    keep = np.ones((rows, d), bool)
+    if rate > 0:
+        keep = ops.dropout_keep_mask(ops.read_step_state(st)["drop_key"], 9, rate, rows * d).reshape(rows, d)
+    z = x + oracle.dropout_fwd(y, keep, rate)
+    want, cache = oracle.layernorm_fwd(z, gamma, beta)
+    out, zz, stats = ops.layernorm_residual_fwd(_dev(x), _dev(y), _dev(gamma), _dev(beta), rate=rate, site=9, state=st)
+    _close(out, want, name="ln fwd")
+    _close(zz, z, name="ln z")
+    dz, dg, db = oracle.layernorm_bwd(dout, cache)
+    gz, gy, gg, gb = ops.layernorm_residual_bwd(_dev(dout), zz, stats, _dev(gamma), rate=rate, site=9, state=st)
+    _close(gz, dz, rtol=5e-5, name="ln dz")
+    _close(gy, oracle.dropout_fwd(dz, keep, rate), rtol=5e-5, name="ln dy")
+    _close(gg, dg, rtol=5e-5, name="ln dgamma")
+    _close(gb, db, rtol=5e-5, name="ln dbeta")
+
+
+# ------------------------------------------------------------------ loss heads
+@pytest.mark.parametrize("V", [1004, 52, 10004])
+def test_recon_softmax_ce(ops, V):
+    B, L = 4, 31
+    rng = np.random.RandomState(V)
+    logits = rng.randn(B, L - 1, V) * 3
+    tar = rng.randint(1, V, size=(B, L)); tar[:, 20:] = 0
+    logits[0, 0, :] = 0.0                      # all-equal row: argmax must be index 0
+    loss, cache = oracle.recon_loss_fwd(tar[:, 1:], logits, weight=1.0)
+    g = oracle.recon_loss_bwd(cache)
+    lg = _dev(logits.reshape(-1, V))
+    rl, rh, _ = ops.softmax_ce(lg, _dev(tar, torch.int64), tgt_cols=L - 1, tgt_off=1, mask_pad=True,
+                               scale=1.0 / (B * (L - 1)))
+    assert abs(rl.sum().item() / (B * (L - 1)) - loss) < 1e-5 * max(1, abs(loss))
+    _close(lg, g.reshape(-1, V), rtol=5e-5, name="dlogits")
+    hits = (logits.argmax(-1) == tar[:, 1:]).reshape(-1)
+    assert np.array_equal(rh.cpu().numpy() > 0.5, hits)
+
+
+def test_class_softmax_ce(ops):
+    B, C_ = 128, 345
+    rng = np.random.RandomState(1)
+    logits = rng.randn(B, C_)
+    lab = rng.randint(0, C_, size=(B, 1))
+    loss, cache = oracle.class_loss_fwd(lab, logits)
+    lg = _dev(logits)
+    rl, rh, probs = ops.softmax_ce(lg, _dev(lab, torch.int64), tgt_cols=1, scale=1.0 / B, want_probs=True)
+    assert abs(rl.mean().item() - loss) < 1e-5
+    _close(lg, oracle.class_loss_bwd(cache), rtol=5e-5, name="dclass")
+    e = np.exp(logits - logits.max(-1, keepdims=True))
+    _close(probs, e / e.sum(-1, keepdims=True), name="probs")
+
+
+# ------------------------------------------------------------------ bottleneck / expander / adam
+def test_pool_and_expander(ops):
+    B, L, U, d = 6, 200, 256, 128
+    rng = np.random.RandomState(2)
+    x = rng.randn(B, L, d)
+    P = {"bottleneck/W_attn": rng.randn(d, U) * 0.05, "bottleneck/b_attn": rng.randn(U) * 0.1,
+         "bottleneck/V_attn": rng.uniform(-0.5, 0.5, (U, 1)), "expand/kernel": rng.randn(1, L), "expand/bias": rng.randn(L)}
+    emb, a, cache = oracle.self_attn_v1_fwd(P, x)
+    u = np.tanh(x @ P["bottleneck/W_attn"] + P["bottleneck/b_attn"])
+    ga, gemb = ops.pool_fwd(_dev(u), _dev(P["bottleneck/V_attn"][:, 0]), _dev(x))
+    _close(gemb, emb, name="pool emb")
+    _close(ga, a[..., 0], name="pool a")
+    demb = rng.randn(B, d)
+    G = {}
+    dx_total = oracle.self_attn_v1_bwd(demb, cache, P, G)
+    dpre, dx, dV = ops.pool_bwd(_dev(u), _dev(P["bottleneck/V_attn"][:, 0]), _dev(x), ga, _dev(demb))
+    _close(dV, G["bottleneck/V_attn"][:, 0], rtol=5e-5, name="dV_attn")
+    dpre_np = dpre.cpu().numpy().astype(np.float64)
+    _close(x.reshape(-1, d).T @ dpre_np.reshape(-1, U), G["bottleneck/W_attn"], rtol=5e-5, name="dW_attn via dpre")
+    _close(dx.cpu().numpy().astype(np.float64) + dpre_np @ P["bottleneck/W_attn"].T, dx_total, rtol=5e-5, name="pool dx")
+    # expander
+    pre, c2 = oracle.dense_expander_fwd(P, emb)
+    _close(ops.expander_fwd(_dev(emb), _dev(P["expand/kernel"][0]), _dev(P["expand/bias"])), pre, name="expander fwd")
+    dpre2 = rng.randn(B, L, d)
+    G2 = {}
+    de = oracle.dense_expander_bwd(dpre2, c2, G2)
+    gde, gdw, gdb = ops.expander_bwd(_dev(dpre2), _dev(emb), _dev(P["expand/kernel"][0]))
+    _close(gde, de, rtol=5e-5, name="expander demb")
+    _close(gdw, G2["expand/kernel"][0], rtol=5e-5, name="expander dw")
+    _close(gdb, G2["expand/bias"], rtol=5e-5, name="expander dbias")
+
+
+def test_warmup_decay_and_adam(ops):
+    n = 10007
+    rng = np.random.RandomState(4)
+    for it in (0, 1, 4999, 5000, 20000):
+        st = ops.new_step_state("cuda", iterations=it)
+        ops.step_prologue(st, schedule=0, p0=128.0, p1=float(5000 ** -1.5))
+        s = ops.read_step_state(st)
+        want_lr = float(oracle.warmup_decay(it, 128, 5000))
+        assert abs(s["lr"] - want_lr) <= 1e-6 * max(want_lr, 1e-12), (it, s["lr"], want_lr)
+        w, g, m, v = rng.randn(n), rng.randn(n), rng.randn(n) * 0.1, np.abs(rng.randn(n)) * 0.01
+        W, M_, V_ = w.copy(), m.copy(), v.copy()
+        oracle.adam_update(W, g * 0.5, M_, V_, it, want_lr)
+        tw, tm, tv = _dev(w), _dev(m), _dev(v)
+        ops.adam_step(tw, _dev(g), tm, tv, st, grad_scale=0.5)
+        _close(tm, M_, name="adam m"); _close(tv, V_, name="adam v")
+        assert np.abs(tw.cpu().numpy() - W).max() <= 1e-6 * max(1.0, want_lr * 1e3), it
+        ops.step_epilogue(st)
+        assert ops.read_step_state(st)["iterations"] == it + 1
+    # KATs K1: lr(1)=2.5e-7, lr(5000)=1.25e-3, lr(20000)=6.25e-4, lr(0)=0
+    for it, want in ((0, 0.0), (1, 2.5e-7), (5000, 1.25e-3), (20000, 6.25e-4)):
+        st = ops.new_step_state("cuda", iterations=it)
+        ops.step_prologue(st)
+        assert abs(ops.read_step_state(st)["lr"] - want) <= 2e-6 * max(want, 1e-9)
