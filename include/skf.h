@@ -36,6 +36,13 @@ int skf_version(void);
 /* name of the device the library will launch on + number of visible devices (host query) */
 int skf_device_info(char* name_host, size_t name_len, int* n_devices_host);
 
+/* Per-launch timing with HIP events on the launch stream (bench.py's roofline leg).  enable(1) clears the
+ * records and starts recording every kernel launch made through this library on the calling process;
+ * report() synchronises the recorded events and writes one JSON array
+ * [{"tag","count","ms","flops","bytes"}...] (algorithmic flops / bytes summed over the launches of a tag). */
+int skf_profiler_enable(int on);
+int skf_profiler_report(char* buf_host, size_t len);
+
 /* ------------------------------------------------------------------ Dense
  * tf.keras.layers.Dense forward / dgrad / wgrad (+bias grad).
  * builders/layers/transformer.py:154-158,196-197; models/sketchformer.py:85-104.

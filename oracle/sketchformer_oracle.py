@@ -26,7 +26,7 @@ import numpy as np
 __all__ = [
     "Config", "param_specs", "init_params", "positional_encoding",
     "create_padding_mask", "create_look_ahead_mask", "create_masks",
-    "dense_fwd", "dense_bwd", "layernorm_fwd", "layernorm_bwd",
+    "dense_fwd", "dense_bwd", "dropout_fwd", "dropout_bwd", "layernorm_fwd", "layernorm_bwd",
     "sdpa_fwd", "sdpa_bwd", "mha_fwd", "mha_bwd", "self_attn_v1_fwd",
     "self_attn_v1_bwd", "dense_expander_fwd", "dense_expander_bwd",
     "recon_loss_fwd", "recon_loss_bwd", "continuous_recon_loss_fwd",

@@ -48,6 +48,8 @@ SIGNATURES = {
     "skf_last_error": (C.c_char_p, []),
     "skf_version": (_I, []),
     "skf_device_info": (_I, [C.c_char_p, _Z, C.POINTER(_I)]),
+    "skf_profiler_enable": (_I, [_I]),
+    "skf_profiler_report": (_I, [C.c_char_p, _Z]),
     "skf_gemm_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "skf_gemm_default_splits": (_I, [_I, _I, _I]),
     "skf_gemm_f32": (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _I, _P, _Z, _P]),

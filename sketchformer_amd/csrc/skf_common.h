@@ -38,6 +38,15 @@ void skf_set_error(const char* fmt, ...);
     }                                                               \
   } while (0)
 
+// Optional per-launch timing (HIP events on the launch stream), used by bench.py for the
+// roofline figures.  Inactive (one branch) unless skf_profiler_enable(1) was called.
+struct SkfProfScope {
+  SkfProfScope(hipStream_t st, const char* tag, double flops, double bytes);
+  ~SkfProfScope();
+  hipStream_t st_;
+  int idx_;
+};
+
 static inline int skf_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---------------------------------------------------------------- device

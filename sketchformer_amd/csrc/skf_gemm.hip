@@ -19,6 +19,7 @@
 // are transposed on the LDS store with a +1 pad that makes the 4 scalar stores
 // conflict-free.  blockIdx is remapped so that consecutive logical tiles (which
 // share an A row-panel) land on the same XCD / L2.
+#include <string>
 #include "skf_common.h"
 
 namespace {
@@ -261,6 +262,10 @@ int launch_variant(const GemmParams& p, int a_kc, int b_kc, int splits, hipStrea
       SKF_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));   \
       attr_done = true;                                                                                        \
     }                                                                                                          \
+    static const std::string tag = std::string(SPLITK ? "gemm_splitk" : "gemm") + "<" + std::to_string(BM) + "x" + \
+        std::to_string(BN) + "," + (AK ? "Ak" : "Am") + (BKC ? "Bk" : "Bn") + ">";                             \
+    SkfProfScope ps(st, tag.c_str(), 2.0 * p.M * p.N * p.K,                                                    \
+                    4.0 * ((double)p.M * p.K + (double)p.K * p.N + (double)p.M * p.N * (p.accumulate ? 2 : 1))); \
     hipLaunchKernelGGL(kfn, grid, block, smem, st, p);                                                         \
   }
   if (a_kc && !b_kc) SKF_GEMM_GO(true, false)
@@ -330,6 +335,7 @@ extern "C" int skf_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K,
   const size_t total = (size_t)M * N + N;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
+  SkfProfScope ps(st, "splitk_reduce", 0.0, 4.0 * ((double)splits + 1) * total);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.slab, splits, M, N, C, ldc, accumulate,
                      p.colsum_slab, bias_grad, bias_grad_accumulate);
   SKF_LAUNCH_CHECK();

@@ -34,6 +34,62 @@ extern "C" int skf_device_info(char* name_host, size_t name_len, int* n_devices_
   return SKF_OK;
 }
 
+// ------------------------------------------------------------------ launch profiler
+namespace {
+struct ProfRec { const char* tag; double flops, bytes; hipEvent_t e0, e1; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+}  // namespace
+
+SkfProfScope::SkfProfScope(hipStream_t st, const char* tag, double flops, double bytes) : st_(st), idx_(-1) {
+  if (!g_prof_on) return;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return;
+  ProfRec r{tag, flops, bytes, nullptr, nullptr};
+  if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+  (void)hipEventRecord(r.e0, st);
+  g_prof.push_back(r);
+  idx_ = (int)g_prof.size() - 1;
+}
+SkfProfScope::~SkfProfScope() {
+  if (idx_ >= 0) (void)hipEventRecord(g_prof[idx_].e1, st_);
+}
+
+extern "C" int skf_profiler_enable(int on) {
+  for (auto& r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  g_prof.clear();
+  g_prof_on = on != 0;
+  return SKF_OK;
+}
+
+extern "C" int skf_profiler_report(char* buf_host, size_t len) {
+  SKF_CHECK_ARG(buf_host && len > 2, "bad buffer");
+  struct Agg { int count = 0; double ms = 0, flops = 0, bytes = 0; };
+  std::vector<std::pair<std::string, Agg>> order;
+  std::map<std::string, size_t> index;
+  for (auto& r : g_prof) {
+    SKF_HIP(hipEventSynchronize(r.e1));
+    float ms = 0.f;
+    SKF_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
+    auto it = index.find(r.tag);
+    if (it == index.end()) { index[r.tag] = order.size(); order.push_back({r.tag, Agg()}); it = index.find(r.tag); }
+    Agg& a = order[it->second].second;
+    a.count += 1; a.ms += ms; a.flops += r.flops; a.bytes += r.bytes;
+  }
+  std::string out = "[";
+  char line[384];
+  for (size_t i = 0; i < order.size(); ++i) {
+    const Agg& a = order[i].second;
+    snprintf(line, sizeof(line), "%s{\"tag\":\"%s\",\"count\":%d,\"ms\":%.6f,\"flops\":%.6e,\"bytes\":%.6e}", i ? "," : "",
+             order[i].first.c_str(), a.count, a.ms, a.flops, a.bytes);
+    out += line;
+  }
+  out += "]";
+  SKF_CHECK_ARG(out.size() + 1 <= len, "report buffer too small");
+  memcpy(buf_host, out.c_str(), out.size() + 1);
+  return SKF_OK;
+}
+
 namespace {
 
 inline size_t pad4(size_t n) { return (n + 3) & ~(size_t)3; }
@@ -500,10 +556,10 @@ int capture_or_run(SkfModel* M, hipGraphExec_t* exec, hipStream_t s, F body) {
     SKF_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     int rc = body();
     hipError_t e = hipStreamEndCapture(s, &graph);
-    if (rc != SKF_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+    if (rc != SKF_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     if (e != hipSuccess) { skf_set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return SKF_EHIP; }
     e = hipGraphInstantiate(exec, graph, nullptr, nullptr, 0);
-    hipGraphDestroy(graph);
+    (void)hipGraphDestroy(graph);
     if (e != hipSuccess) { skf_set_error("hipGraphInstantiate: %s", hipGetErrorString(e)); *exec = nullptr; return SKF_EHIP; }
   }
   SKF_HIP(hipGraphLaunch(*exec, s));
@@ -579,8 +635,8 @@ extern "C" int skf_model_create(const SkfConfig* cfg, SkfModel** out) {
 
 extern "C" void skf_model_destroy(SkfModel* m) {
   if (!m) return;
-  if (m->g_fb) hipGraphExecDestroy(m->g_fb);
-  if (m->g_opt) hipGraphExecDestroy(m->g_opt);
+  if (m->g_fb) (void)hipGraphExecDestroy(m->g_fb);
+  if (m->g_opt) (void)hipGraphExecDestroy(m->g_opt);
   delete m;
 }
 
@@ -592,8 +648,8 @@ extern "C" int skf_model_bind(SkfModel* m, float* params, float* grads, float* a
   SKF_CHECK_ARG((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)adam_m | (uintptr_t)adam_v) & 15) == 0, "flat buffers must be 16-byte aligned");
   m->params = params; m->grads = grads; m->m = adam_m; m->v = adam_v; m->pos = pos;
   m->ws = (char*)workspace; m->metrics = metrics; m->state = step_state;
-  if (m->g_fb) { hipGraphExecDestroy(m->g_fb); m->g_fb = nullptr; }
-  if (m->g_opt) { hipGraphExecDestroy(m->g_opt); m->g_opt = nullptr; }
+  if (m->g_fb) { (void)hipGraphExecDestroy(m->g_fb); m->g_fb = nullptr; }
+  if (m->g_opt) { (void)hipGraphExecDestroy(m->g_opt); m->g_opt = nullptr; }
   return SKF_OK;
 }
 
@@ -622,7 +678,7 @@ extern "C" int skf_model_forward_backward(SkfModel* m, const long long* inp, con
 extern "C" int skf_model_apply_gradients(SkfModel* m, float grad_scale, skf_stream_t stream) {
   SKF_CHECK_ARG(m && m->ws, "model not bound");
   hipStream_t s = (hipStream_t)stream;
-  if (m->g_opt && m->g_opt_scale != grad_scale) { hipGraphExecDestroy(m->g_opt); m->g_opt = nullptr; }
+  if (m->g_opt && m->g_opt_scale != grad_scale) { (void)hipGraphExecDestroy(m->g_opt); m->g_opt = nullptr; }
   m->g_opt_scale = grad_scale;
   return capture_or_run(m, &m->g_opt, s, [&]() -> int {
     SKF_TRY(skf_adam_step(m->params, m->grads, m->m, m->v, m->lay.total, m->state, grad_scale, m->cfg.beta1,

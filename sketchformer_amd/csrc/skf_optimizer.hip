@@ -105,6 +105,7 @@ extern "C" int skf_adam_step(float* w, const float* g, float* m, float* v, size_
   size_t blocks = ((n >> 2) + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
+  SkfProfScope ps((hipStream_t)stream, "adam", 0.0, 28.0 * n);
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, g, m, v, n,
                      (const SkfStepState*)step_state, grad_scale, 1.0f - beta1, 1.0f - beta2, eps);
   SKF_LAUNCH_CHECK();

@@ -411,6 +411,7 @@ extern "C" int skf_embed_fwd(const long long* tokens, int tok_ld, int B, int L, 
   SKF_CHECK_ARG((d & 1) == 0, "d_model must be even");
   SKF_CHECK_ARG(rate == 0.f || step_state, "dropout needs the step state");
   const int rows = B * L;
+  SkfProfScope ps((hipStream_t)stream, "embed_fwd", 0.0, 8.0 * rows * d);
   hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid_for_rows(rows)), dim3(256), 0, (hipStream_t)stream, tokens, tok_ld, L,
                      rows, table, vocab, d, pos, out, rate, site, (const SkfStepState*)step_state);
   SKF_LAUNCH_CHECK();
@@ -432,6 +433,7 @@ extern "C" int skf_embed_bwd(const long long* tokens, int tok_ld, int B, int L, 
   SKF_CHECK_ARG((d & 1) == 0, "d_model must be even");
   const int rows = B * L;
   int grid = skf_cdiv(rows, 256);
+  SkfProfScope ps((hipStream_t)stream, "embed_bwd", 0.0, 8.0 * rows * d);
   hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, tokens, tok_ld, L, rows, dx, vocab,
                      d, dtable, rate, site, (const SkfStepState*)step_state);
   SKF_LAUNCH_CHECK();
@@ -446,6 +448,7 @@ extern "C" int skf_layernorm_residual_fwd(const float* x, float* y_inout_z, cons
   const SkfStepState* st = (const SkfStepState*)step_state;
   dim3 grid(grid_for_rows(rows)), block(256);
   hipStream_t s = (hipStream_t)stream;
+  SkfProfScope ps(s, "ln_fwd", 0.0, 16.0 * rows * d);
   switch (d) {
     case 128: hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, block, 0, s, x, y_inout_z, gamma, beta, out, stats, rows, rate, site, st); break;
     case 256: hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, block, 0, s, x, y_inout_z, gamma, beta, out, stats, rows, rate, site, st); break;
@@ -474,6 +477,7 @@ extern "C" int skf_layernorm_residual_bwd(const float* dout, const float* z, con
   hipStream_t s = (hipStream_t)stream;
   float* part = (float*)workspace;
   float* dyp = rate > 0.f ? dy : nullptr;
+  SkfProfScope ps(s, "ln_bwd", 0.0, (rate > 0.f ? 16.0 : 12.0) * rows * d);
   switch (d) {
     case 128: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, 0, s, dout, z, stats, gamma, dz, dyp, part, rows, rate, site, st); break;
     case 256: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, s, dout, z, stats, gamma, dz, dyp, part, rows, rate, site, st); break;
@@ -501,6 +505,7 @@ extern "C" int skf_softmax_ce(float* logits, int ld, int rows, int ncls, const l
                               float* probs_out, int write_grad, skf_stream_t stream) {
   SKF_CHECK_ARG(logits && target && row_loss && row_hit, "null operand");
   SKF_CHECK_ARG(rows > 0 && ncls > 0 && tgt_cols > 0, "empty problem");
+  SkfProfScope ps((hipStream_t)stream, "softmax_ce", 0.0, 8.0 * rows * ncls);
   hipLaunchKernelGGL(softmax_ce_kernel, dim3(grid_for_rows(rows)), dim3(256), 0, (hipStream_t)stream, logits, ld, rows, ncls,
                      target, tgt_ld, tgt_cols, tgt_off, mask_pad, scale, row_loss, row_hit, probs_out, write_grad);
   SKF_LAUNCH_CHECK();
@@ -520,6 +525,7 @@ extern "C" int skf_metrics_update(const float* recon_loss, const float* recon_hi
 extern "C" int skf_pool_fwd(const float* u, const float* Vw, const float* x, int B, int L, int U, int d, float* a_out,
                             float* emb, skf_stream_t stream) {
   SKF_CHECK_ARG(u && Vw && x && a_out && emb, "null operand");
+  SkfProfScope ps((hipStream_t)stream, "pool_fwd", 0.0, 4.0 * B * L * (U + d));
   hipLaunchKernelGGL(pool_fwd_kernel, dim3(B), dim3(256), L * sizeof(float), (hipStream_t)stream, u, Vw, x, L, U, d, a_out, emb);
   SKF_LAUNCH_CHECK();
   return SKF_OK;
@@ -532,6 +538,7 @@ extern "C" int skf_pool_bwd(float* u_inout_dpre, const float* Vw, const float* x
   SKF_CHECK_ARG(workspace && workspace_bytes >= (size_t)B * U * sizeof(float), "workspace too small");
   hipStream_t s = (hipStream_t)stream;
   float* part = (float*)workspace;
+  SkfProfScope ps(s, "pool_bwd", 0.0, 8.0 * B * L * (U + d));
   hipLaunchKernelGGL(pool_bwd_kernel, dim3(B), dim3(256), 2 * L * sizeof(float), s, u_inout_dpre, Vw, x, a, demb, L, U, d, dx, part);
   hipLaunchKernelGGL(colsum_kernel, dim3(skf_cdiv(U, 64)), dim3(256), 0, s, part, B, U, U, dV, 0);
   SKF_LAUNCH_CHECK();
@@ -543,6 +550,7 @@ extern "C" int skf_expander_fwd(const float* emb, const float* w, const float* b
   SKF_CHECK_ARG(emb && w && bias && pre, "null operand");
   const size_t total = (size_t)B * L * d;
   int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
+  SkfProfScope ps((hipStream_t)stream, "expander_fwd", 0.0, 4.0 * total);
   hipLaunchKernelGGL(expander_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, emb, w, bias, B, L, d, pre);
   SKF_LAUNCH_CHECK();
   return SKF_OK;
@@ -556,6 +564,7 @@ extern "C" int skf_expander_bwd(const float* dpre, const float* emb, const float
   hipStream_t s = (hipStream_t)stream;
   float* p1 = (float*)workspace;
   float* p2 = p1 + (size_t)B * L;
+  SkfProfScope ps(s, "expander_bwd", 0.0, 8.0 * B * L * d);
   hipLaunchKernelGGL(expander_bwd_kernel, dim3(B), dim3(256), 0, s, dpre, emb, w, L, d, demb, demb_accumulate, p1, p2);
   hipLaunchKernelGGL(colsum_kernel, dim3(skf_cdiv(L, 64)), dim3(256), 0, s, p1, B, L, L, dw, 0);
   hipLaunchKernelGGL(colsum_kernel, dim3(skf_cdiv(L, 64)), dim3(256), 0, s, p2, B, L, L, dbias, 0);

@@ -135,6 +135,8 @@ class TrainEngine:
         _lib.call("skf_model_bind", handle, self._p(self.params), self._p(self.grads), self._p(self.adam_m),
                   self._p(self.adam_v), self._p(self.pos), C.c_void_p(self._ws_ptr), ws_bytes, self._p(self.metrics),
                   self._p(self.state))
+        # a dedicated non-default stream: hipGraph capture is illegal on the legacy default stream
+        self.stream = torch.cuda.Stream(device=dev)
         self.pg = process_group
         self.world_size = torch.distributed.get_world_size(process_group) if process_group is not None else 1
 
@@ -151,7 +153,18 @@ class TrainEngine:
         return C.c_void_p(t.data_ptr())
 
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return C.c_void_p(self.stream.cuda_stream)
+
+    def _enter(self):
+        # order after whatever the caller queued on its current stream (H2D copies of the batch, set())
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+
+    def _leave(self):
+        # let the caller's stream observe the step's results
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
+    def synchronize(self):
+        self.stream.synchronize()
 
     # ---- parameters by (Keras-style) name
     def _view(self, flat, name):
@@ -184,19 +197,26 @@ class TrainEngine:
         """Transformer.call: fills the internal buffers (see ``buffer``)."""
         inp = self._dev_tokens(inp)
         tar = inp if tar is None else self._dev_tokens(tar)
+        self._enter()
         _lib.call("skf_model_forward", self.handle, self._p(inp), self._p(tar), tar.stride(0), int(training), self._stream())
+        self._leave()
 
     def forward_backward(self, inp, tar, labels):
         inp = self._dev_tokens(inp)
         tar = inp if tar is None else self._dev_tokens(tar)
         labels = self._dev_tokens(labels)
+        self._enter()
         _lib.call("skf_model_forward_backward", self.handle, self._p(inp), self._p(tar), tar.stride(0), self._p(labels),
                   self._stream())
+        self._leave()
 
     def apply_gradients(self):
+        self._enter()
         if self.world_size > 1:
-            torch.distributed.all_reduce(self.grads, group=self.pg)
+            with torch.cuda.stream(self.stream):
+                torch.distributed.all_reduce(self.grads, group=self.pg)
         _lib.call("skf_model_apply_gradients", self.handle, 1.0 / self.world_size, self._stream())
+        self._leave()
 
     def train_step(self, inp, labels, tar=None):
         """model_trainer(inp, tar, lab) (models/sketchformer.py:325-349); no host sync."""

@@ -85,9 +85,16 @@ def test_losses_and_all_gradients(rate, use_graph):
     acc = (out["recon"].argmax(-1) == x[:, 1:]).mean()
     assert abs(m["recon_acc"] - acc) < 1e-6
     got = eng.state_dict_numpy("grads")
-    worst = max((_rel(got[k], G[k]), k) for k in G)
+    # d loss / d(wk bias) is analytically 0 (softmax is invariant to a per-query shift of all keys' scores):
+    # the oracle gives ~1e-17, fp32 gives ~1e-8 - compare those against the gradient scale of the model instead.
+    floor = 1e-4 * np.median([np.abs(G[k]).max() for k in G])
+    rel = {k: np.abs(got[k].astype(np.float64) - G[k]).max() / max(np.abs(G[k]).max(), floor) for k in G}
+    worst = max((v, k) for k, v in rel.items())
     assert worst[0] < 1e-3, worst                 # acceptance bar; typically ~1e-5
-    assert np.median([_rel(got[k], G[k]) for k in G]) < 5e-5
+    assert np.median(list(rel.values())) < 5e-5
+    for k in G:
+        if k.endswith("wk/bias"):
+            assert np.abs(got[k]).max() < floor, k
 
 
 def test_adam_trajectory_matches_oracle():
@@ -109,7 +116,9 @@ def test_adam_trajectory_matches_oracle():
     for k, v in res.items():
         assert abs(run[k] - v) < 1e-3 * max(1.0, abs(v)), (k, run[k], v)
     got = eng.state_dict_numpy()
-    worst = max((np.abs(got[k] - st.params[k]).max(), k) for k in got)
+    # wk biases have an analytically zero gradient; Adam's m/sqrt(v) turns their rounding noise into +-lr steps
+    # (in the reference too), and they cannot influence the loss - they are excluded from the trajectory check.
+    worst = max((np.abs(got[k] - st.params[k]).max(), k) for k in got if not k.endswith("wk/bias"))
     assert worst[0] < 5e-4, worst
 
 
