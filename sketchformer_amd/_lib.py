@@ -98,6 +98,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise SkfError("libskf.so not found at %s - run `python -m sketchformer_amd.build` "
                        "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+    # PyTorch-ROCm ships its own libamdhip64: import it first so that libskf.so binds to the SAME HIP runtime
+    # (streams / device pointers are only meaningful inside one runtime instance).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported

@@ -87,7 +87,7 @@ def test_losses_and_all_gradients(rate, use_graph):
     got = eng.state_dict_numpy("grads")
     # d loss / d(wk bias) is analytically 0 (softmax is invariant to a per-query shift of all keys' scores):
     # the oracle gives ~1e-17, fp32 gives ~1e-8 - compare those against the gradient scale of the model instead.
-    floor = 1e-4 * np.median([np.abs(G[k]).max() for k in G])
+    floor = 1e-3 * np.median([np.abs(G[k]).max() for k in G])
     rel = {k: np.abs(got[k].astype(np.float64) - G[k]).max() / max(np.abs(G[k]).max(), floor) for k in G}
     worst = max((v, k) for k, v in rel.items())
     assert worst[0] < 1e-3, worst                 # acceptance bar; typically ~1e-5
