@@ -53,10 +53,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   const int nkt = (p.Lk + 15) >> 4, nqt = (p.Lq + 15) >> 4;
   float* Ks = smem;                       // [nkt*16][LD]
   float* Vs = smem + nkt * 16 * LD;       // [nkt*16][LD]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* Ms = Vs + nkt * 16 * LD;         // [nkt*16] additive key mask: 0, -1e9 (padded key) or -inf (key >= Lk)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: loop bounds stay scalar
   const int i = lane & 15, g = lane >> 4;
 
-  // ---- stage K, V (zero-filled tail rows)
+  // ---- stage K, V (zero-filled tail rows) and the key mask
   for (int e = tid; e < nkt * 16 * (DH / 4); e += 256) {
     const int row = e / (DH / 4), c4 = (e % (DH / 4)) * 4;
     float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
@@ -67,12 +69,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     *reinterpret_cast<float4*>(&Ks[row * LD + c4]) = kv;
     *reinterpret_cast<float4*>(&Vs[row * LD + c4]) = vv;
   }
+  for (int key = tid; key < nkt * 16; key += 256) {
+    float mv = -INFINITY;
+    if (key < p.Lk) mv = (p.key_mask && p.key_mask[(size_t)b * p.key_mask_ld + key]) ? -1e9f : 0.f;
+    Ms[key] = mv;
+  }
   __syncthreads();
 
-  const unsigned char* km = p.key_mask ? p.key_mask + (size_t)b * p.key_mask_ld : nullptr;
   // Causal tile skipping is exact only when key 0 is visible to every query
   // (then every row max is a real score and masked probabilities are exactly 0).
-  const bool can_skip = p.causal && !(km && km[0]);
+  const bool can_skip = p.causal && Ms[0] == 0.f;
   const float inv_sqrt = 1.0f / sqrtf((float)DH);
   const bool pow4 = (DH == 16 || DH == 64);
 
@@ -100,13 +106,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
           acc = mfma16(kf.z, qf[c].z, acc);
           acc = mfma16(kf.w, qf[c].w, acc);
         }
+        // logits = (q.k)/sqrt(dh) + max(pad, look_ahead) * -1e9  (one -1e9, never two)
+        const float4 m4 = *reinterpret_cast<const float4*>(&Ms[kt * 16 + g * 4]);
+        const float mr[4] = {m4.x, m4.y, m4.z, m4.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = kt * 16 + g * 4 + r;
-          float v = pow4 ? acc[r] * inv_sqrt : acc[r] / sqrtf((float)DH);
-          const bool masked = (km && key < p.Lk && km[key]) || (p.causal && key > qrow);
-          if (masked) v += -1e9f;
-          if (key >= p.Lk) v = -INFINITY;
+          const float cm = (p.causal && key > qrow) ? -1e9f : 0.f;
+          const float v = (pow4 ? acc[r] * inv_sqrt : acc[r] / sqrtf((float)DH)) + fminf(mr[r], cm);
           s[kt][r] = v;
           mx = fmaxf(mx, v);
         }
@@ -151,7 +158,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   }
 }
 
-template <int DH>
+// KTW = key tiles owned by one wave at a time (register budget: 20*NC*KTW accumulator/fragment registers)
+template <int DH, int KTW>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
   constexpr int NC = DH / 16;
   constexpr int LD = DH + 4;
@@ -159,15 +167,16 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
   const int nkt = (p.Lk + 15) >> 4, nqt = (p.Lq + 15) >> 4;
-  const int QR = nqt * 16;
+  const int QR = nqt * 16, LDT = QR + 4;
   float* Qs = smem;                   // [QR][LD]
   float* dOs = Qs + QR * LD;          // [QR][LD]
-  float* dQs = dOs + QR * LD;         // [QR][LD]
-  float* Mx = dQs + QR * LD;          // [QR]
+  float* dQt = dOs + QR * LD;         // [DH][LDT]  dQ^T accumulator (d-major: the 64 atomic lanes hit 32 banks 2-way)
+  float* Mx = dQt + DH * LDT;         // [QR]
   float* Ri = Mx + QR;                // [QR]
   float* Dl = Ri + QR;                // [QR]  delta = sum_d dO*O
   float* Tr = Dl + QR;                // [4 waves][16][TLD]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, g = lane >> 4;
 
   for (int e = tid; e < QR * (DH / 4); e += 256) {
@@ -179,8 +188,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
     }
     *reinterpret_cast<float4*>(&Qs[row * LD + c4]) = qv;
     *reinterpret_cast<float4*>(&dOs[row * LD + c4]) = dv;
-    *reinterpret_cast<float4*>(&dQs[row * LD + c4]) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  for (int e = tid; e < DH * LDT; e += 256) dQt[e] = 0.f;
   for (int row = tid; row < QR; row += 256) {
     float mx = 0.f, ri = 0.f, dl = 0.f;
     if (row < p.Lq) {
@@ -200,102 +209,138 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
   __syncthreads();
 
   const unsigned char* km = p.key_mask ? p.key_mask + (size_t)b * p.key_mask_ld : nullptr;
+  // skipping fully look-ahead-masked tiles is exact only if key 0 is visible (see forward)
+  const bool can_skip = p.causal && !(km && km[0]);
   const float inv_sqrt = 1.0f / sqrtf((float)DH);
   const bool pow4 = (DH == 16 || DH == 64);
   float* tr = Tr + wave * 16 * TLD;
 
-  for (int kt = wave; kt < nkt; kt += 4) {
-    const int k0 = kt * 16, krow = k0 + i;
-    const bool kok = krow < p.Lk;
+  for (int kg = 0; kg < nkt; kg += 4 * KTW) {
+    const int kt0 = kg + wave;                 // smallest key tile of this wave in this group
+    if (kt0 >= nkt) continue;
     // B-operand fragments (lane = key i, contraction d = 16c+4g+s) and
     // A-operand (transposed) fragments (lane = d 16c+i, contraction key = k0+4g+s)
-    float4 kb[NC], vb[NC];
-    float kT[NC][4];
+    float4 kb[KTW][NC], vb[KTW][NC];
+    float kT[KTW][NC][4];
+    float kadd[KTW], kvalid[KTW];
+    f32x4 dKt[KTW][NC], dVt[KTW][NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      kb[c] = make_float4(0.f, 0.f, 0.f, 0.f); vb[c] = kb[c];
-      if (kok) {
-        kb[c] = *reinterpret_cast<const float4*>(p.K + (size_t)(b * p.Lk + krow) * p.ldk + h * DH + c * 16 + g * 4);
-        vb[c] = *reinterpret_cast<const float4*>(p.V + (size_t)(b * p.Lk + krow) * p.ldv + h * DH + c * 16 + g * 4);
-      }
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int kr = k0 + g * 4 + s;
-        kT[c][s] = kr < p.Lk ? p.K[(size_t)(b * p.Lk + kr) * p.ldk + h * DH + c * 16 + i] : 0.f;
-      }
-    }
-    const bool kmasked = km && kok && km[krow];
-    f32x4 dKt[NC], dVt[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) { dKt[c] = (f32x4){0.f, 0.f, 0.f, 0.f}; dVt[c] = dKt[c]; }
-
-    const int qt_begin = p.causal ? kt : 0;   // tiles with every q < every k contribute exactly 0
-    for (int qt = qt_begin; qt < nqt; ++qt) {
-      const int q0 = qt * 16;
-      f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dpacc = sacc;
+    for (int j = 0; j < KTW; ++j) {
+      const int k0 = (kt0 + 4 * j) * 16, krow = k0 + i;
+      const bool kok = krow < p.Lk;
+      kvalid[j] = kok ? 1.f : 0.f;
+      kadd[j] = (km && kok && km[krow]) ? -1e9f : 0.f;
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        const float4 qa = *reinterpret_cast<const float4*>(&Qs[(q0 + i) * LD + c * 16 + g * 4]);
-        const float4 da = *reinterpret_cast<const float4*>(&dOs[(q0 + i) * LD + c * 16 + g * 4]);
-        sacc = mfma16(qa.x, kb[c].x, sacc);
-        sacc = mfma16(qa.y, kb[c].y, sacc);
-        sacc = mfma16(qa.z, kb[c].z, sacc);
-        sacc = mfma16(qa.w, kb[c].w, sacc);
-        dpacc = mfma16(da.x, vb[c].x, dpacc);
-        dpacc = mfma16(da.y, vb[c].y, dpacc);
-        dpacc = mfma16(da.z, vb[c].z, dpacc);
-        dpacc = mfma16(da.w, vb[c].w, dpacc);
+        kb[j][c] = make_float4(0.f, 0.f, 0.f, 0.f); vb[j][c] = kb[j][c];
+        if (kok) {
+          kb[j][c] = *reinterpret_cast<const float4*>(p.K + (size_t)(b * p.Lk + krow) * p.ldk + h * DH + c * 16 + g * 4);
+          vb[j][c] = *reinterpret_cast<const float4*>(p.V + (size_t)(b * p.Lk + krow) * p.ldv + h * DH + c * 16 + g * 4);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int kr = k0 + g * 4 + s;
+          kT[j][c][s] = kr < p.Lk ? p.K[(size_t)(b * p.Lk + kr) * p.ldk + h * DH + c * 16 + i] : 0.f;
+        }
+        dKt[j][c] = (f32x4){0.f, 0.f, 0.f, 0.f}; dVt[j][c] = dKt[j][c];
       }
-      // lane holds rows q = q0+4g+r, column key = k0+i
-      float pr[4], ds[4];
+    }
+
+    const int qt_begin = can_skip ? kt0 : 0;   // query tiles entirely above the wave's first key tile contribute 0
+    const int nq_act = nqt - qt_begin;
+    for (int it = 0; it < nq_act; ++it) {
+      // each wave starts at a different query tile so the waves' LDS atomics on dQ do not collide
+      const int qt = qt_begin + (it + wave * 3) % nq_act;
+      const int q0 = qt * 16;
+      float4 qa[NC], da[NC];
+      float qT[NC][4], dT[NC][4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int q = q0 + g * 4 + r;
-        float v = pow4 ? sacc[r] * inv_sqrt : sacc[r] / sqrtf((float)DH);
-        if (kmasked || (p.causal && krow > q)) v += -1e9f;
-        float pv = __expf(v - Mx[q]) * Ri[q];
-        if (!kok || q >= p.Lq) pv = 0.f;
-        pr[r] = pv;
-        float d = pv * (dpacc[r] - Dl[q]);
-        ds[r] = pow4 ? d * inv_sqrt : d / sqrtf((float)DH);
-      }
-      // dV^T[d][k] += sum_q dO[q][d] P[q][k];  dK^T[d][k] += sum_q Q[q][d] dS[q][k]
+      for (int c = 0; c < NC; ++c) {
+        qa[c] = *reinterpret_cast<const float4*>(&Qs[(q0 + i) * LD + c * 16 + g * 4]);
+        da[c] = *reinterpret_cast<const float4*>(&dOs[(q0 + i) * LD + c * 16 + g * 4]);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int qr = q0 + g * 4 + r;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-          dVt[c] = mfma16(dOs[qr * LD + c * 16 + i], pr[r], dVt[c]);
-          dKt[c] = mfma16(Qs[qr * LD + c * 16 + i], ds[r], dKt[c]);
+        for (int r = 0; r < 4; ++r) {
+          qT[c][r] = Qs[(q0 + g * 4 + r) * LD + c * 16 + i];
+          dT[c][r] = dOs[(q0 + g * 4 + r) * LD + c * 16 + i];
         }
       }
-      // transpose dS through the wave-private scratch: write [q][k], read [q=i][k=4g..4g+3]
+      const float4 mx4 = *reinterpret_cast<const float4*>(&Mx[q0 + g * 4]);
+      const float4 ri4 = *reinterpret_cast<const float4*>(&Ri[q0 + g * 4]);   // 0 for rows >= Lq
+      const float4 dl4 = *reinterpret_cast<const float4*>(&Dl[q0 + g * 4]);
+      const float mxr[4] = {mx4.x, mx4.y, mx4.z, mx4.w}, rir[4] = {ri4.x, ri4.y, ri4.z, ri4.w},
+                  dlr[4] = {dl4.x, dl4.y, dl4.z, dl4.w};
+      f32x4 dq[NC];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) tr[(g * 4 + r) * TLD + i] = ds[r];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_wave_barrier();
-      const float4 dst = *reinterpret_cast<const float4*>(&tr[i * TLD + g * 4]);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_wave_barrier();
-      // dQ^T[d][q] += sum_k K[k][d] dS[q][k]   (lane: d = 16c+4g+r, q = q0+i)
+      for (int c = 0; c < NC; ++c) dq[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
 #pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        f32x4 dq = {0.f, 0.f, 0.f, 0.f};
-        dq = mfma16(kT[c][0], dst.x, dq);
-        dq = mfma16(kT[c][1], dst.y, dq);
-        dq = mfma16(kT[c][2], dst.z, dq);
-        dq = mfma16(kT[c][3], dst.w, dq);
+      for (int j = 0; j < KTW; ++j) {
+        const int kt = kt0 + 4 * j;
+        if (kt >= nkt || (can_skip && kt > qt)) continue;     // wave-uniform
+        const int krow = kt * 16 + i;
+        f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dpacc = sacc;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(&dQs[(q0 + i) * LD + c * 16 + g * 4 + r], dq[r]);
+        for (int c = 0; c < NC; ++c) {
+          sacc = mfma16(qa[c].x, kb[j][c].x, sacc);
+          sacc = mfma16(qa[c].y, kb[j][c].y, sacc);
+          sacc = mfma16(qa[c].z, kb[j][c].z, sacc);
+          sacc = mfma16(qa[c].w, kb[j][c].w, sacc);
+          dpacc = mfma16(da[c].x, vb[j][c].x, dpacc);
+          dpacc = mfma16(da[c].y, vb[j][c].y, dpacc);
+          dpacc = mfma16(da[c].z, vb[j][c].z, dpacc);
+          dpacc = mfma16(da[c].w, vb[j][c].w, dpacc);
+        }
+        // lane holds rows q = q0+4g+r, column key = k0+i
+        float pr[4], ds[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = q0 + g * 4 + r;
+          const float cm = (p.causal && krow > q) ? -1e9f : 0.f;
+          const float v = (pow4 ? sacc[r] * inv_sqrt : sacc[r] / sqrtf((float)DH)) + fminf(kadd[j], cm);
+          const float pv = __expf(v - mxr[r]) * (rir[r] * kvalid[j]);
+          pr[r] = pv;
+          const float d = pv * (dpacc[r] - dlr[r]);
+          ds[r] = pow4 ? d * inv_sqrt : d / sqrtf((float)DH);
+        }
+        // dV^T[d][k] += sum_q dO[q][d] P[q][k];  dK^T[d][k] += sum_q Q[q][d] dS[q][k]
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            dVt[j][c] = mfma16(dT[c][r], pr[r], dVt[j][c]);
+            dKt[j][c] = mfma16(qT[c][r], ds[r], dKt[j][c]);
+          }
+        // transpose dS through the wave-private scratch: write [q][k], read [q=i][k=4g..4g+3]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tr[(g * 4 + r) * TLD + i] = ds[r];
+        __builtin_amdgcn_wave_barrier();
+        const float4 dst = *reinterpret_cast<const float4*>(&tr[i * TLD + g * 4]);
+        __builtin_amdgcn_wave_barrier();
+        // dQ^T[d][q] += sum_k K[k][d] dS[q][k]   (lane: d = 16c+4g+r, q = q0+i)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          dq[c] = mfma16(kT[j][c][0], dst.x, dq[c]);
+          dq[c] = mfma16(kT[j][c][1], dst.y, dq[c]);
+          dq[c] = mfma16(kT[j][c][2], dst.z, dq[c]);
+          dq[c] = mfma16(kT[j][c][3], dst.w, dq[c]);
+        }
       }
-    }
-    if (kok) {
 #pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        *reinterpret_cast<float4*>(p.dK + (size_t)(b * p.Lk + krow) * p.lddk + h * DH + c * 16 + g * 4) =
-            make_float4(dKt[c][0], dKt[c][1], dKt[c][2], dKt[c][3]);
-        *reinterpret_cast<float4*>(p.dV + (size_t)(b * p.Lk + krow) * p.lddv + h * DH + c * 16 + g * 4) =
-            make_float4(dVt[c][0], dVt[c][1], dVt[c][2], dVt[c][3]);
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(&dQt[(c * 16 + g * 4 + r) * LDT + q0 + i], dq[c][r]);
+    }
+#pragma unroll
+    for (int j = 0; j < KTW; ++j) {
+      const int krow = (kt0 + 4 * j) * 16 + i;
+      if (krow < p.Lk) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          *reinterpret_cast<float4*>(p.dK + (size_t)(b * p.Lk + krow) * p.lddk + h * DH + c * 16 + g * 4) =
+              make_float4(dKt[j][c][0], dKt[j][c][1], dKt[j][c][2], dKt[j][c][3]);
+          *reinterpret_cast<float4*>(p.dV + (size_t)(b * p.Lk + krow) * p.lddv + h * DH + c * 16 + g * 4) =
+              make_float4(dVt[j][c][0], dVt[j][c][1], dVt[j][c][2], dVt[j][c][3]);
+        }
       }
     }
   }
@@ -303,14 +348,14 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
   for (int e = tid; e < p.Lq * (DH / 4); e += 256) {
     const int row = e / (DH / 4), c4 = (e % (DH / 4)) * 4;
     *reinterpret_cast<float4*>(p.dQ + (size_t)(b * p.Lq + row) * p.lddq + h * DH + c4) =
-        *reinterpret_cast<const float4*>(&dQs[row * LD + c4]);
+        make_float4(dQt[(c4 + 0) * LDT + row], dQt[(c4 + 1) * LDT + row], dQt[(c4 + 2) * LDT + row], dQt[(c4 + 3) * LDT + row]);
   }
 }
 
-size_t fwd_smem(int DH, int Lk) { return (size_t)2 * ((Lk + 15) / 16 * 16) * (DH + 4) * sizeof(float); }
+size_t fwd_smem(int DH, int Lk) { return (size_t)((Lk + 15) / 16 * 16) * (2 * (DH + 4) + 1) * sizeof(float); }
 size_t bwd_smem(int DH, int Lq) {
   const size_t QR = (size_t)(Lq + 15) / 16 * 16;
-  return (3 * QR * (DH + 4) + 3 * QR + 4 * 16 * 20) * sizeof(float);
+  return (2 * QR * (DH + 4) + (size_t)DH * (QR + 4) + 3 * QR + 4 * 16 * 20) * sizeof(float);
 }
 
 template <typename K>
@@ -380,7 +425,7 @@ extern "C" int skf_attention_bwd(const float* Q, int ldq, const float* K, int ld
   dim3 grid(B * H), block(256);
 #define SKF_ATTN_BWD(DHV)                                       \
   {                                                             \
-    auto kfn = attn_bwd_kernel<DHV>;                            \
+    auto kfn = attn_bwd_kernel<DHV, 64 / DHV>;                          \
     if ((rc = set_smem(kfn, smem))) return rc;                  \
     hipLaunchKernelGGL(kfn, grid, block, smem, st, p);          \
   }

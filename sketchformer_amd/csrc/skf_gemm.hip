@@ -19,37 +19,26 @@
 // are transposed on the LDS store with a +1 pad that makes the 4 scalar stores
 // conflict-free.  blockIdx is remapped so that consecutive logical tiles (which
 // share an A row-panel) land on the same XCD / L2.
+#include <stdlib.h>
 #include <string>
 #include "skf_common.h"
+#include "skf_gemm_params.h"
 
 namespace {
 
 constexpr int BK = 32;
 
-struct GemmParams {
-  const float* A; const float* B; float* C;
-  int M, N, K;
-  int lda, ldb, ldc;
-  const float* bias;
-  int act;                 // 0 none, 1 relu, 2 tanh
-  const float* relu_src;   // optional: C *= (relu_src > 0)
-  int ld_relu;
-  int accumulate;          // C += result
-  int a_vec, b_vec;        // 16-byte vector loads legal
-  // split-K
-  int k_chunk;             // k range per blockIdx.z (multiple of BK)
-  float* slab;             // [splits][M][N] raw partial tiles (split-K only)
-  float* colsum_slab;      // [splits][N] partial column sums of B (bias grad), or null
-  int tiles_m, tiles_n;
-};
 
 template <int BX, bool KC>
 struct TileLD { static constexpr int value = KC ? BX + 1 : BX + 4; };
 
-// ---- global -> register staging of one BX x BK operand slab
-template <int BX, bool KC>
+// ---- global -> register staging of one BX x BK operand slab.
+// VEC: branch-free path (clamped 16-byte loads + select) - needs 16-byte aligned rows and a
+// contiguous extent that is a multiple of 4, so a float4 is either fully inside or fully outside.
+// Keeping the loads unconditional lets the compiler leave them in flight across the MFMA loop.
+template <int BX, bool KC, bool VEC>
 __device__ __forceinline__ void load_slab(const float* __restrict__ P, int ld, int mn0, int mn_max,
-                                          int k0, int k_end, bool vec, float4 (&r)[BX * BK / 1024]) {
+                                          int k0, int k_end, float4 (&r)[BX * BK / 1024]) {
   const int t = threadIdx.x;
   constexpr int NV = BX * BK / 1024;
 #pragma unroll
@@ -58,55 +47,64 @@ __device__ __forceinline__ void load_slab(const float* __restrict__ P, int ld, i
     if (KC) { mn = mn0 + (t >> 3) + p * 32; k = k0 + (t & 7) * 4; }
     else    { k = k0 + t / (BX / 4) + p * (1024 / BX); mn = mn0 + (t % (BX / 4)) * 4; }
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (KC) {
+    if (VEC) {
+      const bool ok = KC ? (mn < mn_max && k < k_end) : (k < k_end && mn < mn_max);
+      const int mc = ok ? mn : 0, kc = ok ? k : 0;
+      const float* src = KC ? P + (size_t)mc * ld + kc : P + (size_t)kc * ld + mc;
+      v = *reinterpret_cast<const float4*>(src);   // zeroing of out-of-range vectors happens in store_slab
+    } else if (KC) {
       if (mn < mn_max) {
         const float* src = P + (size_t)mn * ld + k;
-        if (vec && k + 3 < k_end) v = *reinterpret_cast<const float4*>(src);
-        else {
-          if (k + 0 < k_end) v.x = src[0];
-          if (k + 1 < k_end) v.y = src[1];
-          if (k + 2 < k_end) v.z = src[2];
-          if (k + 3 < k_end) v.w = src[3];
-        }
+        if (k + 0 < k_end) v.x = src[0];
+        if (k + 1 < k_end) v.y = src[1];
+        if (k + 2 < k_end) v.z = src[2];
+        if (k + 3 < k_end) v.w = src[3];
       }
     } else {
       if (k < k_end) {
         const float* src = P + (size_t)k * ld + mn;
-        if (vec && mn + 3 < mn_max) v = *reinterpret_cast<const float4*>(src);
-        else {
-          if (mn + 0 < mn_max) v.x = src[0];
-          if (mn + 1 < mn_max) v.y = src[1];
-          if (mn + 2 < mn_max) v.z = src[2];
-          if (mn + 3 < mn_max) v.w = src[3];
-        }
+        if (mn + 0 < mn_max) v.x = src[0];
+        if (mn + 1 < mn_max) v.y = src[1];
+        if (mn + 2 < mn_max) v.z = src[2];
+        if (mn + 3 < mn_max) v.w = src[3];
       }
     }
     r[p] = v;
   }
 }
 
-// ---- register -> LDS (k-major image S[k][mn])
-template <int BX, bool KC>
-__device__ __forceinline__ void store_slab(float* __restrict__ S, const float4 (&r)[BX * BK / 1024]) {
+// ---- register -> LDS (k-major image S[k][mn]).  On the VEC path the out-of-range select is applied here,
+// after the MFMAs of the previous slab, so the global loads stay in flight across them.
+template <int BX, bool KC, bool VEC>
+__device__ __forceinline__ void store_slab(float* __restrict__ S, const float4 (&r)[BX * BK / 1024], int mn0, int mn_max,
+                                           int k0, int k_end) {
   const int t = threadIdx.x;
   constexpr int LD = TileLD<BX, KC>::value;
   constexpr int NV = BX * BK / 1024;
 #pragma unroll
   for (int p = 0; p < NV; ++p) {
+    float4 v = r[p];
+    if (VEC) {
+      int mn, k;
+      if (KC) { mn = mn0 + (t >> 3) + p * 32; k = k0 + (t & 7) * 4; }
+      else    { k = k0 + t / (BX / 4) + p * (1024 / BX); mn = mn0 + (t % (BX / 4)) * 4; }
+      const bool ok = mn < mn_max && k < k_end;
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+    }
     if (KC) {
       const int row = (t >> 3) + p * 32, kq = (t & 7) * 4;
-      S[(kq + 0) * LD + row] = r[p].x;
-      S[(kq + 1) * LD + row] = r[p].y;
-      S[(kq + 2) * LD + row] = r[p].z;
-      S[(kq + 3) * LD + row] = r[p].w;
+      S[(kq + 0) * LD + row] = v.x;
+      S[(kq + 1) * LD + row] = v.y;
+      S[(kq + 2) * LD + row] = v.z;
+      S[(kq + 3) * LD + row] = v.w;
     } else {
       const int kr = t / (BX / 4) + p * (1024 / BX), c = (t % (BX / 4)) * 4;
-      *reinterpret_cast<float4*>(&S[kr * LD + c]) = r[p];
+      *reinterpret_cast<float4*>(&S[kr * LD + c]) = v;
     }
   }
 }
 
-template <int BM, int BN, int WGM, bool A_KC, bool B_KC, bool SPLITK>
+template <int BM, int BN, int WGM, bool A_KC, bool B_KC, bool SPLITK, bool VEC>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   constexpr int WGN = 4 / WGM;
   constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -146,22 +144,23 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   const bool do_colsum = SPLITK && p.colsum_slab != nullptr && tile_m == 0;
 
   if (nk > 0) {
-    load_slab<BM, A_KC>(p.A, p.lda, m0, p.M, kb, ke, p.a_vec, ra);
-    load_slab<BN, B_KC>(p.B, p.ldb, n0, p.N, kb, ke, p.b_vec, rb);
-    store_slab<BM, A_KC>(As, ra);
-    store_slab<BN, B_KC>(Bs, rb);
+    load_slab<BM, A_KC, VEC>(p.A, p.lda, m0, p.M, kb, ke, ra);
+    load_slab<BN, B_KC, VEC>(p.B, p.ldb, n0, p.N, kb, ke, rb);
+    store_slab<BM, A_KC, VEC>(As, ra, m0, p.M, kb, ke);
+    store_slab<BN, B_KC, VEC>(Bs, rb, n0, p.N, kb, ke);
   }
   __syncthreads();
 
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     const bool more = kt + 1 < nk;
-    if (more) {
-      load_slab<BM, A_KC>(p.A, p.lda, m0, p.M, kb + (kt + 1) * BK, ke, p.a_vec, ra);
-      load_slab<BN, B_KC>(p.B, p.ldb, n0, p.N, kb + (kt + 1) * BK, ke, p.b_vec, rb);
+    if (more && p.ablate != 3) {
+      load_slab<BM, A_KC, VEC>(p.A, p.lda, m0, p.M, kb + (kt + 1) * BK, ke, ra);
+      load_slab<BN, B_KC, VEC>(p.B, p.ldb, n0, p.N, kb + (kt + 1) * BK, ke, rb);
     }
     const float* Ac = As + cur * A_SZ;
     const float* Bc = Bs + cur * B_SZ;
+    if (p.ablate != 1)
 #pragma unroll
     for (int kp = 0; kp < BK / 2; ++kp) {
       const int k = 2 * kp + lhi;
@@ -181,8 +180,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
       for (int k = 0; k < BK; ++k) colsum += Bc[k * LDB_S + threadIdx.x];
     }
     if (more) {
-      store_slab<BM, A_KC>(As + (cur ^ 1) * A_SZ, ra);
-      store_slab<BN, B_KC>(Bs + (cur ^ 1) * B_SZ, rb);
+      store_slab<BM, A_KC, VEC>(As + (cur ^ 1) * A_SZ, ra, m0, p.M, kb + (kt + 1) * BK, ke);
+      store_slab<BN, B_KC, VEC>(Bs + (cur ^ 1) * B_SZ, rb, n0, p.N, kb + (kt + 1) * BK, ke);
     }
     __syncthreads();
   }
@@ -217,6 +216,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
         if (row >= p.M) continue;
         float v = acc[i][j][r] + bv;
+        if (p.ablate == 2 && v != 12345.678f) continue;
         if (p.act == 1) v = fmaxf(v, 0.f);
         else if (p.act == 2) v = tanhf(v);
         if (p.relu_src && !(p.relu_src[(size_t)row * p.ld_relu + col] > 0.f)) v = 0.f;
@@ -253,26 +253,30 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 template <int BM, int BN, int WGM, bool SPLITK>
 int launch_variant(const GemmParams& p, int a_kc, int b_kc, int splits, hipStream_t st) {
   dim3 grid(p.tiles_m * p.tiles_n, 1, splits), block(256);
-#define SKF_GEMM_GO(AK, BKC)                                                                                   \
+#define SKF_GEMM_GO2(AK, BKC, VECV)                                                                            \
   {                                                                                                            \
     constexpr size_t smem = 2 * BK * (TileLD<BM, AK>::value + TileLD<BN, BKC>::value) * sizeof(float);         \
-    auto kfn = gemm_kernel<BM, BN, WGM, AK, BKC, SPLITK>;                                                      \
+    auto kfn = gemm_kernel<BM, BN, WGM, AK, BKC, SPLITK, VECV>;                                                \
     static bool attr_done = false;                                                                             \
     if (!attr_done) {                                                                                          \
       SKF_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));   \
       attr_done = true;                                                                                        \
     }                                                                                                          \
     static const std::string tag = std::string(SPLITK ? "gemm_splitk" : "gemm") + "<" + std::to_string(BM) + "x" + \
-        std::to_string(BN) + "," + (AK ? "Ak" : "Am") + (BKC ? "Bk" : "Bn") + ">";                             \
+        std::to_string(BN) + "," + (AK ? "Ak" : "Am") + (BKC ? "Bk" : "Bn") + (VECV ? "" : ",scalar") + ">";  \
     SkfProfScope ps(st, tag.c_str(), 2.0 * p.M * p.N * p.K,                                                    \
                     4.0 * ((double)p.M * p.K + (double)p.K * p.N + (double)p.M * p.N * (p.accumulate ? 2 : 1))); \
     hipLaunchKernelGGL(kfn, grid, block, smem, st, p);                                                         \
   }
+#define SKF_GEMM_GO(AK, BKC) { if (vec) SKF_GEMM_GO2(AK, BKC, true) else SKF_GEMM_GO2(AK, BKC, false) }
+  // vector path: 16-byte aligned rows and contiguous extents that are multiples of 4
+  const bool vec = p.a_vec && p.b_vec && ((a_kc ? p.K : p.M) % 4 == 0) && ((b_kc ? p.K : p.N) % 4 == 0);
   if (a_kc && !b_kc) SKF_GEMM_GO(true, false)
   else if (a_kc && b_kc) SKF_GEMM_GO(true, true)
   else if (!a_kc && !b_kc) SKF_GEMM_GO(false, false)
   else SKF_GEMM_GO(false, true)
 #undef SKF_GEMM_GO
+#undef SKF_GEMM_GO2
   SKF_LAUNCH_CHECK();
   return SKF_OK;
 }
@@ -286,12 +290,13 @@ extern "C" size_t skf_gemm_workspace_bytes(int M, int N, int K, int splits, int 
   return ((size_t)M * N + N) * (size_t)splits * sizeof(float);
 }
 
+// split-K problems (wgrad: small output, long contraction) use 64x64 tiles: the partial-tile slab
+// traffic is (#workgroups x tile bytes), so small tiles + ~1 workgroup per CU keep it at ~4 MB.
 extern "C" int skf_gemm_default_splits(int M, int N, int K) {
-  // wgrad-shaped problems: small output, long contraction.  Aim at ~2 workgroups per CU.
-  const int tiles = skf_cdiv(M, 128) * skf_cdiv(N, 128);
-  if (tiles >= 256 || K <= 512) return 1;
-  int splits = 512 / tiles;
-  const int max_splits = skf_cdiv(K, 4 * BK);   // at least 4 slabs per split
+  const int tiles = skf_cdiv(M, 64) * skf_cdiv(N, 64);
+  if (K <= 512) return 1;
+  int splits = 256 / tiles;
+  const int max_splits = skf_cdiv(K, 8 * BK);   // at least 8 slabs per split
   if (splits > max_splits) splits = max_splits;
   return splits < 1 ? 1 : splits;
 }
@@ -312,7 +317,11 @@ extern "C" int skf_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K,
   p.a_vec = ((lda & 3) == 0) && (((uintptr_t)A & 15) == 0);
   p.b_vec = ((ldb & 3) == 0) && (((uintptr_t)B & 15) == 0);
   p.tiles_m = skf_cdiv(M, 128); p.tiles_n = skf_cdiv(N, 128);
+  { const char* ab = getenv("SKF_GEMM_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }
   if (splits <= 1 && !bias_grad) {
+    int handled = 0;
+    int rc = skf_gemm_ws_dispatch(p, a_kcontig, b_kcontig, st, &handled);
+    if (rc != SKF_OK || handled) return rc;
     // 64-row tiles when 128-row tiles would leave most CUs idle
     if (p.tiles_m * p.tiles_n < 400 && M > 64) {
       p.tiles_m = skf_cdiv(M, 64);
@@ -330,7 +339,8 @@ extern "C" int skf_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K,
   p.k_chunk = chunk;
   p.slab = (float*)workspace;
   p.colsum_slab = bias_grad ? p.slab + (size_t)splits * M * N : nullptr;
-  int rc = launch_variant<128, 128, 2, true>(p, a_kcontig, b_kcontig, splits, st);
+  p.tiles_m = skf_cdiv(M, 64); p.tiles_n = skf_cdiv(N, 64);
+  int rc = launch_variant<64, 64, 2, true>(p, a_kcontig, b_kcontig, splits, st);
   if (rc != SKF_OK) return rc;
   const size_t total = (size_t)M * N + N;
   int blocks = (int)((total + 255) / 256);

@@ -1,0 +1,26 @@
+// Shared between the generic tiled GEMM (skf_gemm.hip) and the weight-stationary one (skf_gemm_ws.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string>
+
+struct GemmParams {
+  const float* A; const float* B; float* C;
+  int M, N, K;
+  int lda, ldb, ldc;
+  const float* bias;
+  int act;                 // 0 none, 1 relu, 2 tanh
+  const float* relu_src;   // optional: C *= (relu_src > 0)
+  int ld_relu;
+  int accumulate;          // C += result
+  int a_vec, b_vec;        // 16-byte vector loads legal
+  // split-K
+  int k_chunk;             // k range per blockIdx.z (multiple of BK)
+  float* slab;             // [splits][M][N] raw partial tiles (split-K only)
+  float* colsum_slab;      // [splits][N] partial column sums of B (bias grad), or null
+  int tiles_m, tiles_n;
+  int ablate;              // diagnostics only (env SKF_GEMM_ABLATE): 1 no MFMA, 2 no C store, 3 no global reload
+};
+
+// weight-stationary fast path; sets *handled when it launched the problem
+int skf_gemm_ws_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, hipStream_t st, int* handled);

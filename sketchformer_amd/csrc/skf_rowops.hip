@@ -189,18 +189,29 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   }
 }
 
-// out[j] (=|+=) sum_i in[i*ld + j]
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, int nrows, int ld, int ncols,
-                                                     float* __restrict__ out, int accumulate) {
-  __shared__ float red[4][64];
-  const int col = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
-  float s = 0.f;
-  if (col < ncols)
-    for (int i = rg; i < nrows; i += 4) s += in[(size_t)i * ld + col];
-  red[rg][threadIdx.x & 63] = s;
+// out[j] (=|+=) sum_i in[i*ld + j].  64 columns x 16 row groups per 1024-thread workgroup.
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ in, int nrows, int ld, int ncols,
+                                                      float* __restrict__ out, int accumulate) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (col < ncols) {
+    int i = rg;
+    for (; i + 48 < nrows; i += 64) {
+      s0 += in[(size_t)i * ld + col];
+      s1 += in[(size_t)(i + 16) * ld + col];
+      s2 += in[(size_t)(i + 32) * ld + col];
+      s3 += in[(size_t)(i + 48) * ld + col];
+    }
+    for (; i < nrows; i += 16) s0 += in[(size_t)i * ld + col];
+  }
+  red[rg][lane] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (rg == 0 && col < ncols) {
-    const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][lane];
     out[col] = accumulate ? out[col] + t : t;
   }
 }
@@ -487,15 +498,19 @@ extern "C" int skf_layernorm_residual_bwd(const float* dout, const float* z, con
   }
   SKF_LAUNCH_CHECK();
   // part is [g][2][d] : columns 0..d-1 = dgamma, d..2d-1 = dbeta
-  hipLaunchKernelGGL(colsum_kernel, dim3(skf_cdiv(d, 64)), block, 0, s, part, g, 2 * d, d, dgamma, 0);
-  hipLaunchKernelGGL(colsum_kernel, dim3(skf_cdiv(d, 64)), block, 0, s, part + d, g, 2 * d, d, dbeta, 0);
+  if (dbeta == dgamma + d) {   // adjacent in the flat gradient buffer: one launch over 2d columns
+    hipLaunchKernelGGL(colsum_kernel, dim3(skf_cdiv(2 * d, 64)), dim3(1024), 0, s, part, g, 2 * d, 2 * d, dgamma, 0);
+  } else {
+    hipLaunchKernelGGL(colsum_kernel, dim3(skf_cdiv(d, 64)), dim3(1024), 0, s, part, g, 2 * d, d, dgamma, 0);
+    hipLaunchKernelGGL(colsum_kernel, dim3(skf_cdiv(d, 64)), dim3(1024), 0, s, part + d, g, 2 * d, d, dbeta, 0);
+  }
   SKF_LAUNCH_CHECK();
   return SKF_OK;
 }
 
 extern "C" int skf_colsum(const float* in, int nrows, int ld, int ncols, float* out, int accumulate, skf_stream_t stream) {
   SKF_CHECK_ARG(in && out && nrows > 0 && ncols > 0, "bad argument");
-  hipLaunchKernelGGL(colsum_kernel, dim3(skf_cdiv(ncols, 64)), dim3(256), 0, (hipStream_t)stream, in, nrows, ld, ncols, out, accumulate);
+  hipLaunchKernelGGL(colsum_kernel, dim3(skf_cdiv(ncols, 64)), dim3(1024), 0, (hipStream_t)stream, in, nrows, ld, ncols, out, accumulate);
   SKF_LAUNCH_CHECK();
   return SKF_OK;
 }
@@ -540,7 +555,7 @@ extern "C" int skf_pool_bwd(float* u_inout_dpre, const float* Vw, const float* x
   float* part = (float*)workspace;
   SkfProfScope ps(s, "pool_bwd", 0.0, 8.0 * B * L * (U + d));
   hipLaunchKernelGGL(pool_bwd_kernel, dim3(B), dim3(256), 2 * L * sizeof(float), s, u_inout_dpre, Vw, x, a, demb, L, U, d, dx, part);
-  hipLaunchKernelGGL(colsum_kernel, dim3(skf_cdiv(U, 64)), dim3(256), 0, s, part, B, U, U, dV, 0);
+  hipLaunchKernelGGL(colsum_kernel, dim3(skf_cdiv(U, 64)), dim3(1024), 0, s, part, B, U, U, dV, 0);
   SKF_LAUNCH_CHECK();
   return SKF_OK;
 }
@@ -566,8 +581,8 @@ extern "C" int skf_expander_bwd(const float* dpre, const float* emb, const float
   float* p2 = p1 + (size_t)B * L;
   SkfProfScope ps(s, "expander_bwd", 0.0, 8.0 * B * L * d);
   hipLaunchKernelGGL(expander_bwd_kernel, dim3(B), dim3(256), 0, s, dpre, emb, w, L, d, demb, demb_accumulate, p1, p2);
-  hipLaunchKernelGGL(colsum_kernel, dim3(skf_cdiv(L, 64)), dim3(256), 0, s, p1, B, L, L, dw, 0);
-  hipLaunchKernelGGL(colsum_kernel, dim3(skf_cdiv(L, 64)), dim3(256), 0, s, p2, B, L, L, dbias, 0);
+  hipLaunchKernelGGL(colsum_kernel, dim3(skf_cdiv(L, 64)), dim3(1024), 0, s, p1, B, L, L, dw, 0);
+  hipLaunchKernelGGL(colsum_kernel, dim3(skf_cdiv(L, 64)), dim3(1024), 0, s, p2, B, L, L, dbias, 0);
   SKF_LAUNCH_CHECK();
   return SKF_OK;
 }

@@ -67,6 +67,22 @@ def test_gemm_wgrad_splitk_bias_grad(ops, rows, inf, outf):
     _close(bg, dy.sum(0), rtol=5e-5, name="bias grad")
 
 
+@pytest.mark.parametrize("M,N,K", [(2000, 128, 128), (1100, 384, 128), (1500, 128, 512), (1030, 256, 256),
+                                   (1025, 1004, 128), (3001, 128, 384), (25600, 512, 128)])
+def test_gemm_weight_stationary_path(ops, M, N, K):
+    """K in {128,256,384,512}, M >= 1024: the persistent weight-in-registers kernel (both B layouts, every epilogue)."""
+    rng = np.random.RandomState(M + 7 * N + K)
+    x, w, b = rng.randn(M, K), rng.randn(K, N) / np.sqrt(K), rng.randn(N)
+    h, c0 = rng.randn(M, N), rng.randn(M, N)
+    _close(ops.gemm(_dev(x), _dev(w), bias=_dev(b), act=1), np.maximum(x @ w + b, 0), name="ws fwd relu")
+    _close(ops.gemm(_dev(x), _dev(w), bias=_dev(b), act=2), np.tanh(x @ w + b), name="ws fwd tanh")
+    wt = np.ascontiguousarray(w.T)                      # dgrad layout: B stored [N][K]
+    _close(ops.gemm(_dev(x), _dev(wt), b_kcontig=True, relu_src=_dev(h)), (x @ w) * (h > 0), name="ws dgrad relu mask")
+    out = _dev(c0)
+    ops.gemm(_dev(x), _dev(wt), b_kcontig=True, out=out, accumulate=True)
+    _close(out, c0 + x @ w, name="ws dgrad accumulate")
+
+
 def test_gemm_strided_views(ops):
     """fused QKV layout: W stored [d][3d]; outputs written into a (rows, 3d) buffer at a column offset."""
     rng = np.random.RandomState(5)
