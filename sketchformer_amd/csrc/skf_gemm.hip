@@ -227,25 +227,59 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     }
 }
 
-// C[m][n] (=|+=) sum_z slab[z][m][n];  bias_grad[n] = sum_z colsum_slab[z][n]
+// C[m][n] (=|+=) sum_z slab[z][m][n];  bias_grad[n] = sum_z colsum_slab[z][n].
+// 64 float4 columns x 4 split groups per workgroup: the split loop is 4-way parallel and unrolled.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, int splits, int M, int N,
                                                             float* __restrict__ C, int ldc, int accumulate,
                                                             const float* __restrict__ colsum_slab,
                                                             float* __restrict__ bias_grad, int bias_accumulate) {
-  const size_t total = (size_t)M * N;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total + N; i += stride) {
+  __shared__ f32x4 red[4][64];
+  const size_t total = (size_t)M * N;            // multiple of 4 is NOT required: tail handled per element
+  const size_t total4 = (total + N + 3) / 4;     // [M*N | N] viewed as float4 groups (colsum slab follows the tiles)
+  const int zg = threadIdx.x >> 6;
+  const size_t e4 = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  const size_t base = e4 * 4;
+  const bool vec_ok = ((total & 3) == 0) && ((N & 3) == 0);
+  if (e4 < total4) {
+    if (vec_ok) {
+      // tiles: slab[z][base..], column sums: colsum_slab[z][base - total ..]
+      const bool in_tiles = base < total;
+      const float* src = in_tiles ? slab + base : (colsum_slab ? colsum_slab + (base - total) : nullptr);
+      const size_t zstride = in_tiles ? total : (size_t)N;
+      if (src) {
+        int z = zg;
+        for (; z + 12 < splits; z += 16) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(src + (size_t)z * zstride);
+          const f32x4 b = *reinterpret_cast<const f32x4*>(src + (size_t)(z + 4) * zstride);
+          const f32x4 c = *reinterpret_cast<const f32x4*>(src + (size_t)(z + 8) * zstride);
+          const f32x4 d = *reinterpret_cast<const f32x4*>(src + (size_t)(z + 12) * zstride);
+          s += (a + b) + (c + d);
+        }
+        for (; z < splits; z += 4) s += *reinterpret_cast<const f32x4*>(src + (size_t)z * zstride);
+      }
+    } else {
+      for (int c = 0; c < 4; ++c) {
+        const size_t i = base + c;
+        if (i < total) { for (int z = zg; z < splits; z += 4) s[c] += slab[(size_t)z * total + i]; }
+        else if (i < total + N && colsum_slab) { for (int z = zg; z < splits; z += 4) s[c] += colsum_slab[(size_t)z * N + (i - total)]; }
+      }
+    }
+  }
+  red[zg][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (zg != 0 || e4 >= total4) return;
+  const f32x4 t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const size_t i = base + c;
     if (i < total) {
-      float s = 0.f;
-      for (int z = 0; z < splits; ++z) s += slab[(size_t)z * total + i];
       const int m = (int)(i / N), n = (int)(i % N);
       float* dst = C + (size_t)m * ldc + n;
-      *dst = accumulate ? *dst + s : s;
-    } else if (colsum_slab) {
+      *dst = accumulate ? *dst + t[c] : t[c];
+    } else if (i < total + N && colsum_slab) {
       const int n = (int)(i - total);
-      float s = 0.f;
-      for (int z = 0; z < splits; ++z) s += colsum_slab[(size_t)z * N + n];
-      bias_grad[n] = bias_accumulate ? bias_grad[n] + s : s;
+      bias_grad[n] = bias_accumulate ? bias_grad[n] + t[c] : t[c];
     }
   }
 }
@@ -334,17 +368,19 @@ extern "C" int skf_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K,
   SKF_CHECK_ARG(workspace && workspace_bytes >= skf_gemm_workspace_bytes(M, N, K, splits, 1), "workspace too small");
   SKF_CHECK_ARG(!bias_grad || !b_kcontig, "bias_grad needs B as [K][N]");
   int chunk = skf_cdiv(K, splits);
-  chunk = skf_cdiv(chunk, BK) * BK;
+  chunk = skf_cdiv(chunk, 64) * 64;
   splits = skf_cdiv(K, chunk);
   p.k_chunk = chunk;
   p.slab = (float*)workspace;
   p.colsum_slab = bias_grad ? p.slab + (size_t)splits * M * N : nullptr;
   p.tiles_m = skf_cdiv(M, 64); p.tiles_n = skf_cdiv(N, 64);
-  int rc = launch_variant<64, 64, 2, true>(p, a_kcontig, b_kcontig, splits, st);
+  int handled = 0;
+  int rc = skf_gemm_wgrad_dispatch(p, a_kcontig, b_kcontig, splits, st, &handled);
+  if (rc != SKF_OK) return rc;
+  if (!handled) rc = launch_variant<64, 64, 2, true>(p, a_kcontig, b_kcontig, splits, st);
   if (rc != SKF_OK) return rc;
   const size_t total = (size_t)M * N + N;
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 2048) blocks = 2048;
+  const int blocks = (int)(((total + 3) / 4 + 63) / 64);
   SkfProfScope ps(st, "splitk_reduce", 0.0, 4.0 * ((double)splits + 1) * total);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.slab, splits, M, N, C, ldc, accumulate,
                      p.colsum_slab, bias_grad, bias_grad_accumulate);

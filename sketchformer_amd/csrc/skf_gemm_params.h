@@ -24,3 +24,5 @@ struct GemmParams {
 
 // weight-stationary fast path; sets *handled when it launched the problem
 int skf_gemm_ws_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, hipStream_t st, int* handled);
+// wgrad (X^T.dY) fast path writing the split-K slab; sets *handled when it launched the problem
+int skf_gemm_wgrad_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, int splits, hipStream_t st, int* handled);

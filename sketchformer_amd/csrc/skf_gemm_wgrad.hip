@@ -1,0 +1,146 @@
+// Dense weight-gradient (+ bias-gradient) kernel:  dW[Kin,Nout] = X[M,Kin]^T . dY[M,Nout],  M ~ 25k rows.
+//
+// Both operands are "row = contraction index" matrices, so MFMA fragments can be fed STRAIGHT from global
+// memory with fully coalesced 16-byte loads and no LDS staging at all:
+//   v_mfma_f32_16x16x4_f32 wants A[i][k=g], B[k=g][j=i] for lane (i = l&15, g = l>>4).  For 4 consecutive
+//   rows m0..m0+3 lane (i,g) loads xa = X[m0+g][a0+4i..4i+3] and yb = dY[m0+g][b0+4i..4i+3] (one dwordx4
+//   each; the 16 lanes of a group read 256 contiguous bytes).  MFMA (e,f) with a = xa[e], b = yb[f]
+//   accumulates C_ef[i][j] = dW[a0+4i+e][b0+4j+f]: 16 independent MFMAs per pair of loads cover a 64x64
+//   block of dW, and in the C layout (col = lane&15, row = 4g+r) every lane ends up with float4-contiguous
+//   output columns (f = 0..3), so partial tiles are written with dwordx4 stores.
+// A workgroup owns one 64x64 block of dW and a range of M; its 4 waves interleave 4-row steps of that
+// range (intra-workgroup split-K) and are summed through LDS, so only ONE 16 KB partial per workgroup
+// reaches the split-K slab (~4 MB per wgrad).  The bias gradient (column sums of dY) rides along.
+#include "skf_common.h"
+#include "skf_gemm_params.h"
+
+namespace {
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+constexpr int UN = 4;    // 4-row steps per unrolled iteration (per wave): 16 rows
+
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [4 waves][64][64] + [4][64] column sums
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, g = lane >> 4;
+  const int tile = blockIdx.x, tile_m = tile / p.tiles_n, tile_n = tile % p.tiles_n;
+  const int a0 = tile_m * 64, b0 = tile_n * 64;                   // block origin in dW
+  const int kb = blockIdx.z * p.k_chunk, ke = min(p.K, kb + p.k_chunk);
+  const bool aok = a0 + 4 * i < p.M, bok = b0 + 4 * i < p.N;      // M = Kin, N = Nout (multiples of 4)
+  const float* xp = p.A + (aok ? a0 + 4 * i : 0);
+  const float* yp = p.B + (bok ? b0 + 4 * i : 0);
+  const bool do_colsum = p.colsum_slab != nullptr && tile_m == 0;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int f = 0; f < 4; ++f) acc[e][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+
+  // wave w takes rows kb + 16*(4*it + u) + 4*w + g  (u < UN)
+  f32x4 xa[UN], yb[UN];
+#define row_of(it_, u_) (kb + 16 * (UN * (it_) + (u_)) + 4 * wave + g)
+  const int niter = (ke - kb + 16 * UN - 1) / (16 * UN);
+#pragma unroll
+  for (int u = 0; u < UN; ++u) {
+    const int m = row_of(0, u);
+    const int mc = m < ke ? m : kb;
+    xa[u] = *reinterpret_cast<const f32x4*>(xp + (size_t)mc * p.lda);
+    yb[u] = *reinterpret_cast<const f32x4*>(yp + (size_t)mc * p.ldb);
+  }
+  for (int it = 0; it < niter; ++it) {
+    f32x4 xc[UN], yc[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const bool ok = row_of(it, u) < ke;
+      const float za = (ok && aok) ? 1.f : 0.f, zb = (ok && bok) ? 1.f : 0.f;
+      xc[u] = xa[u] * za; yc[u] = yb[u] * zb;          // rows / columns past the end contribute exact zeros
+    }
+    if (it + 1 < niter) {
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int m = row_of(it + 1, u);
+        const int mc = m < ke ? m : kb;
+        xa[u] = *reinterpret_cast<const f32x4*>(xp + (size_t)mc * p.lda);
+        yb[u] = *reinterpret_cast<const f32x4*>(yp + (size_t)mc * p.ldb);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) acc[e][f] = mfma16(xc[u][e], yc[u][f], acc[e][f]);
+      csum += yc[u];
+    }
+  }
+
+#undef row_of
+  // ---- intra-workgroup reduction through LDS in the final row-major [64][64] layout
+  float* mine = smem + wave * 4096;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * g + 4 * r + e;                          // dW row a0+row
+      *reinterpret_cast<f32x4*>(&mine[row * 64 + 4 * i]) =
+          (f32x4){acc[e][0][r], acc[e][1][r], acc[e][2][r], acc[e][3][r]};
+    }
+  float* cs = smem + 4 * 4096;
+  if (do_colsum) {
+    // lanes with equal i hold the same columns for different rows g: reduce over g, then over waves in LDS
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float v = csum[c];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      csum[c] = v;
+    }
+    if (g == 0) *reinterpret_cast<f32x4*>(&cs[wave * 64 + 4 * i]) = csum;
+  }
+  __syncthreads();
+  float* slab = p.slab + (size_t)blockIdx.z * p.M * p.N;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int e4 = tid + v * 256, row = e4 >> 4, c4 = (e4 & 15) * 4;
+    const f32x4 s = *reinterpret_cast<const f32x4*>(&smem[row * 64 + c4]) +
+                    *reinterpret_cast<const f32x4*>(&smem[4096 + row * 64 + c4]) +
+                    *reinterpret_cast<const f32x4*>(&smem[8192 + row * 64 + c4]) +
+                    *reinterpret_cast<const f32x4*>(&smem[12288 + row * 64 + c4]);
+    if (a0 + row < p.M && b0 + c4 < p.N)
+      *reinterpret_cast<f32x4*>(&slab[(size_t)(a0 + row) * p.N + b0 + c4]) = s;
+  }
+  if (do_colsum && tid < 64 && b0 + tid < p.N)
+    p.colsum_slab[(size_t)blockIdx.z * p.N + b0 + tid] = cs[tid] + cs[64 + tid] + cs[128 + tid] + cs[192 + tid];
+}
+
+}  // namespace
+
+// wgrad fast path: A = X stored [K=rows][M=Kin], B = dY stored [K=rows][N=Nout]; writes the split-K slab
+// (the caller runs the slab reduction).  p.k_chunk must already be set (multiple of 64).
+int skf_gemm_wgrad_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, int splits, hipStream_t st, int* handled) {
+  *handled = 0;
+  const char* off = getenv("SKF_GEMM_NO_WGRAD");
+  if (off && off[0] == '1') return SKF_OK;
+  if (a_kcontig || b_kcontig) return SKF_OK;
+  if ((p.M & 3) || (p.N & 3) || (p.lda & 3) || (p.ldb & 3) || ((uintptr_t)p.A & 15) || ((uintptr_t)p.B & 15)) return SKF_OK;
+  if (((uintptr_t)p.slab & 15) || (p.k_chunk & 63)) return SKF_OK;
+  *handled = 1;
+  GemmParams q = p;
+  q.tiles_m = skf_cdiv(p.M, 64); q.tiles_n = skf_cdiv(p.N, 64);
+  const size_t smem = (size_t)(4 * 4096 + 4 * 64) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    SKF_HIP(hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr_done = true;
+  }
+  SkfProfScope ps(st, "wgrad<64x64>", 2.0 * p.M * p.N * p.K, 4.0 * (double)p.K * (p.M + p.N));
+  hipLaunchKernelGGL(wgrad_kernel, dim3(q.tiles_m * q.tiles_n, 1, splits), dim3(256), smem, st, q);
+  SKF_LAUNCH_CHECK();
+  return SKF_OK;
+}
