@@ -102,7 +102,7 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the step from hipGraphs instead of eager launches + wgrad side stream")
     ap.add_argument("--full-length", action="store_true", help="all rows have n = L (worst case, no padding)")
     args = ap.parse_args()
 
@@ -132,7 +132,7 @@ def main():
     B, L, d, dff, N, V, U, Cn = args.batch, 200, 128, 512, 4, 1004, 256, 345
     cfg_kwargs = dict(batch=B, seq_len=L, d_model=d, num_heads=8, dff=dff, num_layers=N, vocab_size=V, n_classes=Cn,
                       lowerdim=U, dropout_rate=0.1, seed=1234 + rank)
-    eng = engine.TrainEngine(engine.make_config(use_graph=not args.no_graph, **cfg_kwargs), init_seed=0, process_group=pg)
+    eng = engine.TrainEngine(engine.make_config(use_graph=args.graph, **cfg_kwargs), init_seed=0, process_group=pg)
     xs, ys = synthetic.token_batch(B, L, V, Cn, seed=rank, full=args.full_length)
     x = torch.from_numpy(xs).cuda()
     y = torch.from_numpy(ys).cuda()
@@ -168,7 +168,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "cfg2: sketch-transformer-tf2 4L/8H/d128/dff512 L=200 V=1004 C=345 dropout=0.1, "
                                "fwd+bwd+Adam(WarmupDecay)", "global_batch": B * world, "per_gpu_batch": B,
-                   "seq_len": L, "parallelism": "dp%d" % world, "hip_graph": not args.no_graph,
+                   "seq_len": L, "parallelism": "dp%d" % world, "hip_graph": args.graph,
                    "pad_fraction": float((xs == 0).mean())},
         "step_mfma_frac": f_step / (elapsed / args.steps) / (PEAK_F32_MFMA_TFLOPS * 1e12),
         "step_tflops": f_step / (elapsed / args.steps) / 1e12,

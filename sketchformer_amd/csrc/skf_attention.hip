@@ -269,9 +269,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
       const float4 dl4 = *reinterpret_cast<const float4*>(&Dl[q0 + g * 4]);
       const float mxr[4] = {mx4.x, mx4.y, mx4.z, mx4.w}, rir[4] = {ri4.x, ri4.y, ri4.z, ri4.w},
                   dlr[4] = {dl4.x, dl4.y, dl4.z, dl4.w};
-      f32x4 dq[NC];
+      f32x4 dq[NC], dq1[NC];
 #pragma unroll
-      for (int c = 0; c < NC; ++c) dq[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int c = 0; c < NC; ++c) { dq[c] = (f32x4){0.f, 0.f, 0.f, 0.f}; dq1[c] = dq[c]; }
 
 #pragma unroll
       for (int j = 0; j < KTW; ++j) {
@@ -320,15 +320,15 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
           dq[c] = mfma16(kT[j][c][0], dst.x, dq[c]);
-          dq[c] = mfma16(kT[j][c][1], dst.y, dq[c]);
+          dq1[c] = mfma16(kT[j][c][1], dst.y, dq1[c]);
           dq[c] = mfma16(kT[j][c][2], dst.z, dq[c]);
-          dq[c] = mfma16(kT[j][c][3], dst.w, dq[c]);
+          dq1[c] = mfma16(kT[j][c][3], dst.w, dq1[c]);
         }
       }
 #pragma unroll
       for (int c = 0; c < NC; ++c)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(&dQt[(c * 16 + g * 4 + r) * LDT + q0 + i], dq[c][r]);
+        for (int r = 0; r < 4; ++r) atomicAdd(&dQt[(c * 16 + g * 4 + r) * LDT + q0 + i], dq[c][r] + dq1[c][r]);
     }
 #pragma unroll
     for (int j = 0; j < KTW; ++j) {

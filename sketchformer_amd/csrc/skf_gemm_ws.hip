@@ -93,23 +93,22 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GemmParams p, int group
   int cur = 0;
   for (; tile < ntiles; tile += workers) {
     const int next = tile + workers;
-    ws_load_tile<K>(p.A, p.lda, p.M, next < ntiles ? next : tile, ra);   // unconditional: keeps ra in registers
+    if (p.ablate != 3) ws_load_tile<K>(p.A, p.lda, p.M, next < ntiles ? next : tile, ra);
     const float* At = As + cur * TR * LDA_S + i * LDA_S + 4 * g;
     f32x4 acc[NB][2];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) { acc[nb][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[nb][1] = acc[nb][0]; }
+    if (p.ablate != 1)
 #pragma unroll
     for (int j = 0; j < KQ / 4; ++j) {
       const float4 a = *reinterpret_cast<const float4*>(At + 16 * j);
+      // consecutive MFMAs never share an accumulator (dependent latency 40 cycles > 32-cycle issue)
+      const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        f32x4 c = acc[nb][j & 1];                      // two chains per block: 40-cycle dependent latency vs 32 issue
-        c = mfma16(a.x, breg[nb][4 * j + 0], c);
-        c = mfma16(a.y, breg[nb][4 * j + 1], c);
-        c = mfma16(a.z, breg[nb][4 * j + 2], c);
-        c = mfma16(a.w, breg[nb][4 * j + 3], c);
-        acc[nb][j & 1] = c;
-      }
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          acc[nb][e & 1] = mfma16(av[e], breg[nb][4 * j + e], acc[nb][e & 1]);
     }
     // ---- epilogue: lane (i,g) holds C[row 4g+r][col nb*16+i]; bias/act, then through the wave's LDS patch
 #pragma unroll
@@ -131,6 +130,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GemmParams p, int group
       const int row = e / F4_ROW, c4 = (e % F4_ROW) * 4;
       const int grow = tile * TR + row, n = n_wave + c4;
       float4 v = *reinterpret_cast<const float4*>(&cs[row * LDC_S + c4]);
+      if (p.ablate == 2 && v.x != 12345.678f) continue;
       if (grow < p.M && n < p.N) {                     // N % 4 == 0: a float4 is fully in or fully out
         if (p.relu_src) {
           const float4 h = *reinterpret_cast<const float4*>(p.relu_src + (size_t)grow * p.ld_relu + n);
