@@ -1,0 +1,43 @@
+"""builders/losses.py of the reference (:9-85): named, weighted losses; computed by the fused softmax-CE kernel."""
+import torch
+
+from .. import ops
+
+
+class LossManager(object):
+    def __init__(self):
+        self.loss_names, self.loss_fns, self.loss_weights = [], {}, {}
+
+    def _add_loss(self, name, weight, func):
+        self.loss_names.append(name)
+        self.loss_weights[name] = weight
+        self.loss_fns[name] = func
+
+    def add_sparse_categorical_crossentropy(self, name='class', weight=1.0):
+        def fn(labels, probs_or_logits):
+            # the reference feeds the softmax output; in graph mode TF recovers the logits, so logits are expected here
+            x = probs_or_logits.detach().clone().contiguous().view(-1, probs_or_logits.shape[-1])
+            lab = torch.as_tensor(labels, device=x.device).view(-1, 1).to(torch.int64).contiguous()
+            row_loss, _, _ = ops.softmax_ce(x, lab, tgt_cols=1, write_grad=False)
+            return row_loss.mean()
+        self._add_loss(name, weight, fn)
+
+    def add_reconstruction_loss(self, name='recon', weight=1.0):
+        def fn(real, pred):
+            x = pred.detach().clone().contiguous().view(-1, pred.shape[-1])
+            tgt = torch.as_tensor(real, device=x.device).to(torch.int64).contiguous()
+            row_loss, _, _ = ops.softmax_ce(x, tgt, tgt_cols=tgt.shape[1], mask_pad=True, write_grad=False)
+            return row_loss.sum() / row_loss.numel()       # mean over ALL positions, padded ones contribute 0
+        self._add_loss(name, weight, fn)
+
+    def add_continuous_reconstruction_loss(self, name='recon', weight=1.0):
+        def fn(real, pred):
+            raise NotImplementedError("use_continuous_data=True is not implemented on the HIP path yet")
+        self._add_loss(name, weight, fn)
+
+    def compute_all_loss(self, rp_dict):
+        return {n: self.loss_weights[n] * self.loss_fns[n](*rp_dict[n]) for n in self.loss_names}
+
+    def compute_loss(self, name, *args):
+        assert name in self.loss_names, "Error! Loss name {} not found".format(name)
+        return self.loss_weights[name] * self.loss_fns[name](*args)

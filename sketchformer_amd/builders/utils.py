@@ -1,0 +1,66 @@
+"""builders/utils.py of the reference (:12-105): positional encoding, masks, scaled dot-product attention."""
+import numpy as np
+import torch
+
+from .. import ops
+from ..engine import positional_encoding as _pe_table
+
+
+def positional_encoding(position, d_model):
+    """(1, position, d_model) float32 table computed on the host in float64 exactly like the reference."""
+    return torch.from_numpy(_pe_table(position, d_model)[np.newaxis, ...])
+
+
+def create_padding_mask(seq):
+    """(B,1,1,L) float mask: 1 where token == 0 (tokens) or pad bit == 1 (continuous stroke-5)."""
+    seq = torch.as_tensor(seq)
+    if seq.dim() < 3:
+        if seq.is_cuda and seq.dtype == torch.int64:
+            m = ops.padding_mask(seq.contiguous()).to(torch.float32)
+        else:
+            m = (seq == 0).to(torch.float32)
+    else:
+        m = (seq[..., -1] == 1).to(torch.float32)
+    return m[:, None, None, :]
+
+
+def create_look_ahead_mask(size, device=None):
+    return torch.triu(torch.ones(size, size, dtype=torch.float32, device=device), diagonal=1)
+
+
+def create_masks(inp, tar):
+    enc_padding_mask = create_padding_mask(inp)
+    dec_padding_mask = create_padding_mask(inp)
+    look_ahead_mask = create_look_ahead_mask(tar.shape[1], device=enc_padding_mask.device)
+    combined_mask = torch.maximum(create_padding_mask(tar), look_ahead_mask)
+    return enc_padding_mask, combined_mask, dec_padding_mask
+
+
+def _decode_mask(mask, B, Lq, Lk):
+    """A reference-style float mask -> (key padding bytes or None, causal flag) understood by the fused kernel."""
+    if mask is None:
+        return None, False
+    m = torch.broadcast_to(torch.as_tensor(mask), (B, 1, Lq, Lk))[:, 0] != 0      # (B,Lq,Lk) bool
+    key = m[:, -1, :]                                                             # last query row: no look-ahead term
+    la = torch.triu(torch.ones(Lq, Lk, dtype=torch.bool, device=m.device), diagonal=1) if Lq == Lk else None
+    if torch.equal(m, key[:, None, :].expand(B, Lq, Lk)):
+        causal = False
+    elif la is not None and torch.equal(m, key[:, None, :] | la[None]):
+        causal = True
+    else:
+        raise NotImplementedError("only padding masks and padding+look-ahead masks are supported by the fused kernel")
+    km = key.to(torch.uint8).contiguous() if bool(key.any()) else None
+    return km, causal
+
+
+def scaled_dot_product_attention(q, k, v, mask):
+    """q,k,v: (B, H, L, depth) as in the reference.  Returns (output (B,H,Lq,depth), None): the attention
+    weights are never materialised (the train step of the reference drops them, models/sketchformer.py:140-145)."""
+    B, H, Lq, dh = q.shape
+    Lk = k.shape[2]
+    km, causal = _decode_mask(mask, B, Lq, Lk)
+
+    def flat(x):
+        return x.permute(0, 2, 1, 3).reshape(B, x.shape[2], H * dh).contiguous()
+    o, _ = ops.attention_fwd(flat(q), flat(k), flat(v), H, key_mask=km, causal=causal)
+    return o.view(B, Lq, H, dh).permute(0, 2, 1, 3), None

@@ -1,0 +1,48 @@
+"""``stroke3-synthetic``: QuickDraw-shaped synthetic batches behind the reference's loader contract
+(no files).  Used by bench.py / smoke tests; shapes per SURVEY.md section 8(d)."""
+import numpy as np
+
+from ..core.data import BaseDataLoader
+from ..utils import hparams as hp
+from .. import synthetic
+
+
+class _Tok(object):
+    def __init__(self, vocab):
+        self.PAD, self.SEP, self.SOS, self.EOS, self.VOCAB_SIZE = 0, vocab - 3, vocab - 2, vocab - 1, vocab
+
+
+class SyntheticStroke3DataLoader(BaseDataLoader):
+    name = "stroke3-synthetic"
+
+    @classmethod
+    def default_hparams(cls):
+        return hp.HParams(max_seq_len=200, use_continuous_data=False, vocab_size=1004, n_classes=345,
+                          n_samples=128 * 64, seed=0)
+
+    def __init__(self, hps, data_directory=None):
+        h = hps if isinstance(hps, dict) else dict(hps.values())
+        self.tokenizer = _Tok(h["vocab_size"])
+        self.n_classes, self.n_samples = h["n_classes"], h["n_samples"]
+        self.class_names = np.array(["class%d" % i for i in range(self.n_classes)])
+        super().__init__(hps, data_directory)
+
+    def get_data_splits(self):
+        return []
+
+    def load_next_megabatch(self, split_name, selected_file):
+        pass
+
+    def batch_iterator(self, split_name, batch_size, stop_at_end_of_split):
+        seed = self.hps["seed"] + {"train": 0, "valid": 1, "test": 2}.get(split_name, 3) * 100003
+        n_batches = max(1, self.n_samples // batch_size)
+        i = 0
+        while True:
+            if self.hps["use_continuous_data"]:
+                yield synthetic.continuous_batch(batch_size, self.hps["max_seq_len"], self.n_classes, seed + i)
+            else:
+                yield synthetic.token_batch(batch_size, self.hps["max_seq_len"], self.hps["vocab_size"],
+                                            self.n_classes, seed + i)
+            i += 1
+            if stop_at_end_of_split and i >= n_batches:
+                return

@@ -212,10 +212,12 @@ class TrainEngine:
 
     def apply_gradients(self):
         self._enter()
+        scale = 1.0
         if self.world_size > 1:
+            from . import parallel
             with torch.cuda.stream(self.stream):
-                torch.distributed.all_reduce(self.grads, group=self.pg)
-        _lib.call("skf_model_apply_gradients", self.handle, 1.0 / self.world_size, self._stream())
+                scale = parallel.allreduce_flat_gradients(self.grads, self.pg)
+        _lib.call("skf_model_apply_gradients", self.handle, scale, self._stream())
         self._leave()
 
     def train_step(self, inp, labels, tar=None):

@@ -1,0 +1,129 @@
+"""``sketch-transformer-tf2`` on MI355X: the plugin surface of models/sketchformer.py (:17-365) over
+TrainEngine (the C-ABI HIP train step).  Same registry name, hparams, ctor, ``train_on_batch`` contract
+and metric names; the arithmetic runs in libskf.so - there is no CPU / eager fallback.
+"""
+import numpy as np
+
+from .. import builders
+from ..core.models import BaseModel
+from ..utils.hparams import HParams
+
+
+class Transformer(BaseModel):
+    name = 'sketch-transformer-tf2'
+    quick_metrics = ['recon_loss', 'recon_acc', 'class_loss', 'class_acc', 'total_loss']
+    slow_metrics = ["sketch-reconstruction", "val-clas-acc", "tsne", "tsne-predicted"]
+
+    @classmethod
+    def specific_default_hparams(cls):
+        """models/sketchformer.py:25-53 (names, defaults and types unchanged)."""
+        return HParams(
+            num_layers=4, d_model=128, dff=512, num_heads=8, dropout_rate=0.1,
+            lowerdim=256, attn_version=1,
+            do_classification=True, class_weight=1.0, class_buffer_layers=0, class_dropout=0.1,
+            do_reconstruction=True, recon_weight=1.0, blind_decoder_mask=True,
+            is_training=True, optimizer='Adam', lr=0.01, lr_scheduler='WarmupDecay', warmup_steps=10000,
+        )
+
+    def __init__(self, hps, dataset, out_dir, experiment_id, device=None, process_group=None, init_seed=0):
+        self.losses_manager = builders.losses.LossManager()
+        self.metrics_manager = builders.keras_metrics.MetricManager()
+        self.vocab_size = dataset.tokenizer.VOCAB_SIZE if not dataset.hps['use_continuous_data'] else None
+        self.seq_len = dataset.hps['max_seq_len']
+        self._device, self._pg, self._init_seed = device, process_group, init_seed
+        super().__init__(hps, dataset, out_dir, experiment_id)
+
+    def build_model(self):
+        from .. import engine
+        h = self.hps
+        for key, ok, why in (('do_classification', True, 'the classification head is always built'),
+                             ('do_reconstruction', True, 'the decoder is always built'),
+                             ('class_buffer_layers', 0, 'buffer FC layers before the classifier')):
+            if h[key] != ok:
+                raise NotImplementedError("%s=%r is not implemented on the HIP path (%s)" % (key, h[key], why))
+        if h['optimizer'].lower() != 'adam':
+            raise NotImplementedError("optimizer=%r: only Adam is implemented" % h['optimizer'])
+        if self.dataset.hps['use_continuous_data']:
+            self.losses_manager.add_continuous_reconstruction_loss('recon', weight=h['recon_weight'])
+            self.metrics_manager.add_mean_metric('recon_loss')
+        else:
+            self.losses_manager.add_reconstruction_loss('recon', weight=h['recon_weight'])
+            self.metrics_manager.add_mean_metric('recon_loss')
+            self.metrics_manager.add_sparse_categorical_accuracy('recon_acc')
+        self.losses_manager.add_sparse_categorical_crossentropy('class', weight=h['class_weight'])
+        self.metrics_manager.add_mean_metric('class_loss')
+        self.metrics_manager.add_sparse_categorical_accuracy('class_acc')
+        self.metrics_manager.add_mean_metric('total_loss')
+        # WarmupDecay is built with warmup_steps=5000 whatever the hparams say (models/sketchformer.py:113-114)
+        self.learning_rate = (builders.schedulers.WarmupDecay(h['d_model'], warmup_steps=5000)
+                              if h['lr_scheduler'].lower() in ('warmupdecay', 'warmup-decay') else None)
+        cfg = engine.make_config(
+            batch=h['batch_size'], seq_len=self.seq_len, d_model=h['d_model'], num_heads=h['num_heads'], dff=h['dff'],
+            num_layers=h['num_layers'], vocab_size=self.vocab_size or 0, n_classes=self.dataset.n_classes,
+            lowerdim=h['lowerdim'], attn_version=h['attn_version'], continuous=self.dataset.hps['use_continuous_data'],
+            blind_decoder_mask=h['blind_decoder_mask'], dropout_rate=h['dropout_rate'], recon_weight=h['recon_weight'],
+            class_weight=h['class_weight'], lr_scheduler=h['lr_scheduler'], lr=h['lr'], use_graph=False)
+        self.engine = engine.TrainEngine(cfg, device=self._device, init_seed=self._init_seed, process_group=self._pg)
+        self.trainable_variables = [e["name"] for e in self.engine.entries]
+
+    # ---- the train step (models/sketchformer.py:351-359)
+    def train_on_batch(self, batch):
+        data, labels = batch
+        self.engine.train_step(data, labels)
+        res = self.engine.running_metrics()          # Keras running metrics, read back every step like the reference
+        if self.dataset.hps['use_continuous_data']:
+            res.pop('recon_acc', None)
+        return res
+
+    def prepare_for_start_of_epoch(self):
+        pass
+
+    def prepare_for_end_of_epoch(self):
+        self.engine.reset_metrics()
+
+    # ---- inference API (models/sketchformer.py:162-228); inputs are padded to the engine's batch size
+    def _run_forward(self, inp_seq):
+        x = np.asarray(inp_seq)
+        if x.ndim == 1:
+            x = x[None]
+        n, B = x.shape[0], self.engine.cfg.batch
+        if n > B:
+            raise ValueError("at most batch_size=%d sequences per call" % B)
+        pad = np.zeros((B,) + x.shape[1:], dtype=np.int64)
+        pad[:n] = x
+        self.engine.forward(pad, training=False)
+        self.engine.synchronize()
+        return n
+
+    def encode_from_seq(self, inp_seq):
+        n = self._run_forward(inp_seq)
+        return {'enc_output': self.engine.buffer('enc_output').view(self.engine.cfg.batch, self.seq_len, -1)[:n].cpu().numpy(),
+                'embedding': self.engine.buffer('embedding')[:n].cpu().numpy(),
+                'class': self.engine.buffer('class_probs')[:n].cpu().numpy()}
+
+    def predict_class(self, inp_seq):
+        out = self.encode_from_seq(inp_seq)
+        out['class'] = out['class'].argmax(-1).astype(np.int32)
+        return out
+
+    def predict(self, inp_seq):
+        raise NotImplementedError("greedy reconstruction (predict / predict_from_embedding) is the next scope row "
+                                  "(SURVEY.md section 8(f) rank 1); only the train step and the encoder-side "
+                                  "inference API are implemented")
+
+    predict_from_embedding = predict
+
+    # ---- checkpoint payload
+    def state_dict(self):
+        e = self.engine
+        e.synchronize()
+        return {'params': e.params.cpu(), 'adam_m': e.adam_m.cpu(), 'adam_v': e.adam_v.cpu(), 'metrics': e.metrics.cpu(),
+                'iterations': e.iterations, 'entries': e.entries}
+
+    def load_state_dict(self, state):
+        e = self.engine
+        e.params.copy_(state['params'])
+        e.adam_m.copy_(state['adam_m'])
+        e.adam_v.copy_(state['adam_v'])
+        e.metrics.copy_(state['metrics'])
+        e.state[0] = int(state['iterations'])

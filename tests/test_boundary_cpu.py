@@ -1,0 +1,160 @@
+"""CPU tests of the drop-in boundary against goldens captured from the TF-free parts of the reference
+(tests/golden/make_goldens.py -> reference_goldens.json)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = json.load(open(os.path.join(HERE, "golden", "reference_goldens.json")))
+
+
+def test_positional_encoding_matches_reference_bit_for_bit():
+    import oracle
+    from sketchformer_amd import engine
+    for d, want in G["positional_encoding"].items():
+        for fn in (lambda p, dm: engine.positional_encoding(p, dm)[None], oracle.positional_encoding):
+            t = np.ascontiguousarray(fn(1000, int(d)))
+            assert t.dtype == np.float32 and t.shape == (1, 1000, int(d))
+            assert hashlib.sha256(t.tobytes()).hexdigest() == want["sha256"]
+            for r, vals in zip(want["rows"], want["values"]):
+                assert np.array_equal(np.concatenate([t[0, r, :8], t[0, r, -4:]]), np.array(vals, np.float32))
+    # KAT quoted in SURVEY.md section 8(a) a3
+    t = oracle.positional_encoding(1000, 128)
+    assert abs(t[0, 1, 0] - 0.84147096) < 1e-7 and abs(t[0, 1, 1] - 0.54030228) < 1e-7
+
+
+def _mk():
+    from sketchformer_amd.utils.hparams import HParams
+    return HParams(num_layers=4, d_model=128, dropout_rate=0.1, do_classification=True, optimizer="Adam", lr=0.01,
+                   goal="No description")
+
+
+@pytest.mark.parametrize("case", G["hparams_parse"], ids=lambda c: c["text"])
+def test_hparams_parse_behaviour(case):
+    h = _mk()
+    if case["ok"]:
+        assert h.parse(case["text"]).values() == case["values"]
+    else:
+        with pytest.raises(ValueError):
+            h.parse(case["text"])
+
+
+def test_hparams_combine_json_and_config_roundtrip(tmp_path):
+    from sketchformer_amd.utils import hparams as hp
+    assert hp.combine_hparams_into_one(hp.HParams(x=1, y="s"), hp.HParams(y="t", z=2.5)).values() == G["hparams_combine"]
+    assert _mk().to_json(indent=2, sort_keys=True) == G["hparams_to_json_sorted"]
+    p = str(tmp_path / "config.json")
+    h = _mk().parse("num_layers=7")
+    hp.save_config(p, h, verbose=False)
+    h2 = _mk()
+    hp.load_config(h2, p, verbose=False)
+    assert h2.values() == h.values()
+    with pytest.raises(ValueError):
+        h.set_hparam("num_layers", 2.5)
+
+
+def test_default_hparams_and_plugin_attributes_match_reference():
+    from sketchformer_amd import models, dataloaders
+    M = models.get_model_by_name("sketch-transformer-tf2")
+    assert M.specific_default_hparams().values() == G["model_specific_defaults"]
+    assert M.base_default_hparams().values() == G["model_base_defaults"]
+    assert {"name": M.name, "quick_metrics": M.quick_metrics, "slow_metrics": M.slow_metrics} == G["model_attrs"]
+    L = dataloaders.get_dataloader_by_name("stroke3-distributed")
+    assert L.default_hparams().values() == G["loader_defaults"]
+    assert M.default_hparams().values() == {**G["model_specific_defaults"], **G["model_base_defaults"]}
+    with pytest.raises(KeyError):
+        models.get_model_by_name("no-such-model")
+
+
+def test_grid_tokenizer_matches_reference():
+    from sketchformer_amd.utils import GridTokenizer
+    tok = GridTokenizer(resolution=100)
+    assert {k: getattr(tok, k) for k in ("PAD", "SEP", "SOS", "EOS", "VOCAB_SIZE")} == G["grid_tokenizer_ids"]
+    for case in G["grid_tokenizer"]:
+        s = np.array(case["stroke3"], dtype=np.float32)
+        assert tok.encode(s).tolist() == case["tokens"]
+        np.testing.assert_allclose(tok.decode(case["tokens"]), np.array(case["decoded"]), atol=1e-12)
+    assert tok.encode(np.array([[.1, .2, 0], [.1, -.1, 1]], np.float32), seq_len=8).tolist()[-3:] == [0, 0, 0]
+
+
+def test_loader_preprocess_matches_reference():
+    from sketchformer_amd import dataloaders
+    from sketchformer_amd.utils import GridTokenizer
+    L = dataloaders.get_dataloader_by_name("stroke3-distributed")
+    want = G["loader_preprocess"]
+    raw = [np.array(r, dtype=np.float32) for r in want["raw"]]
+
+    def mk(**over):
+        hps = L.default_hparams()
+        hps.parse("token_type=grid,max_seq_len=%d" % want["max_seq_len"])
+        for k, v in over.items():
+            hps.set_hparam(k, v)
+        obj = L.__new__(L)
+        obj.hps, obj.limit, obj.tokenizer = dict(hps.values()), 1000, GridTokenizer(resolution=100)
+        return obj
+    grid = mk().preprocess([r.copy() for r in raw], augment=False)
+    assert grid.shape == np.array(want["grid_tokens"]).shape and np.array_equal(grid, np.array(want["grid_tokens"]))
+    cont = mk(use_continuous_data=True).preprocess([r.copy() for r in raw], augment=False)
+    np.testing.assert_allclose(cont, np.array(want["continuous"]), atol=1e-6)
+
+
+def test_chunk_loader_end_to_end(tmp_path):
+    """stroke3-distributed on a synthetic chunk directory: shapes / dtypes of what the train step receives."""
+    from sketchformer_amd import dataloaders
+    rng = np.random.RandomState(0)
+
+    def sketches(n):
+        out = np.empty(n, dtype=object)
+        for i in range(n):
+            m = rng.randint(5, 40)
+            s = np.zeros((m, 3), np.float32)
+            s[:, :2] = rng.randint(-20, 20, (m, 2))
+            s[:, 2] = rng.rand(m) < 0.2
+            s[-1, 2] = 1
+            out[i] = s
+        return out
+    for name, n in (("train_000", 50), ("train_001", 30), ("valid", 20), ("test", 20)):
+        np.savez(str(tmp_path / (name + ".npz")), x=sketches(n), y=rng.randint(0, 3, n))
+    np.savez(str(tmp_path / "meta.npz"), n_classes=3, n_samples_train=80, class_names=np.array(["a", "b", "c"]), std=1.0)
+    L = dataloaders.get_dataloader_by_name("stroke3-distributed")
+    ld = L(L.parse_hparams("token_type=grid,max_seq_len=64"), str(tmp_path))
+    assert ld.n_classes == 3 and ld.n_samples == 80 and ld.tokenizer.VOCAB_SIZE == 10004
+    it = ld.batch_iterator("train", 16, stop_at_end_of_split=False)
+    for _ in range(8):                                     # crosses chunk boundaries
+        x, y = next(it)
+        assert x.shape == (16, 64) and x.dtype == np.int64 and y.shape == (16, 1)
+        assert (x[:, 0] == ld.tokenizer.SOS).all()
+    n = sum(len(x) for x, _ in ld.batch_iterator("valid", 8, stop_at_end_of_split=True))
+    assert n == 20
+    ldc = L(L.parse_hparams("use_continuous_data=true,max_seq_len=64"), str(tmp_path))
+    x, y = next(ldc.batch_iterator("test", 4, stop_at_end_of_split=True))
+    assert x.shape == (4, 64, 5) and (x[:, -1, 4] == 1).all()
+
+
+def test_schedules_k1():
+    """K1: WarmupDecay(128, 5000): lr(0)=0, lr(1)=2.5e-7, lr(5000)=1.25e-3, lr(20000)=6.25e-4."""
+    import oracle
+    from sketchformer_amd.builders.schedulers import WarmupDecay, StepDecay
+    s = WarmupDecay(128, warmup_steps=5000)
+    for step, want in ((0, 0.0), (1, 2.5e-7), (5000, 1.25e-3), (20000, 6.25e-4)):
+        assert abs(float(s(step)) - want) <= 1e-6 * max(want, 1e-12)
+        assert float(s(step)) == float(oracle.warmup_decay(step, 128, 5000))
+    assert StepDecay(0.01, decay_rate=0.5, decay_steps=5000)(12000) == 0.01 * 0.25
+    assert StepDecay(0.01, decay_rate=0.5, decay_steps=10)(10 ** 6) == 0.01 * 1e-2
+
+
+def test_synthetic_batches_shape_contract():
+    from sketchformer_amd import synthetic
+    x, y = synthetic.token_batch(32, 200, 1004, 345, seed=0)
+    assert x.shape == (32, 200) and x.dtype == np.int64 and y.shape == (32, 1) and y.dtype == np.int64
+    assert (x[:, 0] == 1002).all() and x.max() <= 1003 and 0.3 < (x == 0).mean() < 0.8
+    lens = (x != 0).sum(1)
+    assert all(x[b, lens[b] - 1] == 1003 for b in range(32) if lens[b] < 200)      # EOS closes non-truncated rows
+    xf, _ = synthetic.token_batch(4, 200, 1004, 345, seed=0, full=True)
+    assert (xf != 0).all()
+    c, _ = synthetic.continuous_batch(8, 200, 345, seed=1)
+    assert c.shape == (8, 200, 5) and c.dtype == np.float32 and (c[:, -1, 4] == 1).all()
+    assert np.allclose(c[..., 2:].sum(-1)[c[..., 4] == 0], 1.0)

@@ -1,0 +1,145 @@
+"""The reference's plugin surface on the GPU: registry -> Model(hps, dataset, out_dir, id) -> train() /
+train_on_batch / checkpoint resume / encoder-side inference, plus the builders front-ends against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+SMALL = "num_layers=2,d_model=64,dff=128,num_heads=4,lowerdim=32,dropout_rate=0.1"
+DATA = "max_seq_len=24,vocab_size=52,n_classes=7,n_samples=64"
+
+
+def _build(tmp_path, exp_id="t0", base="batch_size=8,num_epochs=1,log_every=4"):
+    from sketchformer_amd import models, dataloaders
+    Model = models.get_model_by_name("sketch-transformer-tf2")
+    Loader = dataloaders.get_dataloader_by_name("stroke3-synthetic")
+    dataset = Loader(Loader.parse_hparams(DATA), None)
+    model = Model(Model.parse_hparams(base=base, specific=SMALL), dataset, str(tmp_path), exp_id)
+    return model, dataset
+
+
+def test_train_loop_and_metric_contract(tmp_path, capsys):
+    model, dataset = _build(tmp_path)
+    assert sorted(p.name for p in (tmp_path / "sketch-transformer-tf2-t0").iterdir()) == ["plots", "tmp", "weights"]
+    assert model.batches_per_epoch == 8
+    model.train()
+    assert model.current_step == 8 and model.engine.iterations == 8
+    out = capsys.readouterr().out
+    assert "Epoch 0 Batch 4/8|recon_loss=" in out and "|total_loss=" in out
+    for name in ("recon_loss", "recon_acc", "class_loss", "class_acc", "total_loss"):
+        h = model.quick_metrics[name].history
+        assert len(h) == 8 and np.isfinite(h).all()
+    # Keras running means: history[k] is the mean of the first k+1 step values
+    first = model.quick_metrics["total_loss"].history[0]
+    assert abs(first - np.log(52) - np.log(7)) < 1.0
+    # safety checkpoints every 4 steps (safety_save=.5), fixed every 8
+    w = sorted(p.name for p in (tmp_path / "sketch-transformer-tf2-t0" / "weights").iterdir())
+    assert w == ["ckpt-1.pt", "ckpt-2.pt", "step7.pt"]
+
+
+def test_train_on_batch_matches_oracle_running_metrics(tmp_path):
+    model, dataset = _build(tmp_path, "t1")
+    eng = model.engine
+    ocfg = oracle.Config(num_layers=2, d_model=64, dff=128, num_heads=4, dropout_rate=0.0, lowerdim=32, vocab_size=52,
+                         n_classes=7, seq_len=24)
+    eng.cfg.dropout_rate = 0.0                       # parity run: dropout off (TF's RNG stream cannot be reproduced)
+    from sketchformer_amd import engine as E
+    import ctypes as C
+    model.engine = eng = E.TrainEngine(eng.cfg, init_seed=3)
+    st = oracle.TrainState.create({k: v.astype(np.float64) for k, v in eng.state_dict_numpy().items()})
+    it = dataset.batch_iterator("train", 8, False)
+    for _ in range(3):
+        batch = next(it)
+        got = model.train_on_batch(batch)
+        want, _, _, _ = oracle.train_step(st, ocfg, batch[0], batch[0], batch[1])
+        assert set(got) == set(want)
+        for k in want:
+            assert abs(got[k] - want[k]) < 1e-4 * max(1.0, abs(want[k])), (k, got[k], want[k])
+
+
+def test_checkpoint_resume_continues_bit_exactly(tmp_path):
+    a, dataset = _build(tmp_path, "ra", base="batch_size=8,num_epochs=1,log_every=100")
+    a.engine.cfg.dropout_rate = 0.0
+    batches = [next(dataset.batch_iterator("train", 8, False)) for _ in range(1)] * 4
+    for b in batches[:2]:
+        a.train_on_batch(b)
+    a.current_step = 2
+    a._save(str(tmp_path / "mid.pt"))
+    for b in batches[2:]:
+        a.train_on_batch(b)
+    b_model, _ = _build(tmp_path, "rb", base="batch_size=8,num_epochs=1,log_every=100")
+    b_model.restore_checkpoint_if_exists(str(tmp_path / "mid.pt"))
+    assert b_model.current_step == 2 and b_model.engine.iterations == 2
+    for b in batches[2:]:
+        b_model.train_on_batch(b)
+    a.engine.synchronize(); b_model.engine.synchronize()
+    assert torch.equal(a.engine.adam_m, b_model.engine.adam_m)
+    assert torch.equal(a.engine.params, b_model.engine.params)
+
+
+def test_encoder_side_inference_api(tmp_path):
+    model, dataset = _build(tmp_path, "inf")
+    x, _ = next(dataset.batch_iterator("valid", 5, True))
+    out = model.predict_class(x)
+    assert out["class"].shape == (5,) and out["embedding"].shape == (5, 64) and out["enc_output"].shape == (5, 24, 64)
+    P = {k: v.astype(np.float64) for k, v in model.engine.state_dict_numpy().items()}
+    ocfg = oracle.Config(num_layers=2, d_model=64, dff=128, num_heads=4, lowerdim=32, vocab_size=52, n_classes=7, seq_len=24)
+    pad = np.zeros((8, 24), np.int64); pad[:5] = x
+    ref, _ = oracle.forward(P, ocfg, pad, pad[:, :-1], training=False)
+    assert np.abs(out["embedding"] - ref["embedding"][:5]).max() < 1e-4
+    with pytest.raises(NotImplementedError):
+        model.predict(x)
+
+
+def test_builders_front_ends_against_oracle():
+    from sketchformer_amd import builders
+    rng = np.random.RandomState(0)
+    B, H, L, dh = 3, 4, 20, 16
+    tok = rng.randint(1, 50, size=(B, L)); tok[0, 12:] = 0; tok[1, 5:] = 0
+    enc_m, comb_m, dec_m = builders.utils.create_masks(torch.as_tensor(tok).cuda(), torch.as_tensor(tok[:, :-1]).cuda())
+    oe, oc, od = oracle.create_masks(tok, tok[:, :-1])
+    assert np.array_equal(enc_m.cpu().numpy(), oe) and np.array_equal(comb_m.cpu().numpy(), oc)
+    q, k, v = (rng.randn(B, H, L - 1, dh) for _ in range(3))
+    want, _, _ = oracle.sdpa_fwd(q, k, v, oc.astype(np.float64))
+    got, w = builders.utils.scaled_dot_product_attention(*(torch.as_tensor(t, dtype=torch.float32).cuda() for t in (q, k, v)), comb_m)
+    assert w is None and np.abs(got.cpu().numpy() - want).max() < 1e-5
+    with pytest.raises(NotImplementedError):
+        builders.utils.scaled_dot_product_attention(*(torch.as_tensor(t, dtype=torch.float32).cuda() for t in (q, k, v)),
+                                                    torch.rand(B, 1, L - 1, L - 1).cuda().round())
+    # LossManager / MetricManager
+    lm = builders.losses.LossManager()
+    lm.add_reconstruction_loss("recon", weight=0.5)
+    lm.add_sparse_categorical_crossentropy("class")
+    logits = rng.randn(B, L - 1, 50)
+    want_l, _ = oracle.recon_loss_fwd(tok[:, 1:], logits, 0.5)
+    assert abs(float(lm.compute_loss("recon", tok[:, 1:], torch.as_tensor(logits, dtype=torch.float32).cuda())) - want_l) < 1e-5
+    with pytest.raises(AssertionError):
+        lm.compute_loss("nope")
+    mm = builders.keras_metrics.MetricManager()
+    mm.add_mean_metric("m"); mm.add_sparse_categorical_accuracy("a")
+    mm.compute("m", 1.0); mm.compute("m", 3.0); mm.compute("a", tok[:, 1:], torch.as_tensor(logits))
+    assert mm.get_results_as_dict()["m"] == 2.0
+    assert abs(mm.get_results_as_dict()["a"] - (logits.argmax(-1) == tok[:, 1:]).mean()) < 1e-9
+    # layer objects: encoder stack forward == oracle forward with the same weights
+    enc = builders.layers.transformer.Encoder(1, 64, 4, 128, 50, rate=0.1)
+    P = {"encoder/embedding": enc.embedding.cpu().numpy().astype(np.float64)}
+    lay = enc.enc_layers[0]
+    for n, dn in (("wq", lay.mha.wq), ("wk", lay.mha.wk), ("wv", lay.mha.wv), ("dense", lay.mha.dense)):
+        P["encoder/layer0/mha/%s/kernel" % n] = dn.kernel.cpu().numpy().astype(np.float64)
+        P["encoder/layer0/mha/%s/bias" % n] = dn.bias.cpu().numpy().astype(np.float64)
+    for n, dn in (("dense1", lay.ffn.d1), ("dense2", lay.ffn.d2)):
+        P["encoder/layer0/ffn/%s/kernel" % n] = dn.kernel.cpu().numpy().astype(np.float64)
+        P["encoder/layer0/ffn/%s/bias" % n] = dn.bias.cpu().numpy().astype(np.float64)
+    for n in ("layernorm1", "layernorm2"):
+        P["encoder/layer0/%s/gamma" % n] = np.ones(64); P["encoder/layer0/%s/beta" % n] = np.zeros(64)
+    ocfg = oracle.Config(num_layers=1, d_model=64, dff=128, num_heads=4, vocab_size=50, seq_len=L)
+    pos = oracle.positional_encoding(1000, 64).astype(np.float64)
+    x0, _ = oracle.sketchformer_oracle._embed_fwd(P, "encoder/embedding", tok, ocfg, pos, 0.0, None)
+    want_x, _ = oracle.sketchformer_oracle.encoder_layer_fwd(P, "encoder/layer0", x0, oe.astype(np.float64), 4, 0.0, {})
+    got_x = enc(tok, False, enc_m)
+    assert np.abs(got_x.cpu().numpy() - want_x).max() < 1e-4
+    with pytest.raises(NotImplementedError):
+        enc(tok, True, enc_m)
