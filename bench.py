@@ -70,6 +70,28 @@ def cpu_baseline(seconds_budget=25.0):
                       % (len(times), med, os.cpu_count() or 1)}
 
 
+def pmc_traffic(tag):
+    """HBM bytes per launch of the kernel behind a profiler tag, from the committed rocprofv3 PMC passes
+    (profiles/*pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate runs, gfx950 corrections applied)."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    if not files:
+        return None
+    table = json.load(open(files[-1]))
+    m = re.match(r"gemm_ws<K(\d+),CW(\d+)>", tag)
+    if m:
+        prefix = "gemm_ws_kernel<%s, %s," % m.groups()
+    else:
+        prefix = {"wgrad<64x64>": "wgrad_kernel", "attn_bwd<dh16>": "attn_bwd_kernel<16", "attn_fwd<dh16>": "attn_fwd_kernel<16",
+                  "ln_fwd": "ln_fwd_kernel", "ln_bwd": "ln_bwd_kernel"}.get(tag)
+    if not prefix:
+        return None
+    rows = [v for k, v in table.items() if k.startswith(prefix)]
+    n = sum(r["launches"] for r in rows)
+    return sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows) / n if n else None
+
+
 def kernel_profile(engine_mod, cfg_kwargs, x, y, steps=3):
     """Per-kernel launch timing with HIP events (libskf's launch profiler) on an un-captured replica."""
     from sketchformer_amd import _lib
@@ -187,6 +209,8 @@ def main():
             ach = top["bytes"] / (top["ms"] * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
                     "traffic": None}
+        roof["traffic"] = pmc_traffic(top["tag"])
+        roof["algorithmic_per_launch"] = (top["flops"] if is_mfma else top["bytes"]) / top["count"]
         roof.update({"kernel": top["tag"], "launches_per_step": top["count"] // 3, "avg_launch_us": top["avg_us"],
                      "per_step_ms": top["per_step_ms"]})
         out["roofline"] = roof

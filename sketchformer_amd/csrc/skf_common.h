@@ -50,6 +50,12 @@ struct SkfProfScope {
 static inline int skf_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---------------------------------------------------------------- device
+// Bijective XCD-aware remap of a 1-D grid: block b runs on XCD b % 8 (observed dispatch order), so giving
+// every XCD a CONTIGUOUS range of logical ids keeps workgroups that share operand panels on one L2.
+__device__ __forceinline__ int skf_xcd_remap(int orig, int nwg) {
+  const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -27,9 +27,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(GemmParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, g = lane >> 4;
-  const int tile = blockIdx.x, tile_m = tile / p.tiles_n, tile_n = tile % p.tiles_n;
+  // all tiles of one M-range (they read the same X / dY rows) get consecutive logical ids -> same XCD / L2
+  const int ntile = p.tiles_m * p.tiles_n;
+  const int logical = skf_xcd_remap(blockIdx.x, gridDim.x);
+  const int split = logical / ntile, tile = logical % ntile;
+  const int tile_m = tile / p.tiles_n, tile_n = tile % p.tiles_n;
   const int a0 = tile_m * 64, b0 = tile_n * 64;                   // block origin in dW
-  const int kb = blockIdx.z * p.k_chunk, ke = min(p.K, kb + p.k_chunk);
+  const int kb = split * p.k_chunk, ke = min(p.K, kb + p.k_chunk);
   const bool aok = a0 + 4 * i < p.M, bok = b0 + 4 * i < p.N;      // M = Kin, N = Nout (multiples of 4)
   const float* xp = p.A + (aok ? a0 + 4 * i : 0);
   const float* yp = p.B + (bok ? b0 + 4 * i : 0);
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(GemmParams p) {
     if (g == 0) *reinterpret_cast<f32x4*>(&cs[wave * 64 + 4 * i]) = csum;
   }
   __syncthreads();
-  float* slab = p.slab + (size_t)blockIdx.z * p.M * p.N;
+  float* slab = p.slab + (size_t)split * p.M * p.N;
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
     const int e4 = tid + v * 256, row = e4 >> 4, c4 = (e4 & 15) * 4;
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(GemmParams p) {
       *reinterpret_cast<f32x4*>(&slab[(size_t)(a0 + row) * p.N + b0 + c4]) = s;
   }
   if (do_colsum && tid < 64 && b0 + tid < p.N)
-    p.colsum_slab[(size_t)blockIdx.z * p.N + b0 + tid] = cs[tid] + cs[64 + tid] + cs[128 + tid] + cs[192 + tid];
+    p.colsum_slab[(size_t)split * p.N + b0 + tid] = cs[tid] + cs[64 + tid] + cs[128 + tid] + cs[192 + tid];
 }
 
 }  // namespace
@@ -140,7 +144,7 @@ int skf_gemm_wgrad_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, i
     attr_done = true;
   }
   SkfProfScope ps(st, "wgrad<64x64>", 2.0 * p.M * p.N * p.K, 4.0 * (double)p.K * (p.M + p.N));
-  hipLaunchKernelGGL(wgrad_kernel, dim3(q.tiles_m * q.tiles_n, 1, splits), dim3(256), smem, st, q);
+  hipLaunchKernelGGL(wgrad_kernel, dim3(q.tiles_m * q.tiles_n * splits), dim3(256), smem, st, q);
   SKF_LAUNCH_CHECK();
   return SKF_OK;
 }

@@ -60,7 +60,9 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GemmParams p, int group
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, g = lane >> 4;
-  const int group = blockIdx.x % groups, worker = blockIdx.x / groups;
+  // the column groups of one worker read the same A tiles: consecutive logical ids -> same XCD / L2
+  const int logical = skf_xcd_remap(blockIdx.x, gridDim.x);
+  const int group = logical % groups, worker = logical / groups;
   const int n_wave = group * 4 * CW + wave * CW;     // first output column of this wave
   const int ntiles = (p.M + TR - 1) / TR;
 
