@@ -126,6 +126,8 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from hipGraphs instead of eager launches + wgrad side stream")
     ap.add_argument("--full-length", action="store_true", help="all rows have n = L (worst case, no padding)")
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3"],
+                    help="cfg2 = the headline config (default); cfg3 = 6L/d256/dff1024 continuous stroke-5 (parity-test config)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -152,10 +154,16 @@ def main():
         dist.barrier()
 
     B, L, d, dff, N, V, U, Cn = args.batch, 200, 128, 512, 4, 1004, 256, 345
-    cfg_kwargs = dict(batch=B, seq_len=L, d_model=d, num_heads=8, dff=dff, num_layers=N, vocab_size=V, n_classes=Cn,
-                      lowerdim=U, dropout_rate=0.1, seed=1234 + rank)
+    cont = args.workload == "cfg3"
+    if cont:
+        d, dff, N, V = 256, 1024, 6, 5
+    cfg_kwargs = dict(batch=B, seq_len=L, d_model=d, num_heads=8, dff=dff, num_layers=N, vocab_size=None if cont else V,
+                      n_classes=Cn, lowerdim=U, dropout_rate=0.1, seed=1234 + rank, continuous=cont)
     eng = engine.TrainEngine(engine.make_config(use_graph=args.graph, **cfg_kwargs), init_seed=0, process_group=pg)
-    xs, ys = synthetic.token_batch(B, L, V, Cn, seed=rank, full=args.full_length)
+    if cont:
+        xs, ys = synthetic.continuous_batch(B, L, Cn, seed=rank, full=args.full_length)
+    else:
+        xs, ys = synthetic.token_batch(B, L, V, Cn, seed=rank, full=args.full_length)
     x = torch.from_numpy(xs).cuda()
     y = torch.from_numpy(ys).cuda()
 
@@ -188,10 +196,12 @@ def main():
         "value": value, "unit": "stroke-tokens/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "cfg2: sketch-transformer-tf2 4L/8H/d128/dff512 L=200 V=1004 C=345 dropout=0.1, "
-                               "fwd+bwd+Adam(WarmupDecay)", "global_batch": B * world, "per_gpu_batch": B,
+        "config": {"workload": ("cfg3: sketch-transformer-tf2 6L/8H/d256/dff1024 L=200 continuous stroke-5 C=345 dropout=0.1, "
+                                "fwd+bwd+Adam(WarmupDecay)") if cont else
+                               ("cfg2: sketch-transformer-tf2 4L/8H/d128/dff512 L=200 V=1004 C=345 dropout=0.1, "
+                                "fwd+bwd+Adam(WarmupDecay)"), "global_batch": B * world, "per_gpu_batch": B,
                    "seq_len": L, "parallelism": "dp%d" % world, "hip_graph": args.graph,
-                   "pad_fraction": float((xs == 0).mean())},
+                   "pad_fraction": float((xs[..., 4] == 1).mean() if cont else (xs == 0).mean())},
         "step_mfma_frac": f_step / (elapsed / args.steps) / (PEAK_F32_MFMA_TFLOPS * 1e12),
         "step_tflops": f_step / (elapsed / args.steps) / 1e12,
         "final_total_loss": metrics["total_loss"],

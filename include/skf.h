@@ -111,7 +111,27 @@ int skf_softmax_ce(float* logits, int ld, int rows, int ncls, const long long* t
  * [8..12] running totals, [16..20] running counts (Keras Mean / SparseCategoricalAccuracy). */
 int skf_metrics_update(const float* recon_loss, const float* recon_hit, int recon_rows, float recon_weight,
                        const float* class_loss, const float* class_hit, int class_rows, float class_weight,
+                       const float* recon_scalar /* continuous mode: the already reduced recon loss, else NULL */,
                        float* metrics, skf_stream_t stream);
+
+/* ------------------------------------------------------------------ continuous stroke-5 mode (use_continuous_data=True)
+ * x (B, x_ld_rows, 5) float32 stroke-5 rows; the first L rows of every sample are used.
+ * builders/utils.py:35-43 (pad bit), builders/layers/transformer.py:276,288-296 (embedding = Dense(5->d)),
+ * builders/losses.py:43-66 (location MSE + GLOBAL mean pen-state CE, masked, mean over all positions). */
+int skf_padding_mask_continuous(const float* x, int x_ld_rows, int B, int L, unsigned char* out, skf_stream_t stream);
+int skf_embed_continuous_fwd(const float* x, int x_ld_rows, int B, int L, const float* W, const float* bias, int d,
+                             const float* pos, float* out, float rate, unsigned site, const void* step_state,
+                             skf_stream_t stream);
+size_t skf_embed_continuous_bwd_workspace_bytes(int rows, int d);
+int skf_embed_continuous_bwd(const float* x, int x_ld_rows, int B, int L, const float* dx, int d, float* dW, float* dbias,
+                             float rate, unsigned site, const void* step_state, void* workspace, size_t workspace_bytes,
+                             skf_stream_t stream);
+/* pred (rows,5) is overwritten with the gradient when write_grad; target row r =
+ * target[(r / tgt_cols) * tgt_ld_rows + r % tgt_cols + tgt_off]; scalars (4 floats): sum(loc*mask), sum(ce),
+ * sum(mask), weighted loss. */
+int skf_continuous_loss(float* pred_inout_grad, const float* target, int tgt_ld_rows, int tgt_cols, int tgt_off, int rows,
+                        float weight, float* row_loc, float* row_ce, float* row_mask, float* scalars, int write_grad,
+                        skf_stream_t stream);
 
 /* ------------------------------------------------------------------ bottleneck + expander
  * SelfAttnV1.call after u = tanh(xW+b): builders/layers/transformer.py:70-73. */
@@ -175,11 +195,12 @@ void skf_model_destroy(SkfModel* m);
  * metrics: 32 floats; step_state: skf_step_state_bytes bytes.  All device memory owned by the caller. */
 int skf_model_bind(SkfModel* m, float* params, float* grads, float* adam_m, float* adam_v, const float* pos,
                    void* workspace, size_t workspace_bytes, float* metrics, void* step_state);
-/* forward only (Transformer.call); training != 0 enables dropout.  inp (B,L) tar_inp (B,L-1 used, row stride tar_ld). */
-int skf_model_forward(SkfModel* m, const long long* inp, const long long* tar, int tar_ld, int training,
+/* forward only (Transformer.call); training != 0 enables dropout.  inp/tar: (B,L) int64 tokens, or (B,L,5) float32
+ * stroke-5 rows when cfg.continuous; tar has row stride tar_ld (in sequence positions), its first L-1 positions feed the decoder. */
+int skf_model_forward(SkfModel* m, const void* inp, const void* tar, int tar_ld, int training,
                       skf_stream_t stream);
 /* model_trainer minus apply_gradients: forward, losses, metrics, backward into `grads`. labels (B,1) int64. */
-int skf_model_forward_backward(SkfModel* m, const long long* inp, const long long* tar, int tar_ld,
+int skf_model_forward_backward(SkfModel* m, const void* inp, const void* tar, int tar_ld,
                                const long long* labels, skf_stream_t stream);
 /* optimizer.apply_gradients with grads pre-multiplied by grad_scale (1/world_size under data parallelism) */
 int skf_model_apply_gradients(SkfModel* m, float grad_scale, skf_stream_t stream);

@@ -64,7 +64,12 @@ SIGNATURES = {
     "skf_layernorm_residual_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U, _P, _P, _Z, _P]),
     "skf_colsum": (_I, [_P, _I, _I, _I, _P, _I, _P]),
     "skf_softmax_ce": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _I, _F, _P, _P, _P, _I, _P]),
-    "skf_metrics_update": (_I, [_P, _P, _I, _F, _P, _P, _I, _F, _P, _P]),
+    "skf_metrics_update": (_I, [_P, _P, _I, _F, _P, _P, _I, _F, _P, _P, _P]),
+    "skf_padding_mask_continuous": (_I, [_P, _I, _I, _I, _P, _P]),
+    "skf_embed_continuous_fwd": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _P, _F, _U, _P, _P]),
+    "skf_embed_continuous_bwd_workspace_bytes": (_Z, [_I, _I]),
+    "skf_embed_continuous_bwd": (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _F, _U, _P, _P, _Z, _P]),
+    "skf_continuous_loss": (_I, [_P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P, _I, _P]),
     "skf_pool_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "skf_pool_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _Z, _P]),
     "skf_expander_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),

@@ -32,7 +32,17 @@ class LossManager(object):
 
     def add_continuous_reconstruction_loss(self, name='recon', weight=1.0):
         def fn(real, pred):
-            raise NotImplementedError("use_continuous_data=True is not implemented on the HIP path yet")
+            import ctypes as C
+            from .. import _lib
+            p = pred.detach().clone().to(torch.float32).contiguous().view(-1, 5)
+            t = torch.as_tensor(real, device=p.device).to(torch.float32).contiguous()
+            rows = p.shape[0]
+            buf = [torch.empty(rows, dtype=torch.float32, device=p.device) for _ in range(3)]
+            scal = torch.zeros(4, dtype=torch.float32, device=p.device)
+            _lib.call("skf_continuous_loss", C.c_void_p(p.data_ptr()), C.c_void_p(t.data_ptr()), t.shape[1], t.shape[1], 0,
+                      rows, 1.0, *(C.c_void_p(b.data_ptr()) for b in buf), C.c_void_p(scal.data_ptr()), 0,
+                      C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            return scal[3]
         self._add_loss(name, weight, fn)
 
     def compute_all_loss(self, rp_dict):

@@ -104,7 +104,8 @@ struct DecLayerP { SelfMhaP mha1; CrossMhaP mha2; DenseP f1, f2; LnP ln1, ln2, l
 
 struct Layout {
   size_t total = 0;
-  size_t enc_emb = 0, dec_emb = 0;
+  size_t enc_emb = 0, dec_emb = 0;      // token mode: (V,d) tables
+  DenseP enc_embd{}, dec_embd{};         // continuous mode: Dense(5 -> d)
   std::vector<EncLayerP> enc;
   std::vector<DecLayerP> dec;
   DenseP bott_w{};      // W_attn + b_attn
@@ -155,8 +156,12 @@ Layout build_layout(const SkfConfig& c) {
   const int d = c.d_model, E = d;   // attn_version 1: embedding width = d_model
   static const char* const qkv_names[3] = {"wq", "wk", "wv"};
   static const char* const kv_names[2] = {"wk", "wv"};
-  L.enc_emb = alloc(L, (size_t)c.vocab_size * d);
-  add_entry(L, "encoder/embedding", L.enc_emb, c.vocab_size, d, d);
+  if (c.continuous) {
+    L.enc_embd = dense(L, "encoder/embedding", 5, d);
+  } else {
+    L.enc_emb = alloc(L, (size_t)c.vocab_size * d);
+    add_entry(L, "encoder/embedding", L.enc_emb, c.vocab_size, d, d);
+  }
   for (int i = 0; i < c.num_layers; ++i) {
     const std::string p = "encoder/layer" + std::to_string(i);
     EncLayerP e;
@@ -178,8 +183,12 @@ Layout build_layout(const SkfConfig& c) {
   L.exp_w = alloc(L, c.seq_len); L.exp_b = alloc(L, c.seq_len);
   add_entry(L, "expand/kernel", L.exp_w, 1, c.seq_len, c.seq_len);
   add_entry(L, "expand/bias", L.exp_b, 1, c.seq_len, c.seq_len);
-  L.dec_emb = alloc(L, (size_t)c.vocab_size * d);
-  add_entry(L, "decoder/embedding", L.dec_emb, c.vocab_size, d, d);
+  if (c.continuous) {
+    L.dec_embd = dense(L, "decoder/embedding", 5, d);
+  } else {
+    L.dec_emb = alloc(L, (size_t)c.vocab_size * d);
+    add_entry(L, "decoder/embedding", L.dec_emb, c.vocab_size, d, d);
+  }
   for (int i = 0; i < c.num_layers; ++i) {
     const std::string p = "decoder/layer" + std::to_string(i);
     DecLayerP e;
@@ -195,7 +204,7 @@ Layout build_layout(const SkfConfig& c) {
     e.ln3 = lnp(L, p + "/layernorm3", d);
     L.dec.push_back(e);
   }
-  L.out = dense(L, "output", d, c.vocab_size);
+  L.out = dense(L, "output", d, c.continuous ? 5 : c.vocab_size);
   return L;
 }
 
@@ -214,7 +223,7 @@ struct Plan {
   std::vector<EncAct> enc;
   std::vector<DecAct> dec;
   size_t u, pool_a, emb, cls_logits, cls_probs, pre, logits;
-  size_t recon_loss, recon_hit, cls_loss, cls_hit;
+  size_t recon_loss, recon_hit, cls_loss, cls_hit, row_mask, cont_scal;
   size_t gA, gB, gC, dqkv, dh, do_, dpre, dkv2, dq2, demb;
   size_t gemm_ws, gemm_ws_bytes, small_ws, small_ws_bytes;
 };
@@ -228,7 +237,9 @@ Plan build_plan(const SkfConfig& c) {
   Bump b;
   const size_t B = c.batch, L = c.seq_len, Ld = c.seq_len - 1, d = c.d_model, F = c.dff, U = c.lowerdim;
   const size_t Me = B * L, Md = B * Ld, H = c.num_heads, f = sizeof(float);
-  P.inp = b.take(B * L * 8); P.tar = b.take(B * L * 8); P.labels = b.take(B * 8);
+  const size_t in_bytes = c.continuous ? B * L * 5 * 4 : B * L * 8;   // (B,L,5) f32 or (B,L) i64
+  const size_t Vout = c.continuous ? 5 : (size_t)c.vocab_size;
+  P.inp = b.take(in_bytes); P.tar = b.take(in_bytes); P.labels = b.take(B * 8);
   P.enc_mask = b.take(B * L); P.dec_mask = b.take(B * L);
   for (int i = 0; i < c.num_layers; ++i) {
     EncAct a;
@@ -255,19 +266,21 @@ Plan build_plan(const SkfConfig& c) {
   }
   const size_t dec_out = b.take(Md * d * f);
   for (int i = 0; i < c.num_layers; ++i) P.dec[i].out3 = (i + 1 < c.num_layers) ? P.dec[i + 1].x_in : dec_out;
-  P.logits = b.take(Md * (size_t)c.vocab_size * f);
+  P.logits = b.take(Md * Vout * f);
   P.recon_loss = b.take(Md * f); P.recon_hit = b.take(Md * f); P.cls_loss = b.take(B * f); P.cls_hit = b.take(B * f);
+  P.row_mask = b.take(Md * f); P.cont_scal = b.take(64);
   P.gA = b.take(Me * d * f); P.gB = b.take(Me * d * f); P.gC = b.take(Me * d * f);
   P.dqkv = b.take(Me * 3 * d * f); P.dh = b.take(Me * F * f); P.do_ = b.take(Me * d * f);
   P.dpre = b.take(Me * d * f); P.dkv2 = b.take(Me * 2 * d * f); P.dq2 = b.take(Md * d * f); P.demb = b.take(B * d * f);
   size_t g = 0;
   auto mx = [&](size_t v) { if (v > g) g = v; };
   mx(wgrad_ws(d, 3 * d, Me)); mx(wgrad_ws(d, d, Me)); mx(wgrad_ws(d, F, Me)); mx(wgrad_ws(F, d, Me));
-  mx(wgrad_ws(d, 2 * d, Me)); mx(wgrad_ws(d, c.vocab_size, Md)); mx(wgrad_ws(d, U, Me)); mx(wgrad_ws(d, c.n_classes, B));
+  mx(wgrad_ws(d, 2 * d, Me)); mx(wgrad_ws(d, (int)Vout, Md)); mx(wgrad_ws(d, U, Me)); mx(wgrad_ws(d, c.n_classes, B));
   P.gemm_ws_bytes = g; P.gemm_ws = b.take(g);
   size_t s = skf_layernorm_bwd_workspace_bytes((int)Me, (int)d);
   if (B * U * f > s) s = B * U * f;
   if (2 * B * L * f > s) s = 2 * B * L * f;
+  if (c.continuous && skf_embed_continuous_bwd_workspace_bytes((int)Me, (int)d) > s) s = skf_embed_continuous_bwd_workspace_bytes((int)Me, (int)d);
   P.small_ws_bytes = s; P.small_ws = b.take(s);
   P.bytes = b.off;
   return P;
@@ -387,12 +400,23 @@ int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s) {
   unsigned char* emask = M->at<unsigned char>(P.enc_mask);
   unsigned char* dmask = M->at<unsigned char>(P.dec_mask);
 
-  SKF_TRY(skf_padding_mask(inp, Le, B, Le, emask, s));
-  SKF_TRY(skf_padding_mask(tar, Le, B, Ld, dmask, s));
+  const float* inpf = M->at<float>(P.inp);      // continuous mode: (B, L, 5) stroke-5 rows
+  const float* tarf = M->at<float>(P.tar);
+  if (c.continuous) {
+    SKF_TRY(skf_padding_mask_continuous(inpf, Le, B, Le, emask, s));
+    SKF_TRY(skf_padding_mask_continuous(tarf, Le, B, Ld, dmask, s));
+  } else {
+    SKF_TRY(skf_padding_mask(inp, Le, B, Le, emask, s));
+    SKF_TRY(skf_padding_mask(tar, Le, B, Ld, dmask, s));
+  }
 
   // ---------------- encoder (builders/layers/transformer.py:288-301)
-  SKF_TRY(skf_embed_fwd(inp, Le, B, Le, M->P(L.enc_emb), c.vocab_size, d, M->pos, M->at<float>(P.enc[0].x_in), rate,
-                        site_enc_embed(), M->state, s));
+  if (c.continuous)
+    SKF_TRY(skf_embed_continuous_fwd(inpf, Le, B, Le, M->P(L.enc_embd.w), M->P(L.enc_embd.b), d, M->pos,
+                                     M->at<float>(P.enc[0].x_in), rate, site_enc_embed(), M->state, s));
+  else
+    SKF_TRY(skf_embed_fwd(inp, Le, B, Le, M->P(L.enc_emb), c.vocab_size, d, M->pos, M->at<float>(P.enc[0].x_in), rate,
+                          site_enc_embed(), M->state, s));
   for (int i = 0; i < N; ++i) {
     const EncLayerP& w = L.enc[i];
     const EncAct& a = P.enc[i];
@@ -418,8 +442,12 @@ int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s) {
   SKF_TRY(skf_expander_fwd(M->at<float>(P.emb), M->P(L.exp_w), M->P(L.exp_b), B, Le, d, M->at<float>(P.pre), s));
 
   // ---------------- decoder (builders/layers/transformer.py:325-344)
-  SKF_TRY(skf_embed_fwd(tar, Le, B, Ld, M->P(L.dec_emb), c.vocab_size, d, M->pos, M->at<float>(P.dec[0].x_in), rate,
-                        site_dec_embed(N), M->state, s));
+  if (c.continuous)
+    SKF_TRY(skf_embed_continuous_fwd(tarf, Le, B, Ld, M->P(L.dec_embd.w), M->P(L.dec_embd.b), d, M->pos,
+                                     M->at<float>(P.dec[0].x_in), rate, site_dec_embed(N), M->state, s));
+  else
+    SKF_TRY(skf_embed_fwd(tar, Le, B, Ld, M->P(L.dec_emb), c.vocab_size, d, M->pos, M->at<float>(P.dec[0].x_in), rate,
+                          site_dec_embed(N), M->state, s));
   const unsigned char* cross_mask = c.blind_decoder_mask ? nullptr : emask;
   for (int i = 0; i < N; ++i) {
     const DecLayerP& w = L.dec[i];
@@ -451,13 +479,21 @@ int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s) {
   const long long* labels = M->at<long long>(P.labels);
   if (with_loss) {
     // tar_real = tar[:, 1:]  -> target offset 1 within rows of stride L
-    SKF_TRY(skf_softmax_ce(M->at<float>(P.logits), c.vocab_size, Md, c.vocab_size, tar, Le, Ld, 1, 1,
-                           c.recon_weight / (float)Md, M->at<float>(P.recon_loss), M->at<float>(P.recon_hit), nullptr, 1, s));
+    const float* recon_scalar = nullptr;
+    if (c.continuous) {
+      SKF_TRY(skf_continuous_loss(M->at<float>(P.logits), tarf, Le, Ld, 1, Md, c.recon_weight, M->at<float>(P.recon_loss),
+                                  M->at<float>(P.recon_hit), M->at<float>(P.row_mask), M->at<float>(P.cont_scal), 1, s));
+      recon_scalar = M->at<float>(P.cont_scal) + 3;
+    } else {
+      SKF_TRY(skf_softmax_ce(M->at<float>(P.logits), c.vocab_size, Md, c.vocab_size, tar, Le, Ld, 1, 1,
+                             c.recon_weight / (float)Md, M->at<float>(P.recon_loss), M->at<float>(P.recon_hit), nullptr, 1, s));
+    }
     SKF_TRY(skf_softmax_ce(M->at<float>(P.cls_logits), c.n_classes, B, c.n_classes, labels, 1, 1, 0, 0,
                            c.class_weight / (float)B, M->at<float>(P.cls_loss), M->at<float>(P.cls_hit),
                            M->at<float>(P.cls_probs), 1, s));
     SKF_TRY(skf_metrics_update(M->at<float>(P.recon_loss), M->at<float>(P.recon_hit), Md, c.recon_weight,
-                               M->at<float>(P.cls_loss), M->at<float>(P.cls_hit), B, c.class_weight, M->metrics, s));
+                               M->at<float>(P.cls_loss), M->at<float>(P.cls_hit), B, c.class_weight, recon_scalar,
+                               M->metrics, s));
   } else {
     SKF_TRY(skf_softmax_ce(M->at<float>(P.cls_logits), c.n_classes, B, c.n_classes, labels, 1, 1, 0, 0, 0.f,
                            M->at<float>(P.cls_loss), M->at<float>(P.cls_hit), M->at<float>(P.cls_probs), 0, s));
@@ -512,8 +548,8 @@ int run_backward(SkfModel* M, hipStream_t s) {
 
   // output layer: logits buffer now holds dlogits
   const float* dlog = M->at<float>(P.logits);
-  SKF_TRY(dense_wgrad(M, L.out, M->at<float>(P.dec[N - 1].out3), d, dlog, c.vocab_size, Md, s));
-  SKF_TRY(dense_dgrad(M, L.out, dlog, c.vocab_size, Md, G, d, 0, nullptr, 0, s));
+  SKF_TRY(dense_wgrad(M, L.out, M->at<float>(P.dec[N - 1].out3), d, dlog, L.out.out, Md, s));
+  SKF_TRY(dense_dgrad(M, L.out, dlog, L.out.out, Md, G, d, 0, nullptr, 0, s));
 
   const unsigned char* cross_mask = c.blind_decoder_mask ? nullptr : emask;
   for (int i = N - 1; i >= 0; --i) {
@@ -550,8 +586,13 @@ int run_backward(SkfModel* M, hipStream_t s) {
     float* t = G; G = G2; G2 = t;
   }
   // decoder embedding
-  SKF_HIP(hipMemsetAsync(M->G(L.dec_emb), 0, (size_t)c.vocab_size * d * sizeof(float), s));
-  SKF_TRY(skf_embed_bwd(tar, Le, B, Ld, G, c.vocab_size, d, M->G(L.dec_emb), rate, site_dec_embed(N), M->state, s));
+  if (c.continuous) {
+    SKF_TRY(skf_embed_continuous_bwd(M->at<float>(P.tar), Le, B, Ld, G, d, M->G(L.dec_embd.w), M->G(L.dec_embd.b), rate,
+                                     site_dec_embed(N), M->state, M->at<char>(P.small_ws), P.small_ws_bytes, s));
+  } else {
+    SKF_HIP(hipMemsetAsync(M->G(L.dec_emb), 0, (size_t)c.vocab_size * d * sizeof(float), s));
+    SKF_TRY(skf_embed_bwd(tar, Le, B, Ld, G, c.vocab_size, d, M->G(L.dec_emb), rate, site_dec_embed(N), M->state, s));
+  }
   // expander, classifier
   SKF_TRY(skf_expander_bwd(dpre, M->at<float>(P.emb), M->P(L.exp_w), B, Le, d, demb, 0, M->G(L.exp_w), M->G(L.exp_b),
                            M->at<char>(P.small_ws), P.small_ws_bytes, s));
@@ -581,8 +622,13 @@ int run_backward(SkfModel* M, hipStream_t s) {
     SKF_TRY(dense_wgrad(M, w.mha.qkv, M->at<float>(a.x_in), d, dqkv, 3 * d, Me, s));
     SKF_TRY(dense_dgrad(M, w.mha.qkv, dqkv, 3 * d, Me, G, d, 1, nullptr, 0, s));
   }
-  SKF_HIP(hipMemsetAsync(M->G(L.enc_emb), 0, (size_t)c.vocab_size * d * sizeof(float), s));
-  SKF_TRY(skf_embed_bwd(inp, Le, B, Le, G, c.vocab_size, d, M->G(L.enc_emb), rate, site_enc_embed(), M->state, s));
+  if (c.continuous) {
+    SKF_TRY(skf_embed_continuous_bwd(M->at<float>(P.inp), Le, B, Le, G, d, M->G(L.enc_embd.w), M->G(L.enc_embd.b), rate,
+                                     site_enc_embed(), M->state, M->at<char>(P.small_ws), P.small_ws_bytes, s));
+  } else {
+    SKF_HIP(hipMemsetAsync(M->G(L.enc_emb), 0, (size_t)c.vocab_size * d * sizeof(float), s));
+    SKF_TRY(skf_embed_bwd(inp, Le, B, Le, G, c.vocab_size, d, M->G(L.enc_emb), rate, site_enc_embed(), M->state, s));
+  }
   return join_side(M, s);
 }
 
@@ -592,16 +638,18 @@ int prologue(SkfModel* M, hipStream_t s) {
                            c.seed, s);
 }
 
-int stage_inputs(SkfModel* M, const long long* inp, const long long* tar, int tar_ld, const long long* labels, hipStream_t s) {
+int stage_inputs(SkfModel* M, const void* inp, const void* tar, int tar_ld, const long long* labels, hipStream_t s) {
   const SkfConfig& c = M->cfg;
   const Plan& P = M->plan;
   SKF_CHECK_ARG(inp && tar, "null input");
-  SKF_HIP(hipMemcpyAsync(M->at<char>(P.inp), inp, (size_t)c.batch * c.seq_len * 8, hipMemcpyDeviceToDevice, s));
+  const size_t row = c.continuous ? (size_t)c.seq_len * 5 * sizeof(float) : (size_t)c.seq_len * 8;     // bytes per sample
+  const size_t src_row = c.continuous ? (size_t)tar_ld * 5 * sizeof(float) : (size_t)tar_ld * 8;
+  SKF_HIP(hipMemcpyAsync(M->at<char>(P.inp), inp, row * c.batch, hipMemcpyDeviceToDevice, s));
   if (tar_ld == c.seq_len) {
-    SKF_HIP(hipMemcpyAsync(M->at<char>(P.tar), tar, (size_t)c.batch * c.seq_len * 8, hipMemcpyDeviceToDevice, s));
+    SKF_HIP(hipMemcpyAsync(M->at<char>(P.tar), tar, row * c.batch, hipMemcpyDeviceToDevice, s));
   } else {
-    SKF_HIP(hipMemcpy2DAsync(M->at<char>(P.tar), (size_t)c.seq_len * 8, tar, (size_t)tar_ld * 8, (size_t)c.seq_len * 8,
-                             c.batch, hipMemcpyDeviceToDevice, s));
+    SKF_HIP(hipMemcpy2DAsync(M->at<char>(P.tar), row, tar, src_row, row < src_row ? row : src_row, c.batch,
+                             hipMemcpyDeviceToDevice, s));
   }
   if (labels) SKF_HIP(hipMemcpyAsync(M->at<char>(P.labels), labels, (size_t)c.batch * 8, hipMemcpyDeviceToDevice, s));
   else SKF_HIP(hipMemsetAsync(M->at<char>(P.labels), 0, (size_t)c.batch * 8, s));
@@ -637,11 +685,13 @@ extern "C" int skf_config_validate(const SkfConfig* c) {
   if (!(dh == 16 || dh == 32 || dh == 64)) { skf_set_error("head dim %d not in {16,32,64}", dh); return SKF_EUNSUPPORTED; }
   if (!(c->d_model == 64 || c->d_model == 128 || c->d_model == 256 || c->d_model == 512)) {
     skf_set_error("d_model %d not in {64,128,256,512}", c->d_model); return SKF_EUNSUPPORTED; }
-  if (c->continuous) { skf_set_error("use_continuous_data=True is not implemented yet"); return SKF_EUNSUPPORTED; }
   if (c->attn_version != 1) { skf_set_error("attn_version=%d: only SelfAttnV1 is implemented", c->attn_version); return SKF_EUNSUPPORTED; }
   if (c->lowerdim <= 0) { skf_set_error("lowerdim=0 is not implemented"); return SKF_EUNSUPPORTED; }
-  SKF_CHECK_ARG(c->vocab_size > 0 && c->n_classes > 0, "bad vocab / classes");
-  SKF_CHECK_ARG(c->vocab_size % 4 == 0, "vocab_size must be a multiple of 4");
+  SKF_CHECK_ARG(c->n_classes > 0, "bad number of classes");
+  if (!c->continuous) {
+    SKF_CHECK_ARG(c->vocab_size > 0, "bad vocab size");
+    SKF_CHECK_ARG(c->vocab_size % 4 == 0, "vocab_size must be a multiple of 4");
+  }
   SKF_CHECK_ARG(c->dff % 4 == 0 && c->lowerdim % 4 == 0, "dff and lowerdim must be multiples of 4");
   SKF_CHECK_ARG(c->max_pos >= c->seq_len, "max_pos < seq_len");
   SKF_CHECK_ARG(c->dropout_rate >= 0.f && c->dropout_rate < 1.f, "dropout_rate out of range");
@@ -679,7 +729,7 @@ extern "C" int skf_model_create(const SkfConfig* cfg, SkfModel** out) {
   const Plan& P = M->plan;
   const int B = cfg->batch, L = cfg->seq_len, Ld = L - 1, d = cfg->d_model, N = cfg->num_layers;
   auto reg = [&](const char* n, size_t off, int r, int c) { M->named[n] = {off, {r, c}}; };
-  reg("logits", P.logits, B * Ld, cfg->vocab_size);
+  reg("logits", P.logits, B * Ld, cfg->continuous ? 5 : cfg->vocab_size);
   reg("class_probs", P.cls_probs, B, cfg->n_classes);
   reg("class_logits", P.cls_logits, B, cfg->n_classes);
   reg("embedding", P.emb, B, d);
@@ -719,7 +769,7 @@ extern "C" int skf_model_bind(SkfModel* m, float* params, float* grads, float* a
   return SKF_OK;
 }
 
-extern "C" int skf_model_forward(SkfModel* m, const long long* inp, const long long* tar, int tar_ld, int training,
+extern "C" int skf_model_forward(SkfModel* m, const void* inp, const void* tar, int tar_ld, int training,
                                  skf_stream_t stream) {
   SKF_CHECK_ARG(m && m->ws, "model not bound");
   hipStream_t s = (hipStream_t)stream;
@@ -728,7 +778,7 @@ extern "C" int skf_model_forward(SkfModel* m, const long long* inp, const long l
   return run_forward(m, training != 0, false, s);
 }
 
-extern "C" int skf_model_forward_backward(SkfModel* m, const long long* inp, const long long* tar, int tar_ld,
+extern "C" int skf_model_forward_backward(SkfModel* m, const void* inp, const void* tar, int tar_ld,
                                           const long long* labels, skf_stream_t stream) {
   SKF_CHECK_ARG(m && m->ws, "model not bound");
   SKF_CHECK_ARG(labels, "null labels");

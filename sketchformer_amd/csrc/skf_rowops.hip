@@ -265,7 +265,8 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(float* __restrict__ log
 __global__ __launch_bounds__(256) void metrics_kernel(const float* __restrict__ recon_loss, const float* __restrict__ recon_hit,
                                                       int recon_rows, float recon_weight,
                                                       const float* __restrict__ class_loss, const float* __restrict__ class_hit,
-                                                      int class_rows, float class_weight, float* __restrict__ metrics) {
+                                                      int class_rows, float class_weight, const float* __restrict__ recon_scalar,
+                                                      float* __restrict__ metrics) {
   __shared__ float red[4][256];
   float s[4] = {0.f, 0.f, 0.f, 0.f};
   for (int i = threadIdx.x; i < recon_rows; i += 256) { s[0] += recon_loss[i]; s[1] += recon_hit[i]; }
@@ -278,7 +279,8 @@ __global__ __launch_bounds__(256) void metrics_kernel(const float* __restrict__ 
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    const float rl = recon_rows ? recon_weight * red[0][0] / recon_rows : 0.f;
+    const float rl = recon_scalar ? *recon_scalar : (recon_rows ? recon_weight * red[0][0] / recon_rows : 0.f);
+    if (recon_scalar) { red[1][0] = 0.f; recon_rows = 0; }   // no token accuracy in continuous mode
     const float cl = class_rows ? class_weight * red[2][0] / class_rows : 0.f;
     metrics[0] = rl; metrics[1] = recon_rows ? red[1][0] / recon_rows : 0.f;
     metrics[2] = cl; metrics[3] = class_rows ? red[3][0] / class_rows : 0.f;
@@ -529,10 +531,10 @@ extern "C" int skf_softmax_ce(float* logits, int ld, int rows, int ncls, const l
 
 extern "C" int skf_metrics_update(const float* recon_loss, const float* recon_hit, int recon_rows, float recon_weight,
                                   const float* class_loss, const float* class_hit, int class_rows, float class_weight,
-                                  float* metrics, skf_stream_t stream) {
+                                  const float* recon_scalar, float* metrics, skf_stream_t stream) {
   SKF_CHECK_ARG(metrics, "null metrics");
   hipLaunchKernelGGL(metrics_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, recon_loss, recon_hit, recon_rows,
-                     recon_weight, class_loss, class_hit, class_rows, class_weight, metrics);
+                     recon_weight, class_loss, class_hit, class_rows, class_weight, recon_scalar, metrics);
   SKF_LAUNCH_CHECK();
   return SKF_OK;
 }

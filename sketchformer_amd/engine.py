@@ -193,20 +193,33 @@ class TrainEngine:
             t = t.to(torch.int64)
         return t.to(self.device, non_blocking=True).contiguous()
 
+    def _dev_input(self, x):
+        """(B,L) int64 tokens, or (B,L,5) float32 stroke-5 rows in continuous mode (the reference casts the
+        loader's float64 to float32 at the tf.function boundary, models/sketchformer.py:317-319)."""
+        if not self.cfg.continuous:
+            return self._dev_tokens(x)
+        t = torch.as_tensor(x)
+        if t.dim() != 3 or t.shape[-1] != 5:
+            raise ValueError("continuous mode expects (B, L, 5) stroke-5 input")
+        return t.to(self.device, dtype=torch.float32, non_blocking=True).contiguous()
+
+    def _ld(self, t):
+        return t.stride(0) // 5 if self.cfg.continuous else t.stride(0)
+
     def forward(self, inp, tar=None, training=False):
         """Transformer.call: fills the internal buffers (see ``buffer``)."""
-        inp = self._dev_tokens(inp)
-        tar = inp if tar is None else self._dev_tokens(tar)
+        inp = self._dev_input(inp)
+        tar = inp if tar is None else self._dev_input(tar)
         self._enter()
-        _lib.call("skf_model_forward", self.handle, self._p(inp), self._p(tar), tar.stride(0), int(training), self._stream())
+        _lib.call("skf_model_forward", self.handle, self._p(inp), self._p(tar), self._ld(tar), int(training), self._stream())
         self._leave()
 
     def forward_backward(self, inp, tar, labels):
-        inp = self._dev_tokens(inp)
-        tar = inp if tar is None else self._dev_tokens(tar)
+        inp = self._dev_input(inp)
+        tar = inp if tar is None else self._dev_input(tar)
         labels = self._dev_tokens(labels)
         self._enter()
-        _lib.call("skf_model_forward_backward", self.handle, self._p(inp), self._p(tar), tar.stride(0), self._p(labels),
+        _lib.call("skf_model_forward_backward", self.handle, self._p(inp), self._p(tar), self._ld(tar), self._p(labels),
                   self._stream())
         self._leave()
 

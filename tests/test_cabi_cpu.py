@@ -4,6 +4,7 @@ import ctypes as C
 import os
 import re
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -65,11 +66,23 @@ def test_layout_names_match_oracle(lib):
 
 def test_unsupported_configs_fail_loudly(lib):
     from sketchformer_amd import engine
-    cfg = engine.make_config(batch=4, continuous=True)
+    cfg = engine.make_config(batch=4, attn_version=2)
     assert lib.skf_config_validate(C.byref(cfg)) == -2
-    assert b"continuous" in lib.skf_last_error()
+    assert b"attn_version" in lib.skf_last_error()
+    assert lib.skf_config_validate(C.byref(engine.make_config(batch=4, continuous=True, vocab_size=None))) == 0
     with pytest.raises(TypeError):
         engine.make_config(batch=4, lr_scheduler="step-decay")
+
+
+def test_continuous_layout_names_match_oracle(lib):
+    import oracle
+    from sketchformer_amd import engine
+    ocfg = oracle.Config(num_layers=6, d_model=256, dff=1024, num_heads=8, lowerdim=256, n_classes=345, seq_len=200, continuous=True)
+    cfg = engine.make_config(batch=4, num_layers=6, d_model=256, dff=1024, continuous=True, vocab_size=None)
+    want = {n: s for n, s, _ in oracle.param_specs(ocfg)}
+    got = {e["name"]: engine.logical_shape(e) for e in engine.param_entries(cfg)}
+    assert got == want
+    assert sum(int(np.prod(s)) for s in want.values()) == 11218670        # P for cfg 3
 
 
 def test_param_count_matches_survey(lib):

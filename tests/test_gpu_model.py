@@ -195,3 +195,59 @@ def test_full_size_c1_class_head_k3():
     m = eng.step_metrics()
     assert m["class_loss"] == 0.0 and m["class_acc"] == 1.0
     assert np.abs(eng.get("classify/kernel", "grads")).max() == 0.0
+
+
+# ------------------------------------------------------------------ continuous stroke-5 mode (cfg 3 family)
+@pytest.mark.parametrize("rate", [0.0, 0.1])
+def test_continuous_mode_losses_and_gradients(rate):
+    from sketchformer_amd import engine
+    B = 5
+    kw = dict(seq_len=24, d_model=64, num_heads=2, dff=128, num_layers=2, n_classes=7, lowerdim=32)      # dh = 32
+    eng = engine.TrainEngine(engine.make_config(batch=B, continuous=True, vocab_size=None, dropout_rate=rate,
+                                                use_graph=False, seed=3, **kw), init_seed=2)
+    ocfg = oracle.Config(continuous=True, dropout_rate=rate, **kw)
+    rng = np.random.RandomState(4)
+    for e in eng.entries:
+        if e["name"].endswith(("/bias", "/beta", "b_attn")):
+            eng.set(e["name"], rng.normal(0, 0.1, engine.logical_shape(e)))
+    x, y = synthetic.continuous_batch(B, ocfg.seq_len, ocfg.n_classes, seed=6)
+    x[0, 9:] = [0, 0, 0, 0, 1]
+    P = {k: v.astype(np.float64) for k, v in eng.state_dict_numpy().items()}
+    eng.forward_backward(x, None, y)
+    torch.cuda.synchronize()
+    drops = _drops_from_engine(eng, ocfg, B) if rate > 0 else None
+    xd = x.astype(np.float64)
+    losses, out, G = oracle.loss_and_grads(P, ocfg, xd, xd, y, drops)
+    m = eng.step_metrics()
+    for k in ("recon_loss", "class_loss", "total_loss"):
+        assert abs(m[k] - losses[k]) < 2e-5 * max(1.0, abs(losses[k])), (k, m[k], losses[k])
+    got = eng.state_dict_numpy("grads")
+    floor = 1e-3 * np.median([np.abs(G[k]).max() for k in G])
+    rel = {k: np.abs(got[k].astype(np.float64) - G[k]).max() / max(np.abs(G[k]).max(), floor) for k in G}
+    worst = max((v, k) for k, v in rel.items())
+    assert worst[0] < 1e-3, worst
+    eng.forward(x, training=False)
+    torch.cuda.synchronize()
+    ref, _ = oracle.forward(P, ocfg, xd, xd[:, :-1], training=False)
+    assert _rel(eng.buffer("logits").cpu().numpy().reshape(B, -1, 5), ref["recon"]) < 1e-4
+
+
+def test_k4b_pad_asymmetry_continuous():
+    """K4b: contents of pad rows do not change encoder outputs at NON-pad positions (pad keys are masked), but the
+    unmasked bottleneck softmax makes the embedding (hence every decoder logit) depend on them."""
+    from sketchformer_amd import engine
+    B = 4
+    kw = dict(seq_len=24, d_model=64, num_heads=4, dff=128, num_layers=2, n_classes=7, lowerdim=32)
+    eng = engine.TrainEngine(engine.make_config(batch=B, continuous=True, vocab_size=None, dropout_rate=0.0, use_graph=False, **kw))
+    x, _ = synthetic.continuous_batch(B, 24, 7, seed=9)
+    x[:, 12:] = [0, 0, 0, 0, 1]
+    eng.forward(x, training=False)
+    enc_a = eng.buffer("enc_output").clone().view(B, 24, 64); emb_a = eng.buffer("embedding").clone()
+    x2 = x.copy()
+    x2[:, 12:, :2] = np.random.RandomState(0).normal(0, 0.5, size=x2[:, 12:, :2].shape)        # pad bit stays 1
+    eng.forward(x2, training=False)
+    enc_b = eng.buffer("enc_output").view(B, 24, 64); emb_b = eng.buffer("embedding")
+    torch.cuda.synchronize()
+    assert torch.equal(enc_a[:, :12], enc_b[:, :12])
+    assert not torch.equal(enc_a[:, 12:], enc_b[:, 12:])
+    assert not torch.equal(emb_a, emb_b)
