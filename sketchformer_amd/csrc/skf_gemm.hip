@@ -352,6 +352,9 @@ extern "C" int skf_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K,
   p.b_vec = ((ldb & 3) == 0) && (((uintptr_t)B & 15) == 0);
   p.tiles_m = skf_cdiv(M, 128); p.tiles_n = skf_cdiv(N, 128);
   { const char* ab = getenv("SKF_GEMM_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }
+  { const char* xr = getenv("SKF_WS_XCD"); p.xcd_remap = xr ? atoi(xr) : 0; }
+  { const char* ds = getenv("SKF_WS_DIRECT"); p.direct_store = ds ? atoi(ds) : 0; }
+  { const char* db = getenv("SKF_GEMM_DBG"); p.dbg = db ? (long long*)strtoull(db, nullptr, 0) : nullptr; }
   if (splits <= 1 && !bias_grad) {
     int handled = 0;
     int rc = skf_gemm_ws_dispatch(p, a_kcontig, b_kcontig, st, &handled);

@@ -19,6 +19,9 @@ struct GemmParams {
   float* slab;             // [splits][M][N] raw partial tiles (split-K only)
   float* colsum_slab;      // [splits][N] partial column sums of B (bias grad), or null
   int tiles_m, tiles_n;
+  long long* dbg;          // diagnostics only: per-phase s_memtime stamps of a few workgroups (env SKF_GEMM_DBG)
+  int xcd_remap;           // ws kernel: XCD-contiguous logical ids (env SKF_WS_XCD, A/B knob)
+  int direct_store;        // ws kernel: store C straight from the MFMA layout (env SKF_WS_DIRECT, A/B knob)
   int ablate;              // diagnostics only (env SKF_GEMM_ABLATE): 1 no MFMA, 2 no C store, 3 no global reload
 };
 

@@ -61,11 +61,15 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GemmParams p, int group
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, g = lane >> 4;
   // the column groups of one worker read the same A tiles: consecutive logical ids -> same XCD / L2
-  const int logical = skf_xcd_remap(blockIdx.x, gridDim.x);
+  const int logical = p.xcd_remap ? skf_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   const int group = logical % groups, worker = logical / groups;
   const int n_wave = group * 4 * CW + wave * CW;     // first output column of this wave
   const int ntiles = (p.M + TR - 1) / TR;
 
+  long long* dbg = (p.dbg && lane == 0 && wave == 0 && (blockIdx.x % 97) == 0 && blockIdx.x / 97 < 8) ? p.dbg + (blockIdx.x / 97) * 32 : nullptr;
+  int dbi = 0;
+#define SKF_STAMP() do { if (dbg && dbi < 32) dbg[dbi++] = clock64(); } while (0)
+  SKF_STAMP();
   // ---- this wave's weight slice -> registers (once)
   float breg[NB][KQ];
 #pragma unroll
@@ -87,10 +91,19 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GemmParams p, int group
 
   f32x4 ra[NV];
 
+  // bias of this wave's columns: loop invariant, but the compiler cannot hoist the load past the C stores
+  float bias_r[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int n = n_wave + nb * 16 + i;
+    bias_r[nb] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+  }
+  SKF_STAMP();   // B loads issued
   int tile = worker;
   ws_load_tile<K>(p.A, p.lda, p.M, tile < ntiles ? tile : 0, ra);
   ws_store_tile<K>(As, ra);
   __syncthreads();
+  SKF_STAMP();   // first A tile in LDS
   float* cs = Cs + wave * TR * LDC_S;
   int cur = 0;
   for (; tile < ntiles; tile += workers) {
@@ -112,19 +125,47 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GemmParams p, int group
         for (int nb = 0; nb < NB; ++nb)
           acc[nb][e & 1] = mfma16(av[e], breg[nb][4 * j + e], acc[nb][e & 1]);
     }
+    SKF_STAMP();   // MFMAs issued (first use of acc below waits for them)
     // ---- epilogue: lane (i,g) holds C[row 4g+r][col nb*16+i]; bias/act, then through the wave's LDS patch
+    // one wave-uniform switch per tile (a per-element switch costs ~40 scalar branches per tile)
+    float vals[NB][4];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      const int n = n_wave + nb * 16 + i;
-      const float bv = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = acc[nb][0][r] + acc[nb][1][r] + bv;
-        if (p.act == 1) v = fmaxf(v, 0.f);
-        else if (p.act == 2) v = tanhf(v);
-        cs[(4 * g + r) * LDC_S + nb * 16 + i] = v;
-      }
+      for (int r = 0; r < 4; ++r) vals[nb][r] = acc[nb][0][r] + acc[nb][1][r] + bias_r[nb];
+    if (p.act == 1) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vals[nb][r] = fmaxf(vals[nb][r], 0.f);
+    } else if (p.act == 2) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vals[nb][r] = tanhf(vals[nb][r]);
     }
+    if (p.direct_store) {
+      // straight from the MFMA C layout: each store covers 4 rows x 64 contiguous bytes (L2 merges the two column blocks)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int n = n_wave + nb * 16 + i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int grow = tile * TR + 4 * g + r;
+          if (grow < p.M && n < p.N) {
+            float v = vals[nb][r];
+            if (p.relu_src) v = p.relu_src[(size_t)grow * p.ld_relu + n] > 0.f ? v : 0.f;
+            float* dst = p.C + (size_t)grow * p.ldc + n;
+            if (p.accumulate) v += *dst;
+            *dst = v;
+          }
+        }
+      }
+    } else {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cs[(4 * g + r) * LDC_S + nb * 16 + i] = vals[nb][r];
     __builtin_amdgcn_wave_barrier();
     constexpr int F4_ROW = CW / 4;                     // float4 per row of the wave's patch
 #pragma unroll
@@ -144,8 +185,11 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GemmParams p, int group
       }
     }
     __builtin_amdgcn_wave_barrier();
+    }
+    SKF_STAMP();   // C tile stored
     ws_store_tile<K>(As + (cur ^ 1) * TR * LDA_S, ra);
     __syncthreads();
+    SKF_STAMP();   // next A tile in LDS + barrier
     cur ^= 1;
   }
 }
