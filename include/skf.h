@@ -59,6 +59,19 @@ int skf_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K, const float*
                  int splits, float* bias_grad, int bias_grad_accumulate, void* workspace, size_t workspace_bytes,
                  skf_stream_t stream);
 
+/* wgrad split into its two phases so that a caller can run MANY wgrads and reduce all their slabs with one launch:
+ * skf_gemm_wgrad_partial = the partial-tile kernel only (A = X [K][M], B = dY [K][N]; slab layout
+ * [splits][M][N] followed by [splits][N] column sums), skf_splitk_reduce_batch = one launch over a DEVICE array of
+ * descriptors whose block_begin fields are the running sum of skf_splitk_reduce_blocks(M, N). */
+typedef struct SkfReduceDesc {
+  const float* slab; float* C; float* bias_grad; /* bias_grad may be NULL */
+  int32_t splits, M, N, ldc, block_begin, pad;
+} SkfReduceDesc;
+int skf_gemm_wgrad_partial(int M, int N, int K, const float* A, int lda, const float* B, int ldb, int splits,
+                           int with_bias_grad, float* slab, size_t slab_bytes, int* splits_used_host, skf_stream_t stream);
+int skf_splitk_reduce_blocks(int M, int N);
+int skf_splitk_reduce_batch(const SkfReduceDesc* descs_dev, int ndesc, int total_blocks, skf_stream_t stream);
+
 /* ------------------------------------------------------------------ attention
  * builders/utils.py:71-105 scaled_dot_product_attention + the head split / merge of
  * builders/layers/transformer.py:160-186 + the masks of builders/utils.py:35-68.

@@ -52,6 +52,9 @@ SIGNATURES = {
     "skf_profiler_report": (_I, [C.c_char_p, _Z]),
     "skf_gemm_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "skf_gemm_default_splits": (_I, [_I, _I, _I]),
+    "skf_gemm_wgrad_partial": (_I, [_I, _I, _I, _P, _I, _P, _I, _I, _I, _P, _Z, _P, _P]),
+    "skf_splitk_reduce_blocks": (_I, [_I, _I]),
+    "skf_splitk_reduce_batch": (_I, [_P, _I, _I, _P]),
     "skf_gemm_f32": (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _I, _P, _Z, _P]),
     "skf_attention_fwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P]),
     "skf_attention_bwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I,

@@ -22,6 +22,7 @@
 // (row = query) so they feed dV^T += dO^T.P and dK^T += Q^T.dS directly; dS is
 // transposed through a wave-private LDS scratch for dQ^T += K^T.dS^T, which is
 // accumulated across waves with LDS float atomics and written once.
+#include <stdlib.h>
 #include "skf_common.h"
 
 namespace {
@@ -35,6 +36,8 @@ struct AttnParams {
   int B, H, Lq, Lk;
   float* stats;                   // (B, H, Lq, 2): row max, 1/sum
   // backward only
+  int ablate;                     // diagnostics (env SKF_ATTN_ABLATE): 1 = no dQ atomics
+  long long* dbg;                 // diagnostics: s_memtime stamps of a few workgroups (env SKF_ATTN_DBG)
   const float* dO; int lddo;
   float* dQ; float* dK; float* dV;
   int lddq, lddk, lddv;
@@ -69,16 +72,29 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     *reinterpret_cast<float4*>(&Ks[row * LD + c4]) = kv;
     *reinterpret_cast<float4*>(&Vs[row * LD + c4]) = vv;
   }
-  for (int key = tid; key < nkt * 16; key += 256) {
-    float mv = -INFINITY;
-    if (key < p.Lk) mv = (p.key_mask && p.key_mask[(size_t)b * p.key_mask_ld + key]) ? -1e9f : 0.f;
-    Ms[key] = mv;
+  int* last_valid = reinterpret_cast<int*>(Ms + nkt * 16);   // [4]: per-wave index of the last un-padded key
+  {
+    int lv = -1;
+    for (int key = tid; key < nkt * 16; key += 256) {
+      float mv = -INFINITY;
+      if (key < p.Lk) mv = (p.key_mask && p.key_mask[(size_t)b * p.key_mask_ld + key]) ? -1e9f : 0.f;
+      Ms[key] = mv;
+      if (mv == 0.f) lv = key;             // keys ascend within a thread
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lv = max(lv, __shfl_xor(lv, o, 64));
+    if (lane == 0) last_valid[wave] = lv;
   }
   __syncthreads();
 
   // Causal tile skipping is exact only when key 0 is visible to every query
   // (then every row max is a real score and masked probabilities are exactly 0).
   const bool can_skip = p.causal && Ms[0] == 0.f;
+  // Trailing key tiles that hold only padded keys contribute exactly 0 to every row that sees at least one real
+  // key (exp(-1e9 - max) == 0 in fp32), so they are skipped: QuickDraw batches are ~60 % padding.  Not applied when
+  // some row may have no visible key at all (then the reference's softmax is uniform over ALL keys).
+  const int lastk = max(max(last_valid[0], last_valid[1]), max(last_valid[2], last_valid[3]));
+  const int nkt_eff = (lastk >= 0 && (!p.causal || can_skip)) ? (lastk >> 4) + 1 : nkt;
   const float inv_sqrt = 1.0f / sqrtf((float)DH);
   const bool pow4 = (DH == 16 || DH == 64);
 
@@ -91,7 +107,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
       qf[c] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (qok) qf[c] = *reinterpret_cast<const float4*>(p.Q + (size_t)(b * p.Lq + qrow) * p.ldq + h * DH + c * 16 + g * 4);
     }
-    const int nt = can_skip ? min(nkt, qt + 1) : nkt;
+    const int nt = min(can_skip ? qt + 1 : nkt, nkt_eff);
     float s[MAXT][4];
     float mx = -INFINITY;
 #pragma unroll
@@ -159,7 +175,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 }
 
 // KTW = key tiles owned by one wave at a time (register budget: 20*NC*KTW accumulator/fragment registers)
-template <int DH, int KTW>
+// CAUSAL=false: the per-slot body is branch-free (key tiles past Lk are zero-filled dummies) so the compiler can overlap
+// consecutive key tiles, and when nkt = 4*(KTW-1)+1 (L = 193..208 at dh=16) the odd 13th key tile is SHARED: every wave
+// holds its fragments and processes it for the query tiles with (qt & 3) == wave; the four partial dK/dV are summed
+// through LDS at the end (work per wave 42.25 pairs instead of 52 / 39 / 39 / 39).
+template <int DH, int KTW, bool CAUSAL>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
   constexpr int NC = DH / 16;
   constexpr int LD = DH + 4;
@@ -167,11 +187,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
   const int nkt = (p.Lk + 15) >> 4, nqt = (p.Lq + 15) >> 4;
-  const int QR = nqt * 16, LDT = QR + 4;
+  const int QR = nqt * 16;
+  constexpr int RLD = DH + 1;          // row pitch of the dQ reduction slots
   float* Qs = smem;                   // [QR][LD]
   float* dOs = Qs + QR * LD;          // [QR][LD]
-  float* dQt = dOs + QR * LD;         // [DH][LDT]  dQ^T accumulator (d-major: the 64 atomic lanes hit 32 banks 2-way)
-  float* Mx = dQt + DH * LDT;         // [QR]
+  float* Red = dOs + QR * LD;         // [2 parities][4 waves][16 q][RLD]: per-query-tile dQ partials of the 4 waves
+  float* Mx = Red + 2 * 4 * 16 * RLD; // [QR]
   float* Ri = Mx + QR;                // [QR]
   float* Dl = Ri + QR;                // [QR]  delta = sum_d dO*O
   float* Tr = Dl + QR;                // [4 waves][16][TLD]
@@ -179,45 +200,76 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, g = lane >> 4;
 
-  for (int e = tid; e < QR * (DH / 4); e += 256) {
-    const int row = e / (DH / 4), c4 = (e % (DH / 4)) * 4;
-    float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), dv = qv;
-    if (row < p.Lq) {
-      qv = *reinterpret_cast<const float4*>(p.Q + (size_t)(b * p.Lq + row) * p.ldq + h * DH + c4);
-      dv = *reinterpret_cast<const float4*>(p.dO + (size_t)(b * p.Lq + row) * p.lddo + h * DH + c4);
-    }
-    *reinterpret_cast<float4*>(&Qs[row * LD + c4]) = qv;
-    *reinterpret_cast<float4*>(&dOs[row * LD + c4]) = dv;
-  }
-  for (int e = tid; e < DH * LDT; e += 256) dQt[e] = 0.f;
-  for (int row = tid; row < QR; row += 256) {
-    float mx = 0.f, ri = 0.f, dl = 0.f;
-    if (row < p.Lq) {
-      const float2 st = reinterpret_cast<const float2*>(p.stats)[(size_t)bh * p.Lq + row];
-      mx = st.x; ri = st.y;
-      const float* orow = p.O + (size_t)(b * p.Lq + row) * p.ldo + h * DH;
-      const float* drow = p.dO + (size_t)(b * p.Lq + row) * p.lddo + h * DH;
+  long long* dbg = (p.dbg && lane == 0 && (blockIdx.x % 131) == 0 && blockIdx.x / 131 < 8) ? p.dbg + ((blockIdx.x / 131) * 4 + wave) * 32 : nullptr;
+  int dbi = 0;
+#define SKF_STAMP() do { if (dbg && dbi < 32) dbg[dbi++] = clock64(); } while (0)
+  SKF_STAMP();
+  // Staging: all global loads of a batch are issued before the first LDS store (one HBM latency per batch of
+  // 4 float4 x 3 arrays instead of one per element), delta = sum_d dO*O is reduced over the DH/4 lanes of a row.
+  {
+    constexpr int F4 = DH / 4;
+    const int total = QR * F4;
+    for (int e0 = tid; e0 < total; e0 += 1024) {
+      f32x4 qv[4], dv[4], ov[4];
 #pragma unroll
-      for (int c = 0; c < DH; c += 4) {
-        const float4 a = *reinterpret_cast<const float4*>(orow + c);
-        const float4 d = *reinterpret_cast<const float4*>(drow + c);
-        dl += a.x * d.x + a.y * d.y + a.z * d.z + a.w * d.w;
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * 256, row = e / F4, c4 = (e % F4) * 4;
+        const bool ok = e < total && row < p.Lq;
+        const int rr = ok ? row : 0;
+        qv[u] = *reinterpret_cast<const f32x4*>(p.Q + (size_t)(b * p.Lq + rr) * p.ldq + h * DH + c4);
+        dv[u] = *reinterpret_cast<const f32x4*>(p.dO + (size_t)(b * p.Lq + rr) * p.lddo + h * DH + c4);
+        ov[u] = *reinterpret_cast<const f32x4*>(p.O + (size_t)(b * p.Lq + rr) * p.ldo + h * DH + c4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * 256, row = e / F4, c4 = (e % F4) * 4;
+        const bool ok = e < total && row < p.Lq;
+        const float z = ok ? 1.f : 0.f;
+        const f32x4 q4 = qv[u] * z, d4 = dv[u] * z, o4 = ov[u] * z;
+        float dl = d4[0] * o4[0] + d4[1] * o4[1] + d4[2] * o4[2] + d4[3] * o4[3];
+#pragma unroll
+        for (int o = 1; o < F4; o <<= 1) dl += __shfl_xor(dl, o, 64);
+        if (e < total) {
+          *reinterpret_cast<f32x4*>(&Qs[row * LD + c4]) = q4;
+          *reinterpret_cast<f32x4*>(&dOs[row * LD + c4]) = d4;
+          if (c4 == 0) Dl[row] = dl;
+        }
       }
     }
-    Mx[row] = mx; Ri[row] = ri; Dl[row] = dl;
+  }
+  int* last_valid = reinterpret_cast<int*>(Tr + 4 * 16 * TLD);   // [4]: per-wave index of the last un-padded key
+  {
+    int lv = -1;
+    for (int key = tid; key < p.Lk; key += 256)
+      if (!(p.key_mask && p.key_mask[(size_t)b * p.key_mask_ld + key])) lv = key;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lv = max(lv, __shfl_xor(lv, o, 64));
+    if (lane == 0) last_valid[wave] = lv;
+  }
+  for (int row = tid; row < QR; row += 256) {
+    float2 st = make_float2(0.f, 0.f);
+    if (row < p.Lq) st = reinterpret_cast<const float2*>(p.stats)[(size_t)bh * p.Lq + row];
+    Mx[row] = st.x; Ri[row] = st.y;
   }
   __syncthreads();
+  SKF_STAMP();   // staging done
 
   const unsigned char* km = p.key_mask ? p.key_mask + (size_t)b * p.key_mask_ld : nullptr;
   // skipping fully look-ahead-masked tiles is exact only if key 0 is visible (see forward)
   const bool can_skip = p.causal && !(km && km[0]);
+  // trailing all-padding key tiles have P == 0 exactly: their dK/dV are 0 and they add nothing to dQ (see forward)
+  const int lastk = max(max(last_valid[0], last_valid[1]), max(last_valid[2], last_valid[3]));
+  const int nkt_eff = (lastk >= 0 && (!p.causal || can_skip)) ? (lastk >> 4) + 1 : nkt;
   const float inv_sqrt = 1.0f / sqrtf((float)DH);
   const bool pow4 = (DH == 16 || DH == 64);
   float* tr = Tr + wave * 16 * TLD;
+  f32x4 dK_shared[NC], dV_shared[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) { dK_shared[c] = (f32x4){0.f, 0.f, 0.f, 0.f}; dV_shared[c] = dK_shared[c]; }
 
   for (int kg = 0; kg < nkt; kg += 4 * KTW) {
     const int kt0 = kg + wave;                 // smallest key tile of this wave in this group
-    if (kt0 >= nkt) continue;
+    const bool share = !CAUSAL && kg == 0 && KTW > 1 && nkt == 4 * (KTW - 1) + 1;
     // B-operand fragments (lane = key i, contraction d = 16c+4g+s) and
     // A-operand (transposed) fragments (lane = d 16c+i, contraction key = k0+4g+s)
     float4 kb[KTW][NC], vb[KTW][NC];
@@ -226,10 +278,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
     f32x4 dKt[KTW][NC], dVt[KTW][NC];
 #pragma unroll
     for (int j = 0; j < KTW; ++j) {
-      const int k0 = (kt0 + 4 * j) * 16, krow = k0 + i;
+      const int ktj = (share && j == KTW - 1) ? nkt - 1 : kt0 + 4 * j;
+      const int k0 = ktj * 16, krow = k0 + i;
       const bool kok = krow < p.Lk;
       kvalid[j] = kok ? 1.f : 0.f;
-      kadd[j] = (km && kok && km[krow]) ? -1e9f : 0.f;
+      // keys past Lk get -inf (never -1e9): with a fully padded sample the row max itself is -1e9 and exp(x - max) would overflow
+      kadd[j] = kok ? ((km && km[krow]) ? -1e9f : 0.f) : -INFINITY;
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         kb[j][c] = make_float4(0.f, 0.f, 0.f, 0.f); vb[j][c] = kb[j][c];
@@ -246,11 +300,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
       }
     }
 
-    const int qt_begin = can_skip ? kt0 : 0;   // query tiles entirely above the wave's first key tile contribute 0
-    const int nq_act = nqt - qt_begin;
-    for (int it = 0; it < nq_act; ++it) {
-      // each wave starts at a different query tile so the waves' LDS atomics on dQ do not collide
-      const int qt = qt_begin + (it + wave * 3) % nq_act;
+    SKF_STAMP();   // K/V fragments loaded (issued)
+    // every wave walks ALL query tiles in lock step (the trip count must be workgroup-uniform: one barrier per tile)
+    for (int qt = 0; qt < nqt; ++qt) {
+      SKF_STAMP();
       const int q0 = qt * 16;
       float4 qa[NC], da[NC];
       float qT[NC][4], dT[NC][4];
@@ -275,8 +328,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
 
 #pragma unroll
       for (int j = 0; j < KTW; ++j) {
-        const int kt = kt0 + 4 * j;
-        if (kt >= nkt || (can_skip && kt > qt)) continue;     // wave-uniform
+        const int kt = (share && j == KTW - 1) ? nkt - 1 : kt0 + 4 * j;
+        if (kt >= nkt_eff) continue;                            // wave-uniform: all-padding (or non-existent) key tile
+        if (CAUSAL) {
+          if (can_skip && kt > qt) continue;
+        } else if (share && j == KTW - 1) {
+          if ((qt & 3) != wave) continue;                      // the shared tile: one wave per query tile
+        }
         const int krow = kt * 16 + i;
         f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dpacc = sacc;
 #pragma unroll
@@ -325,13 +383,35 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
           dq1[c] = mfma16(kT[j][c][3], dst.w, dq1[c]);
         }
       }
+      // dQ of this query tile = sum of the 4 waves' partials: LDS float atomics cost ~20 cycles per lane on gfx950
+      // (they were 35 % of this kernel), so each wave writes its 16 x DH partial to its own slot, one barrier, and
+      // the workgroup sums the 4 slots straight into global dQ (double-buffered slots -> one barrier per query tile).
+      {
+        float* slot = Red + ((qt & 1) * 4 + wave) * 16 * RLD;
 #pragma unroll
-      for (int c = 0; c < NC; ++c)
+        for (int c = 0; c < NC; ++c)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(&dQt[(c * 16 + g * 4 + r) * LDT + q0 + i], dq[c][r] + dq1[c][r]);
+          for (int r = 0; r < 4; ++r) slot[i * RLD + c * 16 + g * 4 + r] = dq[c][r] + dq1[c][r];
+        __syncthreads();
+        const float* base = Red + (qt & 1) * 4 * 16 * RLD;
+        for (int e = tid; e < 16 * DH; e += 256) {
+          const int qq = e / DH, dd = e % DH;
+          if (q0 + qq < p.Lq) {
+            const float v = base[qq * RLD + dd] + base[16 * RLD + qq * RLD + dd] + base[2 * 16 * RLD + qq * RLD + dd] +
+                            base[3 * 16 * RLD + qq * RLD + dd];
+            float* dst = p.dQ + (size_t)(b * p.Lq + q0 + qq) * p.lddq + h * DH + dd;
+            *dst = kg == 0 ? v : *dst + v;
+          }
+        }
+      }
+    }
+    if (share) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) { dK_shared[c] = dKt[KTW - 1][c]; dV_shared[c] = dVt[KTW - 1][c]; }
     }
 #pragma unroll
     for (int j = 0; j < KTW; ++j) {
+      if (share && j == KTW - 1) continue;                    // reduced across waves below
       const int krow = (kt0 + 4 * j) * 16 + i;
       if (krow < p.Lk) {
 #pragma unroll
@@ -344,18 +424,38 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
       }
     }
   }
+  SKF_STAMP();   // wave done
   __syncthreads();
-  for (int e = tid; e < p.Lq * (DH / 4); e += 256) {
-    const int row = e / (DH / 4), c4 = (e % (DH / 4)) * 4;
-    *reinterpret_cast<float4*>(p.dQ + (size_t)(b * p.Lq + row) * p.lddq + h * DH + c4) =
-        make_float4(dQt[(c4 + 0) * LDT + row], dQt[(c4 + 1) * LDT + row], dQt[(c4 + 2) * LDT + row], dQt[(c4 + 3) * LDT + row]);
+  SKF_STAMP();   // all waves done
+  if (!CAUSAL && KTW > 1 && nkt == 4 * (KTW - 1) + 1) {
+    // partial dK^T / dV^T of the shared key tile: Qs is free now, use it as [4 waves][2][DH][16] scratch
+    float* sh = Qs + wave * 2 * DH * 16;
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        sh[(c * 16 + g * 4 + r) * 16 + i] = dK_shared[c][r];
+        sh[DH * 16 + (c * 16 + g * 4 + r) * 16 + i] = dV_shared[c][r];
+      }
+    __syncthreads();
+    const int krow0 = (nkt - 1) * 16;
+    for (int e = tid; e < 2 * DH * 16; e += 256) {
+      const int which = e / (DH * 16), dd = (e % (DH * 16)) / 16, kk = e % 16;
+      const float v = Qs[e] + Qs[2 * DH * 16 + e] + Qs[4 * DH * 16 + e] + Qs[6 * DH * 16 + e];
+      if (krow0 + kk < p.Lk) {
+        float* dst = which ? p.dV : p.dK;
+        const int ld = which ? p.lddv : p.lddk;
+        dst[(size_t)(b * p.Lk + krow0 + kk) * ld + h * DH + dd] = v;
+      }
+    }
+    __syncthreads();
   }
 }
 
-size_t fwd_smem(int DH, int Lk) { return (size_t)((Lk + 15) / 16 * 16) * (2 * (DH + 4) + 1) * sizeof(float); }
+size_t fwd_smem(int DH, int Lk) { return (size_t)((Lk + 15) / 16 * 16) * (2 * (DH + 4) + 1) * sizeof(float) + 16; }
 size_t bwd_smem(int DH, int Lq) {
   const size_t QR = (size_t)(Lq + 15) / 16 * 16;
-  return (2 * QR * (DH + 4) + (size_t)DH * (QR + 4) + 3 * QR + 4 * 16 * 20) * sizeof(float);
+  return (2 * QR * (DH + 4) + (size_t)2 * 4 * 16 * (DH + 1) + 3 * QR + 4 * 16 * 20 + 4) * sizeof(float);
 }
 
 template <typename K>
@@ -414,6 +514,8 @@ extern "C" int skf_attention_bwd(const float* Q, int ldq, const float* K, int ld
   p.Q = Q; p.K = K; p.V = V; p.O = const_cast<float*>(O); p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
   p.key_mask = key_mask; p.key_mask_ld = key_mask_ld; p.causal = causal; p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk;
   p.stats = const_cast<float*>(stats);
+  { const char* ab = getenv("SKF_ATTN_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }
+  { const char* db = getenv("SKF_ATTN_DBG"); p.dbg = db ? (long long*)strtoull(db, nullptr, 0) : nullptr; }
   p.dO = dO; p.lddo = lddo; p.dQ = dQ; p.dK = dK; p.dV = dV; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
   int rc = check_common(p, dh);
   if (rc) return rc;
@@ -425,9 +527,15 @@ extern "C" int skf_attention_bwd(const float* Q, int ldq, const float* K, int ld
   dim3 grid(B * H), block(256);
 #define SKF_ATTN_BWD(DHV)                                       \
   {                                                             \
-    auto kfn = attn_bwd_kernel<DHV, 64 / DHV>;                          \
-    if ((rc = set_smem(kfn, smem))) return rc;                  \
-    hipLaunchKernelGGL(kfn, grid, block, smem, st, p);          \
+    if (causal) {                                               \
+      auto kfn = attn_bwd_kernel<DHV, 64 / DHV, true>;          \
+      if ((rc = set_smem(kfn, smem))) return rc;                \
+      hipLaunchKernelGGL(kfn, grid, block, smem, st, p);        \
+    } else {                                                    \
+      auto kfn = attn_bwd_kernel<DHV, 64 / DHV, false>;         \
+      if ((rc = set_smem(kfn, smem))) return rc;                \
+      hipLaunchKernelGGL(kfn, grid, block, smem, st, p);        \
+    }                                                           \
   }
   static const char* const tags[3] = {"attn_bwd<dh16>", "attn_bwd<dh32>", "attn_bwd<dh64>"};
   SkfProfScope ps(st, tags[dh == 16 ? 0 : dh == 32 ? 1 : 2], 8.0 * B * H * (double)Lq * Lk * dh,

@@ -335,6 +335,84 @@ extern "C" int skf_gemm_default_splits(int M, int N, int K) {
   return splits < 1 ? 1 : splits;
 }
 
+// ---- deferred split-K reduction of MANY wgrads in one launch (the train step runs ~47 wgrads per step)
+namespace {
+__global__ __launch_bounds__(256) void splitk_reduce_batch_kernel(const SkfReduceDesc* __restrict__ descs, int ndesc) {
+  __shared__ f32x4 red[4][64];
+  int di = 0;
+  while (di + 1 < ndesc && (int)blockIdx.x >= descs[di + 1].block_begin) ++di;    // ndesc is small (tens)
+  const SkfReduceDesc d = descs[di];
+  const int M = d.M, N = d.N, splits = d.splits;
+  const size_t total = (size_t)M * N, total4 = (total + N + 3) / 4;
+  const int zg = threadIdx.x >> 6;
+  const size_t e4 = (size_t)(blockIdx.x - d.block_begin) * 64 + (threadIdx.x & 63);
+  const size_t base = e4 * 4;
+  const float* colsum_slab = d.bias_grad ? d.slab + (size_t)splits * total : nullptr;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (e4 < total4) {
+    const bool in_tiles = base < total;
+    const float* src = in_tiles ? d.slab + base : (colsum_slab ? colsum_slab + (base - total) : nullptr);
+    const size_t zstride = in_tiles ? total : (size_t)N;
+    if (src) {
+      int z = zg;
+      for (; z + 12 < splits; z += 16) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(src + (size_t)z * zstride);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(src + (size_t)(z + 4) * zstride);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(src + (size_t)(z + 8) * zstride);
+        const f32x4 e = *reinterpret_cast<const f32x4*>(src + (size_t)(z + 12) * zstride);
+        s += (a + b) + (c + e);
+      }
+      for (; z < splits; z += 4) s += *reinterpret_cast<const f32x4*>(src + (size_t)z * zstride);
+    }
+  }
+  red[zg][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (zg != 0 || e4 >= total4) return;
+  const f32x4 t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const size_t i = base + c;
+    if (i < total) d.C[(size_t)(i / N) * d.ldc + (i % N)] = t[c];
+    else if (i < total + N && d.bias_grad) d.bias_grad[i - total] = t[c];
+  }
+}
+}  // namespace
+
+extern "C" int skf_splitk_reduce_blocks(int M, int N) { return (int)((((size_t)M * N + N + 3) / 4 + 63) / 64); }
+
+extern "C" int skf_splitk_reduce_batch(const SkfReduceDesc* descs_dev, int ndesc, int total_blocks, skf_stream_t stream) {
+  SKF_CHECK_ARG(descs_dev && ndesc > 0 && total_blocks > 0, "bad argument");
+  SkfProfScope ps((hipStream_t)stream, "splitk_reduce_batch", 0.0, 0.0);
+  hipLaunchKernelGGL(splitk_reduce_batch_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, ndesc);
+  SKF_LAUNCH_CHECK();
+  return SKF_OK;
+}
+
+// wgrad main kernel only: dW partials (+ column sums of B when with_bias_grad) into `slab`
+// ([splits][M][N] then [splits][N]); *splits_used receives the effective split count.  Needs M, N, lda, ldb % 4 == 0.
+extern "C" int skf_gemm_wgrad_partial(int M, int N, int K, const float* A, int lda, const float* B, int ldb, int splits,
+                                      int with_bias_grad, float* slab, size_t slab_bytes, int* splits_used,
+                                      skf_stream_t stream) {
+  SKF_CHECK_ARG(M > 0 && N > 0 && K > 0 && A && B && slab && splits_used, "bad argument");
+  if (splits < 1) splits = 1;
+  int chunk = skf_cdiv(K, splits);
+  chunk = skf_cdiv(chunk, 64) * 64;
+  splits = skf_cdiv(K, chunk);
+  SKF_CHECK_ARG(slab_bytes >= skf_gemm_workspace_bytes(M, N, K, splits, 1), "slab too small");
+  GemmParams p{};
+  p.A = A; p.B = B; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb;
+  p.a_vec = ((lda & 3) == 0) && (((uintptr_t)A & 15) == 0);
+  p.b_vec = ((ldb & 3) == 0) && (((uintptr_t)B & 15) == 0);
+  p.k_chunk = chunk; p.slab = slab;
+  p.colsum_slab = with_bias_grad ? slab + (size_t)splits * M * N : nullptr;
+  p.tiles_m = skf_cdiv(M, 64); p.tiles_n = skf_cdiv(N, 64);
+  *splits_used = splits;
+  int handled = 0;
+  int rc = skf_gemm_wgrad_dispatch(p, 0, 0, splits, (hipStream_t)stream, &handled);
+  if (rc != SKF_OK || handled) return rc;
+  return launch_variant<64, 64, 2, true>(p, 0, 0, splits, (hipStream_t)stream);
+}
+
 extern "C" int skf_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K,
                             const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                             const float* bias, int act, const float* relu_src, int ld_relu, int accumulate,

@@ -226,6 +226,7 @@ struct Plan {
   size_t recon_loss, recon_hit, cls_loss, cls_hit, row_mask, cont_scal;
   size_t gA, gB, gC, dqkv, dh, do_, dpre, dkv2, dq2, demb;
   size_t gemm_ws, gemm_ws_bytes, small_ws, small_ws_bytes;
+  size_t slab_arena, slab_arena_bytes, descs, n_wgrads;   // deferred split-K reduction (eager path)
 };
 
 size_t wgrad_ws(int in, int out, int rows) {
@@ -277,6 +278,10 @@ Plan build_plan(const SkfConfig& c) {
   mx(wgrad_ws(d, 3 * d, Me)); mx(wgrad_ws(d, d, Me)); mx(wgrad_ws(d, F, Me)); mx(wgrad_ws(F, d, Me));
   mx(wgrad_ws(d, 2 * d, Me)); mx(wgrad_ws(d, (int)Vout, Md)); mx(wgrad_ws(d, U, Me)); mx(wgrad_ws(d, c.n_classes, B));
   P.gemm_ws_bytes = g; P.gemm_ws = b.take(g);
+  P.n_wgrads = 3 + 11 * (size_t)c.num_layers;
+  P.slab_arena_bytes = P.n_wgrads * ((g + 255) & ~(size_t)255);
+  P.slab_arena = b.take(P.slab_arena_bytes);
+  P.descs = b.take(P.n_wgrads * sizeof(SkfReduceDesc));
   size_t s = skf_layernorm_bwd_workspace_bytes((int)Me, (int)d);
   if (B * U * f > s) s = B * U * f;
   if (2 * B * L * f > s) s = 2 * B * L * f;
@@ -304,6 +309,10 @@ struct SkfModel {
   size_t next_event = 0;
   std::map<const void*, hipEvent_t> pending_readers;   // buffer -> completion event of its last side-stream reader
   bool side_used = false;
+  std::vector<SkfReduceDesc> descs;     // one per wgrad of the step, in launch order
+  bool descs_uploaded = false;
+  size_t slab_cursor = 0, desc_cursor = 0;
+  int reduce_blocks = 0;
 
   hipEvent_t new_event() {
     if (next_event == events.size()) {
@@ -358,7 +367,26 @@ int dense_wgrad(SkfModel* M, const DenseP& w, const float* x, int ldx, const flo
   SKF_CHECK_ARG(ready && done, "event allocation failed");
   SKF_HIP(hipEventRecord(ready, s));
   SKF_HIP(hipStreamWaitEvent(M->side, ready, 0));
-  SKF_TRY(dense_wgrad_on(M, w, x, ldx, dy, lddy, rows, M->side));
+  {
+    // partial tiles only; every slab of the step is reduced by ONE launch in join_side()
+    const int splits = skf_gemm_default_splits(w.in, w.out, rows);
+    const size_t bytes = (skf_gemm_workspace_bytes(w.in, w.out, rows, splits, 1) + 255) & ~(size_t)255;
+    SKF_CHECK_ARG(M->slab_cursor + bytes <= M->plan.slab_arena_bytes && M->desc_cursor < M->plan.n_wgrads, "slab arena exhausted");
+    float* slab = M->at<float>(M->plan.slab_arena + M->slab_cursor);
+    int used = 0;
+    SKF_TRY(skf_gemm_wgrad_partial(w.in, w.out, rows, x, ldx, dy, lddy, splits, 1, slab, bytes, &used, M->side));
+    SkfReduceDesc d;
+    d.slab = slab; d.C = M->G(w.w); d.bias_grad = M->G(w.b); d.splits = used; d.M = w.in; d.N = w.out; d.ldc = w.ld;
+    d.block_begin = M->reduce_blocks; d.pad = 0;
+    if (!M->descs_uploaded) M->descs.push_back(d);
+    else {
+      const SkfReduceDesc& o = M->descs[M->desc_cursor];
+      SKF_CHECK_ARG(o.slab == d.slab && o.C == d.C && o.splits == d.splits && o.block_begin == d.block_begin, "wgrad sequence changed between steps");
+    }
+    M->reduce_blocks += skf_splitk_reduce_blocks(w.in, w.out);
+    M->slab_cursor += bytes;
+    M->desc_cursor += 1;
+  }
   SKF_HIP(hipEventRecord(done, M->side));
   M->pending_readers[dy] = done;
   M->side_used = true;
@@ -366,6 +394,11 @@ int dense_wgrad(SkfModel* M, const DenseP& w, const float* x, int ldx, const flo
 }
 int join_side(SkfModel* M, hipStream_t s) {
   if (M->side && M->side_used) {
+    if (!M->descs_uploaded) {      // the launch sequence is fixed: descriptors are built and uploaded once
+      SKF_HIP(hipMemcpy(M->at<char>(M->plan.descs), M->descs.data(), M->descs.size() * sizeof(SkfReduceDesc), hipMemcpyHostToDevice));
+      M->descs_uploaded = true;
+    }
+    SKF_TRY(skf_splitk_reduce_batch(M->at<SkfReduceDesc>(M->plan.descs), (int)M->descs.size(), M->reduce_blocks, M->side));
     hipEvent_t e = M->new_event();
     SKF_CHECK_ARG(e, "event allocation failed");
     SKF_HIP(hipEventRecord(e, M->side));
@@ -525,6 +558,7 @@ int run_backward(SkfModel* M, hipStream_t s) {
   M->next_event = 0;
   M->pending_readers.clear();
   M->side_used = false;
+  M->slab_cursor = 0; M->desc_cursor = 0; M->reduce_blocks = 0;
   const SkfConfig& c = M->cfg;
   const Layout& L = M->lay;
   const Plan& P = M->plan;
@@ -766,6 +800,7 @@ extern "C" int skf_model_bind(SkfModel* m, float* params, float* grads, float* a
   m->ws = (char*)workspace; m->metrics = metrics; m->state = step_state;
   if (m->g_fb) { (void)hipGraphExecDestroy(m->g_fb); m->g_fb = nullptr; }
   if (m->g_opt) { (void)hipGraphExecDestroy(m->g_opt); m->g_opt = nullptr; }
+  m->descs.clear(); m->descs_uploaded = false;
   return SKF_OK;
 }
 

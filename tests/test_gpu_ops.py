@@ -160,6 +160,31 @@ def test_attention_fully_padded_sequence_matches_fp32_reference_semantics(ops):
     _close(o, _merge(want_o), rtol=1e-4, name="all-pad row")
 
 
+@pytest.mark.parametrize("causal", [False, True])
+def test_attention_padding_tile_skipping_is_exact(ops, causal):
+    """Short sequences (several trailing all-padding key tiles), holes inside the valid range, one fully padded sample."""
+    B, H, L, dh = 6, 4, 200, 16
+    rng = np.random.RandomState(17)
+    d = H * dh
+    q, k, v, do = (rng.randn(B, L, d) for _ in range(4))
+    lens = np.array([200, 80, 17, 16, 1, 50])
+    km = np.arange(L)[None, :] >= lens[:, None]
+    km[1, 30:40] = True                      # padded keys inside the valid range
+    km[5, :] = True                          # a fully padded sample: uniform attention over every key
+    mask = km[:, None, None, :].astype(np.float32)
+    if causal:
+        mask = np.maximum(mask, oracle.create_look_ahead_mask(L)[None, None])
+    f32 = np.float32
+    want, _, cache = oracle.sdpa_fwd(_split(q, H).astype(f32), _split(k, H).astype(f32), _split(v, H).astype(f32), mask)
+    kmd = _dev(km, torch.uint8)
+    o, stats = ops.attention_fwd(_dev(q), _dev(k), _dev(v), H, key_mask=kmd, causal=causal)
+    _close(o, _merge(want), rtol=1e-4, name="fwd")
+    dq, dk, dv = oracle.sdpa_bwd(_split(do, H).astype(f32), cache)
+    gq, gk, gv = ops.attention_bwd(_dev(q), _dev(k), _dev(v), o, _dev(do), stats, H, key_mask=kmd, causal=causal)
+    _close(gq, _merge(dq), rtol=2e-4, name="dQ"); _close(gk, _merge(dk), rtol=2e-4, name="dK"); _close(gv, _merge(dv), rtol=2e-4, name="dV")
+    assert float(gk[2, 32:].abs().max()) == 0.0 and float(gv[2, 32:].abs().max()) == 0.0     # skipped tiles: exact zeros
+
+
 def test_attention_strided_qkv(ops):
     """q/k/v as column slices of one (B,L,3d) projection buffer, as the train step uses them."""
     B, H, L, dh = 2, 8, 50, 16
