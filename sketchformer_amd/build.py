@@ -11,6 +11,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-ato
          # f32-input MFMA shares the VALU pipe on gfx950 (tools/micro/mfma_valu_overlap.hip): keep accumulators in VGPRs so
          # the epilogues need no v_accvgpr_read/write moves (they were ~30 % of the VALU instructions of the attention loops)
          "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
+FLAGS += os.environ.get("SKF_EXTRA_HIPCC_FLAGS", "").split()   # e.g. -DSKF_WS_STAMPS=1 for tools/ws_timeline.py
 
 
 def _hipcc():

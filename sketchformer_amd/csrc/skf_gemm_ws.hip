@@ -25,16 +25,42 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 
 constexpr int TR = 16;   // rows per tile
 
+template <int N> struct VecOf;
+template <> struct VecOf<1> { typedef float type; typedef unsigned utype; };
+template <> struct VecOf<2> { typedef float __attribute__((ext_vector_type(2))) type; typedef unsigned __attribute__((ext_vector_type(2))) utype; };
+template <> struct VecOf<4> { typedef f32x4 type; typedef unsigned __attribute__((ext_vector_type(4))) utype; };
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// Buffer descriptor over the rows [row0, M) of a row-major matrix: per-lane byte offsets stay constant from
+// tile to tile (no 64-bit address VALU in the loop - f32 MFMA and VALU share the issue pipe on gfx950), and the
+// hardware range check drops stores / zero-fills loads of rows past M.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ws_rows_rsrc(const float* base, int ld, int M, int row0) {
+  long long rem = ((long long)M - row0) * ld * 4;
+  rem = rem < 0 ? 0 : (rem > 0xffffffffLL ? 0xffffffffLL : rem);
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + (long long)row0 * ld), 0, (unsigned)rem, 0x00020000);
+}
+template <int NB>
+__device__ __forceinline__ typename VecOf<NB>::type ws_buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+  typedef typename VecOf<NB>::type vecn;
+  if constexpr (NB == 1) return __builtin_bit_cast(vecn, __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
+  else if constexpr (NB == 2) return __builtin_bit_cast(vecn, __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0));
+  else return __builtin_bit_cast(vecn, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+}
+template <int NB>
+__device__ __forceinline__ void ws_buf_store(typename VecOf<NB>::type v, __amdgpu_buffer_rsrc_t r, unsigned voff) {
+  typedef typename VecOf<NB>::utype uvec;
+  if constexpr (NB == 1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uvec, v), r, voff, 0, 0);
+  else if constexpr (NB == 2) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uvec, v), r, voff, 0, 0);
+  else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uvec, v), r, voff, 0, 0);
+}
+
 template <int K>
 __device__ __forceinline__ void ws_load_tile(const float* __restrict__ A, int lda, int M, int tile,
-                                             f32x4 (&ra)[TR * K / 1024]) {
+                                             const unsigned (&a_voff)[TR * K / 1024], f32x4 (&ra)[TR * K / 1024]) {
+  const __amdgpu_buffer_rsrc_t r = ws_rows_rsrc(A, lda, M, tile * TR);
 #pragma unroll
-  for (int v = 0; v < TR * K / 1024; ++v) {
-    const int e = threadIdx.x + v * 256, row = e / (K / 4), c4 = (e % (K / 4)) * 4;
-    int grow = tile * TR + row;
-    grow = grow < M ? grow : M - 1;             // clamped: rows past M are never stored
-    ra[v] = *reinterpret_cast<const f32x4*>(A + (size_t)grow * lda + c4);   // ext_vector load: stays in VGPRs
-  }
+  for (int v = 0; v < TR * K / 1024; ++v)
+    ra[v] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, a_voff[v], 0, 0));
 }
 
 template <int K>
@@ -46,16 +72,34 @@ __device__ __forceinline__ void ws_store_tile(float* __restrict__ dst, const f32
   }
 }
 
-template <int K, int CW, bool B_KC>
-__global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GemmParams p, int groups, int workers) {
-  constexpr int NB = CW / 16;            // 16-column blocks per wave
+// Column ownership: lane i of a wave owns the NB ADJACENT columns n_wave + NB*i + nb (MFMA block nb uses
+// column nb of every lane).  The MFMA does not care which actual column sits behind "column i", and with
+// this choice (a) a [K][N] weight row is read with one NB-wide vector load per k instead of NB dword loads
+// (the dword version spent 4.2k cycles per workgroup in the texture-address unit), (b) the C fragment of a
+// lane is NB adjacent floats of one row, so it is stored straight from registers as 16 lanes x NB*4 bytes
+// contiguous - no LDS patch, no LDS round trip in the epilogue.
+//
+// Tile pipeline of one wave (t = tile in LDS buffer cur):
+//   after the barrier: ds_read the first A fragments of t | store C of t-1 (kept in registers)   <- fills the LDS latency
+//   MFMAs of t; half way: hand tile t+1 (registers) to LDS buffer cur^1, issue the global loads of t+3 into
+//   those registers, issue the relu-source / accumulate loads of t
+//   barrier
+// so the only MFMA-free stretch per tile is the LDS read latency + the barrier.
+// EXTRA = the epilogue reads a relu source and/or the old C (kept out of the plain variant: even an unused,
+// predicated-off load leaves an s_waitcnt in front of the C stores that also waits for the A prefetch).
+template <int K, int NB, bool B_KC, bool EXTRA>
+__global__ __launch_bounds__(256, (K * NB <= 512 ? 2 : 1)) void gemm_ws_kernel(GemmParams p, int groups, int workers) {
+  constexpr int CW = 16 * NB;            // columns per wave
   constexpr int KQ = K / 4;              // k values per lane group
+  constexpr int NJ = KQ / 4;             // A fragments (ds_read_b128) per tile
+  constexpr int PF = NJ <= 8 ? NJ : 4;   // fragments read ahead of the C stores
+  constexpr int NACC = NB == 1 ? 2 : 1;  // independent accumulators per column block (dependent MFMA latency 40 > 32)
   constexpr int LDA_S = K + 4;           // +16 B: the 16 rows of a ds_read_b128 group land on 16 different slots
-  constexpr int LDC_S = CW + 4;
   constexpr int NV = TR * K / 1024;      // float4 per thread per A tile
+  constexpr unsigned OOB = 0x7ffffff0u;  // byte offset outside any descriptor: load -> 0, store -> dropped
+  typedef typename VecOf<NB>::type vecn;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                                  // [2][TR][LDA_S]
-  float* Cs = smem + 2 * TR * LDA_S;                 // [4 waves][TR][LDC_S]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -63,153 +107,210 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GemmParams p, int group
   // the column groups of one worker read the same A tiles: consecutive logical ids -> same XCD / L2
   const int logical = p.xcd_remap ? skf_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   const int group = logical % groups, worker = logical / groups;
-  const int n_wave = group * 4 * CW + wave * CW;     // first output column of this wave
+  const int n_lane = group * 4 * CW + wave * CW + NB * i;   // first of this lane's NB columns
+  const bool nok = n_lane < p.N;                            // N % NB == 0: all NB columns in or all out
+  const int n_ld = nok ? n_lane : p.N - NB;                 // clamped: loads stay in bounds, stores are guarded
   const int ntiles = (p.M + TR - 1) / TR;
 
   long long* dbg = (p.dbg && lane == 0 && wave == 0 && (blockIdx.x % 97) == 0 && blockIdx.x / 97 < 8) ? p.dbg + (blockIdx.x / 97) * 32 : nullptr;
   int dbi = 0;
+#if SKF_WS_STAMPS   // per-phase s_memtime stamps (tools/ws_timeline.py); off by default: every conditional memory
+                    // operation in the tile loop makes the compiler's s_waitcnt vmcnt counts conservative
 #define SKF_STAMP() do { if (dbg && dbi < 32) dbg[dbi++] = clock64(); } while (0)
+#else
+#define SKF_STAMP() do { (void)dbg; (void)dbi; } while (0)
+#endif
   SKF_STAMP();
-  // ---- this wave's weight slice -> registers (once)
+  // per-lane byte offsets inside a tile (constant for the whole kernel)
+  unsigned a_voff[NV], c_voff[4], h_voff[4];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int e = tid + v * 256, row = e / (K / 4), c4 = (e % (K / 4)) * 4;
+    a_voff[v] = (unsigned)(row * p.lda + c4) * 4u;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    c_voff[r] = nok ? (unsigned)((4 * g + r) * p.ldc + n_lane) * 4u : OOB;
+    h_voff[r] = nok ? (unsigned)((4 * g + r) * p.ld_relu + n_lane) * 4u : OOB;
+  }
+  // A tiles are prefetched TWO tiles ahead (tile t in LDS, t+1 and t+2 in registers): a global load
+  // under a busy chip takes ~3-4k cycles, longer than one tile of MFMAs (2k cycles per wave).
+  // The first two go out before the weight loads so that their latency hides behind those.
+  f32x4 ra0[NV], ra1[NV];
+  int tile = worker;
+  ws_load_tile<K>(p.A, p.lda, p.M, tile, a_voff, ra0);
+  ws_load_tile<K>(p.A, p.lda, p.M, tile + workers, a_voff, ra1);
+  // ---- this wave's weight slice -> registers (once): breg[nb][s] = B[k = 16(s>>2) + 4g + (s&3)][n_lane + nb]
   float breg[NB][KQ];
+  if (B_KC) {                                         // B stored [N][K]: 16-byte loads along k
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
-    const int n = n_wave + nb * 16 + i;
-    const bool nok = n < p.N;
-    if (B_KC) {                                       // B stored [N][K]: 16-byte loads along k
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-      for (int j = 0; j < KQ / 4; ++j) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (nok) v = *reinterpret_cast<const float4*>(p.B + (size_t)n * p.ldb + 16 * j + 4 * g);
-        breg[nb][4 * j + 0] = v.x; breg[nb][4 * j + 1] = v.y; breg[nb][4 * j + 2] = v.z; breg[nb][4 * j + 3] = v.w;
+      for (int j = 0; j < NJ; ++j) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p.B + (size_t)(n_ld + nb) * p.ldb + 16 * j + 4 * g);
+        breg[nb][4 * j + 0] = v[0]; breg[nb][4 * j + 1] = v[1]; breg[nb][4 * j + 2] = v[2]; breg[nb][4 * j + 3] = v[3];
       }
-    } else {                                          // B stored [K][N]
+  } else {                                            // B stored [K][N]: one NB-wide load per k
 #pragma unroll
-      for (int s = 0; s < KQ; ++s) breg[nb][s] = nok ? p.B[(size_t)(16 * (s >> 2) + 4 * g + (s & 3)) * p.ldb + n] : 0.f;
+    for (int s = 0; s < KQ; ++s) {
+      const vecn v = *reinterpret_cast<const vecn*>(p.B + (size_t)(16 * (s >> 2) + 4 * g + (s & 3)) * p.ldb + n_ld);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) breg[nb][s] = reinterpret_cast<const float*>(&v)[nb];
     }
   }
-
-  f32x4 ra[NV];
-
-  // bias of this wave's columns: loop invariant, but the compiler cannot hoist the load past the C stores
   float bias_r[NB];
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
-    const int n = n_wave + nb * 16 + i;
-    bias_r[nb] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
-  }
+  for (int nb = 0; nb < NB; ++nb) bias_r[nb] = p.bias ? p.bias[n_ld + nb] : 0.f;
+
+
   SKF_STAMP();   // B loads issued
-  int tile = worker;
-  ws_load_tile<K>(p.A, p.lda, p.M, tile < ntiles ? tile : 0, ra);
-  ws_store_tile<K>(As, ra);
+  ws_store_tile<K>(As, ra0);
   __syncthreads();
+  ws_load_tile<K>(p.A, p.lda, p.M, tile + 2 * workers, a_voff, ra0);
   SKF_STAMP();   // first A tile in LDS
-  float* cs = Cs + wave * TR * LDC_S;
-  int cur = 0;
-  for (; tile < ntiles; tile += workers) {
-    const int next = tile + workers;
-    if (p.ablate != 3) ws_load_tile<K>(p.A, p.lda, p.M, next < ntiles ? next : tile, ra);
+
+  vecn cprev[4], hsrc[4], oacc[4];   // finished C fragment of the previous tile (+ its relu source / old C)
+  // No branch around any memory operation of the tile loop: "nothing to do" cases use an empty descriptor
+  // (first iteration: prev_tile = ntiles -> zero records -> the stores are dropped by the range check).
+  int prev_tile = ntiles;
+  const bool has_relu = EXTRA && p.relu_src != nullptr;
+  auto store_prev = [&]() {
+    const __amdgpu_buffer_rsrc_t rc = ws_rows_rsrc(p.C, p.ldc, p.M, prev_tile * TR);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      vecn v = cprev[r];
+      if (EXTRA) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          reinterpret_cast<float*>(&v)[nb] = (!has_relu || reinterpret_cast<const float*>(&hsrc[r])[nb] > 0.f) ? reinterpret_cast<const float*>(&v)[nb] : 0.f;
+      }
+      if (EXTRA) {   // old C (zeros from the empty descriptor when not accumulating)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) reinterpret_cast<float*>(&v)[nb] += reinterpret_cast<const float*>(&oacc[r])[nb];
+      }
+      ws_buf_store<NB>(v, rc, c_voff[r]);
+    }
+  };
+
+  // EARLY (every A fragment of a tile fits in registers, K = 128): the workgroup barrier sits at 3/4 of the
+  // MFMAs - by then every wave has written its share of the next tile (done at 1/2) - and the next tile's
+  // fragments are read right behind it into the other fragment set, so the MFMA stream of a wave never waits
+  // for LDS or for the barrier hand-shake.  (All fragments of a tile are in registers before that tile's barrier,
+  // so the buffer it leaves is free to be overwritten half a tile later.)
+  constexpr bool EARLY = NJ <= 8;
+  f32x4 afA[PF], afB[PF];
+  if (EARLY) {
+#pragma unroll
+    for (int j = 0; j < PF; ++j) afA[j] = *reinterpret_cast<const f32x4*>(As + i * LDA_S + 4 * g + 16 * j);
+  }
+
+  // one tile: MFMAs on LDS buffer `cur`; hand `rn` (tile+workers) to the other buffer; refill `rn` with tile+3*workers
+  auto do_tile = [&](int cur, f32x4 (&rn)[NV], f32x4 (&af)[PF], f32x4 (&afn)[PF]) {
     const float* At = As + cur * TR * LDA_S + i * LDA_S + 4 * g;
-    f32x4 acc[NB][2];
+    if (!EARLY) {
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) { acc[nb][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[nb][1] = acc[nb][0]; }
-    if (p.ablate != 1)
+      for (int j = 0; j < PF; ++j) af[j] = *reinterpret_cast<const f32x4*>(At + 16 * j);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    store_prev();
+    __builtin_amdgcn_sched_barrier(0);
+    SKF_STAMP();   // previous C tile stored
+    f32x4 acc[NB][NACC];
 #pragma unroll
-    for (int j = 0; j < KQ / 4; ++j) {
-      const float4 a = *reinterpret_cast<const float4*>(At + 16 * j);
-      // consecutive MFMAs never share an accumulator (dependent latency 40 cycles > 32-cycle issue)
-      const float av[4] = {a.x, a.y, a.z, a.w};
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int c = 0; c < NACC; ++c) {
+        const float b0 = c == 0 ? bias_r[nb] : 0.f;   // bias folded into the accumulator
+        acc[nb][c] = (f32x4){b0, b0, b0, b0};
+      }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      f32x4 a;
+      if (j < PF) a = af[j]; else a = *reinterpret_cast<const f32x4*>(At + 16 * j);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
-          acc[nb][e & 1] = mfma16(av[e], breg[nb][4 * j + e], acc[nb][e & 1]);
+          acc[nb][NACC == 1 ? 0 : (j & 1)] = mfma16(a[e], breg[nb][4 * j + e], acc[nb][NACC == 1 ? 0 : (j & 1)]);
+      if (j == NJ / 2 - 1) {
+        // half way: tile+workers goes to the other LDS buffer (its readers passed the last barrier), then the
+        // registers are refilled with tile+3*workers; loads this tile's epilogue needs are issued now as well
+        __builtin_amdgcn_sched_barrier(0);
+        ws_store_tile<K>(As + (cur ^ 1) * TR * LDA_S, rn);
+        ws_load_tile<K>(p.A, p.lda, p.M, tile + 3 * workers, a_voff, rn);
+        if (EXTRA) {
+          const __amdgpu_buffer_rsrc_t rh = ws_rows_rsrc(has_relu ? p.relu_src : p.C, p.ld_relu, has_relu ? p.M : 0, tile * TR);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) hsrc[r] = ws_buf_load<NB>(rh, h_voff[r]);
+          const __amdgpu_buffer_rsrc_t ro = ws_rows_rsrc(p.C, p.ldc, p.accumulate ? p.M : 0, tile * TR);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) oacc[r] = ws_buf_load<NB>(ro, c_voff[r]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (EARLY && j == (3 * NJ) / 4 - 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        const float* An = As + (cur ^ 1) * TR * LDA_S + i * LDA_S + 4 * g;
+#pragma unroll
+        for (int jj = 0; jj < PF; ++jj) afn[jj] = *reinterpret_cast<const f32x4*>(An + 16 * jj);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
-    SKF_STAMP();   // MFMAs issued (first use of acc below waits for them)
-    // ---- epilogue: lane (i,g) holds C[row 4g+r][col nb*16+i]; bias/act, then through the wave's LDS patch
-    // one wave-uniform switch per tile (a per-element switch costs ~40 scalar branches per tile)
-    float vals[NB][4];
+    SKF_STAMP();   // MFMAs issued
+    // lane (i,g) holds C[row 4g+r][n_lane + nb]; one wave-uniform activation switch per tile
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) vals[nb][r] = acc[nb][0][r] + acc[nb][1][r] + bias_r[nb];
-    if (p.act == 1) {
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) vals[nb][r] = fmaxf(vals[nb][r], 0.f);
-    } else if (p.act == 2) {
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) vals[nb][r] = tanhf(vals[nb][r]);
-    }
-    if (p.direct_store) {
-      // straight from the MFMA C layout: each store covers 4 rows x 64 contiguous bytes (L2 merges the two column blocks)
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        const int n = n_wave + nb * 16 + i;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int grow = tile * TR + 4 * g + r;
-          if (grow < p.M && n < p.N) {
-            float v = vals[nb][r];
-            if (p.relu_src) v = p.relu_src[(size_t)grow * p.ld_relu + n] > 0.f ? v : 0.f;
-            float* dst = p.C + (size_t)grow * p.ldc + n;
-            if (p.accumulate) v += *dst;
-            *dst = v;
-          }
-        }
+        float v = acc[nb][0][r];
+        if (NACC == 2) v += acc[nb][1][r];
+        reinterpret_cast<float*>(&cprev[r])[nb] = v;
       }
-    } else {
+    if (p.act == 1) {
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
+      for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) cs[(4 * g + r) * LDC_S + nb * 16 + i] = vals[nb][r];
-    __builtin_amdgcn_wave_barrier();
-    constexpr int F4_ROW = CW / 4;                     // float4 per row of the wave's patch
+        for (int nb = 0; nb < NB; ++nb) reinterpret_cast<float*>(&cprev[r])[nb] = fmaxf(reinterpret_cast<float*>(&cprev[r])[nb], 0.f);
+    } else if (p.act == 2) {
 #pragma unroll
-    for (int e = lane; e < TR * F4_ROW; e += 64) {
-      const int row = e / F4_ROW, c4 = (e % F4_ROW) * 4;
-      const int grow = tile * TR + row, n = n_wave + c4;
-      float4 v = *reinterpret_cast<const float4*>(&cs[row * LDC_S + c4]);
-      if (p.ablate == 2 && v.x != 12345.678f) continue;
-      if (grow < p.M && n < p.N) {                     // N % 4 == 0: a float4 is fully in or fully out
-        if (p.relu_src) {
-          const float4 h = *reinterpret_cast<const float4*>(p.relu_src + (size_t)grow * p.ld_relu + n);
-          v.x = h.x > 0.f ? v.x : 0.f; v.y = h.y > 0.f ? v.y : 0.f; v.z = h.z > 0.f ? v.z : 0.f; v.w = h.w > 0.f ? v.w : 0.f;
-        }
-        float4* dst = reinterpret_cast<float4*>(p.C + (size_t)grow * p.ldc + n);
-        if (p.accumulate) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-        *dst = v;
-      }
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) reinterpret_cast<float*>(&cprev[r])[nb] = tanhf(reinterpret_cast<float*>(&cprev[r])[nb]);
     }
-    __builtin_amdgcn_wave_barrier();
-    }
-    SKF_STAMP();   // C tile stored
-    ws_store_tile<K>(As + (cur ^ 1) * TR * LDA_S, ra);
-    __syncthreads();
-    SKF_STAMP();   // next A tile in LDS + barrier
-    cur ^= 1;
+    prev_tile = tile;
+    if (!EARLY) __syncthreads();
+    SKF_STAMP();   // barrier
+  };
+  while (tile < ntiles) {
+    do_tile(0, ra1, afA, afB);
+    tile += workers;
+    if (tile >= ntiles) break;
+    do_tile(1, ra0, afB, afA);
+    tile += workers;
   }
+  store_prev();
 }
 
-template <int K, int CW>
+template <int K, int NB>
 int launch_ws(const GemmParams& p, int b_kc, hipStream_t st) {
+  constexpr int CW = 16 * NB;
   const int groups = skf_cdiv(p.N, 4 * CW);
-  // two workgroups per CU: one's epilogue / tile hand-over overlaps the other's MFMAs
-  static const int wg_target = getenv("SKF_WS_WGS") ? atoi(getenv("SKF_WS_WGS")) : (K == 128 ? 768 : 512);
+  static const int wg_target = getenv("SKF_WS_WGS") ? atoi(getenv("SKF_WS_WGS")) : 512;
   int workers = wg_target / groups;
   if (workers < 1) workers = 1;
   const int ntiles = skf_cdiv(p.M, TR);
   if (workers > ntiles) workers = ntiles;
-  const size_t smem = (size_t)(2 * TR * (K + 4) + 4 * TR * (CW + 4)) * sizeof(float);
+  const size_t smem = (size_t)(2 * TR * (K + 4)) * sizeof(float);
   dim3 grid(groups * workers), block(256);
   static const std::string tag = "gemm_ws<K" + std::to_string(K) + ",CW" + std::to_string(CW) + ">";
   SkfProfScope ps(st, tag.c_str(), 2.0 * p.M * p.N * p.K,
                   4.0 * ((double)p.M * p.K + (double)p.K * p.N + (double)p.M * p.N * (p.accumulate ? 2 : 1)));
-  if (b_kc) hipLaunchKernelGGL((gemm_ws_kernel<K, CW, true>), grid, block, smem, st, p, groups, workers);
-  else hipLaunchKernelGGL((gemm_ws_kernel<K, CW, false>), grid, block, smem, st, p, groups, workers);
+  const bool extra = p.relu_src || p.accumulate;
+  if (b_kc && extra) hipLaunchKernelGGL((gemm_ws_kernel<K, NB, true, true>), grid, block, smem, st, p, groups, workers);
+  else if (b_kc) hipLaunchKernelGGL((gemm_ws_kernel<K, NB, true, false>), grid, block, smem, st, p, groups, workers);
+  else if (extra) hipLaunchKernelGGL((gemm_ws_kernel<K, NB, false, true>), grid, block, smem, st, p, groups, workers);
+  else hipLaunchKernelGGL((gemm_ws_kernel<K, NB, false, false>), grid, block, smem, st, p, groups, workers);
   SKF_LAUNCH_CHECK();
   return SKF_OK;
 }
@@ -225,12 +326,13 @@ int skf_gemm_ws_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, hipS
   if (!(p.K == 128 || p.K == 256 || p.K == 384 || p.K == 512)) return SKF_OK;
   if ((p.N & 3) || (p.lda & 3) || (p.ldc & 3) || ((uintptr_t)p.A & 15) || ((uintptr_t)p.C & 15)) return SKF_OK;
   if (b_kcontig && ((p.ldb & 3) || ((uintptr_t)p.B & 15))) return SKF_OK;
+  if (!b_kcontig && ((p.ldb & 1) || ((uintptr_t)p.B & 7))) return SKF_OK;   // NB-wide loads along n
   if (p.relu_src && ((p.ld_relu & 3) || ((uintptr_t)p.relu_src & 15))) return SKF_OK;
   *handled = 1;
   switch (p.K) {
-    case 128: return launch_ws<128, 32>(p, b_kcontig, st);
-    case 256: return launch_ws<256, 16>(p, b_kcontig, st);
-    case 384: return launch_ws<384, 16>(p, b_kcontig, st);
-    default:  return launch_ws<512, 16>(p, b_kcontig, st);
+    case 128: return launch_ws<128, 2>(p, b_kcontig, st);
+    case 256: return launch_ws<256, 2>(p, b_kcontig, st);
+    case 384: return launch_ws<384, 1>(p, b_kcontig, st);
+    default:  return launch_ws<512, 1>(p, b_kcontig, st);
   }
 }
