@@ -8,6 +8,7 @@
 namespace {
 
 constexpr int kMaxGrid = 2048;
+constexpr int kLnBwdGrid = 1024;   // workgroups of the LayerNorm backward (each leaves one [2][d] partial for the column sums)
 
 __global__ void padding_mask_kernel(const long long* __restrict__ tok, int tok_ld, int B, int L,
                                     unsigned char* __restrict__ out) {
@@ -148,6 +149,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      float* __restrict__ part, int rows, float rate, uint32_t site,
                                                      const SkfStepState* st) {
   constexpr int D = VPL * 64;
+  constexpr int UR = 2;            // rows per wave iteration: twice the bytes in flight (the kernel is latency bound)
   __shared__ float red[4][2][D];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t thresh = skf_drop_thresh(rate);
@@ -156,28 +158,44 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   float gm[VPL], dg[VPL], db[VPL];
 #pragma unroll
   for (int v = 0; v < VPL; ++v) { gm[v] = gamma[lane * VPL + v]; dg[v] = 0.f; db[v] = 0.f; }
-  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
-    const size_t off = (size_t)row * D + lane * VPL;
-    const float mean = stats[2 * (size_t)row], rstd = stats[2 * (size_t)row + 1];
-    float xh[VPL], gg[VPL];
-    float s1 = 0.f, s2 = 0.f;
+  const int stride = gridDim.x * 4;
+  for (int row0 = blockIdx.x * 4 + wave; row0 < rows; row0 += UR * stride) {
+    float dv[UR][VPL], zv[UR][VPL], mean[UR], rstd[UR];
+    bool ok[UR];
+    size_t off[UR];
 #pragma unroll
-    for (int v = 0; v < VPL; ++v) {
-      const float d = dout[off + v];
-      xh[v] = (z[off + v] - mean) * rstd;
-      gg[v] = d * gm[v];
-      dg[v] += d * xh[v];
-      db[v] += d;
-      s1 += gg[v];
-      s2 += gg[v] * xh[v];
+    for (int u = 0; u < UR; ++u) {
+      const int row = row0 + u * stride;
+      ok[u] = row < rows;
+      const int rr = ok[u] ? row : row0;             // clamped: loads stay in bounds, nothing is stored / summed
+      off[u] = (size_t)rr * D + lane * VPL;
+      mean[u] = stats[2 * (size_t)rr]; rstd[u] = stats[2 * (size_t)rr + 1];
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) { dv[u][v] = dout[off[u] + v]; zv[u][v] = z[off[u] + v]; }
     }
-    s1 = wave_sum(s1) * (1.0f / D);
-    s2 = wave_sum(s2) * (1.0f / D);
 #pragma unroll
-    for (int v = 0; v < VPL; ++v) {
-      const float g = rstd * (gg[v] - s1 - xh[v] * s2);
-      dz[off + v] = g;
-      if (dy) dy[off + v] = g * (skf_keep(sk, (uint32_t)off + v, thresh) ? inv_keep : 0.f);
+    for (int u = 0; u < UR; ++u) {
+      if (!ok[u]) continue;                          // wave-uniform
+      float xh[VPL], gg[VPL];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) {
+        const float d = dv[u][v];
+        xh[v] = (zv[u][v] - mean[u]) * rstd[u];
+        gg[v] = d * gm[v];
+        dg[v] += d * xh[v];
+        db[v] += d;
+        s1 += gg[v];
+        s2 += gg[v] * xh[v];
+      }
+      s1 = wave_sum(s1) * (1.0f / D);
+      s2 = wave_sum(s2) * (1.0f / D);
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) {
+        const float g = rstd[u] * (gg[v] - s1 - xh[v] * s2);
+        dz[off[u] + v] = g;
+        if (dy) dy[off[u] + v] = g * (skf_keep(sk, (uint32_t)off[u] + v, thresh) ? inv_keep : 0.f);
+      }
     }
   }
 #pragma unroll
@@ -259,6 +277,70 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(float* __restrict__ log
   }
 }
 
+// Same, for rows that fit in registers (ncls <= 256*NV4, ncls % 4 == 0, 16-byte aligned rows): one read and
+// one write of the logits instead of three reads and one write.
+template <int NV4>
+__global__ __launch_bounds__(256) void softmax_ce_reg_kernel(float* __restrict__ logits, int ld, int rows, int ncls,
+                                                             const long long* __restrict__ target, int tgt_ld, int tgt_cols,
+                                                             int tgt_off, int mask_pad, float scale,
+                                                             float* __restrict__ row_loss, float* __restrict__ row_hit,
+                                                             float* __restrict__ probs_out, int write_grad) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n4 = ncls >> 2;
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    float* x = logits + (size_t)row * ld;
+    const long long tg = target[(size_t)(row / tgt_cols) * tgt_ld + (row % tgt_cols) + tgt_off];
+    f32x4 v[NV4];
+    float mx = -INFINITY; int am = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < NV4; ++k) {
+      const int j4 = lane + 64 * k;
+      v[k] = j4 < n4 ? *reinterpret_cast<const f32x4*>(x + 4 * j4) : (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (v[k][e] > mx) { mx = v[k][e]; am = 4 * j4 + e; }   // ascending index inside a lane: first maximum wins
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float om = __shfl_xor(mx, o, 64); const int oa = __shfl_xor(am, o, 64);
+      if (om > mx || (om == mx && oa < am)) { mx = om; am = oa; }
+    }
+    const bool valid = tg >= 0 && tg < ncls;
+    float se = 0.f, xt = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV4; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if ((long long)(4 * (lane + 64 * k) + e) == tg) xt = v[k][e];
+        v[k][e] = __expf(v[k][e] - mx);            // exp(-inf) = 0 for the padding slots
+        se += v[k][e];
+      }
+    se = wave_sum(se);
+    xt = wave_sum(xt);                              // exactly one lane holds the target logit
+    const float lse = mx + __logf(se);
+    const float m = (mask_pad && tg == 0) ? 0.f : 1.f;
+    if (lane == 0) {
+      row_loss[row] = valid ? (lse - xt) * m : 0.f;
+      row_hit[row] = (am == (int)tg) ? 1.f : 0.f;
+    }
+    const float gs = m * scale, rse = 1.0f / se;
+#pragma unroll
+    for (int k = 0; k < NV4; ++k) {
+      const int j4 = lane + 64 * k;
+      if (j4 < n4) {
+        const f32x4 pj = v[k] * rse;
+        if (probs_out) *reinterpret_cast<f32x4*>(probs_out + (size_t)row * ncls + 4 * j4) = pj;
+        if (write_grad) {
+          f32x4 gq;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) gq[e] = (pj[e] - ((long long)(4 * j4 + e) == tg ? 1.f : 0.f)) * gs;
+          *reinterpret_cast<f32x4*>(x + 4 * j4) = gq;
+        }
+      }
+    }
+  }
+}
+
 // Step metrics + running Keras metrics (builders/keras_metrics.py:19-42).
 // metrics layout (floats): [0..4]  this step: recon_loss, recon_acc, class_loss, class_acc, total_loss
 //                          [8..12] running totals, [16..20] running counts
@@ -293,42 +375,73 @@ __global__ __launch_bounds__(256) void metrics_kernel(const float* __restrict__ 
   }
 }
 
+// Sum / max over the 16 waves of a 1024-thread workgroup (red: 16 floats of LDS; result broadcast to all threads).
+__device__ __forceinline__ float block16_sum(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) t += red[k];
+  return t;
+}
+__device__ __forceinline__ float block16_max(float v, float* red) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = red[0];
+#pragma unroll
+  for (int k = 1; k < 16; ++k) t = fmaxf(t, red[k]);
+  return t;
+}
+__device__ __forceinline__ float group16_sum(float v) {   // over the 16 lanes that share lane>>4
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float dot4(f32x4 a, f32x4 b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
+
 // ------------------------------------------------------------------ SelfAttnV1 pool
 // builders/layers/transformer.py:70-73 after u = tanh(xW+b) (a GEMM):
 //   s[t] = u[b,t,:].V ; a = softmax_t(s) (no padding mask) ; emb[b,:] = sum_t a[t] x[b,t,:]
-__global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__ u, const float* __restrict__ Vw,
-                                                       const float* __restrict__ x, int L, int U, int d,
-                                                       float* __restrict__ a_out, float* __restrict__ emb) {
-  extern __shared__ float sm[];   // [L] scores
-  __shared__ float red[4];
-  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int t = wave; t < L; t += 4) {
+// One 1024-thread workgroup per sample.  Rows are read by groups of 16 lanes with 16-byte loads (64 rows in
+// flight per pass); the weighted sum splits the time steps over 1024/(d/4) thread groups and folds through LDS.
+// U % 4 == 0, d % 4 == 0, d <= 4096.
+__global__ __launch_bounds__(1024) void pool_fwd_kernel(const float* __restrict__ u, const float* __restrict__ Vw,
+                                                        const float* __restrict__ x, int L, int U, int d,
+                                                        float* __restrict__ a_out, float* __restrict__ emb) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* part = sm;            // [4096] partial sums of the weighted sum
+  float* sc = sm + 4096;       // [L] scores -> attention weights
+  float* red = sc + L;         // [16]
+  const int b = blockIdx.x, tid = threadIdx.x, l16 = tid & 15, rg = tid >> 4;
+  const int U4 = U >> 2, d4 = d >> 2;
+  for (int t = rg; t < L; t += 64) {
     const float* ur = u + ((size_t)b * L + t) * U;
     float s = 0.f;
-    for (int j = lane; j < U; j += 64) s += ur[j] * Vw[j];
-    s = wave_sum(s);
-    if (lane == 0) sm[t] = s;
+    for (int j4 = l16; j4 < U4; j4 += 16)
+      s += dot4(*reinterpret_cast<const f32x4*>(ur + 4 * j4), *reinterpret_cast<const f32x4*>(Vw + 4 * j4));
+    s = group16_sum(s);
+    if (l16 == 0) sc[t] = s;
   }
   __syncthreads();
-  float mx = -INFINITY;
-  for (int t = threadIdx.x; t < L; t += 256) mx = fmaxf(mx, sm[t]);
-  mx = wave_max(mx);
-  if (lane == 0) red[wave] = mx;
+  const float mx = block16_max(tid < L ? sc[tid] : -INFINITY, red);   // L <= 1024
+  const float e = tid < L ? __expf(sc[tid] - mx) : 0.f;
+  const float se = block16_sum(e, red);
+  if (tid < L) { const float a = e / se; sc[tid] = a; a_out[(size_t)b * L + tid] = a; }
   __syncthreads();
-  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const int ngrp = 1024 / d4, c4 = tid % d4, tg = tid / d4;
+  if (tg < ngrp) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int t = tg; t < L; t += ngrp) acc += sc[t] * *reinterpret_cast<const f32x4*>(x + ((size_t)b * L + t) * d + 4 * c4);
+    *reinterpret_cast<f32x4*>(part + tg * d + 4 * c4) = acc;
+  }
   __syncthreads();
-  float se = 0.f;
-  for (int t = threadIdx.x; t < L; t += 256) { const float e = __expf(sm[t] - mx); sm[t] = e; se += e; }
-  se = wave_sum(se);
-  if (lane == 0) red[wave] = se;
-  __syncthreads();
-  se = red[0] + red[1] + red[2] + red[3];
-  const float rinv = 1.0f / se;
-  for (int t = threadIdx.x; t < L; t += 256) { const float a = sm[t] * rinv; sm[t] = a; a_out[(size_t)b * L + t] = a; }
-  __syncthreads();
-  for (int c = threadIdx.x; c < d; c += 256) {
+  for (int c = tid; c < d; c += 1024) {
     float acc = 0.f;
-    for (int t = 0; t < L; ++t) acc += sm[t] * x[((size_t)b * L + t) * d + c];
+    for (int k = 0; k < ngrp; ++k) acc += part[k * d + c];
     emb[(size_t)b * d + c] = acc;
   }
 }
@@ -336,43 +449,55 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
 // backward of the pool: dx_direct[b,t,c] = a[t] demb[c]; da[t] = demb . x[b,t,:];
 // ds = a (da - sum a da); dpre[b,t,j] = ds[t] V[j] (1 - u^2) (in place over u);
 // dV partial[b][j] = sum_t ds[t] u[b,t,j]
-__global__ __launch_bounds__(256) void pool_bwd_kernel(float* __restrict__ u, const float* __restrict__ Vw,
-                                                       const float* __restrict__ x, const float* __restrict__ a_in,
-                                                       const float* __restrict__ demb, int L, int U, int d,
-                                                       float* __restrict__ dx, float* __restrict__ dV_part) {
-  extern __shared__ float sm[];   // [L] ds, then [L] a
-  __shared__ float red[4];
-  float* ds = sm;
-  float* av = sm + L;
-  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int t = threadIdx.x; t < L; t += 256) av[t] = a_in[(size_t)b * L + t];
+__global__ __launch_bounds__(1024) void pool_bwd_kernel(float* __restrict__ u, const float* __restrict__ Vw,
+                                                        const float* __restrict__ x, const float* __restrict__ a_in,
+                                                        const float* __restrict__ demb, int L, int U, int d,
+                                                        float* __restrict__ dx, float* __restrict__ dV_part) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* part = sm;            // [4096]
+  float* dem = sm + 4096;      // [d]
+  float* ds = dem + d;         // [L]
+  float* av = ds + L;          // [L]
+  float* red = av + L;         // [16]
+  const int b = blockIdx.x, tid = threadIdx.x, l16 = tid & 15, rg = tid >> 4;
+  const int U4 = U >> 2, d4 = d >> 2;
+  for (int t = tid; t < L; t += 1024) av[t] = a_in[(size_t)b * L + t];
+  for (int c = tid; c < d; c += 1024) dem[c] = demb[(size_t)b * d + c];
   __syncthreads();
-  float part = 0.f;
-  for (int t = wave; t < L; t += 4) {
+  for (int t = rg; t < L; t += 64) {
     const float* xr = x + ((size_t)b * L + t) * d;
     float* dxr = dx + ((size_t)b * L + t) * d;
-    float s = 0.f;
     const float at = av[t];
-    for (int c = lane; c < d; c += 64) { const float de = demb[(size_t)b * d + c]; s += de * xr[c]; dxr[c] = at * de; }
-    s = wave_sum(s);
-    if (lane == 0) { ds[t] = s; }
-    part += (lane == 0) ? at * s : 0.f;
-  }
-  part = wave_sum(part);
-  if (lane == 0) red[wave] = part;
-  __syncthreads();
-  const float dot = red[0] + red[1] + red[2] + red[3];
-  for (int t = threadIdx.x; t < L; t += 256) ds[t] = av[t] * (ds[t] - dot);
-  __syncthreads();
-  for (int j = threadIdx.x; j < U; j += 256) {
-    const float vj = Vw[j];
-    float acc = 0.f;
-    for (int t = 0; t < L; ++t) {
-      float* up = u + ((size_t)b * L + t) * U + j;
-      const float uv = *up;
-      acc += ds[t] * uv;
-      *up = ds[t] * vj * (1.f - uv * uv);
+    float s = 0.f;
+    for (int c4 = l16; c4 < d4; c4 += 16) {
+      const f32x4 de = *reinterpret_cast<const f32x4*>(dem + 4 * c4);
+      s += dot4(de, *reinterpret_cast<const f32x4*>(xr + 4 * c4));
+      *reinterpret_cast<f32x4*>(dxr + 4 * c4) = at * de;
     }
+    s = group16_sum(s);
+    if (l16 == 0) ds[t] = s;
+  }
+  __syncthreads();
+  const float dot = block16_sum(tid < L ? av[tid] * ds[tid] : 0.f, red);   // L <= 1024
+  if (tid < L) ds[tid] = av[tid] * (ds[tid] - dot);
+  __syncthreads();
+  const int ngrp = 1024 / U4, j4 = tid % U4, tg = tid / U4;
+  if (tg < ngrp) {
+    const f32x4 vj = *reinterpret_cast<const f32x4*>(Vw + 4 * j4);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int t = tg; t < L; t += ngrp) {
+      f32x4* up = reinterpret_cast<f32x4*>(u + ((size_t)b * L + t) * U + 4 * j4);
+      const f32x4 uv = *up;
+      const float dst = ds[t];
+      acc += dst * uv;
+      *up = dst * vj * (1.f - uv * uv);
+    }
+    *reinterpret_cast<f32x4*>(part + tg * U + 4 * j4) = acc;
+  }
+  __syncthreads();
+  for (int j = tid; j < U; j += 1024) {
+    float acc = 0.f;
+    for (int k = 0; k < ngrp; ++k) acc += part[k * U + j];
     dV_part[(size_t)b * U + j] = acc;
   }
 }
@@ -391,24 +516,55 @@ __global__ __launch_bounds__(256) void expander_fwd_kernel(const float* __restri
   }
 }
 
-// demb[b,c] = sum_t dpre[b,t,c] w[t]; per-b partials dw[b][t] = sum_c dpre*emb, dbias[b][t] = sum_c dpre
-__global__ __launch_bounds__(256) void expander_bwd_kernel(const float* __restrict__ dpre, const float* __restrict__ emb,
-                                                           const float* __restrict__ w, int L, int d,
-                                                           float* __restrict__ demb, int demb_accumulate,
-                                                           float* __restrict__ dw_part, float* __restrict__ db_part) {
-  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int c = threadIdx.x; c < d; c += 256) {
-    float acc = 0.f;
-    for (int t = 0; t < L; ++t) acc += dpre[((size_t)b * L + t) * d + c] * w[t];
-    float* dst = demb + (size_t)b * d + c;
-    *dst = demb_accumulate ? *dst + acc : acc;
+// demb[b,c] = sum_t dpre[b,t,c] w[t]; per-b partials dw[b][t] = sum_c dpre*emb, dbias[b][t] = sum_c dpre.
+// One pass over dpre: a row is read by 16 lanes (KC float4 each, d = 64*KC), which keep the column sums of
+// "their" columns in registers; 1024-thread workgroup per sample, column sums folded wave -> LDS -> global.
+template <int KC>
+__global__ __launch_bounds__(1024) void expander_bwd_kernel(const float* __restrict__ dpre, const float* __restrict__ emb,
+                                                            const float* __restrict__ w, int L,
+                                                            float* __restrict__ demb, int demb_accumulate,
+                                                            float* __restrict__ dw_part, float* __restrict__ db_part) {
+  constexpr int d = 64 * KC;
+  __shared__ __attribute__((aligned(16))) float part[16 * d];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = tid & 15, rg = tid >> 4;
+  f32x4 em[KC], acc[KC];
+#pragma unroll
+  for (int k = 0; k < KC; ++k) {
+    em[k] = *reinterpret_cast<const f32x4*>(emb + (size_t)b * d + 4 * (l16 + 16 * k));
+    acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  for (int t = wave; t < L; t += 4) {
+  for (int t = rg; t < L; t += 64) {
     const float* r = dpre + ((size_t)b * L + t) * d;
+    const float wt = w[t];
     float s1 = 0.f, s2 = 0.f;
-    for (int c = lane; c < d; c += 64) { const float v = r[c]; s1 += v * emb[(size_t)b * d + c]; s2 += v; }
-    s1 = wave_sum(s1); s2 = wave_sum(s2);
-    if (lane == 0) { dw_part[(size_t)b * L + t] = s1; db_part[(size_t)b * L + t] = s2; }
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(r + 4 * (l16 + 16 * k));
+      s1 += dot4(v, em[k]);
+      s2 += (v[0] + v[1]) + (v[2] + v[3]);
+      acc[k] += wt * v;
+    }
+    s1 = group16_sum(s1); s2 = group16_sum(s2);
+    if (l16 == 0) { dw_part[(size_t)b * L + t] = s1; db_part[(size_t)b * L + t] = s2; }
+  }
+#pragma unroll
+  for (int k = 0; k < KC; ++k) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = acc[k][e];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      acc[k][e] = v;
+    }
+    if (lane < 16) *reinterpret_cast<f32x4*>(part + wave * d + 4 * (l16 + 16 * k)) = acc[k];
+  }
+  __syncthreads();
+  for (int c = tid; c < d; c += 1024) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += part[k * d + c];
+    float* dst = demb + (size_t)b * d + c;
+    *dst = demb_accumulate ? *dst + t : t;
   }
 }
 
@@ -474,7 +630,7 @@ extern "C" int skf_layernorm_residual_fwd(const float* x, float* y_inout_z, cons
 }
 
 extern "C" size_t skf_layernorm_bwd_workspace_bytes(int rows, int d) {
-  return (size_t)(grid_for_rows(rows) > 512 ? 512 : grid_for_rows(rows)) * 2 * d * sizeof(float);
+  return (size_t)(grid_for_rows(rows) > kLnBwdGrid ? kLnBwdGrid : grid_for_rows(rows)) * 2 * d * sizeof(float);
 }
 
 extern "C" int skf_layernorm_residual_bwd(const float* dout, const float* z, const float* stats, const float* gamma,
@@ -485,7 +641,7 @@ extern "C" int skf_layernorm_residual_bwd(const float* dout, const float* z, con
   SKF_CHECK_ARG(workspace && workspace_bytes >= skf_layernorm_bwd_workspace_bytes(rows, d), "workspace too small");
   SKF_CHECK_ARG(rate == 0.f || (step_state && dy), "dropout needs the step state and a dy buffer");
   const SkfStepState* st = (const SkfStepState*)step_state;
-  int g = grid_for_rows(rows); if (g > 512) g = 512;
+  int g = grid_for_rows(rows); if (g > kLnBwdGrid) g = kLnBwdGrid;
   dim3 grid(g), block(256);
   hipStream_t s = (hipStream_t)stream;
   float* part = (float*)workspace;
@@ -523,8 +679,18 @@ extern "C" int skf_softmax_ce(float* logits, int ld, int rows, int ncls, const l
   SKF_CHECK_ARG(logits && target && row_loss && row_hit, "null operand");
   SKF_CHECK_ARG(rows > 0 && ncls > 0 && tgt_cols > 0, "empty problem");
   SkfProfScope ps((hipStream_t)stream, "softmax_ce", 0.0, 8.0 * rows * ncls);
+  const bool vec = (ncls & 3) == 0 && (ld & 3) == 0 && ((uintptr_t)logits & 15) == 0 && ncls <= 2048 &&
+                   (!probs_out || ((uintptr_t)probs_out & 15) == 0);
+#define SKF_CE_GO(NV4) hipLaunchKernelGGL(softmax_ce_reg_kernel<NV4>, dim3(grid_for_rows(rows)), dim3(256), 0, (hipStream_t)stream, \
+    logits, ld, rows, ncls, target, tgt_ld, tgt_cols, tgt_off, mask_pad, scale, row_loss, row_hit, probs_out, write_grad)
+  if (vec && ncls <= 256) SKF_CE_GO(1);
+  else if (vec && ncls <= 512) SKF_CE_GO(2);
+  else if (vec && ncls <= 1024) SKF_CE_GO(4);
+  else if (vec) SKF_CE_GO(8);
+  else
   hipLaunchKernelGGL(softmax_ce_kernel, dim3(grid_for_rows(rows)), dim3(256), 0, (hipStream_t)stream, logits, ld, rows, ncls,
                      target, tgt_ld, tgt_cols, tgt_off, mask_pad, scale, row_loss, row_hit, probs_out, write_grad);
+#undef SKF_CE_GO
   SKF_LAUNCH_CHECK();
   return SKF_OK;
 }
@@ -543,7 +709,8 @@ extern "C" int skf_pool_fwd(const float* u, const float* Vw, const float* x, int
                             float* emb, skf_stream_t stream) {
   SKF_CHECK_ARG(u && Vw && x && a_out && emb, "null operand");
   SkfProfScope ps((hipStream_t)stream, "pool_fwd", 0.0, 4.0 * B * L * (U + d));
-  hipLaunchKernelGGL(pool_fwd_kernel, dim3(B), dim3(256), L * sizeof(float), (hipStream_t)stream, u, Vw, x, L, U, d, a_out, emb);
+  SKF_CHECK_ARG(L <= 1024 && (U & 3) == 0 && (d & 3) == 0 && d <= 4096 && U <= 4096, "pool: need L <= 1024, U % 4 == d % 4 == 0, U,d <= 4096");
+  hipLaunchKernelGGL(pool_fwd_kernel, dim3(B), dim3(1024), (4096 + L + 16) * sizeof(float), (hipStream_t)stream, u, Vw, x, L, U, d, a_out, emb);
   SKF_LAUNCH_CHECK();
   return SKF_OK;
 }
@@ -556,7 +723,8 @@ extern "C" int skf_pool_bwd(float* u_inout_dpre, const float* Vw, const float* x
   hipStream_t s = (hipStream_t)stream;
   float* part = (float*)workspace;
   SkfProfScope ps(s, "pool_bwd", 0.0, 8.0 * B * L * (U + d));
-  hipLaunchKernelGGL(pool_bwd_kernel, dim3(B), dim3(256), 2 * L * sizeof(float), s, u_inout_dpre, Vw, x, a, demb, L, U, d, dx, part);
+  SKF_CHECK_ARG(L <= 1024 && (U & 3) == 0 && (d & 3) == 0 && d <= 4096 && U <= 4096, "pool: need L <= 1024, U % 4 == d % 4 == 0, U,d <= 4096");
+  hipLaunchKernelGGL(pool_bwd_kernel, dim3(B), dim3(1024), (4096 + d + 2 * L + 16) * sizeof(float), s, u_inout_dpre, Vw, x, a, demb, L, U, d, dx, part);
   hipLaunchKernelGGL(colsum_kernel, dim3(skf_cdiv(U, 64)), dim3(1024), 0, s, part, B, U, U, dV, 0);
   SKF_LAUNCH_CHECK();
   return SKF_OK;
@@ -582,7 +750,13 @@ extern "C" int skf_expander_bwd(const float* dpre, const float* emb, const float
   float* p1 = (float*)workspace;
   float* p2 = p1 + (size_t)B * L;
   SkfProfScope ps(s, "expander_bwd", 0.0, 8.0 * B * L * d);
-  hipLaunchKernelGGL(expander_bwd_kernel, dim3(B), dim3(256), 0, s, dpre, emb, w, L, d, demb, demb_accumulate, p1, p2);
+  switch (d) {
+    case 64:  hipLaunchKernelGGL(expander_bwd_kernel<1>, dim3(B), dim3(1024), 0, s, dpre, emb, w, L, demb, demb_accumulate, p1, p2); break;
+    case 128: hipLaunchKernelGGL(expander_bwd_kernel<2>, dim3(B), dim3(1024), 0, s, dpre, emb, w, L, demb, demb_accumulate, p1, p2); break;
+    case 256: hipLaunchKernelGGL(expander_bwd_kernel<4>, dim3(B), dim3(1024), 0, s, dpre, emb, w, L, demb, demb_accumulate, p1, p2); break;
+    case 512: hipLaunchKernelGGL(expander_bwd_kernel<8>, dim3(B), dim3(1024), 0, s, dpre, emb, w, L, demb, demb_accumulate, p1, p2); break;
+    default: skf_set_error("skf_expander_bwd: d_model %d not in {64,128,256,512}", d); return SKF_EUNSUPPORTED;
+  }
   hipLaunchKernelGGL(colsum_kernel, dim3(skf_cdiv(L, 64)), dim3(1024), 0, s, p1, B, L, L, dw, 0);
   hipLaunchKernelGGL(colsum_kernel, dim3(skf_cdiv(L, 64)), dim3(1024), 0, s, p2, B, L, L, dbias, 0);
   SKF_LAUNCH_CHECK();

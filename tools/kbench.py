@@ -90,5 +90,15 @@ def main():
     add("softmax_ce 25472x1004", 0, 8.0 * Md * V, lambda: ops.softmax_ce(lg, tgt, tgt_cols=L - 1, tgt_off=1, mask_pad=True, scale=1e-4))
 
 
+    if not only or "embed" in only:
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)) + "/..")
+        from sketchformer_amd import synthetic
+        xs, _ = synthetic.token_batch(B, L, V, 345, seed=0)
+        tok = torch.from_numpy(xs).cuda()
+        dxe = r(B * L, d)
+        dtab = torch.zeros(V, d, device=dev)
+        add("embed_bwd 25600x128", 0, 4.0 * Me * d, lambda: _lib.call("skf_embed_bwd", tok.data_ptr(), L, B, L, dxe.data_ptr(), V, d, dtab.data_ptr(), 0.0, 0, None, torch.cuda.current_stream().cuda_stream))
+
+
 if __name__ == "__main__":
     main()
