@@ -80,8 +80,8 @@ def pmc_traffic(tag):
         return None
     table = json.load(open(files[-1]))
     m = re.match(r"gemm_ws<K(\d+),CW(\d+)>", tag)
-    if m:
-        prefix = "gemm_ws_kernel<%s, %s," % m.groups()
+    if m:   # kernel template is <K, columns per lane = CW/16, ...>
+        prefix = "gemm_ws_kernel<%s, %d," % (m.group(1), int(m.group(2)) // 16)
     else:
         prefix = {"wgrad<64x64>": "wgrad_kernel", "attn_bwd<dh16>": "attn_bwd_kernel<16", "attn_fwd<dh16>": "attn_fwd_kernel<16",
                   "ln_fwd": "ln_fwd_kernel", "ln_bwd": "ln_bwd_kernel"}.get(tag)
