@@ -173,6 +173,24 @@ int skf_adam_step(float* w, const float* g, float* m, float* v, size_t n, const 
 /* host helper for parity tests: the keep-mask the kernels derive for (drop_key, site) */
 int skf_dropout_keep_mask(unsigned drop_key, unsigned site, float rate, size_t n, unsigned char* out_host);
 
+/* ---- single-query attention + token selection of the KV-cached greedy decode ----
+ * skf_attention_decode: scaled_dot_product_attention (builders/utils.py:71-105) for ONE query row per (sample, head):
+ *   Q (B, H*dh) row stride ldq; K/V rows of sample b start at K + b*kv_batch_stride, row stride ld_kv, Lk rows used;
+ *   key_mask (B, key_mask_ld) bytes, 1 = masked (additive -1e9); keys >= key_limit[b] (or key_limit_all if > 0) masked.
+ * skf_decode_init: column 0 of the output = SOS (tokens) or (0,0,1,0,0) (continuous); clears the flags.
+ * skf_decode_select_tokens / _continuous: models/sketchformer.py:285-301 - append argmax (first index on ties) or
+ *   (x, y, softmax(pen)); maintain the target padding mask, the sticky EOS flags and done_step (-1 until the stop test holds). */
+int skf_attention_decode(const float* Q, int ldq, const float* K, const float* V, int ld_kv, long long kv_batch_stride,
+                         const unsigned char* key_mask, int key_mask_ld, const int* key_limit, int key_limit_all, int B,
+                         int H, int Lk, int dh, float* O, int ldo, skf_stream_t stream);
+int skf_decode_init(long long* tokens, int tok_ld, float* cont, int cont_ld_rows, unsigned char* selfmask, int mask_ld,
+                    int* eos_seen, int* done_step, int B, long long sos, skf_stream_t stream);
+int skf_decode_select_tokens(const float* logits, int ld, int B, int V, int n_valid, int step, long long eos,
+                             long long* tokens, int tok_ld, unsigned char* selfmask, int mask_ld, int* eos_seen,
+                             int* done_step, skf_stream_t stream);
+int skf_decode_select_continuous(const float* pred, int ld, int B, int n_valid, int step, float* out, int out_ld_rows,
+                                 unsigned char* selfmask, int mask_ld, int* done_step, skf_stream_t stream);
+
 /* ------------------------------------------------------------------ the train step
  * Transformer.build_model / call / model_trainer, models/sketchformer.py:63-147, 313-349. */
 typedef struct SkfConfig {
@@ -217,6 +235,20 @@ int skf_model_forward_backward(SkfModel* m, const void* inp, const void* tar, in
                                const long long* labels, skf_stream_t stream);
 /* optimizer.apply_gradients with grads pre-multiplied by grad_scale (1/world_size under data parallelism) */
 int skf_model_apply_gradients(SkfModel* m, float grad_scale, skf_stream_t stream);
+/* ---- inference API of the plugin (models/sketchformer.py:162-168, 201-311) ----
+ * skf_model_encode: encode_from_seq / predict_class - encoder + bottleneck + classifier with dropout off; results in
+ *   the buffers "embedding" (B,d), "class_probs" (B,C), "enc_output" (B*L,d).
+ * skf_model_greedy_decode: predict_from_embedding - greedy reconstruction with a per-layer K/V cache.
+ *   embedding: (B,d) device floats, or NULL to use the model's own "embedding" buffer (after skf_model_encode);
+ *   expected_len_host: per-sample key limit of the cross attention, used only when blind_decoder_mask == 0 (NULL = i+1);
+ *   only the first n_valid samples take part in the stop test; sos/eos: tokenizer ids (ignored in continuous mode);
+ *   out: device buffer (B, max_steps+1) int64 tokens [column 0 = SOS] or (B, max_steps+1, 5) float stroke-5 rows
+ *   [row 0 = (0,0,1,0,0)]; *out_len_host = number of valid columns (the reference's output length).
+ *   Blocking: synchronises the stream every 8 tokens to test the stop condition. */
+int skf_model_encode(SkfModel* m, const void* inp, skf_stream_t stream);
+int skf_model_greedy_decode(SkfModel* m, const float* embedding, const int* expected_len_host, int n_valid,
+                            long long sos, long long eos, int max_steps, void* out, int* out_len_host,
+                            skf_stream_t stream);
 /* look up an internal activation by name ("logits", "class_probs", "embedding", "enc_output", ...) */
 int skf_model_buffer(SkfModel* m, const char* name, float** ptr, int* rows, int* cols);
 

@@ -33,6 +33,7 @@ __all__ = [
     "continuous_recon_loss_bwd", "class_loss_fwd", "class_loss_bwd",
     "warmup_decay", "step_decay", "adam_update", "forward", "loss_and_grads",
     "TrainState", "train_step", "dropout_sites", "MetricState",
+    "encode_from_seq", "make_dummy_input", "decode", "predict_from_embedding", "predict",
 ]
 
 
@@ -696,3 +697,111 @@ def train_step(state: TrainState, cfg: Config, inp, tar, labels, drops=None):
         adam_update(state.params[k], G[k], state.m[k], state.v[k], state.iterations, lr)
     state.iterations += 1
     return ms.results(), losses, out, G
+
+# --------------------------------------------------------------------------
+# inference API (models/sketchformer.py:149-168, 201-311) - naive restatement:
+# like the reference, the whole decoder is re-run on the growing prefix for
+# every emitted token (no KV cache); only small cases are meant to run here.
+# --------------------------------------------------------------------------
+def encode_from_seq(P, cfg: Config, inp_seq):
+    """models/sketchformer.py:162-168 (mask computed inside, training=False).
+    Returns dict(enc_output, embedding, class = class probabilities)."""
+    inp = np.asarray(inp_seq)
+    dt = next(iter(P.values())).dtype
+    pos = positional_encoding(cfg.max_pos, cfg.d_model).astype(dt)
+    x, _ = _embed_fwd(P, "encoder/embedding", inp, cfg, pos, 0.0, None)
+    mask = create_padding_mask(inp)
+    for i in range(cfg.num_layers):
+        x, _ = encoder_layer_fwd(P, "encoder/layer%d" % i, x, mask, cfg.num_heads, 0.0, {})
+    emb = self_attn_v1_fwd(P, x)[0] if cfg.attn_version == 1 else self_attn_v2_fwd(P, x)[0]
+    logits, _ = dense_fwd(emb, P["classify/kernel"], P["classify/bias"])
+    e = np.exp(logits - logits.max(-1, keepdims=True))
+    return {"enc_output": x, "embedding": emb, "class": e / e.sum(-1, keepdims=True)}
+
+
+def make_dummy_input(cfg: Config, expected_len, nattn, batch_size):
+    """models/sketchformer.py:230-253: a fake encoder input whose only use is its padding mask:
+    the first nattn positions are 'real', the remaining seq_len - nattn are padding."""
+    L = cfg.seq_len
+    if cfg.continuous:
+        d = np.zeros((batch_size, L, 5), dtype=np.float32)
+        d[:, int(nattn):, 4] = 1.0
+        return d
+    d = np.zeros((batch_size, L), dtype=np.float32)
+    if expected_len is None:
+        d[:, :int(nattn)] = 1.0
+    else:
+        for b, n in enumerate(np.asarray(nattn).reshape(-1)):
+            d[b, :int(n)] = 1.0
+    return d
+
+
+def decode(P, cfg: Config, embedding, target, dec_padding_mask, look_ahead_mask):
+    """models/sketchformer.py:170-181 with training=False -> logits (B, T, V)."""
+    dt = next(iter(P.values())).dtype
+    pos = positional_encoding(cfg.max_pos, cfg.d_model).astype(dt)
+    padding_mask = np.zeros_like(dec_padding_mask) if cfg.blind_decoder_mask else dec_padding_mask
+    pre, _ = dense_expander_fwd(P, embedding)
+    y, _ = _embed_fwd(P, "decoder/embedding", target, cfg, pos, 0.0, None)
+    for i in range(cfg.num_layers):
+        y, _, _, _ = decoder_layer_fwd(P, "decoder/layer%d" % i, y, pre, look_ahead_mask, padding_mask,
+                                       cfg.num_heads, 0.0, {})
+    return dense_fwd(y, P["output/kernel"], P["output/bias"])[0]
+
+
+def predict_from_embedding(P, cfg: Config, emb, sos, eos, expected_len=None):
+    """Greedy reconstruction, models/sketchformer.py:255-311.
+    tokens:     output starts as [SOS]; up to seq_len iterations; every iteration appends argmax of the LAST
+                position's logits (first index on ties, like tf.argmax); EOS flags are sticky per sample and the loop
+                stops after the iteration in which all samples have emitted an EOS at some point; samples that are
+                already finished keep being extended.
+    continuous: output starts as [0,0,1,0,0]; the appended row is (xy, softmax(pen logits)); the loop stops after an
+                iteration in which argmax(pen) == 2 for ALL samples simultaneously.
+    Returns dict(recon = (B, T) int32 tokens incl. the SOS column | (B, T, 5) float rows, class = argmax of the
+    class probabilities)."""
+    dt = next(iter(P.values())).dtype
+    emb = np.asarray(emb, dtype=dt)
+    B = emb.shape[0]
+    if cfg.continuous:
+        output = np.tile(np.array([0., 0., 1., 0., 0.], dtype=dt), (B, 1, 1))
+    else:
+        output = np.full((B, 1), sos, dtype=np.int64)
+        eos_seen = np.zeros(B, dtype=bool)
+    for i in range(cfg.seq_len):
+        nattn = expected_len if expected_len is not None else i + 1
+        dummy = make_dummy_input(cfg, expected_len, nattn, B)
+        _, combined_mask, dec_padding_mask = create_masks(dummy, output)
+        logits = decode(P, cfg, emb, output, dec_padding_mask, combined_mask)
+        last = logits[:, -1:, ...]
+        if cfg.continuous:
+            pen = last[..., 2:]
+            e = np.exp(pen - pen.max(-1, keepdims=True))
+            predicted = np.concatenate([last[..., :2], e / e.sum(-1, keepdims=True)], axis=-1)
+            output = np.concatenate([output, predicted], axis=1)
+            if int(np.sum(np.argmax(predicted[..., 2:], axis=-1) == 2)) == B:
+                break
+        else:
+            predicted = np.argmax(last, axis=-1).astype(np.int64)          # (B, 1)
+            output = np.concatenate([output, predicted], axis=1)
+            eos_seen |= (predicted[:, 0] == eos)
+            if eos_seen.all():
+                break
+    cls_logits, _ = dense_fwd(emb, P["classify/kernel"], P["classify/bias"])
+    return {"recon": output if cfg.continuous else output.astype(np.int32),
+            "class": np.argmax(cls_logits, axis=-1).astype(np.int32)}
+
+
+def predict(P, cfg: Config, inp_seq, sos, eos):
+    """models/sketchformer.py:201-221: encode, class argmax, greedy reconstruction.  With blind_decoder_mask
+    (default) the expected length is not used; otherwise it is the number of non-padding input positions."""
+    out = encode_from_seq(P, cfg, inp_seq)
+    inp = np.asarray(inp_seq)
+    if cfg.blind_decoder_mask:
+        tlen = None
+    elif cfg.continuous:
+        tlen = np.sum(inp[..., -1] != 1, axis=-1)
+    else:
+        tlen = np.sum(inp > 0, axis=-1)
+    dec = predict_from_embedding(P, cfg, out["embedding"], sos, eos, tlen)
+    return {"embedding": out["embedding"], "class": np.argmax(out["class"], axis=-1).astype(np.int32),
+            "class_probs": out["class"], "recon": dec["recon"]}

@@ -82,6 +82,10 @@ SIGNATURES = {
     "skf_step_epilogue": (_I, [_P, _P]),
     "skf_adam_step": (_I, [_P, _P, _P, _P, _Z, _P, _F, _F, _F, _F, _P]),
     "skf_dropout_keep_mask": (_I, [_U, _U, _F, _Z, _P]),
+    "skf_attention_decode": (_I, [_P, _I, _P, _P, _I, C.c_longlong, _P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _P]),
+    "skf_decode_init": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _I, C.c_longlong, _P]),
+    "skf_decode_select_tokens": (_I, [_P, _I, _I, _I, _I, _I, C.c_longlong, _P, _I, _P, _I, _P, _P, _P]),
+    "skf_decode_select_continuous": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P]),
     "skf_config_validate": (_I, [C.POINTER(SkfConfig)]),
     "skf_model_param_floats": (_Z, [C.POINTER(SkfConfig)]),
     "skf_model_param_entries": (_I, [C.POINTER(SkfConfig), C.POINTER(SkfParamEntry), _I]),
@@ -91,6 +95,8 @@ SIGNATURES = {
     "skf_model_bind": (_I, [_P, _P, _P, _P, _P, _P, _P, _Z, _P, _P]),
     "skf_model_forward": (_I, [_P, _P, _P, _I, _I, _P]),
     "skf_model_forward_backward": (_I, [_P, _P, _P, _I, _P, _P]),
+    "skf_model_encode": (_I, [_P, _P, _P]),
+    "skf_model_greedy_decode": (_I, [_P, _P, C.POINTER(_I), _I, C.c_longlong, C.c_longlong, _I, _P, C.POINTER(_I), _P]),
     "skf_model_apply_gradients": (_I, [_P, _F, _P]),
     "skf_model_buffer": (_I, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(_I), C.POINTER(_I)]),
 }

@@ -227,6 +227,9 @@ struct Plan {
   size_t gA, gB, gC, dqkv, dh, do_, dpre, dkv2, dq2, demb;
   size_t gemm_ws, gemm_ws_bytes, small_ws, small_ws_bytes;
   size_t slab_arena, slab_arena_bytes, descs, n_wgrads;   // deferred split-K reduction (eager path)
+  // KV-cached greedy decode (inference): per-layer self-attention K|V cache (B, L, 2d) + one-row-per-sample step buffers
+  std::vector<size_t> dc_cache;
+  size_t dc_x[2], dc_q, dc_o, dc_z, dc_out1, dc_out2, dc_h, dc_logits, dc_stats, dc_mask, dc_flags, dc_limit;
 };
 
 size_t wgrad_ws(int in, int out, int rows) {
@@ -287,6 +290,11 @@ Plan build_plan(const SkfConfig& c) {
   if (2 * B * L * f > s) s = 2 * B * L * f;
   if (c.continuous && skf_embed_continuous_bwd_workspace_bytes((int)Me, (int)d) > s) s = skf_embed_continuous_bwd_workspace_bytes((int)Me, (int)d);
   P.small_ws_bytes = s; P.small_ws = b.take(s);
+  for (int i = 0; i < c.num_layers; ++i) P.dc_cache.push_back(b.take(B * L * 2 * d * f));
+  P.dc_x[0] = b.take(B * d * f); P.dc_x[1] = b.take(B * d * f); P.dc_q = b.take(B * d * f); P.dc_o = b.take(B * d * f);
+  P.dc_z = b.take(B * d * f); P.dc_out1 = b.take(B * d * f); P.dc_out2 = b.take(B * d * f); P.dc_h = b.take(B * F * f);
+  P.dc_logits = b.take(B * Vout * f); P.dc_stats = b.take(B * 2 * f); P.dc_mask = b.take(B * (L + 1));
+  P.dc_flags = b.take((B + 16) * sizeof(int)); P.dc_limit = b.take(B * sizeof(int));
   P.bytes = b.off;
   return P;
 }
@@ -421,7 +429,7 @@ inline unsigned site_enc(int layer, int j) { return 1 + 2 * layer + j; }
 inline unsigned site_dec_embed(int N) { return 1 + 2 * N; }
 inline unsigned site_dec(int N, int layer, int j) { return 2 + 2 * N + 3 * layer + j; }
 
-int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s) {
+int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s, bool encoder_only = false) {
   const SkfConfig& c = M->cfg;
   const Layout& L = M->lay;
   const Plan& P = M->plan;
@@ -472,6 +480,10 @@ int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s) {
   SKF_TRY(skf_pool_fwd(M->at<float>(P.u), M->P(L.bott_v), enc_out, B, Le, c.lowerdim, d, M->at<float>(P.pool_a),
                        M->at<float>(P.emb), s));
   SKF_TRY(dense_fwd(M, L.cls, M->at<float>(P.emb), B, M->at<float>(P.cls_logits), 0, s));
+  if (encoder_only) {   // encode_from_seq / predict_class (models/sketchformer.py:162-168,223-228): class probabilities only
+    return skf_softmax_ce(M->at<float>(P.cls_logits), c.n_classes, B, c.n_classes, M->at<long long>(P.labels), 1, 1, 0, 0, 0.f,
+                          M->at<float>(P.cls_loss), M->at<float>(P.cls_hit), M->at<float>(P.cls_probs), 0, s);
+  }
   SKF_TRY(skf_expander_fwd(M->at<float>(P.emb), M->P(L.exp_w), M->P(L.exp_b), B, Le, d, M->at<float>(P.pre), s));
 
   // ---------------- decoder (builders/layers/transformer.py:325-344)
@@ -666,6 +678,96 @@ int run_backward(SkfModel* M, hipStream_t s) {
   return join_side(M, s);
 }
 
+// KV-cached greedy reconstruction (models/sketchformer.py:255-311).  The reference re-runs the decoder on the whole
+// prefix for every token; one step here touches only the newest position (rows = batch):
+//   x = embed(token_i) * sqrt(d) + pos[i]                                   (transformer.py:325-334, dropout off)
+//   per layer: q = x Wq ; [k|v] = x [Wk|Wv] written straight into cache row i ; attention over keys 0..i with the
+//   target padding mask (look-ahead is implicit: later keys do not exist yet) ; LN ; cross attention over the
+//   cached K/V of pre_decoder ; LN ; FFN ; LN                               (transformer.py:245-262)
+//   logits of position i -> argmax / stroke-5 row -> appended                (sketchformer.py:285-301)
+int run_greedy_decode(SkfModel* M, const float* embedding, const int* expected_len_host, int n_valid, long long sos,
+                      long long eos, int max_steps, void* out, int* out_len_host, hipStream_t s) {
+  const SkfConfig& c = M->cfg;
+  const Layout& L = M->lay;
+  const Plan& P = M->plan;
+  const int B = c.batch, Le = c.seq_len, d = c.d_model, H = c.num_heads, dh = d / H, N = c.num_layers, F = c.dff;
+  const int T = max_steps + 1;                         // columns of the output buffer
+  const int Vout = c.continuous ? 5 : c.vocab_size;
+  (void)F;
+  if (embedding && embedding != M->at<float>(P.emb))
+    SKF_HIP(hipMemcpyAsync(M->at<float>(P.emb), embedding, (size_t)B * d * sizeof(float), hipMemcpyDeviceToDevice, s));
+  int* eos_seen = M->at<int>(P.dc_flags);
+  int* done_step = eos_seen + B;
+  unsigned char* selfmask = M->at<unsigned char>(P.dc_mask);
+  long long* tokens = c.continuous ? nullptr : (long long*)out;
+  float* cont = c.continuous ? (float*)out : nullptr;
+  SKF_TRY(skf_decode_init(tokens, T, cont, T, selfmask, Le + 1, eos_seen, done_step, B, sos, s));
+  int* limit = nullptr;
+  if (!c.blind_decoder_mask && expected_len_host) {
+    limit = M->at<int>(P.dc_limit);
+    SKF_HIP(hipMemcpyAsync(limit, expected_len_host, (size_t)B * sizeof(int), hipMemcpyHostToDevice, s));
+  }
+  // pre_decoder and the cross-attention K/V of every layer: once
+  SKF_TRY(skf_expander_fwd(M->at<float>(P.emb), M->P(L.exp_w), M->P(L.exp_b), B, Le, d, M->at<float>(P.pre), s));
+  for (int l = 0; l < N; ++l)
+    SKF_TRY(dense_fwd(M, L.dec[l].mha2.kv, M->at<float>(P.pre), B * Le, M->at<float>(P.dec[l].kv2), 0, s));
+  SKF_TRY(dense_fwd(M, L.cls, M->at<float>(P.emb), B, M->at<float>(P.cls_logits), 0, s));   // classify_from_embedding
+  SKF_TRY(skf_softmax_ce(M->at<float>(P.cls_logits), c.n_classes, B, c.n_classes, M->at<long long>(P.labels), 1, 1, 0, 0, 0.f,
+                         M->at<float>(P.cls_loss), M->at<float>(P.cls_hit), M->at<float>(P.cls_probs), 0, s));
+
+  float* q = M->at<float>(P.dc_q); float* o = M->at<float>(P.dc_o); float* z = M->at<float>(P.dc_z);
+  float* out1 = M->at<float>(P.dc_out1); float* out2 = M->at<float>(P.dc_out2); float* hbuf = M->at<float>(P.dc_h);
+  float* stats = M->at<float>(P.dc_stats); float* logits = M->at<float>(P.dc_logits);
+  int done = -1, steps_run = 0;
+  for (int i = 0; i < max_steps; ++i) {
+    float* x = M->at<float>(P.dc_x[0]);
+    float* xn = M->at<float>(P.dc_x[1]);
+    if (c.continuous)
+      SKF_TRY(skf_embed_continuous_fwd(cont + (size_t)i * 5, T, B, 1, M->P(L.dec_embd.w), M->P(L.dec_embd.b), d,
+                                       M->pos + (size_t)i * d, x, 0.f, 0, M->state, s));
+    else
+      SKF_TRY(skf_embed_fwd(tokens + i, T, B, 1, M->P(L.dec_emb), c.vocab_size, d, M->pos + (size_t)i * d, x, 0.f, 0,
+                            M->state, s));
+    for (int l = 0; l < N; ++l) {
+      const DecLayerP& w = L.dec[l];
+      float* cache = M->at<float>(P.dc_cache[l]);                       // (B, Le, 2d): K | V of positions 0..i
+      const DenseP wq{w.mha1.qkv.w, w.mha1.qkv.b, d, d, w.mha1.qkv.ld};
+      const DenseP wkv{w.mha1.qkv.w + d, w.mha1.qkv.b + d, d, 2 * d, w.mha1.qkv.ld};
+      SKF_TRY(dense_fwd_ld(M, wq, x, d, B, q, d, 0, s));
+      SKF_TRY(dense_fwd_ld(M, wkv, x, d, B, cache + (size_t)i * 2 * d, Le * 2 * d, 0, s));
+      SKF_TRY(skf_attention_decode(q, d, cache, cache + d, 2 * d, (long long)Le * 2 * d, selfmask, Le + 1, nullptr, 0, B, H,
+                                   i + 1, dh, o, d, s));
+      SKF_TRY(dense_fwd(M, w.mha1.o, o, B, z, 0, s));
+      SKF_TRY(skf_layernorm_residual_fwd(x, z, M->P(w.ln1.g), M->P(w.ln1.b), out1, stats, B, d, 0.f, 0, M->state, s));
+      const float* kv2 = M->at<float>(P.dec[l].kv2);
+      SKF_TRY(dense_fwd(M, w.mha2.q, out1, B, q, 0, s));
+      // cross mask (models/sketchformer.py:172,279-283): none when blind, else keys >= nattn (expected length or i+1)
+      SKF_TRY(skf_attention_decode(q, d, kv2, kv2 + d, 2 * d, (long long)Le * 2 * d, nullptr, 0, limit,
+                                   (c.blind_decoder_mask || limit) ? 0 : i + 1, B, H, Le, dh, o, d, s));
+      SKF_TRY(dense_fwd(M, w.mha2.o, o, B, z, 0, s));
+      SKF_TRY(skf_layernorm_residual_fwd(out1, z, M->P(w.ln2.g), M->P(w.ln2.b), out2, stats, B, d, 0.f, 0, M->state, s));
+      SKF_TRY(dense_fwd(M, w.f1, out2, B, hbuf, 1, s));
+      SKF_TRY(dense_fwd(M, w.f2, hbuf, B, z, 0, s));
+      SKF_TRY(skf_layernorm_residual_fwd(out2, z, M->P(w.ln3.g), M->P(w.ln3.b), xn, stats, B, d, 0.f, 0, M->state, s));
+      float* t = x; x = xn; xn = t;
+    }
+    SKF_TRY(dense_fwd(M, L.out, x, B, logits, 0, s));
+    if (c.continuous)
+      SKF_TRY(skf_decode_select_continuous(logits, Vout, B, n_valid, i, cont, T, selfmask, Le + 1, done_step, s));
+    else
+      SKF_TRY(skf_decode_select_tokens(logits, Vout, B, Vout, n_valid, i, eos, tokens, T, selfmask, Le + 1, eos_seen,
+                                       done_step, s));
+    steps_run = i + 1;
+    if ((i & 7) == 7 || i + 1 == max_steps) {            // the reference syncs every token; every 8th is enough here
+      SKF_HIP(hipMemcpyAsync(&done, done_step, sizeof(int), hipMemcpyDeviceToHost, s));
+      SKF_HIP(hipStreamSynchronize(s));
+      if (done >= 0) break;
+    }
+  }
+  if (out_len_host) *out_len_host = (done >= 0 ? done + 1 : steps_run) + 1;   // start symbol + emitted positions
+  return SKF_OK;
+}
+
 int prologue(SkfModel* M, hipStream_t s) {
   const SkfConfig& c = M->cfg;
   return skf_step_prologue(M->state, c.schedule, c.sched_p0, c.sched_p1, c.sched_p2, c.sched_p3, c.beta1, c.beta2,
@@ -811,6 +913,24 @@ extern "C" int skf_model_forward(SkfModel* m, const void* inp, const void* tar, 
   SKF_TRY(stage_inputs(m, inp, tar, tar_ld, nullptr, s));
   if (training) SKF_TRY(prologue(m, s));
   return run_forward(m, training != 0, false, s);
+}
+
+extern "C" int skf_model_encode(SkfModel* m, const void* inp, skf_stream_t stream) {
+  SKF_CHECK_ARG(m && m->ws, "model not bound");
+  hipStream_t s = (hipStream_t)stream;
+  SKF_TRY(stage_inputs(m, inp, inp, m->cfg.seq_len, nullptr, s));
+  return run_forward(m, false, false, s, true);
+}
+
+extern "C" int skf_model_greedy_decode(SkfModel* m, const float* embedding, const int* expected_len_host, int n_valid,
+                                       long long sos, long long eos, int max_steps, void* out, int* out_len_host,
+                                       skf_stream_t stream) {
+  SKF_CHECK_ARG(m && m->ws, "model not bound");
+  SKF_CHECK_ARG(out, "null output");
+  SKF_CHECK_ARG(n_valid > 0 && n_valid <= m->cfg.batch, "n_valid must be in [1, batch]");
+  SKF_CHECK_ARG(max_steps > 0 && max_steps <= m->cfg.seq_len, "max_steps must be in [1, seq_len]");
+  return run_greedy_decode(m, embedding, expected_len_host, n_valid, sos, eos, max_steps, out, out_len_host,
+                           (hipStream_t)stream);
 }
 
 extern "C" int skf_model_forward_backward(SkfModel* m, const void* inp, const void* tar, int tar_ld,

@@ -214,6 +214,48 @@ class TrainEngine:
         _lib.call("skf_model_forward", self.handle, self._p(inp), self._p(tar), self._ld(tar), int(training), self._stream())
         self._leave()
 
+    def encode(self, inp):
+        """encode_from_seq (models/sketchformer.py:162-168): encoder + bottleneck + classifier, dropout off.
+        Results in the buffers 'embedding', 'class_probs', 'enc_output'."""
+        inp = self._dev_input(inp)
+        self._enter()
+        _lib.call("skf_model_encode", self.handle, self._p(inp), self._stream())
+        self._leave()
+
+    def greedy_decode(self, embedding=None, expected_len=None, n_valid=None, sos=0, eos=0, max_steps=None):
+        """predict_from_embedding (models/sketchformer.py:255-311) with a K/V cache.  embedding: (B,d) array / tensor
+        or None (= the model's own 'embedding' buffer, i.e. right after ``encode``).  Returns the reconstruction as a
+        host array: (n_valid, T) int32 tokens incl. the SOS column, or (n_valid, T, 5) float32 stroke-5 rows."""
+        B, L = self.cfg.batch, self.cfg.seq_len
+        n_valid = B if n_valid is None else int(n_valid)
+        max_steps = L if max_steps is None else int(max_steps)
+        emb_ptr = None
+        if embedding is not None:
+            e = torch.as_tensor(np.asarray(embedding, dtype=np.float32) if not torch.is_tensor(embedding) else embedding)
+            e = e.to(self.device, dtype=torch.float32).contiguous()
+            if e.shape != (B, self.cfg.d_model):
+                raise ValueError("embedding must be (batch=%d, d_model=%d)" % (B, self.cfg.d_model))
+            emb_ptr = self._p(e)
+        lim = None
+        if expected_len is not None:
+            arr = np.zeros(B, dtype=np.int32)
+            v = np.asarray(expected_len).astype(np.int32).reshape(-1)
+            arr[:len(v)] = v
+            arr[len(v):] = L
+            lim = (C.c_int * B)(*arr.tolist())
+        if self.cfg.continuous:
+            out = torch.zeros(B, max_steps + 1, 5, dtype=torch.float32, device=self.device)
+        else:
+            out = torch.zeros(B, max_steps + 1, dtype=torch.int64, device=self.device)
+        n_out = C.c_int(0)
+        self._enter()
+        _lib.call("skf_model_greedy_decode", self.handle, emb_ptr, lim, n_valid, int(sos), int(eos), max_steps, self._p(out),
+                  C.byref(n_out), self._stream())
+        self._leave()
+        self.synchronize()
+        res = out[:n_valid, :n_out.value].cpu().numpy()
+        return res if self.cfg.continuous else res.astype(np.int32)
+
     def forward_backward(self, inp, tar, labels):
         inp = self._dev_input(inp)
         tar = inp if tar is None else self._dev_input(tar)

@@ -81,22 +81,24 @@ class Transformer(BaseModel):
     def prepare_for_end_of_epoch(self):
         self.engine.reset_metrics()
 
-    # ---- inference API (models/sketchformer.py:162-228); inputs are padded to the engine's batch size
-    def _run_forward(self, inp_seq):
-        x = np.asarray(inp_seq)
-        if x.ndim == 1:
+    # ---- inference API (models/sketchformer.py:162-311); inputs are padded to the engine's batch size
+    def _pad_batch(self, x):
+        x = np.asarray(x)
+        if x.ndim == (2 if self.engine.cfg.continuous else 1):
             x = x[None]
         n, B = x.shape[0], self.engine.cfg.batch
         if n > B:
             raise ValueError("at most batch_size=%d sequences per call" % B)
-        pad = np.zeros((B,) + x.shape[1:], dtype=np.int64)
+        pad = np.zeros((B,) + x.shape[1:], dtype=np.float32 if self.engine.cfg.continuous else np.int64)
+        if self.engine.cfg.continuous:
+            pad[..., 4] = 1.0                      # stroke-5 padding rows
         pad[:n] = x
-        self.engine.forward(pad, training=False)
-        self.engine.synchronize()
-        return n
+        return pad, n
 
     def encode_from_seq(self, inp_seq):
-        n = self._run_forward(inp_seq)
+        pad, n = self._pad_batch(inp_seq)
+        self.engine.encode(pad)
+        self.engine.synchronize()
         return {'enc_output': self.engine.buffer('enc_output').view(self.engine.cfg.batch, self.seq_len, -1)[:n].cpu().numpy(),
                 'embedding': self.engine.buffer('embedding')[:n].cpu().numpy(),
                 'class': self.engine.buffer('class_probs')[:n].cpu().numpy()}
@@ -106,12 +108,62 @@ class Transformer(BaseModel):
         out['class'] = out['class'].argmax(-1).astype(np.int32)
         return out
 
-    def predict(self, inp_seq):
-        raise NotImplementedError("greedy reconstruction (predict / predict_from_embedding) is the next scope row "
-                                  "(SURVEY.md section 8(f) rank 1); only the train step and the encoder-side "
-                                  "inference API are implemented")
+    def make_dummy_input(self, expected_len, nattn, batch_size):
+        """models/sketchformer.py:230-253: fake encoder input, only its padding mask matters (first nattn positions real)."""
+        if self.engine.cfg.continuous:
+            d = np.zeros((batch_size, self.seq_len, 5), dtype=np.float32)
+            d[:, int(nattn):, 4] = 1.0
+            return d
+        d = np.zeros((batch_size, self.seq_len), dtype=np.float32)
+        if expected_len is None:
+            d[:, :int(nattn)] = 1.0
+        else:
+            for b, n in enumerate(np.asarray(nattn).reshape(-1)):
+                d[b, :int(n)] = 1.0
+        return d
 
-    predict_from_embedding = predict
+    def predict_from_embedding(self, emb, expected_len=None):
+        """Greedy reconstruction from the bottleneck (models/sketchformer.py:255-311), KV-cached on the device.
+        Returns {'recon', 'class', 'attn_weights'}; attention weights are never materialised here (no consumer in the
+        reference reads them: evaluation_mixin.py:25-35, experiments/*.py) -> None."""
+        if not self.hps['do_reconstruction']:
+            raise ValueError("do_reconstruction is off")
+        emb = np.asarray(emb, dtype=np.float32)
+        if emb.ndim == 1:
+            emb = emb[None]
+        n, B = emb.shape[0], self.engine.cfg.batch
+        if n > B:
+            raise ValueError("at most batch_size=%d embeddings per call" % B)
+        pad = np.zeros((B, emb.shape[1]), dtype=np.float32)
+        pad[:n] = emb
+        tok = self.dataset.tokenizer
+        if self.hps['blind_decoder_mask']:
+            expected_len = None                     # "will be ignored if blind_decoder_mask=True"
+        recon = self.engine.greedy_decode(pad, expected_len=expected_len, n_valid=n,
+                                          sos=getattr(tok, 'SOS', 0) if tok is not None else 0,
+                                          eos=getattr(tok, 'EOS', 0) if tok is not None else 0)
+        out = {'recon': recon, 'attn_weights': None}
+        if self.hps['do_classification']:
+            out['class'] = self.engine.buffer('class_probs')[:n].cpu().numpy().argmax(-1).astype(np.int32)
+        return out
+
+    def predict(self, inp_seq):
+        """models/sketchformer.py:201-221."""
+        out = self.encode_from_seq(inp_seq)
+        if self.hps['do_classification']:
+            out['class'] = out['class'].argmax(-1).astype(np.int32)
+        if self.hps['do_reconstruction']:
+            x = np.asarray(inp_seq)
+            if self.hps['blind_decoder_mask']:
+                tlen = None
+            elif self.engine.cfg.continuous:
+                tlen = np.sum(x[..., -1] != 1, axis=-1).reshape(-1)
+            else:
+                tlen = np.sum(x > 0, axis=-1).reshape(-1)
+            dec = self.predict_from_embedding(out['embedding'], tlen)
+            out['recon'] = dec['recon']
+            out['attn_weights'] = dec['attn_weights']
+        return out
 
     # ---- checkpoint payload
     def state_dict(self):

@@ -91,6 +91,19 @@ def attention_fwd(q, k, v, num_heads, key_mask=None, causal=False):
     return o, stats
 
 
+def attention_decode(q, k, v, num_heads, n_keys=None, key_mask=None, key_limit=None, key_limit_all=0):
+    """One query row per (sample, head): q (B,d), k/v (B,Lcap,d) cache views with unit inner stride, the first
+    n_keys rows of each sample are used -> o (B,d)."""
+    B, d = q.shape
+    Lk = k.shape[1] if n_keys is None else int(n_keys)
+    assert k.stride(0) == v.stride(0) and k.stride(1) == v.stride(1)
+    o = torch.empty(B, d, dtype=torch.float32, device=q.device)
+    _lib.call("skf_attention_decode", _p(q), q.stride(0), _p(k), _p(v), k.stride(1), k.stride(0), _p(key_mask),
+              key_mask.stride(0) if key_mask is not None else 0, _p(key_limit), int(key_limit_all), B, num_heads, Lk,
+              d // num_heads, _p(o), o.stride(0), _stream())
+    return o
+
+
 def attention_bwd(q, k, v, o, do, stats, num_heads, key_mask=None, causal=False):
     B, Lq, d = q.shape
     Lk = k.shape[1]

@@ -251,3 +251,91 @@ def test_k4b_pad_asymmetry_continuous():
     assert torch.equal(enc_a[:, :12], enc_b[:, :12])
     assert not torch.equal(enc_a[:, 12:], enc_b[:, 12:])
     assert not torch.equal(emb_a, emb_b)
+
+
+# ------------------------------------------------------------------ greedy decode with a K/V cache
+def _force_eos_bias(eng, ocfg, eos, amount):
+    """Raise the EOS logit so that random-weight models terminate at different steps per sample."""
+    b = eng.get("output/bias")
+    b[eos] += amount
+    eng.set("output/bias", b)
+
+
+@pytest.mark.parametrize("blind", [True, False])
+def test_greedy_decode_tokens_match_oracle(blind):
+    B = 6
+    eng, ocfg = _mk(B, blind=blind)
+    sos, eos = ocfg.vocab_size - 2, ocfg.vocab_size - 1
+    x, _ = synthetic.token_batch(B, ocfg.seq_len, ocfg.vocab_size, ocfg.n_classes, seed=5)
+    x[0, 7:] = 0
+    x[1, 3:] = 0
+    P = {k: v.astype(np.float64) for k, v in eng.state_dict_numpy().items()}
+    want = oracle.predict(P, ocfg, x, sos, eos)
+    eng.encode(x)
+    tlen = None if blind else np.sum(x > 0, axis=-1)
+    got = eng.greedy_decode(None, expected_len=tlen, sos=sos, eos=eos)
+    assert got.shape == want["recon"].shape == (B, ocfg.seq_len + 1)       # nobody emits EOS at random init: full length
+    assert np.array_equal(got, want["recon"])
+    # an explicit embedding gives the same answer, n_valid limits the stop test / the returned rows
+    emb = eng.buffer("embedding").cpu().numpy()
+    got2 = eng.greedy_decode(emb, expected_len=tlen, n_valid=3, sos=sos, eos=eos)
+    assert np.array_equal(got2, want["recon"][:3])
+
+
+def test_greedy_decode_stops_after_all_samples_emitted_eos():
+    B = 4
+    eng, ocfg = _mk(B)
+    sos, eos = ocfg.vocab_size - 2, ocfg.vocab_size - 1
+    _force_eos_bias(eng, ocfg, eos, 3.0)
+    x, _ = synthetic.token_batch(B, ocfg.seq_len, ocfg.vocab_size, ocfg.n_classes, seed=8)
+    P = {k: v.astype(np.float64) for k, v in eng.state_dict_numpy().items()}
+    want = oracle.predict(P, ocfg, x, sos, eos)["recon"]
+    assert 2 < want.shape[1] < ocfg.seq_len + 1, want.shape               # the case really stops early
+    eng.encode(x)
+    got = eng.greedy_decode(None, sos=sos, eos=eos)
+    assert got.shape == want.shape and np.array_equal(got, want)
+    assert (got == eos).any(axis=1).all()                                  # sticky flags: every sample has an EOS somewhere
+
+
+def test_greedy_decode_pad_token_masks_later_steps():
+    """A generated PAD (id 0) becomes a masked key for all later positions (create_masks on the running output)."""
+    B = 3
+    eng, ocfg = _mk(B)
+    sos, eos = ocfg.vocab_size - 2, ocfg.vocab_size - 1
+    b = eng.get("output/bias"); b[0] += 2.5; eng.set("output/bias", b)     # PAD gets emitted often
+    x, _ = synthetic.token_batch(B, ocfg.seq_len, ocfg.vocab_size, ocfg.n_classes, seed=3)
+    P = {k: v.astype(np.float64) for k, v in eng.state_dict_numpy().items()}
+    want = oracle.predict(P, ocfg, x, sos, eos)["recon"]
+    assert (want[:, 1:] == 0).any()
+    eng.encode(x)
+    got = eng.greedy_decode(None, sos=sos, eos=eos)
+    assert np.array_equal(got, want)
+
+
+def test_greedy_decode_continuous_matches_oracle():
+    from sketchformer_amd import engine
+    B = 4
+    kw = dict(seq_len=20, d_model=64, num_heads=2, dff=128, num_layers=2, n_classes=7, lowerdim=32)      # dh = 32
+    eng = engine.TrainEngine(engine.make_config(batch=B, continuous=True, vocab_size=None, dropout_rate=0.0,
+                                                use_graph=False, seed=3, **kw), init_seed=2)
+    ocfg = oracle.Config(continuous=True, dropout_rate=0.0, **kw)
+    rng = np.random.RandomState(4)
+    for e in eng.entries:
+        if e["name"].endswith(("/bias", "/beta", "b_attn")):
+            eng.set(e["name"], rng.normal(0, 0.1, engine.logical_shape(e)))
+    x, _ = synthetic.continuous_batch(B, ocfg.seq_len, ocfg.n_classes, seed=6)
+    P = {k: v.astype(np.float64) for k, v in eng.state_dict_numpy().items()}
+    want = oracle.predict(P, ocfg, x.astype(np.float64), 0, 0)["recon"]
+    eng.encode(x)
+    got = eng.greedy_decode(None)
+    assert got.shape == want.shape and got.dtype == np.float32
+    assert np.array_equal(got[:, 0], np.tile([0, 0, 1, 0, 0], (B, 1)))
+    assert np.abs(got - want).max() < 2e-4 * max(1.0, np.abs(want).max())
+    # forcing the 'end of sketch' pen state makes every sample finish in the same step -> early stop
+    bias = eng.get("output/bias"); bias[4] += 30.0; eng.set("output/bias", bias)
+    P = {k: v.astype(np.float64) for k, v in eng.state_dict_numpy().items()}
+    want = oracle.predict(P, ocfg, x.astype(np.float64), 0, 0)["recon"]
+    assert want.shape[1] == 2
+    eng.encode(x)
+    got = eng.greedy_decode(None)
+    assert got.shape == want.shape and np.abs(got - want).max() < 2e-4 * max(1.0, np.abs(want).max())

@@ -332,3 +332,33 @@ def test_warmup_decay_and_adam(ops):
         st = ops.new_step_state("cuda", iterations=it)
         ops.step_prologue(st)
         assert abs(ops.read_step_state(st)["lr"] - want) <= 2e-6 * max(want, 1e-9)
+
+
+@pytest.mark.parametrize("dh,Lk,cap", [(16, 1, 8), (16, 37, 64), (32, 200, 200), (64, 300, 320)])
+def test_attention_decode_single_query(ops, dh, Lk, cap):
+    """skf_attention_decode == scaled_dot_product_attention for one query row per (sample, head), reading the first Lk
+    rows of a (B, cap, 2d) K|V cache, with a byte key mask and a per-sample key limit."""
+    B, H = 5, 4
+    d = H * dh
+    rng = np.random.RandomState(dh + Lk)
+    q = rng.randn(B, d).astype(np.float32)
+    cache = rng.randn(B, cap, 2 * d).astype(np.float32)
+    mask = (rng.rand(B, cap) < 0.3)
+    mask[0, :] = True                       # fully masked sample: uniform weights over its Lk keys
+    limit = rng.randint(1, Lk + 1, size=B).astype(np.int32)
+    ct = torch.from_numpy(cache).cuda()
+    for use_mask, use_limit in ((False, False), (True, False), (True, True)):
+        o = ops.attention_decode(torch.from_numpy(q).cuda(), ct[:, :, :d], ct[:, :, d:], H, n_keys=Lk,
+                                 key_mask=torch.from_numpy(mask.astype(np.uint8)).cuda() if use_mask else None,
+                                 key_limit=torch.from_numpy(limit).cuda() if use_limit else None)
+        m = np.zeros((B, 1, 1, Lk), np.float32)
+        if use_mask:
+            m = np.maximum(m, mask[:, None, None, :Lk].astype(np.float32))
+        if use_limit:
+            m = np.maximum(m, (np.arange(Lk)[None, :] >= limit[:, None])[:, None, None, :].astype(np.float32))
+        # float32 oracle: for the fully masked sample the reference's fp32 `logits + (-1e9)` rounds to exactly -1e9
+        # (uniform weights); a float64 oracle would keep the score differences
+        sp = lambda t, n: t.reshape(B, n, H, dh).transpose(0, 2, 1, 3).astype(np.float32)  # noqa: E731
+        want, _, _ = oracle.sdpa_fwd(sp(q[:, None, :], 1), sp(cache[:, :Lk, :d], Lk), sp(cache[:, :Lk, d:], Lk), m)
+        want = want.transpose(0, 2, 1, 3).reshape(B, d)
+        _close(o, want, 3e-5, "attention_decode mask=%s limit=%s" % (use_mask, use_limit))
