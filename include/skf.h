@@ -170,7 +170,13 @@ int skf_step_prologue(void* step_state, int schedule, float p0, float p1, float 
 int skf_step_epilogue(void* step_state, skf_stream_t stream);
 int skf_adam_step(float* w, const float* g, float* m, float* v, size_t n, const void* step_state, float grad_scale,
                   float beta1, float beta2, float eps, skf_stream_t stream);
+/* tf.keras.optimizers.SGD(lr_schedule, momentum), nesterov=False: velocity = momentum*velocity - lr*g*grad_scale; w += velocity */
+int skf_sgd_momentum_step(float* w, const float* g, float* velocity, size_t n, const void* step_state, float grad_scale,
+                          float momentum, skf_stream_t stream);
 /* host helper for parity tests: the keep-mask the kernels derive for (drop_key, site) */
+/* y = inverted dropout of x (n floats, y may alias x) with the mask of (step key, site, element index);
+ * applied to an upstream gradient it is the backward.  rate 0 = copy. */
+int skf_dropout(const float* x, float* y, size_t n, float rate, unsigned site, const void* step_state, skf_stream_t stream);
 int skf_dropout_keep_mask(unsigned drop_key, unsigned site, float rate, size_t n, unsigned char* out_host);
 
 /* ---- single-query attention + token selection of the KV-cached greedy decode ----
@@ -203,6 +209,10 @@ typedef struct SkfConfig {
   float beta1, beta2, eps;
   uint32_t seed;
   int32_t use_graph; /* capture the step into hipGraphs and replay them */
+  int32_t optimizer; /* 0 = Keras Adam (beta1, beta2, eps above), 1 = Keras SGD with momentum (models/sketchformer.py:120-126) */
+  float momentum;
+  int32_t class_buffer_layers; /* Dense(lowerdim, relu) + Dropout(class_dropout) layers before classify (models/sketchformer.py:44-45,101-104) */
+  float class_dropout;
 } SkfConfig;
 
 typedef struct SkfParamEntry {

@@ -34,6 +34,7 @@ __all__ = [
     "warmup_decay", "step_decay", "adam_update", "forward", "loss_and_grads",
     "TrainState", "train_step", "dropout_sites", "MetricState",
     "encode_from_seq", "make_dummy_input", "decode", "predict_from_embedding", "predict",
+    "classify_from_embedding_fwd", "classify_from_embedding_bwd", "sgd_momentum_update",
 ]
 
 
@@ -62,6 +63,9 @@ class Config:
     seq_len: int = 200              # dataset.hps['max_seq_len']
     continuous: bool = False        # dataset.hps['use_continuous_data']
     max_pos: int = 1000             # builders/layers/transformer.py:268,307
+    class_buffer_layers: int = 0    # models/sketchformer.py:44,101-104
+    class_dropout: float = 0.1      # models/sketchformer.py:45
+    optimizer: str = "adam"         # models/sketchformer.py:120-126 ('adam' | 'sgd')
 
     def as_dict(self):
         return asdict(self)
@@ -120,7 +124,9 @@ def param_specs(cfg: Config) -> List[Tuple[str, Tuple[int, ...], str]]:
         specs.append(("bottleneck/V_attn", (d, 1), "uniform05"))
         dense("bottleneck/embeding_layer", d, U)
         emb_dim = U
-    dense("classify", emb_dim, cfg.n_classes)
+    for i in range(cfg.class_buffer_layers):               # Dense(lowerdim, relu) buffers, models/sketchformer.py:101
+        dense("class_buffer/%d" % i, emb_dim if i == 0 else U, U)
+    dense("classify", U if cfg.class_buffer_layers else emb_dim, cfg.n_classes)
     dense("expand", 1, L)
     embed("decoder/embedding")
     for i in range(cfg.num_layers):
@@ -578,6 +584,14 @@ def adam_update(w, g, m, v, iterations, lr, beta1=0.9, beta2=0.98, eps=1e-9):
 # --------------------------------------------------------------------------
 # models/sketchformer.py
 # --------------------------------------------------------------------------
+def sgd_momentum_update(w, g, vel, lr, momentum=0.9):
+    """tf.keras.optimizers.SGD(lr_schedule, momentum=0.9) (models/sketchformer.py:124-126), nesterov=False:
+    velocity = momentum * velocity - lr * g ; w += velocity.  In place."""
+    vel *= momentum
+    vel -= lr * g
+    w += vel
+
+
 def dropout_sites(cfg: Config) -> List[Tuple[str, str]]:
     """All dropout call sites in forward order: (name, 'enc'|'dec') where the
     tag gives the tensor shape (B,L,d) or (B,L-1,d).  The index in this list
@@ -588,7 +602,33 @@ def dropout_sites(cfg: Config) -> List[Tuple[str, str]]:
     sites.append(("decoder/dropout", "dec"))
     for i in range(cfg.num_layers):
         sites += [("decoder/layer%d/dropout%d" % (i, j), "dec") for j in (1, 2, 3)]
+    sites += [("class_dropout/%d" % i, "cls") for i in range(cfg.class_buffer_layers)]   # (B, lowerdim), rate class_dropout
     return sites
+
+
+def classify_from_embedding_fwd(P, cfg: Config, emb, drops=None, training=False):
+    """models/sketchformer.py:183-199: optional Dense(lowerdim, relu) + Dropout(class_dropout) buffers, then the
+    classify layer -> LOGITS (the softmax of Dense(activation='softmax') is applied by the caller)."""
+    drops = drops or {}
+    rate = cfg.class_dropout if training else 0.0
+    fc, caches = emb, []
+    for i in range(cfg.class_buffer_layers):
+        fc, cd = dense_fwd(fc, P["class_buffer/%d/kernel" % i], P["class_buffer/%d/bias" % i], "relu")
+        keep = drops.get("class_dropout/%d" % i)
+        fc = dropout_fwd(fc, keep, rate)
+        caches.append((cd, keep, rate))
+    logits, c = dense_fwd(fc, P["classify/kernel"], P["classify/bias"])
+    return logits, (caches, c)
+
+
+def classify_from_embedding_bwd(dlogits, cache, G):
+    caches, c = cache
+    d, G["classify/kernel"], G["classify/bias"] = dense_bwd(dlogits, c)
+    for i in reversed(range(len(caches))):
+        cd, keep, rate = caches[i]
+        d = dropout_bwd(d, keep, rate)
+        d, G["class_buffer/%d/kernel" % i], G["class_buffer/%d/bias" % i] = dense_bwd(d, cd)
+    return d
 
 
 def forward(P, cfg: Config, inp, tar_inp, drops: Optional[dict] = None, training=True):
@@ -612,7 +652,7 @@ def forward(P, cfg: Config, inp, tar_inp, drops: Optional[dict] = None, training
         emb, bott_w, c_bott = self_attn_v1_fwd(P, enc_output)
     else:
         emb, bott_w, c_bott = self_attn_v2_fwd(P, enc_output)
-    cls_logits, c_cls = dense_fwd(emb, P["classify/kernel"], P["classify/bias"])
+    cls_logits, c_cls = classify_from_embedding_fwd(P, cfg, emb, drops, training)
     e = np.exp(cls_logits - cls_logits.max(-1, keepdims=True))
     cls_probs = e / e.sum(-1, keepdims=True)            # Dense(activation='softmax')
 
@@ -655,8 +695,7 @@ def loss_and_grads(P, cfg: Config, inp, tar, labels, drops=None, want_grads=True
         dpre = dpre + dp
     _embed_bwd(dy, c_demb, "decoder/embedding", cfg, P, G)
     demb = dense_expander_bwd(dpre, c_exp, G)
-    dcl, G["classify/kernel"], G["classify/bias"] = dense_bwd(class_loss_bwd(c_cl), c_cls)
-    demb = demb + dcl
+    demb = demb + classify_from_embedding_bwd(class_loss_bwd(c_cl), c_cls, G)
     if cfg.attn_version == 1:
         dx = self_attn_v1_bwd(demb, c_bott, P, G)
     else:
@@ -694,7 +733,10 @@ def train_step(state: TrainState, cfg: Config, inp, tar, labels, drops=None):
     ms.update_mean("total_loss", losses["total_loss"])
     lr = warmup_decay(state.iterations, cfg.d_model, 5000)
     for k in state.params:
-        adam_update(state.params[k], G[k], state.m[k], state.v[k], state.iterations, lr)
+        if cfg.optimizer == "sgd":
+            sgd_momentum_update(state.params[k], G[k], state.m[k], lr)          # m doubles as the velocity slot
+        else:
+            adam_update(state.params[k], G[k], state.m[k], state.v[k], state.iterations, lr)
     state.iterations += 1
     return ms.results(), losses, out, G
 
@@ -714,7 +756,7 @@ def encode_from_seq(P, cfg: Config, inp_seq):
     for i in range(cfg.num_layers):
         x, _ = encoder_layer_fwd(P, "encoder/layer%d" % i, x, mask, cfg.num_heads, 0.0, {})
     emb = self_attn_v1_fwd(P, x)[0] if cfg.attn_version == 1 else self_attn_v2_fwd(P, x)[0]
-    logits, _ = dense_fwd(emb, P["classify/kernel"], P["classify/bias"])
+    logits, _ = classify_from_embedding_fwd(P, cfg, emb)
     e = np.exp(logits - logits.max(-1, keepdims=True))
     return {"enc_output": x, "embedding": emb, "class": e / e.sum(-1, keepdims=True)}
 
@@ -786,7 +828,7 @@ def predict_from_embedding(P, cfg: Config, emb, sos, eos, expected_len=None):
             eos_seen |= (predicted[:, 0] == eos)
             if eos_seen.all():
                 break
-    cls_logits, _ = dense_fwd(emb, P["classify/kernel"], P["classify/bias"])
+    cls_logits, _ = classify_from_embedding_fwd(P, cfg, emb)
     return {"recon": output if cfg.continuous else output.astype(np.int32),
             "class": np.argmax(cls_logits, axis=-1).astype(np.int32)}
 

@@ -29,6 +29,8 @@ class SkfConfig(C.Structure):
         ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
         ("seed", C.c_uint32),
         ("use_graph", C.c_int32),
+        ("optimizer", C.c_int32), ("momentum", C.c_float),
+        ("class_buffer_layers", C.c_int32), ("class_dropout", C.c_float),
     ]
 
 
@@ -81,6 +83,8 @@ SIGNATURES = {
     "skf_step_prologue": (_I, [_P, _I, _F, _F, _F, _F, _F, _F, _U, _P]),
     "skf_step_epilogue": (_I, [_P, _P]),
     "skf_adam_step": (_I, [_P, _P, _P, _P, _Z, _P, _F, _F, _F, _F, _P]),
+    "skf_sgd_momentum_step": (_I, [_P, _P, _P, _Z, _P, _F, _F, _P]),
+    "skf_dropout": (_I, [_P, _P, _Z, _F, _U, _P, _P]),
     "skf_dropout_keep_mask": (_I, [_U, _U, _F, _Z, _P]),
     "skf_attention_decode": (_I, [_P, _I, _P, _P, _I, C.c_longlong, _P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _P]),
     "skf_decode_init": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _I, C.c_longlong, _P]),

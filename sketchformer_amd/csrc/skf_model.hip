@@ -110,6 +110,9 @@ struct Layout {
   std::vector<DecLayerP> dec;
   DenseP bott_w{};      // W_attn + b_attn
   size_t bott_v = 0;    // V_attn
+  DenseP bott_e{};      // SelfAttnV2 only: Dense(lowerdim) after the pooling (builders/layers/transformer.py:92,128)
+  std::vector<DenseP> cbuf;   // class_buffer Dense(lowerdim, relu) layers (models/sketchformer.py:101-104)
+  int E = 0, Ua = 0;    // embedding width (d for V1, lowerdim for V2); units of the attention scorer (lowerdim / d)
   DenseP cls{}, out{};
   size_t exp_w = 0, exp_b = 0;
   std::vector<SkfParamEntry> entries;
@@ -153,7 +156,10 @@ LnP lnp(Layout& L, const std::string& name, int d) {
 
 Layout build_layout(const SkfConfig& c) {
   Layout L;
-  const int d = c.d_model, E = d;   // attn_version 1: embedding width = d_model
+  const int d = c.d_model;
+  const int E = c.attn_version == 2 ? c.lowerdim : d;     // SelfAttnV1 returns (B,d), V2 projects to (B,lowerdim)
+  const int Ua = c.attn_version == 2 ? d : c.lowerdim;    // W_attn is (d,units) in V1, (d,d) in V2
+  L.E = E; L.Ua = Ua;
   static const char* const qkv_names[3] = {"wq", "wk", "wv"};
   static const char* const kv_names[2] = {"wk", "wv"};
   if (c.continuous) {
@@ -173,13 +179,16 @@ Layout build_layout(const SkfConfig& c) {
     e.ln2 = lnp(L, p + "/layernorm2", d);
     L.enc.push_back(e);
   }
-  L.bott_w.in = d; L.bott_w.out = c.lowerdim; L.bott_w.ld = c.lowerdim;
-  L.bott_w.w = alloc(L, (size_t)d * c.lowerdim); L.bott_w.b = alloc(L, c.lowerdim);
-  L.bott_v = alloc(L, c.lowerdim);
-  add_entry(L, "bottleneck/W_attn", L.bott_w.w, d, c.lowerdim, c.lowerdim);
-  add_entry(L, "bottleneck/b_attn", L.bott_w.b, 1, c.lowerdim, c.lowerdim);
-  add_entry(L, "bottleneck/V_attn", L.bott_v, c.lowerdim, 1, 1);
-  L.cls = dense(L, "classify", E, c.n_classes);
+  L.bott_w.in = d; L.bott_w.out = Ua; L.bott_w.ld = Ua;
+  L.bott_w.w = alloc(L, (size_t)d * Ua); L.bott_w.b = alloc(L, Ua);
+  L.bott_v = alloc(L, Ua);
+  add_entry(L, "bottleneck/W_attn", L.bott_w.w, d, Ua, Ua);
+  add_entry(L, "bottleneck/b_attn", L.bott_w.b, 1, Ua, Ua);
+  add_entry(L, "bottleneck/V_attn", L.bott_v, Ua, 1, 1);
+  if (c.attn_version == 2) L.bott_e = dense(L, "bottleneck/embeding_layer", d, c.lowerdim);
+  for (int i = 0; i < c.class_buffer_layers; ++i)
+    L.cbuf.push_back(dense(L, "class_buffer/" + std::to_string(i), i == 0 ? E : c.lowerdim, c.lowerdim));
+  L.cls = dense(L, "classify", c.class_buffer_layers ? c.lowerdim : E, c.n_classes);
   L.exp_w = alloc(L, c.seq_len); L.exp_b = alloc(L, c.seq_len);
   add_entry(L, "expand/kernel", L.exp_w, 1, c.seq_len, c.seq_len);
   add_entry(L, "expand/bias", L.exp_b, 1, c.seq_len, c.seq_len);
@@ -222,7 +231,9 @@ struct Plan {
   size_t inp, tar, labels, enc_mask, dec_mask;
   std::vector<EncAct> enc;
   std::vector<DecAct> dec;
-  size_t u, pool_a, emb, cls_logits, cls_probs, pre, logits;
+  size_t u, pool_a, emb, pooled, dpooled, cls_logits, cls_probs, pre, logits;
+  std::vector<size_t> cb_h, cb_f;       // class buffers: relu output, post-dropout output  (B, lowerdim) each
+  size_t dcb[2];
   size_t recon_loss, recon_hit, cls_loss, cls_hit, row_mask, cont_scal;
   size_t gA, gB, gC, dqkv, dh, do_, dpre, dkv2, dq2, demb;
   size_t gemm_ws, gemm_ws_bytes, small_ws, small_ws_bytes;
@@ -241,6 +252,7 @@ Plan build_plan(const SkfConfig& c) {
   Bump b;
   const size_t B = c.batch, L = c.seq_len, Ld = c.seq_len - 1, d = c.d_model, F = c.dff, U = c.lowerdim;
   const size_t Me = B * L, Md = B * Ld, H = c.num_heads, f = sizeof(float);
+  const size_t E = c.attn_version == 2 ? U : d, Ua = c.attn_version == 2 ? d : U;
   const size_t in_bytes = c.continuous ? B * L * 5 * 4 : B * L * 8;   // (B,L,5) f32 or (B,L) i64
   const size_t Vout = c.continuous ? 5 : (size_t)c.vocab_size;
   P.inp = b.take(in_bytes); P.tar = b.take(in_bytes); P.labels = b.take(B * 8);
@@ -255,14 +267,17 @@ Plan build_plan(const SkfConfig& c) {
   }
   const size_t enc_out = b.take(Me * d * f);
   for (int i = 0; i < c.num_layers; ++i) P.enc[i].x2 = (i + 1 < c.num_layers) ? P.enc[i + 1].x_in : enc_out;
-  P.u = b.take(Me * U * f); P.pool_a = b.take(B * L * f); P.emb = b.take(B * d * f);
+  P.u = b.take(Me * Ua * f); P.pool_a = b.take(B * L * f); P.emb = b.take(B * E * f);
+  P.pooled = b.take(B * d * f); P.dpooled = b.take(B * d * f);
+  for (int i = 0; i < c.class_buffer_layers; ++i) { P.cb_h.push_back(b.take(B * U * f)); P.cb_f.push_back(b.take(B * U * f)); }
+  P.dcb[0] = b.take(B * U * f); P.dcb[1] = b.take(B * U * f);
   P.cls_logits = b.take(B * c.n_classes * f); P.cls_probs = b.take(B * c.n_classes * f);
-  P.pre = b.take(Me * d * f);
+  P.pre = b.take(Me * E * f);
   for (int i = 0; i < c.num_layers; ++i) {
     DecAct a;
     a.x_in = b.take(Md * d * f); a.qkv = b.take(Md * 3 * d * f); a.o1 = b.take(Md * d * f); a.z1 = b.take(Md * d * f);
     a.st1 = b.take(Md * 2 * f); a.astats1 = b.take(B * H * Ld * 2 * f); a.out1 = b.take(Md * d * f);
-    a.q2 = b.take(Md * d * f); a.kv2 = b.take(Me * 2 * d * f); a.o2 = b.take(Md * d * f);
+    a.q2 = b.take(Md * d * f); a.kv2 = b.take(Me * 2 * d * f); a.o2 = b.take(Md * d * f);   // kv2 = pre (Me,E) . Wkv (E,2d)
     a.astats2 = b.take(B * H * Ld * 2 * f); a.z2 = b.take(Md * d * f); a.st2 = b.take(Md * 2 * f);
     a.out2 = b.take(Md * d * f); a.h = b.take(Md * F * f); a.z3 = b.take(Md * d * f); a.st3 = b.take(Md * 2 * f);
     a.out3 = 0;
@@ -275,18 +290,19 @@ Plan build_plan(const SkfConfig& c) {
   P.row_mask = b.take(Md * f); P.cont_scal = b.take(64);
   P.gA = b.take(Me * d * f); P.gB = b.take(Me * d * f); P.gC = b.take(Me * d * f);
   P.dqkv = b.take(Me * 3 * d * f); P.dh = b.take(Me * F * f); P.do_ = b.take(Me * d * f);
-  P.dpre = b.take(Me * d * f); P.dkv2 = b.take(Me * 2 * d * f); P.dq2 = b.take(Md * d * f); P.demb = b.take(B * d * f);
+  P.dpre = b.take(Me * E * f); P.dkv2 = b.take(Me * 2 * d * f); P.dq2 = b.take(Md * d * f); P.demb = b.take(B * E * f);
   size_t g = 0;
   auto mx = [&](size_t v) { if (v > g) g = v; };
   mx(wgrad_ws(d, 3 * d, Me)); mx(wgrad_ws(d, d, Me)); mx(wgrad_ws(d, F, Me)); mx(wgrad_ws(F, d, Me));
-  mx(wgrad_ws(d, 2 * d, Me)); mx(wgrad_ws(d, (int)Vout, Md)); mx(wgrad_ws(d, U, Me)); mx(wgrad_ws(d, c.n_classes, B));
+  mx(wgrad_ws((int)E, 2 * d, Me)); mx(wgrad_ws(d, (int)Vout, Md)); mx(wgrad_ws(d, (int)Ua, Me));
+  mx(wgrad_ws((int)E, c.n_classes, B)); mx(wgrad_ws(U, c.n_classes, B)); mx(wgrad_ws(d, U, B)); mx(wgrad_ws((int)E, U, B)); mx(wgrad_ws(U, U, B));
   P.gemm_ws_bytes = g; P.gemm_ws = b.take(g);
-  P.n_wgrads = 3 + 11 * (size_t)c.num_layers;
+  P.n_wgrads = 4 + 11 * (size_t)c.num_layers + (size_t)c.class_buffer_layers;
   P.slab_arena_bytes = P.n_wgrads * ((g + 255) & ~(size_t)255);
   P.slab_arena = b.take(P.slab_arena_bytes);
   P.descs = b.take(P.n_wgrads * sizeof(SkfReduceDesc));
   size_t s = skf_layernorm_bwd_workspace_bytes((int)Me, (int)d);
-  if (B * U * f > s) s = B * U * f;
+  if (B * Ua * f > s) s = B * Ua * f;
   if (2 * B * L * f > s) s = 2 * B * L * f;
   if (c.continuous && skf_embed_continuous_bwd_workspace_bytes((int)Me, (int)d) > s) s = skf_embed_continuous_bwd_workspace_bytes((int)Me, (int)d);
   P.small_ws_bytes = s; P.small_ws = b.take(s);
@@ -427,7 +443,26 @@ int dense_dgrad(SkfModel* M, const DenseP& w, const float* dy, int lddy, int row
 inline unsigned site_enc_embed() { return 0; }
 inline unsigned site_enc(int layer, int j) { return 1 + 2 * layer + j; }
 inline unsigned site_dec_embed(int N) { return 1 + 2 * N; }
+inline unsigned site_class(int N, int i) { return 2 + 5 * N + i; }   // after the 1 + 2N encoder and 1 + 3N decoder sites
 inline unsigned site_dec(int N, int layer, int j) { return 2 + 2 * N + 3 * layer + j; }
+
+// classify_from_embedding (models/sketchformer.py:183-199): optional Dense(lowerdim, relu) + Dropout(class_dropout)
+// buffers, then the classify layer -> logits in P.cls_logits (its softmax is fused into the CE kernel).
+int classify_fwd(SkfModel* M, bool training, hipStream_t s) {
+  const SkfConfig& c = M->cfg;
+  const Layout& L = M->lay;
+  const Plan& P = M->plan;
+  const float* fc = M->at<float>(P.emb);
+  for (int i = 0; i < c.class_buffer_layers; ++i) {
+    float* h = M->at<float>(P.cb_h[i]);
+    float* fdrop = M->at<float>(P.cb_f[i]);
+    SKF_TRY(dense_fwd(M, L.cbuf[i], fc, c.batch, h, 1, s));
+    const float r = training ? c.class_dropout : 0.f;
+    SKF_TRY(skf_dropout(h, fdrop, (size_t)c.batch * c.lowerdim, r, site_class(c.num_layers, i), M->state, s));
+    fc = fdrop;
+  }
+  return dense_fwd(M, L.cls, fc, c.batch, M->at<float>(P.cls_logits), 0, s);
+}
 
 int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s, bool encoder_only = false) {
   const SkfConfig& c = M->cfg;
@@ -476,15 +511,18 @@ int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s, bool 
   }
   float* enc_out = M->at<float>(P.enc[N - 1].x2);
   // ---------------- bottleneck + classifier + expander (models/sketchformer.py:149-160,183-199,170-176)
+  const int E = L.E, Ua = L.Ua;
   SKF_TRY(dense_fwd(M, L.bott_w, enc_out, Me, M->at<float>(P.u), 2, s));
-  SKF_TRY(skf_pool_fwd(M->at<float>(P.u), M->P(L.bott_v), enc_out, B, Le, c.lowerdim, d, M->at<float>(P.pool_a),
-                       M->at<float>(P.emb), s));
-  SKF_TRY(dense_fwd(M, L.cls, M->at<float>(P.emb), B, M->at<float>(P.cls_logits), 0, s));
+  SKF_TRY(skf_pool_fwd(M->at<float>(P.u), M->P(L.bott_v), enc_out, B, Le, Ua, d, M->at<float>(P.pool_a),
+                       M->at<float>(c.attn_version == 2 ? P.pooled : P.emb), s));
+  if (c.attn_version == 2)   // SelfAttnV2: o = embeding_layer(o) (builders/layers/transformer.py:128-129)
+    SKF_TRY(dense_fwd(M, L.bott_e, M->at<float>(P.pooled), B, M->at<float>(P.emb), 0, s));
+  SKF_TRY(classify_fwd(M, training, s));
   if (encoder_only) {   // encode_from_seq / predict_class (models/sketchformer.py:162-168,223-228): class probabilities only
     return skf_softmax_ce(M->at<float>(P.cls_logits), c.n_classes, B, c.n_classes, M->at<long long>(P.labels), 1, 1, 0, 0, 0.f,
                           M->at<float>(P.cls_loss), M->at<float>(P.cls_hit), M->at<float>(P.cls_probs), 0, s);
   }
-  SKF_TRY(skf_expander_fwd(M->at<float>(P.emb), M->P(L.exp_w), M->P(L.exp_b), B, Le, d, M->at<float>(P.pre), s));
+  SKF_TRY(skf_expander_fwd(M->at<float>(P.emb), M->P(L.exp_w), M->P(L.exp_b), B, Le, E, M->at<float>(P.pre), s));
 
   // ---------------- decoder (builders/layers/transformer.py:325-344)
   if (c.continuous)
@@ -616,8 +654,8 @@ int run_backward(SkfModel* M, hipStream_t s) {
                               dkv2 + d, 2 * d, s));
     SKF_TRY(dense_wgrad(M, w.mha2.q, M->at<float>(a.out1), d, dq2, d, Md, s));
     SKF_TRY(dense_dgrad(M, w.mha2.q, dq2, d, Md, G, d, 1, nullptr, 0, s));
-    SKF_TRY(dense_wgrad(M, w.mha2.kv, M->at<float>(P.pre), d, dkv2, 2 * d, Me, s));
-    SKF_TRY(dense_dgrad(M, w.mha2.kv, dkv2, 2 * d, Me, dpre, d, i != N - 1, nullptr, 0, s));
+    SKF_TRY(dense_wgrad(M, w.mha2.kv, M->at<float>(P.pre), L.E, dkv2, 2 * d, Me, s));
+    SKF_TRY(dense_dgrad(M, w.mha2.kv, dkv2, 2 * d, Me, dpre, L.E, i != N - 1, nullptr, 0, s));
     // out1 = LN1(x + drop(mha1(x,x,x)))
     SKF_TRY(ln_bwd(M, w.ln1, G, M->at<float>(a.z1), M->at<float>(a.st1), G2, dybuf(G2), Md, rate, site_dec(N, i, 0), s));
     SKF_TRY(dense_wgrad(M, w.mha1.o, M->at<float>(a.o1), d, dybuf(G2), d, Md, s));
@@ -640,18 +678,48 @@ int run_backward(SkfModel* M, hipStream_t s) {
     SKF_TRY(skf_embed_bwd(tar, Le, B, Ld, G, c.vocab_size, d, M->G(L.dec_emb), rate, site_dec_embed(N), M->state, s));
   }
   // expander, classifier
-  SKF_TRY(skf_expander_bwd(dpre, M->at<float>(P.emb), M->P(L.exp_w), B, Le, d, demb, 0, M->G(L.exp_w), M->G(L.exp_b),
+  const int E = L.E, Ua = L.Ua, U = c.lowerdim, NB = c.class_buffer_layers;
+  SKF_TRY(skf_expander_bwd(dpre, M->at<float>(P.emb), M->P(L.exp_w), B, Le, E, demb, 0, M->G(L.exp_w), M->G(L.exp_b),
                            M->at<char>(P.small_ws), P.small_ws_bytes, s));
+  // classifier (+ class buffers): d fc_i = dropout'(.) then relu'(.) - both are element-wise masks and commute
   const float* dcls = M->at<float>(P.cls_logits);
-  SKF_TRY(dense_wgrad(M, L.cls, M->at<float>(P.emb), d, dcls, c.n_classes, B, s));
-  SKF_TRY(dense_dgrad(M, L.cls, dcls, c.n_classes, B, demb, d, 1, nullptr, 0, s));
+  if (NB == 0) {
+    SKF_TRY(dense_wgrad(M, L.cls, M->at<float>(P.emb), E, dcls, c.n_classes, B, s));
+    SKF_TRY(dense_dgrad(M, L.cls, dcls, c.n_classes, B, demb, E, 1, nullptr, 0, s));
+  } else {
+    float* dz = M->at<float>(P.dcb[0]);
+    float* dz2 = M->at<float>(P.dcb[1]);
+    SKF_TRY(before_write(M, dz, s));
+    SKF_TRY(dense_wgrad(M, L.cls, M->at<float>(P.cb_f[NB - 1]), U, dcls, c.n_classes, B, s));
+    SKF_TRY(dense_dgrad(M, L.cls, dcls, c.n_classes, B, dz, U, 0, M->at<float>(P.cb_h[NB - 1]), U, s));
+    for (int i = NB - 1; i >= 0; --i) {
+      SKF_TRY(skf_dropout(dz, dz, (size_t)B * U, c.class_dropout, site_class(N, i), M->state, s));
+      const float* in = i == 0 ? M->at<float>(P.emb) : M->at<float>(P.cb_f[i - 1]);
+      const int in_w = i == 0 ? E : U;
+      SKF_TRY(dense_wgrad(M, L.cbuf[i], in, in_w, dz, U, B, s));
+      if (i == 0) {
+        SKF_TRY(dense_dgrad(M, L.cbuf[0], dz, U, B, demb, E, 1, nullptr, 0, s));
+      } else {
+        SKF_TRY(before_write(M, dz2, s));
+        SKF_TRY(dense_dgrad(M, L.cbuf[i], dz, U, B, dz2, U, 0, M->at<float>(P.cb_h[i - 1]), U, s));
+        float* t = dz; dz = dz2; dz2 = t;
+      }
+    }
+  }
   // bottleneck
   float* enc_out = M->at<float>(P.enc[N - 1].x2);
+  const float* dpool = demb;
+  if (c.attn_version == 2) {
+    SKF_TRY(before_write(M, M->at<float>(P.dpooled), s));
+    SKF_TRY(dense_wgrad(M, L.bott_e, M->at<float>(P.pooled), d, demb, U, B, s));
+    SKF_TRY(dense_dgrad(M, L.bott_e, demb, U, B, M->at<float>(P.dpooled), d, 0, nullptr, 0, s));
+    dpool = M->at<float>(P.dpooled);
+  }
   SKF_TRY(before_write(M, G, s));
-  SKF_TRY(skf_pool_bwd(M->at<float>(P.u), M->P(L.bott_v), enc_out, M->at<float>(P.pool_a), demb, B, Le, c.lowerdim, d,
+  SKF_TRY(skf_pool_bwd(M->at<float>(P.u), M->P(L.bott_v), enc_out, M->at<float>(P.pool_a), dpool, B, Le, Ua, d,
                        G, M->G(L.bott_v), M->at<char>(P.small_ws), P.small_ws_bytes, s));
-  SKF_TRY(dense_wgrad(M, L.bott_w, enc_out, d, M->at<float>(P.u), c.lowerdim, Me, s));
-  SKF_TRY(dense_dgrad(M, L.bott_w, M->at<float>(P.u), c.lowerdim, Me, G, d, 1, nullptr, 0, s));
+  SKF_TRY(dense_wgrad(M, L.bott_w, enc_out, d, M->at<float>(P.u), Ua, Me, s));
+  SKF_TRY(dense_dgrad(M, L.bott_w, M->at<float>(P.u), Ua, Me, G, d, 1, nullptr, 0, s));
   for (int i = N - 1; i >= 0; --i) {
     const EncLayerP& w = L.enc[i];
     const EncAct& a = P.enc[i];
@@ -695,7 +763,7 @@ int run_greedy_decode(SkfModel* M, const float* embedding, const int* expected_l
   const int Vout = c.continuous ? 5 : c.vocab_size;
   (void)F;
   if (embedding && embedding != M->at<float>(P.emb))
-    SKF_HIP(hipMemcpyAsync(M->at<float>(P.emb), embedding, (size_t)B * d * sizeof(float), hipMemcpyDeviceToDevice, s));
+    SKF_HIP(hipMemcpyAsync(M->at<float>(P.emb), embedding, (size_t)B * L.E * sizeof(float), hipMemcpyDeviceToDevice, s));
   int* eos_seen = M->at<int>(P.dc_flags);
   int* done_step = eos_seen + B;
   unsigned char* selfmask = M->at<unsigned char>(P.dc_mask);
@@ -708,10 +776,10 @@ int run_greedy_decode(SkfModel* M, const float* embedding, const int* expected_l
     SKF_HIP(hipMemcpyAsync(limit, expected_len_host, (size_t)B * sizeof(int), hipMemcpyHostToDevice, s));
   }
   // pre_decoder and the cross-attention K/V of every layer: once
-  SKF_TRY(skf_expander_fwd(M->at<float>(P.emb), M->P(L.exp_w), M->P(L.exp_b), B, Le, d, M->at<float>(P.pre), s));
+  SKF_TRY(skf_expander_fwd(M->at<float>(P.emb), M->P(L.exp_w), M->P(L.exp_b), B, Le, L.E, M->at<float>(P.pre), s));
   for (int l = 0; l < N; ++l)
     SKF_TRY(dense_fwd(M, L.dec[l].mha2.kv, M->at<float>(P.pre), B * Le, M->at<float>(P.dec[l].kv2), 0, s));
-  SKF_TRY(dense_fwd(M, L.cls, M->at<float>(P.emb), B, M->at<float>(P.cls_logits), 0, s));   // classify_from_embedding
+  SKF_TRY(classify_fwd(M, false, s));                                                         // classify_from_embedding
   SKF_TRY(skf_softmax_ce(M->at<float>(P.cls_logits), c.n_classes, B, c.n_classes, M->at<long long>(P.labels), 1, 1, 0, 0, 0.f,
                          M->at<float>(P.cls_loss), M->at<float>(P.cls_hit), M->at<float>(P.cls_probs), 0, s));
 
@@ -821,8 +889,13 @@ extern "C" int skf_config_validate(const SkfConfig* c) {
   if (!(dh == 16 || dh == 32 || dh == 64)) { skf_set_error("head dim %d not in {16,32,64}", dh); return SKF_EUNSUPPORTED; }
   if (!(c->d_model == 64 || c->d_model == 128 || c->d_model == 256 || c->d_model == 512)) {
     skf_set_error("d_model %d not in {64,128,256,512}", c->d_model); return SKF_EUNSUPPORTED; }
-  if (c->attn_version != 1) { skf_set_error("attn_version=%d: only SelfAttnV1 is implemented", c->attn_version); return SKF_EUNSUPPORTED; }
-  if (c->lowerdim <= 0) { skf_set_error("lowerdim=0 is not implemented"); return SKF_EUNSUPPORTED; }
+  SKF_CHECK_ARG(c->attn_version == 1 || c->attn_version == 2, "attn_version must be 1 (SelfAttnV1) or 2 (SelfAttnV2)");
+  if (c->lowerdim <= 0) { skf_set_error("lowerdim=0 (no bottleneck) is not implemented"); return SKF_EUNSUPPORTED; }
+  if (c->attn_version == 2 && !(c->lowerdim == 64 || c->lowerdim == 128 || c->lowerdim == 256 || c->lowerdim == 512)) {
+    skf_set_error("attn_version=2: lowerdim %d (the embedding width) not in {64,128,256,512}", c->lowerdim); return SKF_EUNSUPPORTED; }
+  SKF_CHECK_ARG(c->class_buffer_layers >= 0 && c->class_buffer_layers <= 8, "class_buffer_layers must be in [0, 8]");
+  SKF_CHECK_ARG(c->class_dropout >= 0.f && c->class_dropout < 1.f, "class_dropout out of range");
+  SKF_CHECK_ARG(c->optimizer == 0 || c->optimizer == 1, "optimizer must be 0 (Adam) or 1 (SGD with momentum)");
   SKF_CHECK_ARG(c->n_classes > 0, "bad number of classes");
   if (!c->continuous) {
     SKF_CHECK_ARG(c->vocab_size > 0, "bad vocab size");
@@ -868,10 +941,10 @@ extern "C" int skf_model_create(const SkfConfig* cfg, SkfModel** out) {
   reg("logits", P.logits, B * Ld, cfg->continuous ? 5 : cfg->vocab_size);
   reg("class_probs", P.cls_probs, B, cfg->n_classes);
   reg("class_logits", P.cls_logits, B, cfg->n_classes);
-  reg("embedding", P.emb, B, d);
+  reg("embedding", P.emb, B, M->lay.E);
   reg("enc_output", P.enc[N - 1].x2, B * L, d);
   reg("dec_output", P.dec[N - 1].out3, B * Ld, d);
-  reg("pre_decoder", P.pre, B * L, d);
+  reg("pre_decoder", P.pre, B * L, M->lay.E);
   reg("bottleneck_attn", P.pool_a, B, L);
   reg("enc_embed_out", P.enc[0].x_in, B * L, d);
   reg("dec_embed_out", P.dec[0].x_in, B * Ld, d);
@@ -952,8 +1025,11 @@ extern "C" int skf_model_apply_gradients(SkfModel* m, float grad_scale, skf_stre
   if (m->g_opt && m->g_opt_scale != grad_scale) { (void)hipGraphExecDestroy(m->g_opt); m->g_opt = nullptr; }
   m->g_opt_scale = grad_scale;
   return capture_or_run(m, &m->g_opt, s, [&]() -> int {
-    SKF_TRY(skf_adam_step(m->params, m->grads, m->m, m->v, m->lay.total, m->state, grad_scale, m->cfg.beta1,
-                          m->cfg.beta2, m->cfg.eps, s));
+    if (m->cfg.optimizer == 1)   // tf.keras.optimizers.SGD(lr_schedule, momentum) - the Adam m buffer is the velocity slot
+      SKF_TRY(skf_sgd_momentum_step(m->params, m->grads, m->m, m->lay.total, m->state, grad_scale, m->cfg.momentum, s));
+    else
+      SKF_TRY(skf_adam_step(m->params, m->grads, m->m, m->v, m->lay.total, m->state, grad_scale, m->cfg.beta1,
+                            m->cfg.beta2, m->cfg.eps, s));
     return skf_step_epilogue(m->state, s);
   });
 }

@@ -77,7 +77,35 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const 
   }
 }
 
+// tf.keras.optimizers.SGD(lr_schedule, momentum=0.9), nesterov=False (models/sketchformer.py:124-126):
+//   velocity = momentum * velocity - lr * g ;  w += velocity       (lr from the schedule, pre-increment step)
+__global__ __launch_bounds__(256) void sgd_momentum_kernel(float* __restrict__ w, const float* __restrict__ g,
+                                                           float* __restrict__ vel, size_t n,
+                                                           const SkfStepState* __restrict__ st, float grad_scale,
+                                                           float momentum) {
+  const float lr = st->lr;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const float v = momentum * vel[i] - lr * (g[i] * grad_scale);
+    vel[i] = v;
+    w[i] += v;
+  }
+}
+
 }  // namespace
+
+extern "C" int skf_sgd_momentum_step(float* w, const float* g, float* velocity, size_t n, const void* step_state,
+                                     float grad_scale, float momentum, skf_stream_t stream) {
+  SKF_CHECK_ARG(w && g && velocity && step_state, "null operand");
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  SkfProfScope ps((hipStream_t)stream, "sgd_momentum", 0.0, 20.0 * n);
+  hipLaunchKernelGGL(sgd_momentum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, g, velocity, n,
+                     (const SkfStepState*)step_state, grad_scale, momentum);
+  SKF_LAUNCH_CHECK();
+  return SKF_OK;
+}
 
 extern "C" size_t skf_step_state_bytes(void) { return sizeof(SkfStepState); }
 

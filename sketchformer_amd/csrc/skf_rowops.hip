@@ -568,6 +568,17 @@ __global__ __launch_bounds__(1024) void expander_bwd_kernel(const float* __restr
   }
 }
 
+// Inverted dropout of a flat tensor with the counter-hash mask of (step key, site, element index); the same call
+// with the upstream gradient is its backward.  y may alias x.
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n,
+                                                      float rate, uint32_t site, const SkfStepState* st) {
+  const uint32_t thresh = skf_drop_thresh(rate);
+  const float inv_keep = 1.0f / (1.0f - rate);
+  const uint32_t sk = rate > 0.f ? skf_site_key(st->drop_key, site) : 0u;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    y[i] = rate > 0.f ? x[i] * (skf_keep(sk, (uint32_t)i, thresh) ? inv_keep : 0.f) : x[i];
+}
+
 int grid_for_rows(int rows) { int g = skf_cdiv(rows, 4); return g > kMaxGrid ? kMaxGrid : g; }
 
 }  // namespace
@@ -759,6 +770,19 @@ extern "C" int skf_expander_bwd(const float* dpre, const float* emb, const float
   }
   hipLaunchKernelGGL(colsum_kernel, dim3(skf_cdiv(L, 64)), dim3(1024), 0, s, p1, B, L, L, dw, 0);
   hipLaunchKernelGGL(colsum_kernel, dim3(skf_cdiv(L, 64)), dim3(1024), 0, s, p2, B, L, L, dbias, 0);
+  SKF_LAUNCH_CHECK();
+  return SKF_OK;
+}
+
+extern "C" int skf_dropout(const float* x, float* y, size_t n, float rate, unsigned site, const void* step_state,
+                           skf_stream_t stream) {
+  SKF_CHECK_ARG(x && y, "null operand");
+  SKF_CHECK_ARG(rate >= 0.f && rate < 1.f, "rate out of range");
+  SKF_CHECK_ARG(rate == 0.f || step_state, "dropout needs the step state");
+  if (n == 0 || (rate == 0.f && x == y)) return SKF_OK;
+  size_t blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, n, rate, site,
+                     (const SkfStepState*)step_state);
   SKF_LAUNCH_CHECK();
   return SKF_OK;
 }

@@ -35,7 +35,7 @@ def positional_encoding(position, d_model):
 def make_config(batch, seq_len=200, d_model=128, num_heads=8, dff=512, num_layers=4, vocab_size=1004, n_classes=345,
                 lowerdim=256, attn_version=1, continuous=False, blind_decoder_mask=True, dropout_rate=0.1,
                 recon_weight=1.0, class_weight=1.0, lr_scheduler="WarmupDecay", lr=0.01, seed=0, use_graph=True,
-                max_pos=1000):
+                max_pos=1000, optimizer="Adam", class_buffer_layers=0, class_dropout=0.1):
     cfg = SkfConfig()
     cfg.batch, cfg.seq_len, cfg.d_model, cfg.num_heads, cfg.dff, cfg.num_layers = batch, seq_len, d_model, num_heads, dff, num_layers
     cfg.vocab_size, cfg.n_classes, cfg.lowerdim, cfg.attn_version = vocab_size or 0, n_classes, lowerdim, attn_version
@@ -52,6 +52,14 @@ def make_config(batch, seq_len=200, d_model=128, num_heads=8, dff=512, num_layer
         raise ValueError("unknown lr_scheduler %r" % lr_scheduler)
     cfg.beta1, cfg.beta2, cfg.eps = 0.9, 0.98, 1e-9   # models/sketchformer.py:122-124
     cfg.seed, cfg.use_graph = seed, int(use_graph)
+    # models/sketchformer.py:120-126: Adam(schedule, 0.9, 0.98, 1e-9) or SGD(schedule, momentum=0.9)
+    if optimizer.lower() == "adam":
+        cfg.optimizer, cfg.momentum = 0, 0.0
+    elif optimizer.lower() == "sgd":
+        cfg.optimizer, cfg.momentum = 1, 0.9
+    else:
+        raise ValueError("unknown optimizer %r" % optimizer)
+    cfg.class_buffer_layers, cfg.class_dropout = int(class_buffer_layers), float(class_dropout)
     return cfg
 
 
@@ -233,8 +241,9 @@ class TrainEngine:
         if embedding is not None:
             e = torch.as_tensor(np.asarray(embedding, dtype=np.float32) if not torch.is_tensor(embedding) else embedding)
             e = e.to(self.device, dtype=torch.float32).contiguous()
-            if e.shape != (B, self.cfg.d_model):
-                raise ValueError("embedding must be (batch=%d, d_model=%d)" % (B, self.cfg.d_model))
+            E = self.cfg.lowerdim if self.cfg.attn_version == 2 else self.cfg.d_model    # SelfAttnV2 projects to lowerdim
+            if e.shape != (B, E):
+                raise ValueError("embedding must be (batch=%d, %d)" % (B, E))
             emb_ptr = self._p(e)
         lim = None
         if expected_len is not None:

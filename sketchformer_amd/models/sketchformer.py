@@ -37,12 +37,14 @@ class Transformer(BaseModel):
         from .. import engine
         h = self.hps
         for key, ok, why in (('do_classification', True, 'the classification head is always built'),
-                             ('do_reconstruction', True, 'the decoder is always built'),
-                             ('class_buffer_layers', 0, 'buffer FC layers before the classifier')):
+                             ('do_reconstruction', True, 'the decoder is always built')):
             if h[key] != ok:
                 raise NotImplementedError("%s=%r is not implemented on the HIP path (%s)" % (key, h[key], why))
-        if h['optimizer'].lower() != 'adam':
-            raise NotImplementedError("optimizer=%r: only Adam is implemented" % h['optimizer'])
+        if not h['lowerdim']:
+            raise NotImplementedError("lowerdim=0 (no bottleneck: the decoder attends to the encoder output) is not "
+                                      "implemented on the HIP path")
+        if h['optimizer'].lower() not in ('adam', 'sgd'):
+            raise ValueError("optimizer=%r: the reference builds Adam or SGD (models/sketchformer.py:120-126)" % h['optimizer'])
         if self.dataset.hps['use_continuous_data']:
             self.losses_manager.add_continuous_reconstruction_loss('recon', weight=h['recon_weight'])
             self.metrics_manager.add_mean_metric('recon_loss')
@@ -62,7 +64,8 @@ class Transformer(BaseModel):
             num_layers=h['num_layers'], vocab_size=self.vocab_size or 0, n_classes=self.dataset.n_classes,
             lowerdim=h['lowerdim'], attn_version=h['attn_version'], continuous=self.dataset.hps['use_continuous_data'],
             blind_decoder_mask=h['blind_decoder_mask'], dropout_rate=h['dropout_rate'], recon_weight=h['recon_weight'],
-            class_weight=h['class_weight'], lr_scheduler=h['lr_scheduler'], lr=h['lr'], use_graph=False)
+            class_weight=h['class_weight'], lr_scheduler=h['lr_scheduler'], lr=h['lr'], use_graph=False,
+            optimizer=h['optimizer'], class_buffer_layers=h['class_buffer_layers'], class_dropout=h['class_dropout'])
         self.engine = engine.TrainEngine(cfg, device=self._device, init_seed=self._init_seed, process_group=self._pg)
         self.trainable_variables = [e["name"] for e in self.engine.entries]
 

@@ -64,11 +64,33 @@ def test_layout_names_match_oracle(lib):
     assert got == want
 
 
+@pytest.mark.parametrize("attn_version,cbuf", [(2, 0), (1, 2), (2, 1)])
+def test_variant_layout_names_match_oracle(lib, attn_version, cbuf):
+    """SelfAttnV2 (builders/layers/transformer.py:76-131: W (d,d), Dense(lowerdim) -> embedding width = lowerdim, which is
+    also the cross-attention K/V input width) and class_buffer_layers (models/sketchformer.py:101-104)."""
+    import oracle
+    from sketchformer_amd import engine
+    ocfg = oracle.Config(num_layers=2, d_model=64, dff=128, num_heads=4, lowerdim=128, vocab_size=52, n_classes=7, seq_len=24,
+                         attn_version=attn_version, class_buffer_layers=cbuf)
+    cfg = engine.make_config(batch=4, seq_len=24, d_model=64, num_heads=4, dff=128, num_layers=2, vocab_size=52,
+                             n_classes=7, lowerdim=128, attn_version=attn_version, class_buffer_layers=cbuf)
+    want = {n: s for n, s, _ in oracle.param_specs(ocfg)}
+    got = {e["name"]: engine.logical_shape(e) for e in engine.param_entries(cfg)}
+    assert got == want
+    assert [e["name"] for e in engine.param_entries(cfg) if "/mha" not in e["name"]] == \
+           [n for n, _, _ in oracle.param_specs(ocfg) if "/mha" not in n]          # same forward order
+
+
 def test_unsupported_configs_fail_loudly(lib):
     from sketchformer_amd import engine
-    cfg = engine.make_config(batch=4, attn_version=2)
+    cfg = engine.make_config(batch=4, lowerdim=0)
     assert lib.skf_config_validate(C.byref(cfg)) == -2
-    assert b"attn_version" in lib.skf_last_error()
+    assert b"lowerdim" in lib.skf_last_error()
+    assert lib.skf_config_validate(C.byref(engine.make_config(batch=4, attn_version=3))) == -1
+    assert lib.skf_config_validate(C.byref(engine.make_config(batch=4, attn_version=2, lowerdim=100))) == -2
+    assert lib.skf_config_validate(C.byref(engine.make_config(batch=4, attn_version=2, class_buffer_layers=2, optimizer="sgd"))) == 0
+    with pytest.raises(ValueError):
+        engine.make_config(batch=4, optimizer="rmsprop")
     assert lib.skf_config_validate(C.byref(engine.make_config(batch=4, continuous=True, vocab_size=None))) == 0
     with pytest.raises(TypeError):
         engine.make_config(batch=4, lr_scheduler="step-decay")

@@ -20,7 +20,9 @@ def _mk(batch, rate=0.0, use_graph=False, blind=True, **kw):
     ocfg = oracle.Config(num_layers=small["num_layers"], d_model=small["d_model"], dff=small["dff"],
                          num_heads=small["num_heads"], dropout_rate=rate, lowerdim=small["lowerdim"],
                          vocab_size=small["vocab_size"], n_classes=small["n_classes"], seq_len=small["seq_len"],
-                         blind_decoder_mask=blind)
+                         blind_decoder_mask=blind, attn_version=small.get("attn_version", 1),
+                         class_buffer_layers=small.get("class_buffer_layers", 0),
+                         class_dropout=small.get("class_dropout", 0.1), optimizer=small.get("optimizer", "adam").lower())
     eng = engine.TrainEngine(cfg, init_seed=1)
     # make biases / LN parameters non-trivial
     rng = np.random.RandomState(9)
@@ -42,6 +44,9 @@ def _drops_from_engine(eng, ocfg, B):
     key = ops.read_step_state(eng.state)["drop_key"]
     drops = {}
     for site, (name, tag) in enumerate(oracle.dropout_sites(ocfg)):
+        if tag == "cls":                       # class-buffer dropout: (B, lowerdim) at rate class_dropout
+            drops[name] = ops.dropout_keep_mask(key, site, ocfg.class_dropout, B * ocfg.lowerdim).reshape(B, ocfg.lowerdim)
+            continue
         L = ocfg.seq_len if tag == "enc" else ocfg.seq_len - 1
         drops[name] = ops.dropout_keep_mask(key, site, ocfg.dropout_rate, B * L * ocfg.d_model).reshape(B, L, ocfg.d_model)
     return drops
@@ -339,3 +344,76 @@ def test_greedy_decode_continuous_matches_oracle():
     eng.encode(x)
     got = eng.greedy_decode(None)
     assert got.shape == want.shape and np.abs(got - want).max() < 2e-4 * max(1.0, np.abs(want).max())
+
+
+# ------------------------------------------------------------------ non-default variants of the step
+@pytest.mark.parametrize("kw", [dict(attn_version=2, lowerdim=128), dict(class_buffer_layers=2, class_dropout=0.2),
+                                dict(attn_version=2, lowerdim=64, class_buffer_layers=1)], ids=["selfattn_v2", "class_buffers", "both"])
+@pytest.mark.parametrize("rate", [0.0, 0.1])
+def test_variants_losses_and_all_gradients(kw, rate):
+    """SelfAttnV2 bottleneck (embedding width = lowerdim, also the K/V input width of the cross attention) and the
+    class_buffer Dense+Dropout layers: logits, losses and every gradient against the oracle, identical dropout masks."""
+    B = 5
+    kw = dict(kw)
+    if rate == 0.0:
+        kw["class_dropout"] = 0.0                      # no-dropout case: switch the class-buffer dropout off as well
+    eng, ocfg = _mk(B, rate=rate, **kw)
+    x, y = synthetic.token_batch(B, ocfg.seq_len, ocfg.vocab_size, ocfg.n_classes, seed=13)
+    x[2, 5:] = 0
+    P = {k: v.astype(np.float64) for k, v in eng.state_dict_numpy().items()}
+    assert set(P) == {n for n, _, _ in oracle.param_specs(ocfg)}
+    eng.forward_backward(x, None, y)
+    torch.cuda.synchronize()
+    drops = _drops_from_engine(eng, ocfg, B) if rate > 0 else None
+    losses, out, G = oracle.loss_and_grads(P, ocfg, x, x, y, drops)
+    m = eng.step_metrics()
+    for k in ("recon_loss", "class_loss", "total_loss"):
+        assert abs(m[k] - losses[k]) < 1e-5 * max(1.0, abs(losses[k])), (k, m[k], losses[k])
+    got = eng.state_dict_numpy("grads")
+    floor = 1e-3 * np.median([np.abs(G[k]).max() for k in G])
+    rel = {k: np.abs(got[k].astype(np.float64) - G[k]).max() / max(np.abs(G[k]).max(), floor) for k in G}
+    worst = max((v, k) for k, v in rel.items())
+    assert worst[0] < 1e-3, worst
+    assert np.median(list(rel.values())) < 5e-5
+    # inference path: logits, embedding width, greedy reconstruction through the wider embedding
+    eng.forward(x, training=False)
+    torch.cuda.synchronize()
+    ref, _ = oracle.forward(P, ocfg, x, x[:, :-1], training=False)
+    assert _rel(eng.buffer("logits").cpu().numpy().reshape(B, ocfg.seq_len - 1, -1), ref["recon"]) < 1e-4
+    assert eng.buffer("embedding").shape == (B, ocfg.lowerdim if ocfg.attn_version == 2 else ocfg.d_model)
+    assert _rel(eng.buffer("class_probs").cpu().numpy(), ref["class"]) < 1e-4
+    sos, eos = ocfg.vocab_size - 2, ocfg.vocab_size - 1
+    want = oracle.predict(P, ocfg, x, sos, eos)
+    eng.encode(x)
+    assert np.array_equal(eng.greedy_decode(None, sos=sos, eos=eos), want["recon"])
+    assert np.array_equal(eng.buffer("class_probs").cpu().numpy().argmax(-1), want["class"])
+
+
+def test_sgd_momentum_trajectory_matches_oracle():
+    """optimizer='sgd' (models/sketchformer.py:124-126): Keras SGD(schedule, momentum=0.9); the schedule is evaluated on
+    the pre-increment step, so the very first update is a no-op here too."""
+    B = 4
+    eng, ocfg = _mk(B, rate=0.0, optimizer="sgd")
+    P = {k: v.astype(np.float64) for k, v in eng.state_dict_numpy().items()}
+    x, y = synthetic.token_batch(B, ocfg.seq_len, ocfg.vocab_size, ocfg.n_classes, seed=30)
+    before = eng.params.clone()
+    eng.train_step(x, y)
+    torch.cuda.synchronize()
+    assert torch.equal(before, eng.params) and eng.iterations == 1     # lr(0) = 0: velocity = 0 - 0*g
+    st = oracle.TrainState.create(P)
+    st.iterations = 4000
+    eng.state[0] = 4000
+    eng.adam_m.zero_()
+    for step in range(5):
+        x, y = synthetic.token_batch(B, ocfg.seq_len, ocfg.vocab_size, ocfg.n_classes, seed=40 + step)
+        _, losses, _, _ = oracle.train_step(st, ocfg, x, x, y)
+        eng.train_step(x, y)
+        torch.cuda.synchronize()
+        m = eng.step_metrics()
+        assert abs(m["total_loss"] - losses["total_loss"]) < 1e-3 * abs(losses["total_loss"]), (step, m, losses)
+    got = eng.state_dict_numpy()
+    worst = max((np.abs(got[k] - st.params[k]).max() / max(np.abs(st.params[k]).max(), 1e-3), k) for k in got)
+    assert worst[0] < 2e-4, worst
+    vel = eng.state_dict_numpy("adam_m")
+    worst = max((np.abs(vel[k] - st.m[k]).max() / max(np.abs(st.m[k]).max(), 1e-12), k) for k in vel if np.abs(st.m[k]).max() > 1e-9)
+    assert worst[0] < 2e-3, worst

@@ -7,24 +7,29 @@ from sketchformer_amd import synthetic
 import witness_torch
 
 
-def _tiny(continuous=False, attn_version=1, blind=True):
+def _tiny(continuous=False, attn_version=1, blind=True, class_buffer_layers=0):
     return oracle.Config(num_layers=2, d_model=16, dff=32, num_heads=4, dropout_rate=0.1, lowerdim=8,
                          attn_version=attn_version, vocab_size=24, n_classes=5, seq_len=12,
-                         continuous=continuous, blind_decoder_mask=blind, max_pos=32)
+                         continuous=continuous, blind_decoder_mask=blind, max_pos=32,
+                         class_buffer_layers=class_buffer_layers, class_dropout=0.2)
 
 
 def _drops(cfg, B, seed=1):
     rng = np.random.RandomState(seed)
     out = {}
     for name, tag in oracle.dropout_sites(cfg):
+        if tag == "cls":
+            out[name] = rng.rand(B, cfg.lowerdim) >= cfg.class_dropout
+            continue
         L = cfg.seq_len if tag == "enc" else cfg.seq_len - 1
         out[name] = rng.rand(B, L, cfg.d_model) >= cfg.dropout_rate
     return out
 
 
-@pytest.mark.parametrize("continuous,attn_version,blind", [(False, 1, True), (False, 2, False), (True, 1, True)])
-def test_oracle_matches_autograd(continuous, attn_version, blind):
-    cfg = _tiny(continuous, attn_version, blind)
+@pytest.mark.parametrize("continuous,attn_version,blind,cbuf", [(False, 1, True, 0), (False, 2, False, 0), (True, 1, True, 0),
+                                                                 (False, 1, True, 2), (False, 2, True, 1)])
+def test_oracle_matches_autograd(continuous, attn_version, blind, cbuf):
+    cfg = _tiny(continuous, attn_version, blind, cbuf)
     B = 3
     if continuous:
         x, y = synthetic.continuous_batch(B, cfg.seq_len, cfg.n_classes, seed=3)

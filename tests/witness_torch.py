@@ -89,7 +89,11 @@ def loss_and_grads(params_np, cfg, inp, tar, labels, drops=None):
     emb = (x * a).sum(1)
     if cfg.attn_version != 1:
         emb = emb @ P["bottleneck/embeding_layer/kernel"] + P["bottleneck/embeding_layer/bias"]
-    cls_logits = emb @ P["classify/kernel"] + P["classify/bias"]
+    fc = emb
+    for i in range(getattr(cfg, "class_buffer_layers", 0)):
+        fc = torch.relu(fc @ P["class_buffer/%d/kernel" % i] + P["class_buffer/%d/bias" % i])
+        fc = _drop(fc, drops.get("class_dropout/%d" % i), cfg.class_dropout if rate > 0 else 0.0)
+    cls_logits = fc @ P["classify/kernel"] + P["classify/bias"]
     pre = emb[:, None, :] * P["expand/kernel"][0][None, :, None] + P["expand/bias"][None, :, None]
 
     y = _embed(P, "decoder/embedding", tar_inp, cfg, pos, drops.get("decoder/dropout"), rate)
