@@ -245,6 +245,17 @@ int skf_model_forward_backward(SkfModel* m, const void* inp, const void* tar, in
                                const long long* labels, skf_stream_t stream);
 /* optimizer.apply_gradients with grads pre-multiplied by grad_scale (1/world_size under data parallelism) */
 int skf_model_apply_gradients(SkfModel* m, float grad_scale, skf_stream_t stream);
+/* ---- data-parallel hooks: the flat gradient buffer becomes final in pieces ("buckets", in production order:
+ * [decoder embedding .. output layer] after the decoder backward, then [encoder .. expander]).  A caller that
+ * all-reduces gradients makes its communication stream wait for a bucket, reduces that slice of `grads`, and applies the
+ * optimizer per slice - the all-reduce of bucket 0 overlaps the encoder backward, that of bucket 1 the optimizer sweep of
+ * bucket 0.  skf_model_grad_buckets returns the number of buckets (1 when the step is replayed from hipGraphs);
+ * offsets/counts in floats.  skf_model_apply_gradients_range == skf_model_apply_gradients on one slice
+ * (last != 0: also ends the step, iterations += 1). */
+int skf_model_grad_buckets(SkfModel* m, int max_buckets, size_t* offsets_host, size_t* counts_host);
+int skf_model_wait_grad_bucket(SkfModel* m, int bucket, skf_stream_t stream);
+int skf_model_apply_gradients_range(SkfModel* m, size_t offset, size_t count, float grad_scale, int last,
+                                    skf_stream_t stream);
 /* ---- inference API of the plugin (models/sketchformer.py:162-168, 201-311) ----
  * skf_model_encode: encode_from_seq / predict_class - encoder + bottleneck + classifier with dropout off; results in
  *   the buffers "embedding" (B,d), "class_probs" (B,C), "enc_output" (B*L,d).

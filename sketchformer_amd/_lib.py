@@ -99,6 +99,9 @@ SIGNATURES = {
     "skf_model_bind": (_I, [_P, _P, _P, _P, _P, _P, _P, _Z, _P, _P]),
     "skf_model_forward": (_I, [_P, _P, _P, _I, _I, _P]),
     "skf_model_forward_backward": (_I, [_P, _P, _P, _I, _P, _P]),
+    "skf_model_grad_buckets": (_I, [_P, _I, C.POINTER(_Z), C.POINTER(_Z)]),
+    "skf_model_wait_grad_bucket": (_I, [_P, _I, _P]),
+    "skf_model_apply_gradients_range": (_I, [_P, _Z, _Z, _F, _I, _P]),
     "skf_model_encode": (_I, [_P, _P, _P]),
     "skf_model_greedy_decode": (_I, [_P, _P, C.POINTER(_I), _I, C.c_longlong, C.c_longlong, _I, _P, C.POINTER(_I), _P]),
     "skf_model_apply_gradients": (_I, [_P, _F, _P]),

@@ -337,6 +337,12 @@ struct SkfModel {
   bool descs_uploaded = false;
   size_t slab_cursor = 0, desc_cursor = 0;
   int reduce_blocks = 0;
+  // gradient buckets (data parallelism): the flat gradient buffer becomes final in two pieces, in production order -
+  // [dec_off, total) after the decoder backward, [0, dec_off) at the end; an event marks each piece complete so that
+  // its all-reduce can start while the encoder backward / the previous piece's optimizer sweep still runs
+  size_t phase_desc_begin = 0;
+  hipEvent_t bucket_ready[2] = {nullptr, nullptr};
+  int n_buckets = 1;
 
   hipEvent_t new_event() {
     if (next_event == events.size()) {
@@ -416,20 +422,39 @@ int dense_wgrad(SkfModel* M, const DenseP& w, const float* x, int ldx, const flo
   M->side_used = true;
   return SKF_OK;
 }
-int join_side(SkfModel* M, hipStream_t s) {
-  if (M->side && M->side_used) {
-    if (!M->descs_uploaded) {      // the launch sequence is fixed: descriptors are built and uploaded once
-      SKF_HIP(hipMemcpy(M->at<char>(M->plan.descs), M->descs.data(), M->descs.size() * sizeof(SkfReduceDesc), hipMemcpyHostToDevice));
-      M->descs_uploaded = true;
+// Reduce the split-K partials of the wgrads issued since the last flush (one batched launch on the side stream) and
+// mark gradient bucket `bucket` complete.  final = the main stream waits for the side stream (before the optimizer).
+int flush_wgrads(SkfModel* M, hipStream_t s, int bucket, bool final) {
+  const size_t begin = M->phase_desc_begin, end = M->desc_cursor;
+  hipStream_t ready_on = s;
+  if (M->side && M->side_used && end > begin) {
+    if (!M->descs_uploaded) {      // the launch sequence is fixed: descriptors are built and uploaded once (first step)
+      SKF_HIP(hipMemcpy(M->at<SkfReduceDesc>(M->plan.descs) + begin, M->descs.data() + begin,
+                        (end - begin) * sizeof(SkfReduceDesc), hipMemcpyHostToDevice));
+      if (final) M->descs_uploaded = true;
     }
-    SKF_TRY(skf_splitk_reduce_batch(M->at<SkfReduceDesc>(M->plan.descs), (int)M->descs.size(), M->reduce_blocks, M->side));
-    hipEvent_t e = M->new_event();
-    SKF_CHECK_ARG(e, "event allocation failed");
-    SKF_HIP(hipEventRecord(e, M->side));
-    SKF_HIP(hipStreamWaitEvent(s, e, 0));
+    SKF_TRY(skf_splitk_reduce_batch(M->at<SkfReduceDesc>(M->plan.descs) + begin, (int)(end - begin), M->reduce_blocks, M->side));
+    // LayerNorm / embedding / bias-free gradients of this bucket were written by the main stream: order after both
+    hipEvent_t em = M->new_event();
+    SKF_CHECK_ARG(em, "event allocation failed");
+    SKF_HIP(hipEventRecord(em, s));
+    SKF_HIP(hipStreamWaitEvent(M->side, em, 0));
+    ready_on = M->side;
+    if (final) {
+      hipEvent_t e = M->new_event();
+      SKF_CHECK_ARG(e, "event allocation failed");
+      SKF_HIP(hipEventRecord(e, M->side));
+      SKF_HIP(hipStreamWaitEvent(s, e, 0));
+      ready_on = s;
+    }
   }
-  M->pending_readers.clear();
-  M->side_used = false;
+  if (M->bucket_ready[bucket]) SKF_HIP(hipEventRecord(M->bucket_ready[bucket], ready_on));
+  M->phase_desc_begin = end;
+  M->reduce_blocks = 0;                 // block numbering of the next batch starts again at 0
+  if (final) {
+    M->pending_readers.clear();
+    M->side_used = false;
+  }
   return SKF_OK;
 }
 int dense_dgrad(SkfModel* M, const DenseP& w, const float* dy, int lddy, int rows, float* dx, int lddx, int accumulate,
@@ -608,7 +633,7 @@ int run_backward(SkfModel* M, hipStream_t s) {
   M->next_event = 0;
   M->pending_readers.clear();
   M->side_used = false;
-  M->slab_cursor = 0; M->desc_cursor = 0; M->reduce_blocks = 0;
+  M->slab_cursor = 0; M->desc_cursor = 0; M->reduce_blocks = 0; M->phase_desc_begin = 0;
   const SkfConfig& c = M->cfg;
   const Layout& L = M->lay;
   const Plan& P = M->plan;
@@ -677,6 +702,8 @@ int run_backward(SkfModel* M, hipStream_t s) {
     SKF_HIP(hipMemsetAsync(M->G(L.dec_emb), 0, (size_t)c.vocab_size * d * sizeof(float), s));
     SKF_TRY(skf_embed_bwd(tar, Le, B, Ld, G, c.vocab_size, d, M->G(L.dec_emb), rate, site_dec_embed(N), M->state, s));
   }
+  // every gradient of [decoder embedding .. output layer] is issued: first bucket of the flat buffer
+  if (M->n_buckets == 2) SKF_TRY(flush_wgrads(M, s, 0, false));
   // expander, classifier
   const int E = L.E, Ua = L.Ua, U = c.lowerdim, NB = c.class_buffer_layers;
   SKF_TRY(skf_expander_bwd(dpre, M->at<float>(P.emb), M->P(L.exp_w), B, Le, E, demb, 0, M->G(L.exp_w), M->G(L.exp_b),
@@ -743,7 +770,7 @@ int run_backward(SkfModel* M, hipStream_t s) {
     SKF_HIP(hipMemsetAsync(M->G(L.enc_emb), 0, (size_t)c.vocab_size * d * sizeof(float), s));
     SKF_TRY(skf_embed_bwd(inp, Le, B, Le, G, c.vocab_size, d, M->G(L.enc_emb), rate, site_enc_embed(), M->state, s));
   }
-  return join_side(M, s);
+  return flush_wgrads(M, s, M->n_buckets - 1, true);
 }
 
 // KV-cached greedy reconstruction (models/sketchformer.py:255-311).  The reference re-runs the decoder on the whole
@@ -952,6 +979,10 @@ extern "C" int skf_model_create(const SkfConfig* cfg, SkfModel** out) {
   // streams do not overlap, 7.50 vs 7.72 ms/step), so the side stream is only used on the eager path
   if (!cfg->use_graph && !(getenv("SKF_NO_SIDE_STREAM") && getenv("SKF_NO_SIDE_STREAM")[0] == '1'))
     SKF_HIP(hipStreamCreateWithFlags(&M->side, hipStreamNonBlocking));
+  if (!cfg->use_graph) {     // events cannot be recorded for outside waiters inside a captured graph: one bucket there
+    M->n_buckets = 2;
+    for (int i = 0; i < 2; ++i) SKF_HIP(hipEventCreateWithFlags(&M->bucket_ready[i], hipEventDisableTiming));
+  }
   *out = M;
   return SKF_OK;
 }
@@ -961,6 +992,7 @@ extern "C" void skf_model_destroy(SkfModel* m) {
   if (m->g_fb) (void)hipGraphExecDestroy(m->g_fb);
   if (m->g_opt) (void)hipGraphExecDestroy(m->g_opt);
   for (hipEvent_t e : m->events) (void)hipEventDestroy(e);
+  for (int i = 0; i < 2; ++i) if (m->bucket_ready[i]) (void)hipEventDestroy(m->bucket_ready[i]);
   if (m->side) (void)hipStreamDestroy(m->side);
   delete m;
 }
@@ -1032,6 +1064,40 @@ extern "C" int skf_model_apply_gradients(SkfModel* m, float grad_scale, skf_stre
                             m->cfg.beta2, m->cfg.eps, s));
     return skf_step_epilogue(m->state, s);
   });
+}
+
+extern "C" int skf_model_grad_buckets(SkfModel* m, int max_buckets, size_t* offsets_host, size_t* counts_host) {
+  SKF_CHECK_ARG(m && offsets_host && counts_host && max_buckets >= 2, "bad argument");
+  const size_t dec_off = m->cfg.continuous ? m->lay.dec_embd.w : m->lay.dec_emb;
+  if (m->n_buckets == 2) {
+    offsets_host[0] = dec_off; counts_host[0] = m->lay.total - dec_off;      // decoder embedding .. output layer
+    offsets_host[1] = 0; counts_host[1] = dec_off;                           // encoder .. expander
+  } else {
+    offsets_host[0] = 0; counts_host[0] = m->lay.total;
+  }
+  return m->n_buckets;
+}
+
+extern "C" int skf_model_wait_grad_bucket(SkfModel* m, int bucket, skf_stream_t stream) {
+  SKF_CHECK_ARG(m && bucket >= 0 && bucket < m->n_buckets, "bad bucket");
+  if (m->bucket_ready[bucket]) SKF_HIP(hipStreamWaitEvent((hipStream_t)stream, m->bucket_ready[bucket], 0));
+  return SKF_OK;
+}
+
+extern "C" int skf_model_apply_gradients_range(SkfModel* m, size_t offset, size_t count, float grad_scale, int last,
+                                               skf_stream_t stream) {
+  SKF_CHECK_ARG(m && m->ws, "model not bound");
+  SKF_CHECK_ARG((offset & 3) == 0 && offset + count <= m->lay.total, "range must start on a multiple of 4 floats inside the buffer");
+  hipStream_t s = (hipStream_t)stream;
+  if (count) {
+    if (m->cfg.optimizer == 1)
+      SKF_TRY(skf_sgd_momentum_step(m->params + offset, m->grads + offset, m->m + offset, count, m->state, grad_scale,
+                                    m->cfg.momentum, s));
+    else
+      SKF_TRY(skf_adam_step(m->params + offset, m->grads + offset, m->m + offset, m->v + offset, count, m->state,
+                            grad_scale, m->cfg.beta1, m->cfg.beta2, m->cfg.eps, s));
+  }
+  return last ? skf_step_epilogue(m->state, s) : SKF_OK;
 }
 
 extern "C" int skf_model_buffer(SkfModel* m, const char* name, float** ptr, int* rows, int* cols) {

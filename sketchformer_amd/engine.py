@@ -145,6 +145,7 @@ class TrainEngine:
                   self._p(self.state))
         # a dedicated non-default stream: hipGraph capture is illegal on the legacy default stream
         self.stream = torch.cuda.Stream(device=dev)
+        self._comm = None                # communication stream of the data-parallel gradient buckets
         self.pg = process_group
         self.world_size = torch.distributed.get_world_size(process_group) if process_group is not None else 1
 
@@ -274,14 +275,43 @@ class TrainEngine:
                   self._stream())
         self._leave()
 
-    def apply_gradients(self):
+    def grad_buckets(self):
+        """[(offset, count)] slices of the flat gradient buffer in the order they become final during backward."""
+        off, cnt = (C.c_size_t * 2)(), (C.c_size_t * 2)()
+        n = int(self.lib.skf_model_grad_buckets(self.handle, 2, off, cnt))      # returns the count (negative = error)
+        if n <= 0:
+            _lib.check(n if n < 0 else -1, "skf_model_grad_buckets")
+        return [(int(off[i]), int(cnt[i])) for i in range(n)]
+
+    def apply_gradients(self, bucketed=None):
+        """optimizer.apply_gradients (models/sketchformer.py:348).  Data parallel: every gradient bucket is all-reduced
+        on a communication stream as soon as backward has finished it (bucket 0 = decoder part, overlaps the encoder
+        backward; bucket 1 overlaps the optimizer sweep of bucket 0), then the optimizer runs per bucket with the 1/W
+        factor fused.  ``bucketed=True`` forces that schedule without a process group (single-GPU test of the plumbing)."""
+        if bucketed is None:
+            bucketed = self.world_size > 1
         self._enter()
-        scale = 1.0
-        if self.world_size > 1:
-            from . import parallel
+        if not bucketed:
+            _lib.call("skf_model_apply_gradients", self.handle, 1.0, self._stream())
+            self._leave()
+            return
+        from . import parallel
+        if self._comm is None:
+            self._comm = torch.cuda.Stream(device=self.device)
+        buckets = self.grad_buckets()
+        scale = 1.0 / max(self.world_size, 1)
+        works = []
+        for i, (off, cnt) in enumerate(buckets):
+            _lib.call("skf_model_wait_grad_bucket", self.handle, i, C.c_void_p(self._comm.cuda_stream))
+            with torch.cuda.stream(self._comm):
+                works.append(parallel.allreduce_bucket(self.grads[off:off + cnt], self.pg))
+        for i, (off, cnt) in enumerate(buckets):
             with torch.cuda.stream(self.stream):
-                scale = parallel.allreduce_flat_gradients(self.grads, self.pg)
-        _lib.call("skf_model_apply_gradients", self.handle, scale, self._stream())
+                if works[i] is not None:
+                    works[i].wait()                      # engine stream waits for this bucket's all-reduce
+                else:
+                    self.stream.wait_stream(self._comm)
+            _lib.call("skf_model_apply_gradients_range", self.handle, off, cnt, scale, int(i == len(buckets) - 1), self._stream())
         self._leave()
 
     def train_step(self, inp, labels, tar=None):

@@ -41,3 +41,13 @@ def allreduce_flat_gradients(flat_grads, group=None):
     if world > 1:
         dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)
     return 1.0 / world
+
+
+def allreduce_bucket(view, group=None):
+    """Start the in-place SUM all-reduce of one gradient bucket (a contiguous slice of the flat buffer) on the current
+    stream; returns the async work handle, or None when there is nothing to reduce (no process group / one rank)."""
+    if group is None and not dist.is_initialized():
+        return None
+    if dist.get_world_size(group) <= 1:
+        return None
+    return dist.all_reduce(view, op=dist.ReduceOp.SUM, group=group, async_op=True)

@@ -417,3 +417,26 @@ def test_sgd_momentum_trajectory_matches_oracle():
     vel = eng.state_dict_numpy("adam_m")
     worst = max((np.abs(vel[k] - st.m[k]).max() / max(np.abs(st.m[k]).max(), 1e-12), k) for k in vel if np.abs(st.m[k]).max() > 1e-9)
     assert worst[0] < 2e-3, worst
+
+
+def test_bucketed_apply_gradients_equals_plain():
+    """The data-parallel schedule (gradient buckets handed to a communication stream through events, optimizer per
+    bucket) on one GPU, without a process group: same parameters / moments / step counter as the plain path."""
+    B = 4
+    res = []
+    for bucketed in (False, True):
+        eng, ocfg = _mk(B, rate=0.1)
+        assert eng.grad_buckets()[0][0] > 0 and sum(c for _, c in eng.grad_buckets()) == eng.n_floats
+        off0, cnt0 = eng.grad_buckets()[0]
+        dec_first = min(e["offset"] for e in eng.entries if e["name"].startswith(("decoder/", "output/")))
+        assert off0 == dec_first and off0 + cnt0 == eng.n_floats          # bucket 0 = decoder embedding .. output layer
+        eng.state[0] = 3000
+        for step in range(3):
+            x, y = synthetic.token_batch(B, ocfg.seq_len, ocfg.vocab_size, ocfg.n_classes, seed=50 + step)
+            eng.forward_backward(x, None, y)
+            eng.apply_gradients(bucketed=bucketed)
+        torch.cuda.synchronize()
+        assert eng.iterations == 3003
+        res.append((eng.params.clone(), eng.adam_m.clone(), eng.adam_v.clone()))
+    for a, b in zip(*res):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)                   # embedding-gradient atomics reorder sums

@@ -69,3 +69,36 @@ def test_single_process_is_identity():
     x, y = np.arange(12).reshape(6, 2), np.arange(6)
     xs, ys = parallel.shard_batch(x, y, 1, 3)
     assert xs.tolist() == [[2, 3], [8, 9]] and ys.tolist() == [1, 4]
+
+
+def _bucket_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    _, _, _, pg = parallel.init_from_env(backend="gloo")
+    g = torch.Generator().manual_seed(100 + rank)
+    flat = torch.randn(1003, generator=g, dtype=torch.float64)
+    whole = flat.clone()
+    parallel.allreduce_flat_gradients(whole, pg)
+    # the engine's schedule: buckets in production order (tail of the buffer first), async work handles, wait per bucket
+    buckets = [(600, 403), (0, 600)]
+    works = [parallel.allreduce_bucket(flat[o:o + n], pg) for o, n in buckets]
+    assert all(w is not None for w in works)
+    for w in works:
+        w.wait()
+    if rank == 0:
+        out.put(float((flat - whole).abs().max()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_equals_whole_buffer_allreduce():
+    """N>1 path of TrainEngine.apply_gradients: all-reducing the gradient buckets (slices of the flat buffer, started
+    asynchronously in production order) gives exactly the all-reduce of the whole buffer."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    out = ctx.SimpleQueue()
+    mp.spawn(_bucket_worker, args=(2, port, out), nprocs=2, join=True)
+    assert out.get() == 0.0
+    assert parallel.allreduce_bucket(torch.zeros(4), None) is None          # single process: nothing to reduce
