@@ -36,6 +36,7 @@ struct AttnParams {
   int B, H, Lq, Lk;
   float* stats;                   // (B, H, Lq, 2): row max, 1/sum
   // backward only
+  int xcd_remap;                  // XCD-contiguous (sample, head) ids (default on; env SKF_ATTN_XCD=0 turns it off)
   int ablate;                     // diagnostics (env SKF_ATTN_ABLATE): 1 = no dQ atomics
   long long* dbg;                 // diagnostics: s_memtime stamps of a few workgroups (env SKF_ATTN_DBG)
   const float* dO; int lddo;
@@ -52,7 +53,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   constexpr int NC = DH / 16;
   constexpr int LD = DH + 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
+  // A head is a 64..256-byte slice of every activation row, i.e. half (or less) of each 128-byte line it touches; the
+  // other half belongs to the neighbouring head.  XCD-contiguous ids put all heads of a sample on ONE XCD (one L2),
+  // consecutively in time, so the neighbour's half is an L2 hit instead of a second HBM fetch of the same line.
+  const int bh = p.xcd_remap ? skf_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x, b = bh / p.H, h = bh % p.H;
   const int nkt = (p.Lk + 15) >> 4, nqt = (p.Lq + 15) >> 4;
   float* Ks = smem;                       // [nkt*16][LD]
   float* Vs = smem + nkt * 16 * LD;       // [nkt*16][LD]
@@ -98,7 +102,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   const float inv_sqrt = 1.0f / sqrtf((float)DH);
   const bool pow4 = (DH == 16 || DH == 64);
 
-  for (int qt = wave; qt < nqt; qt += 4) {
+  // Query tiles are dealt to the waves round-robin starting at a per-workgroup offset: with 13 tiles one wave gets 4 and
+  // the others 3, and wave w always runs on SIMD w - without the rotation SIMD 0 of every CU carries the extra tile of
+  // every resident workgroup.
+  for (int qt = (wave + bh) & 3; qt < nqt; qt += 4) {
     const int q0 = qt * 16, qrow = q0 + i;
     const bool qok = qrow < p.Lq;
     float4 qf[NC];
@@ -185,7 +192,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
   constexpr int LD = DH + 4;
   constexpr int TLD = 20;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
+  // A head is a 64..256-byte slice of every activation row, i.e. half (or less) of each 128-byte line it touches; the
+  // other half belongs to the neighbouring head.  XCD-contiguous ids put all heads of a sample on ONE XCD (one L2),
+  // consecutively in time, so the neighbour's half is an L2 hit instead of a second HBM fetch of the same line.
+  const int bh = p.xcd_remap ? skf_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x, b = bh / p.H, h = bh % p.H;
   const int nkt = (p.Lk + 15) >> 4, nqt = (p.Lq + 15) >> 4;
   const int QR = nqt * 16;
   constexpr int RLD = DH + 1;          // row pitch of the dQ reduction slots
@@ -267,8 +277,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
 #pragma unroll
   for (int c = 0; c < NC; ++c) { dK_shared[c] = (f32x4){0.f, 0.f, 0.f, 0.f}; dV_shared[c] = dK_shared[c]; }
 
+  // key-tile ownership rotates with the workgroup id (see forward): the wave with the most key tiles (padding- and
+  // causal-skipping make the load uneven) lands on a different SIMD for each of the co-resident workgroups
+  const int wv = (wave + bh) & 3;
   for (int kg = 0; kg < nkt; kg += 4 * KTW) {
-    const int kt0 = kg + wave;                 // smallest key tile of this wave in this group
+    const int kt0 = kg + wv;                   // smallest key tile of this wave in this group
     const bool share = !CAUSAL && kg == 0 && KTW > 1 && nkt == 4 * (KTW - 1) + 1;
     // B-operand fragments (lane = key i, contraction d = 16c+4g+s) and
     // A-operand (transposed) fragments (lane = d 16c+i, contraction key = k0+4g+s)
@@ -333,7 +346,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
         if (CAUSAL) {
           if (can_skip && kt > qt) continue;
         } else if (share && j == KTW - 1) {
-          if ((qt & 3) != wave) continue;                      // the shared tile: one wave per query tile
+          if ((qt & 3) != wv) continue;                        // the shared tile: one wave per query tile
         }
         const int krow = kt * 16 + i;
         f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dpacc = sacc;
@@ -480,6 +493,7 @@ extern "C" int skf_attention_fwd(const float* Q, int ldq, const float* K, int ld
   AttnParams p{};
   p.Q = Q; p.K = K; p.V = V; p.O = O; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
   p.key_mask = key_mask; p.key_mask_ld = key_mask_ld; p.causal = causal; p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.stats = stats;
+  { const char* e = getenv("SKF_ATTN_XCD"); p.xcd_remap = !(e && e[0] == '0'); }
   int rc = check_common(p, dh);
   if (rc) return rc;
   SKF_CHECK_ARG(Q && K && V && O, "null operand");
@@ -515,6 +529,7 @@ extern "C" int skf_attention_bwd(const float* Q, int ldq, const float* K, int ld
   p.key_mask = key_mask; p.key_mask_ld = key_mask_ld; p.causal = causal; p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk;
   p.stats = const_cast<float*>(stats);
   { const char* ab = getenv("SKF_ATTN_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }
+  { const char* e = getenv("SKF_ATTN_XCD"); p.xcd_remap = !(e && e[0] == '0'); }
   { const char* db = getenv("SKF_ATTN_DBG"); p.dbg = db ? (long long*)strtoull(db, nullptr, 0) : nullptr; }
   p.dO = dO; p.lddo = lddo; p.dQ = dQ; p.dK = dK; p.dV = dV; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
   int rc = check_common(p, dh);

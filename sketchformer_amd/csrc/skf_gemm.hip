@@ -433,6 +433,12 @@ extern "C" int skf_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K,
   { const char* xr = getenv("SKF_WS_XCD"); p.xcd_remap = xr ? atoi(xr) : 0; }
   { const char* ds = getenv("SKF_WS_DIRECT"); p.direct_store = ds ? atoi(ds) : 0; }
   { const char* db = getenv("SKF_GEMM_DBG"); p.dbg = db ? (long long*)strtoull(db, nullptr, 0) : nullptr; }
+  SKF_CHECK_ARG(!bias_grad || !b_kcontig, "bias_grad needs B as [K][N]");
+  {
+    int handled = 0;
+    int rc = skf_gemm_small_dispatch(p, a_kcontig, b_kcontig, bias_grad, bias_grad_accumulate, st, &handled);
+    if (rc != SKF_OK || handled) return rc;
+  }
   if (splits <= 1 && !bias_grad) {
     int handled = 0;
     int rc = skf_gemm_ws_dispatch(p, a_kcontig, b_kcontig, st, &handled);

@@ -29,3 +29,6 @@ struct GemmParams {
 int skf_gemm_ws_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, hipStream_t st, int* handled);
 // wgrad (X^T.dY) fast path writing the split-K slab; sets *handled when it launched the problem
 int skf_gemm_wgrad_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, int splits, hipStream_t st, int* handled);
+// small-problem path (M*N*K <= 2^25): any layout, all epilogues, optional bias gradient (column sums of B) in the same launch
+int skf_gemm_small_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, float* bias_grad, int bias_grad_accumulate,
+                            hipStream_t st, int* handled);

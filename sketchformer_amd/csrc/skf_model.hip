@@ -397,7 +397,10 @@ int dense_wgrad(SkfModel* M, const DenseP& w, const float* x, int ldx, const flo
   SKF_CHECK_ARG(ready && done, "event allocation failed");
   SKF_HIP(hipEventRecord(ready, s));
   SKF_HIP(hipStreamWaitEvent(M->side, ready, 0));
-  {
+  if ((double)w.in * w.out * rows <= 33554432.0) {
+    // batch-sized problems (classifier, class buffers, SelfAttnV2 projection): one small-GEMM launch, no split-K slab
+    SKF_TRY(dense_wgrad_on(M, w, x, ldx, dy, lddy, rows, M->side));
+  } else {
     // partial tiles only; every slab of the step is reduced by ONE launch in join_side()
     const int splits = skf_gemm_default_splits(w.in, w.out, rows);
     const size_t bytes = (skf_gemm_workspace_bytes(w.in, w.out, rows, splits, 1) + 255) & ~(size_t)255;
