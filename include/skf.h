@@ -106,6 +106,9 @@ int skf_layernorm_residual_fwd(const float* x, float* y_inout_z, const float* ga
                                skf_stream_t stream);
 size_t skf_layernorm_bwd_workspace_bytes(int rows, int d);
 /* dz = d(x + drop(y)); dy = dz * dropout mask (only written when rate > 0; with rate == 0 dy == dz). */
+/* dgamma == dbeta == NULL: only the per-workgroup partials are written, workspace = [g][2][d] floats with
+ * g = skf_layernorm_bwd_workspace_bytes(rows, d) / (8*d) (row 2k = dgamma part, as one [g][2d] matrix); the caller
+ * column-sums them later (the train step batches all of them into its split-K reduction launch). */
 int skf_layernorm_residual_bwd(const float* dout, const float* z, const float* stats, const float* gamma, float* dz,
                                float* dy, float* dgamma, float* dbeta, int rows, int d, float rate, unsigned site,
                                const void* step_state, void* workspace, size_t workspace_bytes, skf_stream_t stream);

@@ -238,6 +238,7 @@ struct Plan {
   size_t gA, gB, gC, dqkv, dh, do_, dpre, dkv2, dq2, demb;
   size_t gemm_ws, gemm_ws_bytes, small_ws, small_ws_bytes;
   size_t slab_arena, slab_arena_bytes, descs, n_wgrads;   // deferred split-K reduction (eager path)
+  size_t ln_part, ln_part_stride;                          // per-LayerNorm dgamma|dbeta partials [5N][g][2d], reduced in the same batch
   // KV-cached greedy decode (inference): per-layer self-attention K|V cache (B, L, 2d) + one-row-per-sample step buffers
   std::vector<size_t> dc_cache;
   size_t dc_x[2], dc_q, dc_o, dc_z, dc_out1, dc_out2, dc_h, dc_logits, dc_stats, dc_mask, dc_flags, dc_limit;
@@ -297,7 +298,9 @@ Plan build_plan(const SkfConfig& c) {
   mx(wgrad_ws((int)E, 2 * d, Me)); mx(wgrad_ws(d, (int)Vout, Md)); mx(wgrad_ws(d, (int)Ua, Me));
   mx(wgrad_ws((int)E, c.n_classes, B)); mx(wgrad_ws(U, c.n_classes, B)); mx(wgrad_ws(d, U, B)); mx(wgrad_ws((int)E, U, B)); mx(wgrad_ws(U, U, B));
   P.gemm_ws_bytes = g; P.gemm_ws = b.take(g);
-  P.n_wgrads = 4 + 11 * (size_t)c.num_layers + (size_t)c.class_buffer_layers;
+  P.n_wgrads = 4 + 11 * (size_t)c.num_layers + (size_t)c.class_buffer_layers + 5 * (size_t)c.num_layers;   // + one entry per LayerNorm
+  P.ln_part_stride = (skf_layernorm_bwd_workspace_bytes((int)Me, (int)d) + 255) & ~(size_t)255;
+  P.ln_part = b.take(5 * (size_t)c.num_layers * P.ln_part_stride);
   P.slab_arena_bytes = P.n_wgrads * ((g + 255) & ~(size_t)255);
   P.slab_arena = b.take(P.slab_arena_bytes);
   P.descs = b.take(P.n_wgrads * sizeof(SkfReduceDesc));
@@ -335,7 +338,7 @@ struct SkfModel {
   bool side_used = false;
   std::vector<SkfReduceDesc> descs;     // one per wgrad of the step, in launch order
   bool descs_uploaded = false;
-  size_t slab_cursor = 0, desc_cursor = 0;
+  size_t slab_cursor = 0, desc_cursor = 0, ln_cursor = 0;
   int reduce_blocks = 0;
   // gradient buckets (data parallelism): the flat gradient buffer becomes final in two pieces, in production order -
   // [dec_off, total) after the decoder backward, [0, dec_off) at the end; an event marks each piece complete so that
@@ -436,12 +439,13 @@ int flush_wgrads(SkfModel* M, hipStream_t s, int bucket, bool final) {
                         (end - begin) * sizeof(SkfReduceDesc), hipMemcpyHostToDevice));
       if (final) M->descs_uploaded = true;
     }
-    SKF_TRY(skf_splitk_reduce_batch(M->at<SkfReduceDesc>(M->plan.descs) + begin, (int)(end - begin), M->reduce_blocks, M->side));
-    // LayerNorm / embedding / bias-free gradients of this bucket were written by the main stream: order after both
+    // LayerNorm partials and the embedding gradients of this bucket were written by the main stream: the batched
+    // reduction (wgrad slabs + LayerNorm partials) and the bucket-ready event are ordered after both streams
     hipEvent_t em = M->new_event();
     SKF_CHECK_ARG(em, "event allocation failed");
     SKF_HIP(hipEventRecord(em, s));
     SKF_HIP(hipStreamWaitEvent(M->side, em, 0));
+    SKF_TRY(skf_splitk_reduce_batch(M->at<SkfReduceDesc>(M->plan.descs) + begin, (int)(end - begin), M->reduce_blocks, M->side));
     ready_on = M->side;
     if (final) {
       hipEvent_t e = M->new_event();
@@ -626,17 +630,39 @@ int ffn_bwd(SkfModel* M, const DenseP& f1, const DenseP& f2, const float* x_in, 
 int ln_bwd(SkfModel* M, const LnP& ln, const float* dout, const float* z, const float* st, float* dz, float* dy,
            int rows, float rate, unsigned site, hipStream_t s) {
   const Plan& P = M->plan;
+  const int d = M->cfg.d_model;
   SKF_TRY(before_write(M, dz, s));
   if (dy != dz) SKF_TRY(before_write(M, dy, s));
-  return skf_layernorm_residual_bwd(dout, z, st, M->P(ln.g), dz, dy, M->G(ln.g), M->G(ln.b), rows, M->cfg.d_model, rate,
-                                    site, M->state, M->at<char>(P.small_ws), P.small_ws_bytes, s);
+  if (!M->side || ln.b != ln.g + (size_t)d)
+    return skf_layernorm_residual_bwd(dout, z, st, M->P(ln.g), dz, dy, M->G(ln.g), M->G(ln.b), rows, d, rate,
+                                      site, M->state, M->at<char>(P.small_ws), P.small_ws_bytes, s);
+  // eager path: leave the [g][2d] partials in this LayerNorm's own slice; their column sums ride in the batched
+  // split-K reduction of the wgrads (a "slab" of g splits of a 1 x 2d matrix) instead of one tiny launch per LayerNorm
+  SKF_CHECK_ARG(M->ln_cursor < 5 * (size_t)M->cfg.num_layers && M->desc_cursor < P.n_wgrads, "LayerNorm partial arena exhausted");
+  float* part = M->at<float>(P.ln_part + M->ln_cursor * P.ln_part_stride);
+  const size_t bytes = skf_layernorm_bwd_workspace_bytes(rows, d);
+  SKF_TRY(skf_layernorm_residual_bwd(dout, z, st, M->P(ln.g), dz, dy, nullptr, nullptr, rows, d, rate, site, M->state, part,
+                                     bytes, s));
+  SkfReduceDesc r;
+  r.slab = part; r.C = M->G(ln.g); r.bias_grad = nullptr; r.splits = (int)(bytes / (8 * (size_t)d)); r.M = 1; r.N = 2 * d;
+  r.ldc = 2 * d; r.block_begin = M->reduce_blocks; r.pad = 0;
+  if (!M->descs_uploaded) M->descs.push_back(r);
+  else {
+    const SkfReduceDesc& o = M->descs[M->desc_cursor];
+    SKF_CHECK_ARG(o.slab == r.slab && o.C == r.C && o.splits == r.splits && o.block_begin == r.block_begin, "reduction sequence changed between steps");
+  }
+  M->reduce_blocks += skf_splitk_reduce_blocks(1, 2 * d);
+  M->desc_cursor += 1;
+  M->ln_cursor += 1;
+  M->side_used = true;
+  return SKF_OK;
 }
 
 int run_backward(SkfModel* M, hipStream_t s) {
   M->next_event = 0;
   M->pending_readers.clear();
   M->side_used = false;
-  M->slab_cursor = 0; M->desc_cursor = 0; M->reduce_blocks = 0; M->phase_desc_begin = 0;
+  M->slab_cursor = 0; M->desc_cursor = 0; M->reduce_blocks = 0; M->phase_desc_begin = 0; M->ln_cursor = 0;
   const SkfConfig& c = M->cfg;
   const Layout& L = M->lay;
   const Plan& P = M->plan;

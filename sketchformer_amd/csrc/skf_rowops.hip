@@ -8,7 +8,7 @@
 namespace {
 
 constexpr int kMaxGrid = 2048;
-constexpr int kLnBwdGrid = 1024;   // workgroups of the LayerNorm backward (each leaves one [2][d] partial for the column sums)
+constexpr int kLnBwdGrid = 512;    // workgroups of the LayerNorm backward (each leaves one [2][d] partial for the column sums)
 
 __global__ void padding_mask_kernel(const long long* __restrict__ tok, int tok_ld, int B, int L,
                                     unsigned char* __restrict__ out) {
@@ -648,7 +648,8 @@ extern "C" int skf_layernorm_residual_bwd(const float* dout, const float* z, con
                                           float* dz, float* dy, float* dgamma, float* dbeta, int rows, int d, float rate,
                                           unsigned site, const void* step_state, void* workspace, size_t workspace_bytes,
                                           skf_stream_t stream) {
-  SKF_CHECK_ARG(dout && z && stats && gamma && dz && dgamma && dbeta, "null operand");
+  SKF_CHECK_ARG(dout && z && stats && gamma && dz, "null operand");
+  SKF_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "dgamma and dbeta must both be given or both be NULL");
   SKF_CHECK_ARG(workspace && workspace_bytes >= skf_layernorm_bwd_workspace_bytes(rows, d), "workspace too small");
   SKF_CHECK_ARG(rate == 0.f || (step_state && dy), "dropout needs the step state and a dy buffer");
   const SkfStepState* st = (const SkfStepState*)step_state;
@@ -667,6 +668,7 @@ extern "C" int skf_layernorm_residual_bwd(const float* dout, const float* z, con
   }
   SKF_LAUNCH_CHECK();
   // part is [g][2][d] : columns 0..d-1 = dgamma, d..2d-1 = dbeta
+  if (!dgamma) return SKF_OK;   // the caller sums the g = workspace_bytes/(8d) partial rows itself (batched with other reductions)
   if (dbeta == dgamma + d) {   // adjacent in the flat gradient buffer: one launch over 2d columns
     hipLaunchKernelGGL(colsum_kernel, dim3(skf_cdiv(2 * d, 64)), dim3(1024), 0, s, part, g, 2 * d, 2 * d, dgamma, 0);
   } else {
