@@ -95,22 +95,36 @@ class BaseDataLoader(object, metaclass=ABCMeta):
             self._swap(split_name)
 
     def batch_iterator(self, split_name, batch_size, stop_at_end_of_split):
+        """core/data.py:147-176 of the reference: yields [x, y] of batch_size samples in the shuffled order of the
+        current megabatch, crossing into the next megabatch when one runs out.  Same sequence of samples; a batch is
+        gathered with one fancy-index per megabatch piece instead of a Python loop over samples."""
         self._ready(split_name)
         split = self.splits[split_name]
         while True:
-            xs, ys = [], []
-            while len(xs) < batch_size:
+            xs, ys, have = [], [], 0
+            while have < batch_size:
                 if split.cursor >= len(split.order):
                     finished = self._swap(split_name)
                     if finished and stop_at_end_of_split:
-                        if xs:
-                            yield np.array(xs), np.array(ys)
+                        if have:
+                            yield np.concatenate(xs, axis=0), np.concatenate(ys, axis=0)
                         return
-                x, y = self.get_sample(split.current, split.order[split.cursor])
-                split.cursor += 1
+                take = min(batch_size - have, len(split.order) - split.cursor)
+                x, y = self.get_samples(split.current, split.order[split.cursor:split.cursor + take])
+                split.cursor += take
+                have += take
                 xs.append(x)
                 ys.append(y)
-            yield np.array(xs), np.array(ys)
+            yield (xs[0], ys[0]) if len(xs) == 1 else (np.concatenate(xs, axis=0), np.concatenate(ys, axis=0))
+
+    def get_samples(self, data, idx):
+        """Vectorised get_sample: rows idx of the megabatch -> (x (n, ...), y (n, 1))."""
+        idx = np.asarray(idx, dtype=np.int64)
+        x, y = data["x"], data["y"]
+        if isinstance(x, np.ndarray) and x.dtype != object and isinstance(y, np.ndarray) and y.dtype != object:
+            return x[idx], np.expand_dims(y[idx], axis=-1)
+        pairs = [self.get_sample(data, i) for i in idx]
+        return np.array([p[0] for p in pairs]), np.array([p[1] for p in pairs])
 
     def get_n_samples_from(self, split_name, n, shuffled=False, seeded=False):
         self._ready(split_name)

@@ -158,3 +158,59 @@ def test_synthetic_batches_shape_contract():
     c, _ = synthetic.continuous_batch(8, 200, 345, seed=1)
     assert c.shape == (8, 200, 5) and c.dtype == np.float32 and (c[:, -1, 4] == 1).all()
     assert np.allclose(c[..., 2:].sum(-1)[c[..., 4] == 0], 1.0)
+
+
+def _random_sketches(rng, n_s, lo, hi):
+    data = []
+    for k in range(n_s):
+        n = rng.randint(lo, hi)
+        s = np.zeros((n, 3), np.float32)
+        s[:, :2] = rng.randint(-30, 30, size=(n, 2))
+        s[:, 2] = rng.rand(n) < 0.15
+        s[-1, 2] = 1
+        if k % 3 == 0:
+            s[-1, 2] = 0                 # unfinished last stroke: points after the last pen lift are dropped
+        if k % 7 == 0:
+            s[:, 2] = 0                  # no pen lift at all
+        if k % 11 == 0:
+            s[rng.randint(n), 0] = 5000  # hits the +-1000 clamp
+        data.append(s)
+    return data
+
+
+@pytest.mark.parametrize("mode", ["grid", "continuous", "dictionary"])
+def test_block_preprocessing_is_bit_identical_to_per_sketch_pipeline(mode, tmp_path):
+    """the loader preprocesses a whole chunk with array operations (the reference loops over
+    sketches in Python, ~14k sketches/s/core, below what one GPU consumes); outputs are bit-identical to the per-sketch
+    pipeline that the reference goldens pin (test_loader_preprocess_matches_reference), incl. augmentation draws."""
+    import pickle
+    from sklearn.cluster import KMeans
+    from sketchformer_amd import dataloaders
+    from sketchformer_amd.utils import GridTokenizer, Tokenizer
+    L = dataloaders.get_dataloader_by_name("stroke3-distributed")
+    rng = np.random.RandomState(0)
+    data = _random_sketches(rng, 700, 1, 260)
+    obj = L.__new__(L)
+    obj.hps = dict(L.default_hparams().values())
+    obj.hps.update(token_type="grid" if mode != "dictionary" else "dictionary", use_continuous_data=mode == "continuous")
+    obj.limit = 1000
+    if mode == "dictionary":
+        km = KMeans(n_clusters=64, n_init=1, max_iter=3, random_state=0).fit(rng.normal(0, 0.1, size=(2000, 2)))
+        with open(tmp_path / "dict.pkl", "wb") as f:
+            pickle.dump(km, f)
+        obj.tokenizer = Tokenizer(str(tmp_path / "dict.pkl"))
+        assert obj.tokenizer.VOCAB_SIZE == 68
+        # sklearn's predict (what the reference calls) == explicit nearest centre
+        p = rng.normal(0, 0.1, size=(500, 2))
+        d2 = ((p[:, None, :] - km.cluster_centers_[None]) ** 2).sum(-1)
+        assert np.array_equal(obj.tokenizer.nearest_center(p[:, 0], p[:, 1]), d2.argmin(1))
+    else:
+        obj.tokenizer = GridTokenizer(resolution=100)
+    a = obj.preprocess_per_sketch([d.copy() for d in data])
+    b = obj.preprocess([d.copy() for d in data])
+    assert a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b)
+    np.random.seed(3)
+    a = obj.preprocess_per_sketch([d.copy() for d in data[:300]], augment=True)
+    np.random.seed(3)
+    b = obj.preprocess([d.copy() for d in data[:300]], augment=True)
+    assert np.array_equal(a, b)
