@@ -236,6 +236,10 @@ struct Plan {
   size_t dcb[2];
   size_t recon_loss, recon_hit, cls_loss, cls_hit, row_mask, cont_scal;
   size_t gA, gB, gC, dqkv, dh, do_, dpre, dkv2, dq2, demb;
+  // Buffers that weight-gradient GEMMs read (dY operands).  Two sets, alternating by layer: the wgrads of a layer are
+  // issued together on the side stream at the end of that layer, so their operands must stay untouched until the
+  // layer after next starts (every cross-stream event costs ~5 us of dead time on the main stream).
+  struct GradSet { size_t dy[3], dh, dq2, dkv2, dqkv; } gs[2];
   size_t gemm_ws, gemm_ws_bytes, small_ws, small_ws_bytes;
   size_t slab_arena, slab_arena_bytes, descs, n_wgrads;   // deferred split-K reduction (eager path)
   size_t ln_part, ln_part_stride;                          // per-LayerNorm dgamma|dbeta partials [5N][g][2d], reduced in the same batch
@@ -292,6 +296,13 @@ Plan build_plan(const SkfConfig& c) {
   P.gA = b.take(Me * d * f); P.gB = b.take(Me * d * f); P.gC = b.take(Me * d * f);
   P.dqkv = b.take(Me * 3 * d * f); P.dh = b.take(Me * F * f); P.do_ = b.take(Me * d * f);
   P.dpre = b.take(Me * E * f); P.dkv2 = b.take(Me * 2 * d * f); P.dq2 = b.take(Md * d * f); P.demb = b.take(B * E * f);
+  for (int k = 0; k < 2; ++k) {
+    for (int j = 0; j < 3; ++j) P.gs[k].dy[j] = b.take(Me * d * f);
+    P.gs[k].dh = k == 0 ? P.dh : b.take(Me * F * f);
+    P.gs[k].dq2 = k == 0 ? P.dq2 : b.take(Md * d * f);
+    P.gs[k].dkv2 = k == 0 ? P.dkv2 : b.take(Me * 2 * d * f);
+    P.gs[k].dqkv = k == 0 ? P.dqkv : b.take(Me * 3 * d * f);
+  }
   size_t g = 0;
   auto mx = [&](size_t v) { if (v > g) g = v; };
   mx(wgrad_ws(d, 3 * d, Me)); mx(wgrad_ws(d, d, Me)); mx(wgrad_ws(d, F, Me)); mx(wgrad_ws(F, d, Me));
@@ -335,6 +346,8 @@ struct SkfModel {
   std::vector<hipEvent_t> events;
   size_t next_event = 0;
   std::map<const void*, hipEvent_t> pending_readers;   // buffer -> completion event of its last side-stream reader
+  struct QueuedWgrad { DenseP w; const float* x; int ldx; const float* dy; int lddy; int rows; };
+  std::vector<QueuedWgrad> wq;                         // wgrads of the current layer, not yet issued
   bool side_used = false;
   std::vector<SkfReduceDesc> descs;     // one per wgrad of the step, in launch order
   bool descs_uploaded = false;
@@ -384,33 +397,48 @@ int dense_wgrad_on(SkfModel* M, const DenseP& w, const float* x, int ldx, const 
   return skf_gemm_f32(0, 0, w.in, w.out, rows, x, ldx, dy, lddy, M->G(w.w), w.ld, nullptr, 0, nullptr, 0, 0, splits,
                       M->G(w.b), 0, M->at<char>(M->plan.gemm_ws), M->plan.gemm_ws_bytes, s);
 }
-// Main-stream kernels that overwrite `buf` must first wait for the side-stream wgrad that still reads it.
+int issue_wgrads(SkfModel* M, hipStream_t s);
+// Main-stream kernels that overwrite `buf` must first wait for the side-stream wgrad that still reads it
+// (a wgrad that is still queued is issued first; with the alternating gradient-buffer sets this is the rare case).
 int before_write(SkfModel* M, const void* buf, hipStream_t s) {
+  for (const auto& q : M->wq)
+    if (q.dy == buf || q.x == buf) { SKF_TRY(issue_wgrads(M, s)); break; }
   auto it = M->pending_readers.find(buf);
   if (it == M->pending_readers.end()) return SKF_OK;
   SKF_HIP(hipStreamWaitEvent(s, it->second, 0));
   M->pending_readers.erase(it);
   return SKF_OK;
 }
-// dW = X^T dY (+ bias grad) on the side stream: ordered after everything queued on `s` so far (dY is complete),
-// serialized with the other wgrads (they share the split-K slab), and joined before the optimizer.
+// dW = X^T dY (+ bias grad).  Eager path: queued, and issued per layer on the side stream by issue_wgrads().
 int dense_wgrad(SkfModel* M, const DenseP& w, const float* x, int ldx, const float* dy, int lddy, int rows, hipStream_t s) {
   if (!M->side) return dense_wgrad_on(M, w, x, ldx, dy, lddy, rows, s);
+  M->wq.push_back({w, x, ldx, dy, lddy, rows});
+  return SKF_OK;
+}
+// Issue the queued wgrads on the side stream: ONE ready event (everything queued on `s` so far is complete before they
+// start) and ONE done event for the whole group; they are serialized among themselves and joined before the optimizer.
+int issue_wgrads(SkfModel* M, hipStream_t s) {
+  if (M->wq.empty()) return SKF_OK;
+  std::vector<SkfModel::QueuedWgrad> group;
+  group.swap(M->wq);
   hipEvent_t ready = M->new_event(), done = M->new_event();
   SKF_CHECK_ARG(ready && done, "event allocation failed");
   SKF_HIP(hipEventRecord(ready, s));
   SKF_HIP(hipStreamWaitEvent(M->side, ready, 0));
-  if ((double)w.in * w.out * rows <= 33554432.0) {
-    // batch-sized problems (classifier, class buffers, SelfAttnV2 projection): one small-GEMM launch, no split-K slab
-    SKF_TRY(dense_wgrad_on(M, w, x, ldx, dy, lddy, rows, M->side));
-  } else {
-    // partial tiles only; every slab of the step is reduced by ONE launch in join_side()
-    const int splits = skf_gemm_default_splits(w.in, w.out, rows);
-    const size_t bytes = (skf_gemm_workspace_bytes(w.in, w.out, rows, splits, 1) + 255) & ~(size_t)255;
+  for (const auto& q : group) {
+    const DenseP& w = q.w;
+    if ((double)w.in * w.out * q.rows <= 33554432.0) {
+      // batch-sized problems (classifier, class buffers, SelfAttnV2 projection): one small-GEMM launch, no split-K slab
+      SKF_TRY(dense_wgrad_on(M, w, q.x, q.ldx, q.dy, q.lddy, q.rows, M->side));
+      continue;
+    }
+    // partial tiles only; every slab of the phase is reduced by ONE launch in flush_wgrads()
+    const int splits = skf_gemm_default_splits(w.in, w.out, q.rows);
+    const size_t bytes = (skf_gemm_workspace_bytes(w.in, w.out, q.rows, splits, 1) + 255) & ~(size_t)255;
     SKF_CHECK_ARG(M->slab_cursor + bytes <= M->plan.slab_arena_bytes && M->desc_cursor < M->plan.n_wgrads, "slab arena exhausted");
     float* slab = M->at<float>(M->plan.slab_arena + M->slab_cursor);
     int used = 0;
-    SKF_TRY(skf_gemm_wgrad_partial(w.in, w.out, rows, x, ldx, dy, lddy, splits, 1, slab, bytes, &used, M->side));
+    SKF_TRY(skf_gemm_wgrad_partial(w.in, w.out, q.rows, q.x, q.ldx, q.dy, q.lddy, splits, 1, slab, bytes, &used, M->side));
     SkfReduceDesc d;
     d.slab = slab; d.C = M->G(w.w); d.bias_grad = M->G(w.b); d.splits = used; d.M = w.in; d.N = w.out; d.ldc = w.ld;
     d.block_begin = M->reduce_blocks; d.pad = 0;
@@ -424,13 +452,14 @@ int dense_wgrad(SkfModel* M, const DenseP& w, const float* x, int ldx, const flo
     M->desc_cursor += 1;
   }
   SKF_HIP(hipEventRecord(done, M->side));
-  M->pending_readers[dy] = done;
+  for (const auto& q : group) { M->pending_readers[q.dy] = done; M->pending_readers[q.x] = done; }
   M->side_used = true;
   return SKF_OK;
 }
 // Reduce the split-K partials of the wgrads issued since the last flush (one batched launch on the side stream) and
 // mark gradient bucket `bucket` complete.  final = the main stream waits for the side stream (before the optimizer).
 int flush_wgrads(SkfModel* M, hipStream_t s, int bucket, bool final) {
+  SKF_TRY(issue_wgrads(M, s));
   const size_t begin = M->phase_desc_begin, end = M->desc_cursor;
   hipStream_t ready_on = s;
   if (M->side && M->side_used && end > begin) {
@@ -617,9 +646,7 @@ int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s, bool 
 }
 
 int ffn_bwd(SkfModel* M, const DenseP& f1, const DenseP& f2, const float* x_in, const float* h, const float* dy,
-            float* dx_acc, int rows, hipStream_t s) {
-  const Plan& P = M->plan;
-  float* dh = M->at<float>(P.dh);
+            float* dh, float* dx_acc, int rows, hipStream_t s) {
   SKF_TRY(dense_wgrad(M, f2, h, f2.in, dy, f2.out, rows, s));
   SKF_TRY(dense_dgrad(M, f2, dy, f2.out, rows, dh, f2.in, 0, h, f2.in, s));
   SKF_TRY(dense_wgrad(M, f1, x_in, f1.in, dh, f1.out, rows, s));
@@ -675,31 +702,32 @@ int run_backward(SkfModel* M, hipStream_t s) {
   const unsigned char* dmask = M->at<unsigned char>(P.dec_mask);
   float* G = M->at<float>(P.gA);
   float* G2 = M->at<float>(P.gB);
-  float* G3 = M->at<float>(P.gC);
-  float* dqkv = M->at<float>(P.dqkv);
   float* dO = M->at<float>(P.do_);
   float* dpre = M->at<float>(P.dpre);
-  float* dkv2 = M->at<float>(P.dkv2);
-  float* dq2 = M->at<float>(P.dq2);
   float* demb = M->at<float>(P.demb);
-  auto dybuf = [&](float* dz) { return rate > 0.f ? G3 : dz; };
+  M->wq.clear();
+  int layer_no = 0;     // running layer counter: picks the gradient-buffer set
 
   // output layer: logits buffer now holds dlogits
   const float* dlog = M->at<float>(P.logits);
   SKF_TRY(dense_wgrad(M, L.out, M->at<float>(P.dec[N - 1].out3), d, dlog, L.out.out, Md, s));
   SKF_TRY(dense_dgrad(M, L.out, dlog, L.out.out, Md, G, d, 0, nullptr, 0, s));
 
+  SKF_TRY(issue_wgrads(M, s));
   const unsigned char* cross_mask = c.blind_decoder_mask ? nullptr : emask;
-  for (int i = N - 1; i >= 0; --i) {
+  for (int i = N - 1; i >= 0; --i, ++layer_no) {
     const DecLayerP& w = L.dec[i];
     const DecAct& a = P.dec[i];
+    const Plan::GradSet& gs = P.gs[layer_no & 1];
+    float* dy3 = M->at<float>(gs.dy[0]); float* dy2 = M->at<float>(gs.dy[1]); float* dy1 = M->at<float>(gs.dy[2]);
+    float* dqkv = M->at<float>(gs.dqkv); float* dkv2 = M->at<float>(gs.dkv2); float* dq2 = M->at<float>(gs.dq2);
     // out3 = LN3(out2 + drop(ffn(out2)))
-    SKF_TRY(ln_bwd(M, w.ln3, G, M->at<float>(a.z3), M->at<float>(a.st3), G2, dybuf(G2), Md, rate, site_dec(N, i, 2), s));
-    SKF_TRY(ffn_bwd(M, w.f1, w.f2, M->at<float>(a.out2), M->at<float>(a.h), dybuf(G2), G2, Md, s));
+    SKF_TRY(ln_bwd(M, w.ln3, G, M->at<float>(a.z3), M->at<float>(a.st3), G2, dy3, Md, rate, site_dec(N, i, 2), s));
+    SKF_TRY(ffn_bwd(M, w.f1, w.f2, M->at<float>(a.out2), M->at<float>(a.h), dy3, M->at<float>(gs.dh), G2, Md, s));
     // out2 = LN2(out1 + drop(mha2(pre, pre, out1)))
-    SKF_TRY(ln_bwd(M, w.ln2, G2, M->at<float>(a.z2), M->at<float>(a.st2), G, dybuf(G), Md, rate, site_dec(N, i, 1), s));
-    SKF_TRY(dense_wgrad(M, w.mha2.o, M->at<float>(a.o2), d, dybuf(G), d, Md, s));
-    SKF_TRY(dense_dgrad(M, w.mha2.o, dybuf(G), d, Md, dO, d, 0, nullptr, 0, s));
+    SKF_TRY(ln_bwd(M, w.ln2, G2, M->at<float>(a.z2), M->at<float>(a.st2), G, dy2, Md, rate, site_dec(N, i, 1), s));
+    SKF_TRY(dense_wgrad(M, w.mha2.o, M->at<float>(a.o2), d, dy2, d, Md, s));
+    SKF_TRY(dense_dgrad(M, w.mha2.o, dy2, d, Md, dO, d, 0, nullptr, 0, s));
     const float* kv2 = M->at<float>(a.kv2);
     SKF_TRY(before_write(M, dq2, s));
     SKF_TRY(before_write(M, dkv2, s));
@@ -711,9 +739,9 @@ int run_backward(SkfModel* M, hipStream_t s) {
     SKF_TRY(dense_wgrad(M, w.mha2.kv, M->at<float>(P.pre), L.E, dkv2, 2 * d, Me, s));
     SKF_TRY(dense_dgrad(M, w.mha2.kv, dkv2, 2 * d, Me, dpre, L.E, i != N - 1, nullptr, 0, s));
     // out1 = LN1(x + drop(mha1(x,x,x)))
-    SKF_TRY(ln_bwd(M, w.ln1, G, M->at<float>(a.z1), M->at<float>(a.st1), G2, dybuf(G2), Md, rate, site_dec(N, i, 0), s));
-    SKF_TRY(dense_wgrad(M, w.mha1.o, M->at<float>(a.o1), d, dybuf(G2), d, Md, s));
-    SKF_TRY(dense_dgrad(M, w.mha1.o, dybuf(G2), d, Md, dO, d, 0, nullptr, 0, s));
+    SKF_TRY(ln_bwd(M, w.ln1, G, M->at<float>(a.z1), M->at<float>(a.st1), G2, dy1, Md, rate, site_dec(N, i, 0), s));
+    SKF_TRY(dense_wgrad(M, w.mha1.o, M->at<float>(a.o1), d, dy1, d, Md, s));
+    SKF_TRY(dense_dgrad(M, w.mha1.o, dy1, d, Md, dO, d, 0, nullptr, 0, s));
     const float* qkv = M->at<float>(a.qkv);
     SKF_TRY(before_write(M, dqkv, s));
     SKF_TRY(skf_attention_bwd(qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, M->at<float>(a.o1), d, dO, d,
@@ -722,6 +750,7 @@ int run_backward(SkfModel* M, hipStream_t s) {
     SKF_TRY(dense_wgrad(M, w.mha1.qkv, M->at<float>(a.x_in), d, dqkv, 3 * d, Md, s));
     SKF_TRY(dense_dgrad(M, w.mha1.qkv, dqkv, 3 * d, Md, G2, d, 1, nullptr, 0, s));
     float* t = G; G = G2; G2 = t;
+    SKF_TRY(issue_wgrads(M, s));          // the 8 weight gradients of this layer: one event pair
   }
   // decoder embedding
   if (c.continuous) {
@@ -776,14 +805,18 @@ int run_backward(SkfModel* M, hipStream_t s) {
                        G, M->G(L.bott_v), M->at<char>(P.small_ws), P.small_ws_bytes, s));
   SKF_TRY(dense_wgrad(M, L.bott_w, enc_out, d, M->at<float>(P.u), Ua, Me, s));
   SKF_TRY(dense_dgrad(M, L.bott_w, M->at<float>(P.u), Ua, Me, G, d, 1, nullptr, 0, s));
-  for (int i = N - 1; i >= 0; --i) {
+  SKF_TRY(issue_wgrads(M, s));            // expander / classifier / bottleneck group
+  for (int i = N - 1; i >= 0; --i, ++layer_no) {
     const EncLayerP& w = L.enc[i];
     const EncAct& a = P.enc[i];
-    SKF_TRY(ln_bwd(M, w.ln2, G, M->at<float>(a.z2), M->at<float>(a.st2), G2, dybuf(G2), Me, rate, site_enc(i, 1), s));
-    SKF_TRY(ffn_bwd(M, w.f1, w.f2, M->at<float>(a.x1), M->at<float>(a.h), dybuf(G2), G2, Me, s));
-    SKF_TRY(ln_bwd(M, w.ln1, G2, M->at<float>(a.z1), M->at<float>(a.st1), G, dybuf(G), Me, rate, site_enc(i, 0), s));
-    SKF_TRY(dense_wgrad(M, w.mha.o, M->at<float>(a.o), d, dybuf(G), d, Me, s));
-    SKF_TRY(dense_dgrad(M, w.mha.o, dybuf(G), d, Me, dO, d, 0, nullptr, 0, s));
+    const Plan::GradSet& gs = P.gs[layer_no & 1];
+    float* dy2 = M->at<float>(gs.dy[0]); float* dy1 = M->at<float>(gs.dy[1]);
+    float* dqkv = M->at<float>(gs.dqkv);
+    SKF_TRY(ln_bwd(M, w.ln2, G, M->at<float>(a.z2), M->at<float>(a.st2), G2, dy2, Me, rate, site_enc(i, 1), s));
+    SKF_TRY(ffn_bwd(M, w.f1, w.f2, M->at<float>(a.x1), M->at<float>(a.h), dy2, M->at<float>(gs.dh), G2, Me, s));
+    SKF_TRY(ln_bwd(M, w.ln1, G2, M->at<float>(a.z1), M->at<float>(a.st1), G, dy1, Me, rate, site_enc(i, 0), s));
+    SKF_TRY(dense_wgrad(M, w.mha.o, M->at<float>(a.o), d, dy1, d, Me, s));
+    SKF_TRY(dense_dgrad(M, w.mha.o, dy1, d, Me, dO, d, 0, nullptr, 0, s));
     const float* qkv = M->at<float>(a.qkv);
     SKF_TRY(before_write(M, dqkv, s));
     SKF_TRY(skf_attention_bwd(qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, M->at<float>(a.o), d, dO, d,
@@ -791,6 +824,7 @@ int run_backward(SkfModel* M, hipStream_t s) {
                               dqkv + 2 * d, 3 * d, s));
     SKF_TRY(dense_wgrad(M, w.mha.qkv, M->at<float>(a.x_in), d, dqkv, 3 * d, Me, s));
     SKF_TRY(dense_dgrad(M, w.mha.qkv, dqkv, 3 * d, Me, G, d, 1, nullptr, 0, s));
+    SKF_TRY(issue_wgrads(M, s));
   }
   if (c.continuous) {
     SKF_TRY(skf_embed_continuous_bwd(M->at<float>(P.inp), Le, B, Le, G, d, M->G(L.enc_embd.w), M->G(L.enc_embd.b), rate,

@@ -652,12 +652,13 @@ extern "C" int skf_layernorm_residual_bwd(const float* dout, const float* z, con
   SKF_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "dgamma and dbeta must both be given or both be NULL");
   SKF_CHECK_ARG(workspace && workspace_bytes >= skf_layernorm_bwd_workspace_bytes(rows, d), "workspace too small");
   SKF_CHECK_ARG(rate == 0.f || (step_state && dy), "dropout needs the step state and a dy buffer");
+  SKF_CHECK_ARG(rate > 0.f || !dy || dy == dz || step_state, "a separate dy buffer needs the step state");
   const SkfStepState* st = (const SkfStepState*)step_state;
   int g = grid_for_rows(rows); if (g > kLnBwdGrid) g = kLnBwdGrid;
   dim3 grid(g), block(256);
   hipStream_t s = (hipStream_t)stream;
   float* part = (float*)workspace;
-  float* dyp = rate > 0.f ? dy : nullptr;
+  float* dyp = (dy && (rate > 0.f || dy != dz)) ? dy : nullptr;   // rate 0 with a separate dy buffer: dy = dz
   SkfProfScope ps(s, "ln_bwd", 0.0, (rate > 0.f ? 16.0 : 12.0) * rows * d);
   switch (d) {
     case 128: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, 0, s, dout, z, stats, gamma, dz, dyp, part, rows, rate, site, st); break;
