@@ -77,8 +77,8 @@ int skf_splitk_reduce_batch(const SkfReduceDesc* descs_dev, int ndesc, int total
  * builders/layers/transformer.py:160-186 + the masks of builders/utils.py:35-68.
  * Q (B,Lq,ldq) K,V (B,Lk,ld*) O (B,Lq,ldo); head h = columns [h*dh,(h+1)*dh).
  * key_mask: (B, key_mask_ld) bytes, 1 = padded key (create_padding_mask), may be NULL.
- * causal: add the look-ahead mask (needs Lq == Lk).  stats: (B,H,Lq,2) row max and
- * 1/row-sum, kept for the backward.  dh in {16,32,64}. */
+ * causal: add the look-ahead mask (needs Lq == Lk).  stats: (B,H,Lq,2) row max of the base-2 logits
+ * (q.k * log2(e)/sqrt(dh)) and 1/row-sum - opaque to the caller, kept for the backward.  dh in {16,32,64}. */
 int skf_attention_fwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
                       const unsigned char* key_mask, int key_mask_ld, int causal, int B, int H, int Lq, int Lk, int dh,
                       float* O, int ldo, float* stats, skf_stream_t stream);

@@ -48,6 +48,14 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// Softmax runs in the base-2 domain: s2 = (q.k) * log2(e)/sqrt(dh), p = 2^(s2 - max2) (one v_exp_f32, no extra
+// multiply), the saved row statistics are (max2, 1/sum) and the backward recomputes p the same way.  Masked logits are
+// SET to -1e9 (pad / look-ahead) or -inf (key >= Lk) instead of added: identical probabilities whenever a row sees at
+// least one real key (the reference's fp32 `x + -1e9` already rounds to -1e9), and exactly uniform weights for a
+// fully masked row.  f32 MFMA and VALU share the issue pipe on gfx950, so every per-score VALU instruction counts:
+// the mask work is only done on key tiles that contain a masked key (or the diagonal tile of a causal row), the
+// 1/sum normalisation is applied to the 16 x dh output instead of the L scores, V sits transposed in LDS so that
+// one ds_read_b128 feeds four MFMAs.
 template <int DH, int MAXT>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   constexpr int NC = DH / 16;
@@ -58,14 +66,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   // consecutively in time, so the neighbour's half is an L2 hit instead of a second HBM fetch of the same line.
   const int bh = p.xcd_remap ? skf_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x, b = bh / p.H, h = bh % p.H;
   const int nkt = (p.Lk + 15) >> 4, nqt = (p.Lq + 15) >> 4;
+  const int VP = nkt * 16 + 4;            // pitch of the transposed V image
   float* Ks = smem;                       // [nkt*16][LD]
-  float* Vs = smem + nkt * 16 * LD;       // [nkt*16][LD]
-  float* Ms = Vs + nkt * 16 * LD;         // [nkt*16] additive key mask: 0, -1e9 (padded key) or -inf (key >= Lk)
+  float* Vt = smem + nkt * 16 * LD;       // [DH][VP]   V transposed: Vt[d][key]
+  float* Ms = Vt + DH * VP;               // [nkt*16] key mask: 0, -1e9 (padded key) or -inf (key >= Lk)
+  int* Tf = reinterpret_cast<int*>(Ms + nkt * 16);   // [nkt] 1 = the key tile holds a masked key
+  int* last_valid = Tf + nkt;             // [4]: per-wave index of the last un-padded key
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: loop bounds stay scalar
   const int i = lane & 15, g = lane >> 4;
 
-  // ---- stage K, V (zero-filled tail rows) and the key mask
+  // ---- stage K, V^T (zero-filled tail rows) and the key mask
   for (int e = tid; e < nkt * 16 * (DH / 4); e += 256) {
     const int row = e / (DH / 4), c4 = (e % (DH / 4)) * 4;
     float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
@@ -74,9 +85,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
       vv = *reinterpret_cast<const float4*>(p.V + (size_t)(b * p.Lk + row) * p.ldv + h * DH + c4);
     }
     *reinterpret_cast<float4*>(&Ks[row * LD + c4]) = kv;
-    *reinterpret_cast<float4*>(&Vs[row * LD + c4]) = vv;
+    Vt[(c4 + 0) * VP + row] = vv.x; Vt[(c4 + 1) * VP + row] = vv.y; Vt[(c4 + 2) * VP + row] = vv.z; Vt[(c4 + 3) * VP + row] = vv.w;
   }
-  int* last_valid = reinterpret_cast<int*>(Ms + nkt * 16);   // [4]: per-wave index of the last un-padded key
   {
     int lv = -1;
     for (int key = tid; key < nkt * 16; key += 256) {
@@ -90,17 +100,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     if (lane == 0) last_valid[wave] = lv;
   }
   __syncthreads();
+  if (tid < nkt) {
+    int f = 0;
+    for (int k = 0; k < 16; ++k) f |= Ms[tid * 16 + k] != 0.f;
+    Tf[tid] = f;
+  }
+  __syncthreads();
 
   // Causal tile skipping is exact only when key 0 is visible to every query
   // (then every row max is a real score and masked probabilities are exactly 0).
   const bool can_skip = p.causal && Ms[0] == 0.f;
   // Trailing key tiles that hold only padded keys contribute exactly 0 to every row that sees at least one real
-  // key (exp(-1e9 - max) == 0 in fp32), so they are skipped: QuickDraw batches are ~60 % padding.  Not applied when
-  // some row may have no visible key at all (then the reference's softmax is uniform over ALL keys).
+  // key (2^(-1e9 - max) == 0 in fp32), so they are skipped: QuickDraw batches are ~60 % padding.  Not applied when
+  // some row may have no visible key at all (then the softmax is uniform over ALL keys).
   const int lastk = max(max(last_valid[0], last_valid[1]), max(last_valid[2], last_valid[3]));
   const int nkt_eff = (lastk >= 0 && (!p.causal || can_skip)) ? (lastk >> 4) + 1 : nkt;
-  const float inv_sqrt = 1.0f / sqrtf((float)DH);
-  const bool pow4 = (DH == 16 || DH == 64);
+  const float c2 = 1.44269504088896340736f / sqrtf((float)DH);
 
   // Query tiles are dealt to the waves round-robin starting at a per-workgroup offset: with 13 tiles one wave gets 4 and
   // the others 3, and wave w always runs on SIMD w - without the rotation SIMD 0 of every CU carries the extra tile of
@@ -129,50 +144,54 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
           acc = mfma16(kf.z, qf[c].z, acc);
           acc = mfma16(kf.w, qf[c].w, acc);
         }
-        // logits = (q.k)/sqrt(dh) + max(pad, look_ahead) * -1e9  (one -1e9, never two)
-        const float4 m4 = *reinterpret_cast<const float4*>(&Ms[kt * 16 + g * 4]);
-        const float mr[4] = {m4.x, m4.y, m4.z, m4.w};
+        // wave-uniform: does this tile need any masking at all?
+        const bool need_mask = __builtin_amdgcn_readfirstlane(Tf[kt]) != 0 || (p.causal && kt >= qt);
+        if (need_mask) {
+          const float4 m4 = *reinterpret_cast<const float4*>(&Ms[kt * 16 + g * 4]);
+          const float mr[4] = {m4.x, m4.y, m4.z, m4.w};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = kt * 16 + g * 4 + r;
-          const float cm = (p.causal && key > qrow) ? -1e9f : 0.f;
-          const float v = (pow4 ? acc[r] * inv_sqrt : acc[r] / sqrtf((float)DH)) + fminf(mr[r], cm);
-          s[kt][r] = v;
-          mx = fmaxf(mx, v);
+          for (int r = 0; r < 4; ++r) {
+            const int key = kt * 16 + g * 4 + r;
+            const float m = fminf(mr[r], (p.causal && key > qrow) ? -1e9f : 0.f);   // one -1e9, never two
+            const float v = m < 0.f ? m : acc[r] * c2;
+            s[kt][r] = v;
+            mx = fmaxf(mx, v);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { s[kt][r] = acc[r] * c2; mx = fmaxf(mx, s[kt][r]); }
         }
       }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     float sum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < MAXT; ++kt)
-      if (kt < nt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { s[kt][r] = __expf(s[kt][r] - mx); sum += s[kt][r]; }
-      }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    const float rinv = 1.0f / sum;
     f32x4 o[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) o[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kt = 0; kt < MAXT; ++kt)
       if (kt < nt) {
+        float pe[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float pv = s[kt][r] * rinv;
+        for (int r = 0; r < 4; ++r) { pe[r] = __builtin_amdgcn_exp2f(s[kt][r] - mx); sum += pe[r]; }
 #pragma unroll
-          for (int c = 0; c < NC; ++c)
-            o[c] = mfma16(Vs[(kt * 16 + g * 4 + r) * LD + c * 16 + i], pv, o[c]);
+        for (int c = 0; c < NC; ++c) {
+          const float4 vt = *reinterpret_cast<const float4*>(&Vt[(c * 16 + i) * VP + kt * 16 + g * 4]);
+          o[c] = mfma16(vt.x, pe[0], o[c]);
+          o[c] = mfma16(vt.y, pe[1], o[c]);
+          o[c] = mfma16(vt.z, pe[2], o[c]);
+          o[c] = mfma16(vt.w, pe[3], o[c]);
         }
       }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float rinv = 1.0f / sum;
     if (qok) {
 #pragma unroll
       for (int c = 0; c < NC; ++c)
         *reinterpret_cast<float4*>(p.O + (size_t)(b * p.Lq + qrow) * p.ldo + h * DH + c * 16 + g * 4) =
-            make_float4(o[c][0], o[c][1], o[c][2], o[c][3]);
+            make_float4(o[c][0] * rinv, o[c][1] * rinv, o[c][2] * rinv, o[c][3] * rinv);
       if (g == 0 && p.stats) {
         float2* st = reinterpret_cast<float2*>(p.stats) + ((size_t)bh * p.Lq + qrow);
         *st = make_float2(mx, rinv);
@@ -272,6 +291,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
   const int nkt_eff = (lastk >= 0 && (!p.causal || can_skip)) ? (lastk >> 4) + 1 : nkt;
   const float inv_sqrt = 1.0f / sqrtf((float)DH);
   const bool pow4 = (DH == 16 || DH == 64);
+  const float c2 = 1.44269504088896340736f / sqrtf((float)DH);
   float* tr = Tr + wave * 16 * TLD;
   f32x4 dK_shared[NC], dV_shared[NC];
 #pragma unroll
@@ -366,9 +386,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int q = q0 + g * 4 + r;
-          const float cm = (p.causal && krow > q) ? -1e9f : 0.f;
-          const float v = (pow4 ? sacc[r] * inv_sqrt : sacc[r] / sqrtf((float)DH)) + fminf(kadd[j], cm);
-          const float pv = __expf(v - mxr[r]) * (rir[r] * kvalid[j]);
+          const float m = fminf(kadd[j], (p.causal && krow > q) ? -1e9f : 0.f);
+          const float v = m < 0.f ? m : sacc[r] * c2;             // base-2 logits, masked ones SET (see forward)
+          const float pv = __builtin_amdgcn_exp2f(v - mxr[r]) * (rir[r] * kvalid[j]);
           pr[r] = pv;
           const float d = pv * (dpacc[r] - dlr[r]);
           ds[r] = pow4 ? d * inv_sqrt : d / sqrtf((float)DH);
@@ -465,7 +485,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
   }
 }
 
-size_t fwd_smem(int DH, int Lk) { return (size_t)((Lk + 15) / 16 * 16) * (2 * (DH + 4) + 1) * sizeof(float) + 16; }
+size_t fwd_smem(int DH, int Lk) {
+  const size_t n16 = (size_t)(Lk + 15) / 16 * 16;
+  return (n16 * (DH + 4) + (size_t)DH * (n16 + 4) + n16 + n16 / 16 + 4) * sizeof(float);
+}
 size_t bwd_smem(int DH, int Lq) {
   const size_t QR = (size_t)(Lq + 15) / 16 * 16;
   return (2 * QR * (DH + 4) + (size_t)2 * 4 * 16 * (DH + 1) + 3 * QR + 4 * 16 * 20 + 4) * sizeof(float);
