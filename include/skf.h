@@ -216,6 +216,9 @@ typedef struct SkfConfig {
   float momentum;
   int32_t class_buffer_layers; /* Dense(lowerdim, relu) + Dropout(class_dropout) layers before classify (models/sketchformer.py:44-45,101-104) */
   float class_dropout;
+  /* models/sketchformer.py:42,46,76-108: the class head needs lowerdim > 0 and do_classification; the decoder / output
+   * layer / expander need do_reconstruction; lowerdim == 0 = no bottleneck, the decoder attends to the encoder output */
+  int32_t do_classification, do_reconstruction;
 } SkfConfig;
 
 typedef struct SkfParamEntry {

@@ -66,6 +66,17 @@ class Config:
     class_buffer_layers: int = 0    # models/sketchformer.py:44,101-104
     class_dropout: float = 0.1      # models/sketchformer.py:45
     optimizer: str = "adam"         # models/sketchformer.py:120-126 ('adam' | 'sgd')
+    do_classification: bool = True  # models/sketchformer.py:42,99 (needs lowerdim > 0)
+    do_reconstruction: bool = True  # models/sketchformer.py:46,76
+
+    @property
+    def has_bottleneck(self):
+        return self.lowerdim > 0
+
+    @property
+    def has_classifier(self):
+        """the class head only exists inside the `if lowerdim:` block (models/sketchformer.py:96-108)"""
+        return self.lowerdim > 0 and self.do_classification
 
     def as_dict(self):
         return asdict(self)
@@ -113,31 +124,35 @@ def param_specs(cfg: Config) -> List[Tuple[str, Tuple[int, ...], str]]:
         ffn(p + "/ffn")
         ln(p + "/layernorm1")
         ln(p + "/layernorm2")
-    if cfg.attn_version == 1:
-        specs.append(("bottleneck/W_attn", (d, U), "normal05"))
-        specs.append(("bottleneck/b_attn", (U,), "zeros"))
-        specs.append(("bottleneck/V_attn", (U, 1), "uniform05"))
-        emb_dim = d
-    else:
-        specs.append(("bottleneck/W_attn", (d, d), "normal05"))
-        specs.append(("bottleneck/b_attn", (d,), "zeros"))
-        specs.append(("bottleneck/V_attn", (d, 1), "uniform05"))
-        dense("bottleneck/embeding_layer", d, U)
-        emb_dim = U
-    for i in range(cfg.class_buffer_layers):               # Dense(lowerdim, relu) buffers, models/sketchformer.py:101
-        dense("class_buffer/%d" % i, emb_dim if i == 0 else U, U)
-    dense("classify", U if cfg.class_buffer_layers else emb_dim, cfg.n_classes)
-    dense("expand", 1, L)
-    embed("decoder/embedding")
-    for i in range(cfg.num_layers):
-        p = "decoder/layer%d" % i
-        mha(p + "/mha1", d)
-        mha(p + "/mha2", emb_dim)
-        ffn(p + "/ffn")
-        ln(p + "/layernorm1")
-        ln(p + "/layernorm2")
-        ln(p + "/layernorm3")
-    dense("output", d, 5 if cfg.continuous else cfg.vocab_size)
+    emb_dim = d                                            # lowerdim == 0: the decoder attends to the encoder output
+    if cfg.has_bottleneck:
+        if cfg.attn_version == 1:
+            specs.append(("bottleneck/W_attn", (d, U), "normal05"))
+            specs.append(("bottleneck/b_attn", (U,), "zeros"))
+            specs.append(("bottleneck/V_attn", (U, 1), "uniform05"))
+        else:
+            specs.append(("bottleneck/W_attn", (d, d), "normal05"))
+            specs.append(("bottleneck/b_attn", (d,), "zeros"))
+            specs.append(("bottleneck/V_attn", (d, 1), "uniform05"))
+            dense("bottleneck/embeding_layer", d, U)
+            emb_dim = U
+    if cfg.has_classifier:
+        for i in range(cfg.class_buffer_layers):           # Dense(lowerdim, relu) buffers, models/sketchformer.py:101
+            dense("class_buffer/%d" % i, emb_dim if i == 0 else U, U)
+        dense("classify", U if cfg.class_buffer_layers else emb_dim, cfg.n_classes)
+    if cfg.do_reconstruction:
+        if cfg.has_bottleneck:
+            dense("expand", 1, L)                          # only built (Keras: on first call) when the decoder uses it
+        embed("decoder/embedding")
+        for i in range(cfg.num_layers):
+            p = "decoder/layer%d" % i
+            mha(p + "/mha1", d)
+            mha(p + "/mha2", emb_dim)
+            ffn(p + "/ffn")
+            ln(p + "/layernorm1")
+            ln(p + "/layernorm2")
+            ln(p + "/layernorm3")
+        dense("output", d, 5 if cfg.continuous else cfg.vocab_size)
     return specs
 
 
@@ -599,7 +614,7 @@ def dropout_sites(cfg: Config) -> List[Tuple[str, str]]:
     sites = [("encoder/dropout", "enc")]
     for i in range(cfg.num_layers):
         sites += [("encoder/layer%d/dropout1" % i, "enc"), ("encoder/layer%d/dropout2" % i, "enc")]
-    sites.append(("decoder/dropout", "dec"))
+    sites.append(("decoder/dropout", "dec"))               # site ids are fixed; unused ones simply never get drawn
     for i in range(cfg.num_layers):
         sites += [("decoder/layer%d/dropout%d" % (i, j), "dec") for j in (1, 2, 3)]
     sites += [("class_dropout/%d" % i, "cls") for i in range(cfg.class_buffer_layers)]   # (B, lowerdim), rate class_dropout
@@ -648,25 +663,37 @@ def forward(P, cfg: Config, inp, tar_inp, drops: Optional[dict] = None, training
         x, c = encoder_layer_fwd(P, "encoder/layer%d" % i, x, enc_mask, H, rate, drops)
         c_enc.append(c)
     enc_output = x
-    if cfg.attn_version == 1:
-        emb, bott_w, c_bott = self_attn_v1_fwd(P, enc_output)
+    out = {"enc_output": enc_output}
+    c_bott = c_cls = c_exp = c_demb = c_dec = c_out = None
+    if cfg.has_bottleneck:
+        if cfg.attn_version == 1:
+            emb, bott_w, c_bott = self_attn_v1_fwd(P, enc_output)
+        else:
+            emb, bott_w, c_bott = self_attn_v2_fwd(P, enc_output)
+        out["bottleneck_attn"] = bott_w
     else:
-        emb, bott_w, c_bott = self_attn_v2_fwd(P, enc_output)
-    cls_logits, c_cls = classify_from_embedding_fwd(P, cfg, emb, drops, training)
-    e = np.exp(cls_logits - cls_logits.max(-1, keepdims=True))
-    cls_probs = e / e.sum(-1, keepdims=True)            # Dense(activation='softmax')
+        emb = enc_output                                   # models/sketchformer.py:158-159
+    out["embedding"] = emb
+    if cfg.has_classifier:
+        cls_logits, c_cls = classify_from_embedding_fwd(P, cfg, emb, drops, training)
+        e = np.exp(cls_logits - cls_logits.max(-1, keepdims=True))
+        out["class"] = e / e.sum(-1, keepdims=True)     # Dense(activation='softmax')
+        out["class_logits"] = cls_logits
 
     # ---- decode (models/sketchformer.py:170-181)
-    padding_mask = np.zeros_like(dec_pad_mask) if cfg.blind_decoder_mask else dec_pad_mask
-    pre, c_exp = dense_expander_fwd(P, emb)
-    y, c_demb = _embed_fwd(P, "decoder/embedding", tar_inp, cfg, pos, rate, drops.get("decoder/dropout"))
-    c_dec = []
-    for i in range(cfg.num_layers):
-        y, _, _, c = decoder_layer_fwd(P, "decoder/layer%d" % i, y, pre, combined_mask, padding_mask, H, rate, drops)
-        c_dec.append(c)
-    logits, c_out = dense_fwd(y, P["output/kernel"], P["output/bias"])
-    out = {"embedding": emb, "class": cls_probs, "class_logits": cls_logits, "recon": logits,
-           "enc_output": enc_output, "pre_decoder": pre, "dec_output": y, "bottleneck_attn": bott_w}
+    if cfg.do_reconstruction:
+        padding_mask = np.zeros_like(dec_pad_mask) if cfg.blind_decoder_mask else dec_pad_mask
+        if cfg.has_bottleneck:
+            pre, c_exp = dense_expander_fwd(P, emb)
+        else:
+            pre = emb
+        y, c_demb = _embed_fwd(P, "decoder/embedding", tar_inp, cfg, pos, rate, drops.get("decoder/dropout"))
+        c_dec = []
+        for i in range(cfg.num_layers):
+            y, _, _, c = decoder_layer_fwd(P, "decoder/layer%d" % i, y, pre, combined_mask, padding_mask, H, rate, drops)
+            c_dec.append(c)
+        logits, c_out = dense_fwd(y, P["output/kernel"], P["output/bias"])
+        out.update({"recon": logits, "pre_decoder": pre, "dec_output": y})
     cache = (c_eemb, c_enc, c_bott, c_cls, c_exp, c_demb, c_dec, c_out)
     return out, cache
 
@@ -677,26 +704,38 @@ def loss_and_grads(P, cfg: Config, inp, tar, labels, drops=None, want_grads=True
     tar_inp, tar_real = tar[:, :-1, ...], tar[:, 1:, ...]
     out, cache = forward(P, cfg, inp, tar_inp, drops, training=True)
     c_eemb, c_enc, c_bott, c_cls, c_exp, c_demb, c_dec, c_out = cache
-    if cfg.continuous:
-        recon, c_rl = continuous_recon_loss_fwd(tar_real.astype(out["recon"].dtype), out["recon"], cfg.recon_weight)
-    else:
-        recon, c_rl = recon_loss_fwd(tar_real, out["recon"], cfg.recon_weight)
-    clas, c_cl = class_loss_fwd(labels, out["class_logits"], cfg.class_weight)
-    losses = {"recon_loss": recon, "class_loss": clas, "total_loss": recon + clas}
+    losses, total = {}, 0.0
+    if cfg.do_reconstruction:
+        if cfg.continuous:
+            recon, c_rl = continuous_recon_loss_fwd(tar_real.astype(out["recon"].dtype), out["recon"], cfg.recon_weight)
+        else:
+            recon, c_rl = recon_loss_fwd(tar_real, out["recon"], cfg.recon_weight)
+        losses["recon_loss"] = recon
+        total = total + recon
+    if cfg.has_classifier:
+        clas, c_cl = class_loss_fwd(labels, out["class_logits"], cfg.class_weight)
+        losses["class_loss"] = clas
+        total = total + clas
+    losses["total_loss"] = total
     if not want_grads:
         return losses, out, None
 
     G: Dict[str, np.ndarray] = {}
-    dlogits = continuous_recon_loss_bwd(c_rl) if cfg.continuous else recon_loss_bwd(c_rl)
-    dy, G["output/kernel"], G["output/bias"] = dense_bwd(dlogits, c_out)
-    dpre = 0.0
-    for i in reversed(range(cfg.num_layers)):
-        dy, dp = decoder_layer_bwd(dy, c_dec[i], G)
-        dpre = dpre + dp
-    _embed_bwd(dy, c_demb, "decoder/embedding", cfg, P, G)
-    demb = dense_expander_bwd(dpre, c_exp, G)
-    demb = demb + classify_from_embedding_bwd(class_loss_bwd(c_cl), c_cls, G)
-    if cfg.attn_version == 1:
+    demb = 0.0
+    if cfg.do_reconstruction:
+        dlogits = continuous_recon_loss_bwd(c_rl) if cfg.continuous else recon_loss_bwd(c_rl)
+        dy, G["output/kernel"], G["output/bias"] = dense_bwd(dlogits, c_out)
+        dpre = 0.0
+        for i in reversed(range(cfg.num_layers)):
+            dy, dp = decoder_layer_bwd(dy, c_dec[i], G)
+            dpre = dpre + dp
+        _embed_bwd(dy, c_demb, "decoder/embedding", cfg, P, G)
+        demb = dense_expander_bwd(dpre, c_exp, G) if cfg.has_bottleneck else dpre
+    if cfg.has_classifier:
+        demb = demb + classify_from_embedding_bwd(class_loss_bwd(c_cl), c_cls, G)
+    if not cfg.has_bottleneck:
+        dx = demb
+    elif cfg.attn_version == 1:
         dx = self_attn_v1_bwd(demb, c_bott, P, G)
     else:
         dx = self_attn_v2_bwd(demb, c_bott, P, G)
@@ -725,11 +764,13 @@ def train_step(state: TrainState, cfg: Config, inp, tar, labels, drops=None):
     (models/sketchformer.py:351-359).  Returns the quick-metrics dict."""
     losses, out, G = loss_and_grads(state.params, cfg, inp, tar, labels, drops)
     ms = state.metrics
-    ms.update_mean("recon_loss", losses["recon_loss"])
-    if not cfg.continuous:
-        ms.update_acc("recon_acc", tar[:, 1:], out["recon"])
-    ms.update_mean("class_loss", losses["class_loss"])
-    ms.update_acc("class_acc", labels, out["class"])
+    if cfg.do_reconstruction:
+        ms.update_mean("recon_loss", losses["recon_loss"])
+        if not cfg.continuous:
+            ms.update_acc("recon_acc", tar[:, 1:], out["recon"])
+    if cfg.has_classifier:
+        ms.update_mean("class_loss", losses["class_loss"])
+        ms.update_acc("class_acc", labels, out["class"])
     ms.update_mean("total_loss", losses["total_loss"])
     lr = warmup_decay(state.iterations, cfg.d_model, 5000)
     for k in state.params:
@@ -755,7 +796,11 @@ def encode_from_seq(P, cfg: Config, inp_seq):
     mask = create_padding_mask(inp)
     for i in range(cfg.num_layers):
         x, _ = encoder_layer_fwd(P, "encoder/layer%d" % i, x, mask, cfg.num_heads, 0.0, {})
+    if not cfg.has_bottleneck:
+        return {"enc_output": x, "embedding": x, "class": None}
     emb = self_attn_v1_fwd(P, x)[0] if cfg.attn_version == 1 else self_attn_v2_fwd(P, x)[0]
+    if not cfg.has_classifier:
+        return {"enc_output": x, "embedding": emb, "class": None}
     logits, _ = classify_from_embedding_fwd(P, cfg, emb)
     e = np.exp(logits - logits.max(-1, keepdims=True))
     return {"enc_output": x, "embedding": emb, "class": e / e.sum(-1, keepdims=True)}
@@ -783,7 +828,7 @@ def decode(P, cfg: Config, embedding, target, dec_padding_mask, look_ahead_mask)
     dt = next(iter(P.values())).dtype
     pos = positional_encoding(cfg.max_pos, cfg.d_model).astype(dt)
     padding_mask = np.zeros_like(dec_padding_mask) if cfg.blind_decoder_mask else dec_padding_mask
-    pre, _ = dense_expander_fwd(P, embedding)
+    pre = dense_expander_fwd(P, embedding)[0] if cfg.has_bottleneck else embedding
     y, _ = _embed_fwd(P, "decoder/embedding", target, cfg, pos, 0.0, None)
     for i in range(cfg.num_layers):
         y, _, _, _ = decoder_layer_fwd(P, "decoder/layer%d" % i, y, pre, look_ahead_mask, padding_mask,
@@ -828,9 +873,11 @@ def predict_from_embedding(P, cfg: Config, emb, sos, eos, expected_len=None):
             eos_seen |= (predicted[:, 0] == eos)
             if eos_seen.all():
                 break
-    cls_logits, _ = classify_from_embedding_fwd(P, cfg, emb)
-    return {"recon": output if cfg.continuous else output.astype(np.int32),
-            "class": np.argmax(cls_logits, axis=-1).astype(np.int32)}
+    res = {"recon": output if cfg.continuous else output.astype(np.int32)}
+    if cfg.has_classifier:
+        cls_logits, _ = classify_from_embedding_fwd(P, cfg, emb)
+        res["class"] = np.argmax(cls_logits, axis=-1).astype(np.int32)
+    return res
 
 
 def predict(P, cfg: Config, inp_seq, sos, eos):
@@ -844,6 +891,9 @@ def predict(P, cfg: Config, inp_seq, sos, eos):
         tlen = np.sum(inp[..., -1] != 1, axis=-1)
     else:
         tlen = np.sum(inp > 0, axis=-1)
-    dec = predict_from_embedding(P, cfg, out["embedding"], sos, eos, tlen)
-    return {"embedding": out["embedding"], "class": np.argmax(out["class"], axis=-1).astype(np.int32),
-            "class_probs": out["class"], "recon": dec["recon"]}
+    res = {"embedding": out["embedding"]}
+    if cfg.has_classifier:
+        res.update({"class": np.argmax(out["class"], axis=-1).astype(np.int32), "class_probs": out["class"]})
+    if cfg.do_reconstruction:
+        res["recon"] = predict_from_embedding(P, cfg, out["embedding"], sos, eos, tlen)["recon"]
+    return res

@@ -31,6 +31,7 @@ class SkfConfig(C.Structure):
         ("use_graph", C.c_int32),
         ("optimizer", C.c_int32), ("momentum", C.c_float),
         ("class_buffer_layers", C.c_int32), ("class_dropout", C.c_float),
+        ("do_classification", C.c_int32), ("do_reconstruction", C.c_int32),
     ]
 
 

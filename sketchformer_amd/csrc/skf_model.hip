@@ -102,6 +102,12 @@ struct CrossMhaP { DenseP q, kv, o; };
 struct EncLayerP { SelfMhaP mha; DenseP f1, f2; LnP ln1, ln2; };
 struct DecLayerP { SelfMhaP mha1; CrossMhaP mha2; DenseP f1, f2; LnP ln1, ln2, ln3; };
 
+// models/sketchformer.py:76-108: the bottleneck (+ expander) exists when lowerdim > 0, the class head only inside that
+// block and only with do_classification, the decoder / output layer only with do_reconstruction
+inline bool has_bott(const SkfConfig& c) { return c.lowerdim > 0; }
+inline bool has_cls(const SkfConfig& c) { return c.lowerdim > 0 && c.do_classification != 0; }
+inline bool do_recon(const SkfConfig& c) { return c.do_reconstruction != 0; }
+
 struct Layout {
   size_t total = 0;
   size_t enc_emb = 0, dec_emb = 0;      // token mode: (V,d) tables
@@ -112,6 +118,7 @@ struct Layout {
   size_t bott_v = 0;    // V_attn
   DenseP bott_e{};      // SelfAttnV2 only: Dense(lowerdim) after the pooling (builders/layers/transformer.py:92,128)
   std::vector<DenseP> cbuf;   // class_buffer Dense(lowerdim, relu) layers (models/sketchformer.py:101-104)
+  size_t dec_off = 0;   // offset of the decoder embedding (== total when there is no decoder)
   int E = 0, Ua = 0;    // embedding width (d for V1, lowerdim for V2); units of the attention scorer (lowerdim / d)
   DenseP cls{}, out{};
   size_t exp_w = 0, exp_b = 0;
@@ -157,7 +164,8 @@ LnP lnp(Layout& L, const std::string& name, int d) {
 Layout build_layout(const SkfConfig& c) {
   Layout L;
   const int d = c.d_model;
-  const int E = c.attn_version == 2 ? c.lowerdim : d;     // SelfAttnV1 returns (B,d), V2 projects to (B,lowerdim)
+  // SelfAttnV1 returns (B,d), V2 projects to (B,lowerdim); without a bottleneck the "embedding" is the encoder output
+  const int E = (has_bott(c) && c.attn_version == 2) ? c.lowerdim : d;
   const int Ua = c.attn_version == 2 ? d : c.lowerdim;    // W_attn is (d,units) in V1, (d,d) in V2
   L.E = E; L.Ua = Ua;
   static const char* const qkv_names[3] = {"wq", "wk", "wv"};
@@ -179,19 +187,28 @@ Layout build_layout(const SkfConfig& c) {
     e.ln2 = lnp(L, p + "/layernorm2", d);
     L.enc.push_back(e);
   }
-  L.bott_w.in = d; L.bott_w.out = Ua; L.bott_w.ld = Ua;
-  L.bott_w.w = alloc(L, (size_t)d * Ua); L.bott_w.b = alloc(L, Ua);
-  L.bott_v = alloc(L, Ua);
-  add_entry(L, "bottleneck/W_attn", L.bott_w.w, d, Ua, Ua);
-  add_entry(L, "bottleneck/b_attn", L.bott_w.b, 1, Ua, Ua);
-  add_entry(L, "bottleneck/V_attn", L.bott_v, Ua, 1, 1);
-  if (c.attn_version == 2) L.bott_e = dense(L, "bottleneck/embeding_layer", d, c.lowerdim);
-  for (int i = 0; i < c.class_buffer_layers; ++i)
-    L.cbuf.push_back(dense(L, "class_buffer/" + std::to_string(i), i == 0 ? E : c.lowerdim, c.lowerdim));
-  L.cls = dense(L, "classify", c.class_buffer_layers ? c.lowerdim : E, c.n_classes);
-  L.exp_w = alloc(L, c.seq_len); L.exp_b = alloc(L, c.seq_len);
-  add_entry(L, "expand/kernel", L.exp_w, 1, c.seq_len, c.seq_len);
-  add_entry(L, "expand/bias", L.exp_b, 1, c.seq_len, c.seq_len);
+  if (has_bott(c)) {
+    L.bott_w.in = d; L.bott_w.out = Ua; L.bott_w.ld = Ua;
+    L.bott_w.w = alloc(L, (size_t)d * Ua); L.bott_w.b = alloc(L, Ua);
+    L.bott_v = alloc(L, Ua);
+    add_entry(L, "bottleneck/W_attn", L.bott_w.w, d, Ua, Ua);
+    add_entry(L, "bottleneck/b_attn", L.bott_w.b, 1, Ua, Ua);
+    add_entry(L, "bottleneck/V_attn", L.bott_v, Ua, 1, 1);
+    if (c.attn_version == 2) L.bott_e = dense(L, "bottleneck/embeding_layer", d, c.lowerdim);
+  }
+  if (has_cls(c)) {
+    for (int i = 0; i < c.class_buffer_layers; ++i)
+      L.cbuf.push_back(dense(L, "class_buffer/" + std::to_string(i), i == 0 ? E : c.lowerdim, c.lowerdim));
+    L.cls = dense(L, "classify", c.class_buffer_layers ? c.lowerdim : E, c.n_classes);
+  }
+  L.dec_off = L.total;                   // first float of the decoder-side variables (gradient bucket boundary)
+  if (!do_recon(c)) return L;
+  if (has_bott(c)) {
+    L.exp_w = alloc(L, c.seq_len); L.exp_b = alloc(L, c.seq_len);
+    add_entry(L, "expand/kernel", L.exp_w, 1, c.seq_len, c.seq_len);
+    add_entry(L, "expand/bias", L.exp_b, 1, c.seq_len, c.seq_len);
+  }
+  L.dec_off = L.total;
   if (c.continuous) {
     L.dec_embd = dense(L, "decoder/embedding", 5, d);
   } else {
@@ -257,7 +274,7 @@ Plan build_plan(const SkfConfig& c) {
   Bump b;
   const size_t B = c.batch, L = c.seq_len, Ld = c.seq_len - 1, d = c.d_model, F = c.dff, U = c.lowerdim;
   const size_t Me = B * L, Md = B * Ld, H = c.num_heads, f = sizeof(float);
-  const size_t E = c.attn_version == 2 ? U : d, Ua = c.attn_version == 2 ? d : U;
+  const size_t E = (has_bott(c) && c.attn_version == 2) ? U : d, Ua = c.attn_version == 2 ? d : U;
   const size_t in_bytes = c.continuous ? B * L * 5 * 4 : B * L * 8;   // (B,L,5) f32 or (B,L) i64
   const size_t Vout = c.continuous ? 5 : (size_t)c.vocab_size;
   P.inp = b.take(in_bytes); P.tar = b.take(in_bytes); P.labels = b.take(B * 8);
@@ -306,8 +323,11 @@ Plan build_plan(const SkfConfig& c) {
   size_t g = 0;
   auto mx = [&](size_t v) { if (v > g) g = v; };
   mx(wgrad_ws(d, 3 * d, Me)); mx(wgrad_ws(d, d, Me)); mx(wgrad_ws(d, F, Me)); mx(wgrad_ws(F, d, Me));
-  mx(wgrad_ws((int)E, 2 * d, Me)); mx(wgrad_ws(d, (int)Vout, Md)); mx(wgrad_ws(d, (int)Ua, Me));
-  mx(wgrad_ws((int)E, c.n_classes, B)); mx(wgrad_ws(U, c.n_classes, B)); mx(wgrad_ws(d, U, B)); mx(wgrad_ws((int)E, U, B)); mx(wgrad_ws(U, U, B));
+  mx(wgrad_ws((int)E, 2 * d, Me)); mx(wgrad_ws(d, (int)Vout, Md));
+  if (has_bott(c)) {
+    mx(wgrad_ws(d, (int)Ua, Me));
+    mx(wgrad_ws((int)E, c.n_classes, B)); mx(wgrad_ws(U, c.n_classes, B)); mx(wgrad_ws(d, U, B)); mx(wgrad_ws((int)E, U, B)); mx(wgrad_ws(U, U, B));
+  }
   P.gemm_ws_bytes = g; P.gemm_ws = b.take(g);
   P.n_wgrads = 4 + 11 * (size_t)c.num_layers + (size_t)c.class_buffer_layers + 5 * (size_t)c.num_layers;   // + one entry per LayerNorm
   P.ln_part_stride = (skf_layernorm_bwd_workspace_bytes((int)Me, (int)d) + 255) & ~(size_t)255;
@@ -573,19 +593,29 @@ int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s, bool 
   float* enc_out = M->at<float>(P.enc[N - 1].x2);
   // ---------------- bottleneck + classifier + expander (models/sketchformer.py:149-160,183-199,170-176)
   const int E = L.E, Ua = L.Ua;
-  SKF_TRY(dense_fwd(M, L.bott_w, enc_out, Me, M->at<float>(P.u), 2, s));
-  SKF_TRY(skf_pool_fwd(M->at<float>(P.u), M->P(L.bott_v), enc_out, B, Le, Ua, d, M->at<float>(P.pool_a),
-                       M->at<float>(c.attn_version == 2 ? P.pooled : P.emb), s));
-  if (c.attn_version == 2)   // SelfAttnV2: o = embeding_layer(o) (builders/layers/transformer.py:128-129)
-    SKF_TRY(dense_fwd(M, L.bott_e, M->at<float>(P.pooled), B, M->at<float>(P.emb), 0, s));
-  SKF_TRY(classify_fwd(M, training, s));
-  if (encoder_only) {   // encode_from_seq / predict_class (models/sketchformer.py:162-168,223-228): class probabilities only
-    return skf_softmax_ce(M->at<float>(P.cls_logits), c.n_classes, B, c.n_classes, M->at<long long>(P.labels), 1, 1, 0, 0, 0.f,
-                          M->at<float>(P.cls_loss), M->at<float>(P.cls_hit), M->at<float>(P.cls_probs), 0, s);
+  const bool bott = has_bott(c), cls = has_cls(c), recon = do_recon(c);
+  if (bott) {
+    SKF_TRY(dense_fwd(M, L.bott_w, enc_out, Me, M->at<float>(P.u), 2, s));
+    SKF_TRY(skf_pool_fwd(M->at<float>(P.u), M->P(L.bott_v), enc_out, B, Le, Ua, d, M->at<float>(P.pool_a),
+                         M->at<float>(c.attn_version == 2 ? P.pooled : P.emb), s));
+    if (c.attn_version == 2)   // SelfAttnV2: o = embeding_layer(o) (builders/layers/transformer.py:128-129)
+      SKF_TRY(dense_fwd(M, L.bott_e, M->at<float>(P.pooled), B, M->at<float>(P.emb), 0, s));
   }
-  SKF_TRY(skf_expander_fwd(M->at<float>(P.emb), M->P(L.exp_w), M->P(L.exp_b), B, Le, E, M->at<float>(P.pre), s));
+  if (cls) SKF_TRY(classify_fwd(M, training, s));
+  if (encoder_only || !recon) {
+    if (encoder_only || !with_loss) {   // encode_from_seq / predict_class (models/sketchformer.py:162-168,223-228): class probabilities only
+      if (!cls) return SKF_OK;
+      return skf_softmax_ce(M->at<float>(P.cls_logits), c.n_classes, B, c.n_classes, M->at<long long>(P.labels), 1, 1, 0, 0, 0.f,
+                            M->at<float>(P.cls_loss), M->at<float>(P.cls_hit), M->at<float>(P.cls_probs), 0, s);
+    }
+  }
+  // pre_decoder: the expanded embedding, or the encoder output itself when there is no bottleneck (:172-176)
+  float* pre = bott ? M->at<float>(P.pre) : enc_out;
+  if (recon && bott)
+    SKF_TRY(skf_expander_fwd(M->at<float>(P.emb), M->P(L.exp_w), M->P(L.exp_b), B, Le, E, pre, s));
 
   // ---------------- decoder (builders/layers/transformer.py:325-344)
+  if (recon) {
   if (c.continuous)
     SKF_TRY(skf_embed_continuous_fwd(tarf, Le, B, Ld, M->P(L.dec_embd.w), M->P(L.dec_embd.b), d, M->pos,
                                      M->at<float>(P.dec[0].x_in), rate, site_dec_embed(N), M->state, s));
@@ -606,7 +636,7 @@ int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s, bool 
                                        M->at<float>(a.st1), Md, d, rate, site_dec(N, i, 0), M->state, s));
     float* kv2 = M->at<float>(a.kv2);
     SKF_TRY(dense_fwd(M, w.mha2.q, M->at<float>(a.out1), Md, M->at<float>(a.q2), 0, s));
-    SKF_TRY(dense_fwd(M, w.mha2.kv, M->at<float>(P.pre), Me, kv2, 0, s));
+    SKF_TRY(dense_fwd(M, w.mha2.kv, pre, Me, kv2, 0, s));
     SKF_TRY(skf_attention_fwd(M->at<float>(a.q2), d, kv2, 2 * d, kv2 + d, 2 * d, cross_mask, Le, 0, B, H, Ld, Le, dh,
                               M->at<float>(a.o2), d, M->at<float>(a.astats2), s));
     SKF_TRY(dense_fwd(M, w.mha2.o, M->at<float>(a.o2), Md, M->at<float>(a.z2), 0, s));
@@ -618,27 +648,32 @@ int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s, bool 
                                        M->at<float>(a.out3), M->at<float>(a.st3), Md, d, rate, site_dec(N, i, 2), M->state, s));
   }
   SKF_TRY(dense_fwd(M, L.out, M->at<float>(P.dec[N - 1].out3), Md, M->at<float>(P.logits), 0, s));
+  }
 
   // ---------------- losses + metrics (models/sketchformer.py:334-346)
   const long long* labels = M->at<long long>(P.labels);
   if (with_loss) {
     // tar_real = tar[:, 1:]  -> target offset 1 within rows of stride L
     const float* recon_scalar = nullptr;
-    if (c.continuous) {
-      SKF_TRY(skf_continuous_loss(M->at<float>(P.logits), tarf, Le, Ld, 1, Md, c.recon_weight, M->at<float>(P.recon_loss),
-                                  M->at<float>(P.recon_hit), M->at<float>(P.row_mask), M->at<float>(P.cont_scal), 1, s));
-      recon_scalar = M->at<float>(P.cont_scal) + 3;
-    } else {
-      SKF_TRY(skf_softmax_ce(M->at<float>(P.logits), c.vocab_size, Md, c.vocab_size, tar, Le, Ld, 1, 1,
-                             c.recon_weight / (float)Md, M->at<float>(P.recon_loss), M->at<float>(P.recon_hit), nullptr, 1, s));
+    if (recon) {
+      if (c.continuous) {
+        SKF_TRY(skf_continuous_loss(M->at<float>(P.logits), tarf, Le, Ld, 1, Md, c.recon_weight, M->at<float>(P.recon_loss),
+                                    M->at<float>(P.recon_hit), M->at<float>(P.row_mask), M->at<float>(P.cont_scal), 1, s));
+        recon_scalar = M->at<float>(P.cont_scal) + 3;
+      } else {
+        SKF_TRY(skf_softmax_ce(M->at<float>(P.logits), c.vocab_size, Md, c.vocab_size, tar, Le, Ld, 1, 1,
+                               c.recon_weight / (float)Md, M->at<float>(P.recon_loss), M->at<float>(P.recon_hit), nullptr, 1, s));
+      }
     }
-    SKF_TRY(skf_softmax_ce(M->at<float>(P.cls_logits), c.n_classes, B, c.n_classes, labels, 1, 1, 0, 0,
-                           c.class_weight / (float)B, M->at<float>(P.cls_loss), M->at<float>(P.cls_hit),
-                           M->at<float>(P.cls_probs), 1, s));
-    SKF_TRY(skf_metrics_update(M->at<float>(P.recon_loss), M->at<float>(P.recon_hit), Md, c.recon_weight,
-                               M->at<float>(P.cls_loss), M->at<float>(P.cls_hit), B, c.class_weight, recon_scalar,
+    if (cls)
+      SKF_TRY(skf_softmax_ce(M->at<float>(P.cls_logits), c.n_classes, B, c.n_classes, labels, 1, 1, 0, 0,
+                             c.class_weight / (float)B, M->at<float>(P.cls_loss), M->at<float>(P.cls_hit),
+                             M->at<float>(P.cls_probs), 1, s));
+    // absent heads contribute 0 rows: their loss is 0 in total_loss (sum(all_losses), models/sketchformer.py:345)
+    SKF_TRY(skf_metrics_update(M->at<float>(P.recon_loss), M->at<float>(P.recon_hit), recon ? Md : 0, c.recon_weight,
+                               M->at<float>(P.cls_loss), M->at<float>(P.cls_hit), cls ? B : 0, c.class_weight, recon_scalar,
                                M->metrics, s));
-  } else {
+  } else if (cls) {
     SKF_TRY(skf_softmax_ce(M->at<float>(P.cls_logits), c.n_classes, B, c.n_classes, labels, 1, 1, 0, 0, 0.f,
                            M->at<float>(P.cls_loss), M->at<float>(P.cls_hit), M->at<float>(P.cls_probs), 0, s));
   }
@@ -708,6 +743,10 @@ int run_backward(SkfModel* M, hipStream_t s) {
   M->wq.clear();
   int layer_no = 0;     // running layer counter: picks the gradient-buffer set
 
+  const bool bott = has_bott(c), cls = has_cls(c), recon = do_recon(c);
+  float* enc_out = M->at<float>(P.enc[N - 1].x2);
+  const float* pre = bott ? M->at<float>(P.pre) : enc_out;      // pre_decoder (see run_forward)
+  if (recon) {
   // output layer: logits buffer now holds dlogits
   const float* dlog = M->at<float>(P.logits);
   SKF_TRY(dense_wgrad(M, L.out, M->at<float>(P.dec[N - 1].out3), d, dlog, L.out.out, Md, s));
@@ -736,7 +775,7 @@ int run_backward(SkfModel* M, hipStream_t s) {
                               dkv2 + d, 2 * d, s));
     SKF_TRY(dense_wgrad(M, w.mha2.q, M->at<float>(a.out1), d, dq2, d, Md, s));
     SKF_TRY(dense_dgrad(M, w.mha2.q, dq2, d, Md, G, d, 1, nullptr, 0, s));
-    SKF_TRY(dense_wgrad(M, w.mha2.kv, M->at<float>(P.pre), L.E, dkv2, 2 * d, Me, s));
+    SKF_TRY(dense_wgrad(M, w.mha2.kv, pre, L.E, dkv2, 2 * d, Me, s));
     SKF_TRY(dense_dgrad(M, w.mha2.kv, dkv2, 2 * d, Me, dpre, L.E, i != N - 1, nullptr, 0, s));
     // out1 = LN1(x + drop(mha1(x,x,x)))
     SKF_TRY(ln_bwd(M, w.ln1, G, M->at<float>(a.z1), M->at<float>(a.st1), G2, dy1, Md, rate, site_dec(N, i, 0), s));
@@ -762,49 +801,57 @@ int run_backward(SkfModel* M, hipStream_t s) {
   }
   // every gradient of [decoder embedding .. output layer] is issued: first bucket of the flat buffer
   if (M->n_buckets == 2) SKF_TRY(flush_wgrads(M, s, 0, false));
-  // expander, classifier
+  }   // recon
   const int E = L.E, Ua = L.Ua, U = c.lowerdim, NB = c.class_buffer_layers;
-  SKF_TRY(skf_expander_bwd(dpre, M->at<float>(P.emb), M->P(L.exp_w), B, Le, E, demb, 0, M->G(L.exp_w), M->G(L.exp_b),
-                           M->at<char>(P.small_ws), P.small_ws_bytes, s));
-  // classifier (+ class buffers): d fc_i = dropout'(.) then relu'(.) - both are element-wise masks and commute
-  const float* dcls = M->at<float>(P.cls_logits);
-  if (NB == 0) {
-    SKF_TRY(dense_wgrad(M, L.cls, M->at<float>(P.emb), E, dcls, c.n_classes, B, s));
-    SKF_TRY(dense_dgrad(M, L.cls, dcls, c.n_classes, B, demb, E, 1, nullptr, 0, s));
-  } else {
-    float* dz = M->at<float>(P.dcb[0]);
-    float* dz2 = M->at<float>(P.dcb[1]);
-    SKF_TRY(before_write(M, dz, s));
-    SKF_TRY(dense_wgrad(M, L.cls, M->at<float>(P.cb_f[NB - 1]), U, dcls, c.n_classes, B, s));
-    SKF_TRY(dense_dgrad(M, L.cls, dcls, c.n_classes, B, dz, U, 0, M->at<float>(P.cb_h[NB - 1]), U, s));
-    for (int i = NB - 1; i >= 0; --i) {
-      SKF_TRY(skf_dropout(dz, dz, (size_t)B * U, c.class_dropout, site_class(N, i), M->state, s));
-      const float* in = i == 0 ? M->at<float>(P.emb) : M->at<float>(P.cb_f[i - 1]);
-      const int in_w = i == 0 ? E : U;
-      SKF_TRY(dense_wgrad(M, L.cbuf[i], in, in_w, dz, U, B, s));
-      if (i == 0) {
-        SKF_TRY(dense_dgrad(M, L.cbuf[0], dz, U, B, demb, E, 1, nullptr, 0, s));
-      } else {
-        SKF_TRY(before_write(M, dz2, s));
-        SKF_TRY(dense_dgrad(M, L.cbuf[i], dz, U, B, dz2, U, 0, M->at<float>(P.cb_h[i - 1]), U, s));
-        float* t = dz; dz = dz2; dz2 = t;
+  if (bott) {
+    // expander, classifier
+    if (recon)
+      SKF_TRY(skf_expander_bwd(dpre, M->at<float>(P.emb), M->P(L.exp_w), B, Le, E, demb, 0, M->G(L.exp_w), M->G(L.exp_b),
+                               M->at<char>(P.small_ws), P.small_ws_bytes, s));
+    const int acc_emb = recon ? 1 : 0;        // without a decoder the class head is the only source of d(embedding)
+    // classifier (+ class buffers): d fc_i = dropout'(.) then relu'(.) - both are element-wise masks and commute
+    const float* dcls = M->at<float>(P.cls_logits);
+    if (cls && NB == 0) {
+      SKF_TRY(dense_wgrad(M, L.cls, M->at<float>(P.emb), E, dcls, c.n_classes, B, s));
+      SKF_TRY(dense_dgrad(M, L.cls, dcls, c.n_classes, B, demb, E, acc_emb, nullptr, 0, s));
+    } else if (cls) {
+      float* dz = M->at<float>(P.dcb[0]);
+      float* dz2 = M->at<float>(P.dcb[1]);
+      SKF_TRY(before_write(M, dz, s));
+      SKF_TRY(dense_wgrad(M, L.cls, M->at<float>(P.cb_f[NB - 1]), U, dcls, c.n_classes, B, s));
+      SKF_TRY(dense_dgrad(M, L.cls, dcls, c.n_classes, B, dz, U, 0, M->at<float>(P.cb_h[NB - 1]), U, s));
+      for (int i = NB - 1; i >= 0; --i) {
+        SKF_TRY(skf_dropout(dz, dz, (size_t)B * U, c.class_dropout, site_class(N, i), M->state, s));
+        const float* in = i == 0 ? M->at<float>(P.emb) : M->at<float>(P.cb_f[i - 1]);
+        const int in_w = i == 0 ? E : U;
+        SKF_TRY(dense_wgrad(M, L.cbuf[i], in, in_w, dz, U, B, s));
+        if (i == 0) {
+          SKF_TRY(dense_dgrad(M, L.cbuf[0], dz, U, B, demb, E, acc_emb, nullptr, 0, s));
+        } else {
+          SKF_TRY(before_write(M, dz2, s));
+          SKF_TRY(dense_dgrad(M, L.cbuf[i], dz, U, B, dz2, U, 0, M->at<float>(P.cb_h[i - 1]), U, s));
+          float* t = dz; dz = dz2; dz2 = t;
+        }
       }
     }
+    // bottleneck
+    const float* dpool = demb;
+    if (c.attn_version == 2) {
+      SKF_TRY(before_write(M, M->at<float>(P.dpooled), s));
+      SKF_TRY(dense_wgrad(M, L.bott_e, M->at<float>(P.pooled), d, demb, U, B, s));
+      SKF_TRY(dense_dgrad(M, L.bott_e, demb, U, B, M->at<float>(P.dpooled), d, 0, nullptr, 0, s));
+      dpool = M->at<float>(P.dpooled);
+    }
+    SKF_TRY(before_write(M, G, s));
+    SKF_TRY(skf_pool_bwd(M->at<float>(P.u), M->P(L.bott_v), enc_out, M->at<float>(P.pool_a), dpool, B, Le, Ua, d,
+                         G, M->G(L.bott_v), M->at<char>(P.small_ws), P.small_ws_bytes, s));
+    SKF_TRY(dense_wgrad(M, L.bott_w, enc_out, d, M->at<float>(P.u), Ua, Me, s));
+    SKF_TRY(dense_dgrad(M, L.bott_w, M->at<float>(P.u), Ua, Me, G, d, 1, nullptr, 0, s));
+  } else {
+    // no bottleneck: d(enc_output) is what the cross-attention K/V projections of all decoder layers sent back
+    float* spare = (G == M->at<float>(P.gA)) ? M->at<float>(P.gB) : M->at<float>(P.gA);
+    G = dpre; G2 = spare;
   }
-  // bottleneck
-  float* enc_out = M->at<float>(P.enc[N - 1].x2);
-  const float* dpool = demb;
-  if (c.attn_version == 2) {
-    SKF_TRY(before_write(M, M->at<float>(P.dpooled), s));
-    SKF_TRY(dense_wgrad(M, L.bott_e, M->at<float>(P.pooled), d, demb, U, B, s));
-    SKF_TRY(dense_dgrad(M, L.bott_e, demb, U, B, M->at<float>(P.dpooled), d, 0, nullptr, 0, s));
-    dpool = M->at<float>(P.dpooled);
-  }
-  SKF_TRY(before_write(M, G, s));
-  SKF_TRY(skf_pool_bwd(M->at<float>(P.u), M->P(L.bott_v), enc_out, M->at<float>(P.pool_a), dpool, B, Le, Ua, d,
-                       G, M->G(L.bott_v), M->at<char>(P.small_ws), P.small_ws_bytes, s));
-  SKF_TRY(dense_wgrad(M, L.bott_w, enc_out, d, M->at<float>(P.u), Ua, Me, s));
-  SKF_TRY(dense_dgrad(M, L.bott_w, M->at<float>(P.u), Ua, Me, G, d, 1, nullptr, 0, s));
   SKF_TRY(issue_wgrads(M, s));            // expander / classifier / bottleneck group
   for (int i = N - 1; i >= 0; --i, ++layer_no) {
     const EncLayerP& w = L.enc[i];
@@ -852,8 +899,17 @@ int run_greedy_decode(SkfModel* M, const float* embedding, const int* expected_l
   const int T = max_steps + 1;                         // columns of the output buffer
   const int Vout = c.continuous ? 5 : c.vocab_size;
   (void)F;
-  if (embedding && embedding != M->at<float>(P.emb))
-    SKF_HIP(hipMemcpyAsync(M->at<float>(P.emb), embedding, (size_t)B * L.E * sizeof(float), hipMemcpyDeviceToDevice, s));
+  const bool bott = has_bott(c);
+  float* enc_out = M->at<float>(P.enc[N - 1].x2);
+  // the embedding is (B, E) with a bottleneck, else the whole encoder output (B, L, d) = pre_decoder itself
+  const float* pre = bott ? M->at<float>(P.pre) : enc_out;
+  if (bott) {
+    if (embedding && embedding != M->at<float>(P.emb))
+      SKF_HIP(hipMemcpyAsync(M->at<float>(P.emb), embedding, (size_t)B * L.E * sizeof(float), hipMemcpyDeviceToDevice, s));
+  } else if (embedding && embedding != enc_out) {
+    SKF_HIP(hipMemcpyAsync(M->at<float>(P.pre), embedding, (size_t)B * Le * d * sizeof(float), hipMemcpyDeviceToDevice, s));
+    pre = M->at<float>(P.pre);
+  }
   int* eos_seen = M->at<int>(P.dc_flags);
   int* done_step = eos_seen + B;
   unsigned char* selfmask = M->at<unsigned char>(P.dc_mask);
@@ -866,12 +922,15 @@ int run_greedy_decode(SkfModel* M, const float* embedding, const int* expected_l
     SKF_HIP(hipMemcpyAsync(limit, expected_len_host, (size_t)B * sizeof(int), hipMemcpyHostToDevice, s));
   }
   // pre_decoder and the cross-attention K/V of every layer: once
-  SKF_TRY(skf_expander_fwd(M->at<float>(P.emb), M->P(L.exp_w), M->P(L.exp_b), B, Le, L.E, M->at<float>(P.pre), s));
+  if (bott)
+    SKF_TRY(skf_expander_fwd(M->at<float>(P.emb), M->P(L.exp_w), M->P(L.exp_b), B, Le, L.E, M->at<float>(P.pre), s));
   for (int l = 0; l < N; ++l)
-    SKF_TRY(dense_fwd(M, L.dec[l].mha2.kv, M->at<float>(P.pre), B * Le, M->at<float>(P.dec[l].kv2), 0, s));
-  SKF_TRY(classify_fwd(M, false, s));                                                         // classify_from_embedding
-  SKF_TRY(skf_softmax_ce(M->at<float>(P.cls_logits), c.n_classes, B, c.n_classes, M->at<long long>(P.labels), 1, 1, 0, 0, 0.f,
-                         M->at<float>(P.cls_loss), M->at<float>(P.cls_hit), M->at<float>(P.cls_probs), 0, s));
+    SKF_TRY(dense_fwd(M, L.dec[l].mha2.kv, pre, B * Le, M->at<float>(P.dec[l].kv2), 0, s));
+  if (has_cls(c)) {
+    SKF_TRY(classify_fwd(M, false, s));                                                       // classify_from_embedding
+    SKF_TRY(skf_softmax_ce(M->at<float>(P.cls_logits), c.n_classes, B, c.n_classes, M->at<long long>(P.labels), 1, 1, 0, 0, 0.f,
+                           M->at<float>(P.cls_loss), M->at<float>(P.cls_hit), M->at<float>(P.cls_probs), 0, s));
+  }
 
   float* q = M->at<float>(P.dc_q); float* o = M->at<float>(P.dc_o); float* z = M->at<float>(P.dc_z);
   float* out1 = M->at<float>(P.dc_out1); float* out2 = M->at<float>(P.dc_out2); float* hbuf = M->at<float>(P.dc_h);
@@ -980,8 +1039,12 @@ extern "C" int skf_config_validate(const SkfConfig* c) {
   if (!(c->d_model == 64 || c->d_model == 128 || c->d_model == 256 || c->d_model == 512)) {
     skf_set_error("d_model %d not in {64,128,256,512}", c->d_model); return SKF_EUNSUPPORTED; }
   SKF_CHECK_ARG(c->attn_version == 1 || c->attn_version == 2, "attn_version must be 1 (SelfAttnV1) or 2 (SelfAttnV2)");
-  if (c->lowerdim <= 0) { skf_set_error("lowerdim=0 (no bottleneck) is not implemented"); return SKF_EUNSUPPORTED; }
-  if (c->attn_version == 2 && !(c->lowerdim == 64 || c->lowerdim == 128 || c->lowerdim == 256 || c->lowerdim == 512)) {
+  SKF_CHECK_ARG(c->lowerdim >= 0, "lowerdim must be >= 0");
+  // models/sketchformer.py:96-108,338: the class head only exists with a bottleneck; asking for it without one fails
+  // in the reference too (the 'class' loss is never registered)
+  SKF_CHECK_ARG(c->lowerdim > 0 || !c->do_classification, "do_classification needs lowerdim > 0");
+  SKF_CHECK_ARG(c->do_reconstruction || (c->lowerdim > 0 && c->do_classification), "nothing to train: no decoder and no class head");
+  if (c->lowerdim > 0 && c->attn_version == 2 && !(c->lowerdim == 64 || c->lowerdim == 128 || c->lowerdim == 256 || c->lowerdim == 512)) {
     skf_set_error("attn_version=2: lowerdim %d (the embedding width) not in {64,128,256,512}", c->lowerdim); return SKF_EUNSUPPORTED; }
   SKF_CHECK_ARG(c->class_buffer_layers >= 0 && c->class_buffer_layers <= 8, "class_buffer_layers must be in [0, 8]");
   SKF_CHECK_ARG(c->class_dropout >= 0.f && c->class_dropout < 1.f, "class_dropout out of range");
@@ -1031,10 +1094,11 @@ extern "C" int skf_model_create(const SkfConfig* cfg, SkfModel** out) {
   reg("logits", P.logits, B * Ld, cfg->continuous ? 5 : cfg->vocab_size);
   reg("class_probs", P.cls_probs, B, cfg->n_classes);
   reg("class_logits", P.cls_logits, B, cfg->n_classes);
-  reg("embedding", P.emb, B, M->lay.E);
+  if (has_bott(*cfg)) reg("embedding", P.emb, B, M->lay.E);
+  else reg("embedding", P.enc[N - 1].x2, B * L, d);              // no bottleneck: the encoder output (models/sketchformer.py:158-159)
   reg("enc_output", P.enc[N - 1].x2, B * L, d);
   reg("dec_output", P.dec[N - 1].out3, B * Ld, d);
-  reg("pre_decoder", P.pre, B * L, M->lay.E);
+  reg("pre_decoder", has_bott(*cfg) ? P.pre : P.enc[N - 1].x2, B * L, M->lay.E);
   reg("bottleneck_attn", P.pool_a, B, L);
   reg("enc_embed_out", P.enc[0].x_in, B * L, d);
   reg("dec_embed_out", P.dec[0].x_in, B * Ld, d);
@@ -1043,7 +1107,7 @@ extern "C" int skf_model_create(const SkfConfig* cfg, SkfModel** out) {
   if (!cfg->use_graph && !(getenv("SKF_NO_SIDE_STREAM") && getenv("SKF_NO_SIDE_STREAM")[0] == '1'))
     SKF_HIP(hipStreamCreateWithFlags(&M->side, hipStreamNonBlocking));
   if (!cfg->use_graph) {     // events cannot be recorded for outside waiters inside a captured graph: one bucket there
-    M->n_buckets = 2;
+    M->n_buckets = do_recon(*cfg) ? 2 : 1;
     for (int i = 0; i < 2; ++i) SKF_HIP(hipEventCreateWithFlags(&M->bucket_ready[i], hipEventDisableTiming));
   }
   *out = M;
@@ -1097,6 +1161,7 @@ extern "C" int skf_model_greedy_decode(SkfModel* m, const float* embedding, cons
   SKF_CHECK_ARG(out, "null output");
   SKF_CHECK_ARG(n_valid > 0 && n_valid <= m->cfg.batch, "n_valid must be in [1, batch]");
   SKF_CHECK_ARG(max_steps > 0 && max_steps <= m->cfg.seq_len, "max_steps must be in [1, seq_len]");
+  SKF_CHECK_ARG(m->cfg.do_reconstruction, "the model was built without a decoder (do_reconstruction = 0)");
   return run_greedy_decode(m, embedding, expected_len_host, n_valid, sos, eos, max_steps, out, out_len_host,
                            (hipStream_t)stream);
 }
@@ -1131,7 +1196,7 @@ extern "C" int skf_model_apply_gradients(SkfModel* m, float grad_scale, skf_stre
 
 extern "C" int skf_model_grad_buckets(SkfModel* m, int max_buckets, size_t* offsets_host, size_t* counts_host) {
   SKF_CHECK_ARG(m && offsets_host && counts_host && max_buckets >= 2, "bad argument");
-  const size_t dec_off = m->cfg.continuous ? m->lay.dec_embd.w : m->lay.dec_emb;
+  const size_t dec_off = m->lay.dec_off;
   if (m->n_buckets == 2) {
     offsets_host[0] = dec_off; counts_host[0] = m->lay.total - dec_off;      // decoder embedding .. output layer
     offsets_host[1] = 0; counts_host[1] = dec_off;                           // encoder .. expander

@@ -35,7 +35,8 @@ def positional_encoding(position, d_model):
 def make_config(batch, seq_len=200, d_model=128, num_heads=8, dff=512, num_layers=4, vocab_size=1004, n_classes=345,
                 lowerdim=256, attn_version=1, continuous=False, blind_decoder_mask=True, dropout_rate=0.1,
                 recon_weight=1.0, class_weight=1.0, lr_scheduler="WarmupDecay", lr=0.01, seed=0, use_graph=True,
-                max_pos=1000, optimizer="Adam", class_buffer_layers=0, class_dropout=0.1):
+                max_pos=1000, optimizer="Adam", class_buffer_layers=0, class_dropout=0.1, do_classification=True,
+                do_reconstruction=True):
     cfg = SkfConfig()
     cfg.batch, cfg.seq_len, cfg.d_model, cfg.num_heads, cfg.dff, cfg.num_layers = batch, seq_len, d_model, num_heads, dff, num_layers
     cfg.vocab_size, cfg.n_classes, cfg.lowerdim, cfg.attn_version = vocab_size or 0, n_classes, lowerdim, attn_version
@@ -60,6 +61,7 @@ def make_config(batch, seq_len=200, d_model=128, num_heads=8, dff=512, num_layer
     else:
         raise ValueError("unknown optimizer %r" % optimizer)
     cfg.class_buffer_layers, cfg.class_dropout = int(class_buffer_layers), float(class_dropout)
+    cfg.do_classification, cfg.do_reconstruction = int(bool(do_classification)), int(bool(do_reconstruction))
     return cfg
 
 
@@ -242,9 +244,12 @@ class TrainEngine:
         if embedding is not None:
             e = torch.as_tensor(np.asarray(embedding, dtype=np.float32) if not torch.is_tensor(embedding) else embedding)
             e = e.to(self.device, dtype=torch.float32).contiguous()
-            E = self.cfg.lowerdim if self.cfg.attn_version == 2 else self.cfg.d_model    # SelfAttnV2 projects to lowerdim
-            if e.shape != (B, E):
-                raise ValueError("embedding must be (batch=%d, %d)" % (B, E))
+            if self.cfg.lowerdim == 0:      # no bottleneck: the "embedding" is the encoder output (B, L, d)
+                want = (B, L, self.cfg.d_model)
+            else:                           # SelfAttnV2 projects to lowerdim
+                want = (B, self.cfg.lowerdim if self.cfg.attn_version == 2 else self.cfg.d_model)
+            if tuple(e.shape) != want:
+                raise ValueError("embedding must have shape %r" % (want,))
             emb_ptr = self._p(e)
         lim = None
         if expected_len is not None:

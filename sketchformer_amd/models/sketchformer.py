@@ -36,25 +36,25 @@ class Transformer(BaseModel):
     def build_model(self):
         from .. import engine
         h = self.hps
-        for key, ok, why in (('do_classification', True, 'the classification head is always built'),
-                             ('do_reconstruction', True, 'the decoder is always built')):
-            if h[key] != ok:
-                raise NotImplementedError("%s=%r is not implemented on the HIP path (%s)" % (key, h[key], why))
-        if not h['lowerdim']:
-            raise NotImplementedError("lowerdim=0 (no bottleneck: the decoder attends to the encoder output) is not "
-                                      "implemented on the HIP path")
         if h['optimizer'].lower() not in ('adam', 'sgd'):
             raise ValueError("optimizer=%r: the reference builds Adam or SGD (models/sketchformer.py:120-126)" % h['optimizer'])
-        if self.dataset.hps['use_continuous_data']:
-            self.losses_manager.add_continuous_reconstruction_loss('recon', weight=h['recon_weight'])
-            self.metrics_manager.add_mean_metric('recon_loss')
-        else:
-            self.losses_manager.add_reconstruction_loss('recon', weight=h['recon_weight'])
-            self.metrics_manager.add_mean_metric('recon_loss')
-            self.metrics_manager.add_sparse_categorical_accuracy('recon_acc')
-        self.losses_manager.add_sparse_categorical_crossentropy('class', weight=h['class_weight'])
-        self.metrics_manager.add_mean_metric('class_loss')
-        self.metrics_manager.add_sparse_categorical_accuracy('class_acc')
+        # models/sketchformer.py:76-108: decoder / losses / metrics are only registered for the heads that exist
+        self._has_cls = bool(h['lowerdim']) and bool(h['do_classification'])
+        if h['do_classification'] and not h['lowerdim']:
+            raise ValueError("do_classification needs lowerdim > 0 (models/sketchformer.py:96-108: the class head lives "
+                             "inside the bottleneck block; the reference fails on the unregistered 'class' loss)")
+        if h['do_reconstruction']:
+            if self.dataset.hps['use_continuous_data']:
+                self.losses_manager.add_continuous_reconstruction_loss('recon', weight=h['recon_weight'])
+                self.metrics_manager.add_mean_metric('recon_loss')
+            else:
+                self.losses_manager.add_reconstruction_loss('recon', weight=h['recon_weight'])
+                self.metrics_manager.add_mean_metric('recon_loss')
+                self.metrics_manager.add_sparse_categorical_accuracy('recon_acc')
+        if self._has_cls:
+            self.losses_manager.add_sparse_categorical_crossentropy('class', weight=h['class_weight'])
+            self.metrics_manager.add_mean_metric('class_loss')
+            self.metrics_manager.add_sparse_categorical_accuracy('class_acc')
         self.metrics_manager.add_mean_metric('total_loss')
         # WarmupDecay is built with warmup_steps=5000 whatever the hparams say (models/sketchformer.py:113-114)
         self.learning_rate = (builders.schedulers.WarmupDecay(h['d_model'], warmup_steps=5000)
@@ -65,7 +65,8 @@ class Transformer(BaseModel):
             lowerdim=h['lowerdim'], attn_version=h['attn_version'], continuous=self.dataset.hps['use_continuous_data'],
             blind_decoder_mask=h['blind_decoder_mask'], dropout_rate=h['dropout_rate'], recon_weight=h['recon_weight'],
             class_weight=h['class_weight'], lr_scheduler=h['lr_scheduler'], lr=h['lr'], use_graph=False,
-            optimizer=h['optimizer'], class_buffer_layers=h['class_buffer_layers'], class_dropout=h['class_dropout'])
+            optimizer=h['optimizer'], class_buffer_layers=h['class_buffer_layers'], class_dropout=h['class_dropout'],
+            do_classification=h['do_classification'], do_reconstruction=h['do_reconstruction'])
         self.engine = engine.TrainEngine(cfg, device=self._device, init_seed=self._init_seed, process_group=self._pg)
         self.trainable_variables = [e["name"] for e in self.engine.entries]
 
@@ -74,8 +75,13 @@ class Transformer(BaseModel):
         data, labels = batch
         self.engine.train_step(data, labels)
         res = self.engine.running_metrics()          # Keras running metrics, read back every step like the reference
-        if self.dataset.hps['use_continuous_data']:
+        if self.dataset.hps['use_continuous_data'] or not self.hps['do_reconstruction']:
             res.pop('recon_acc', None)
+        if not self.hps['do_reconstruction']:
+            res.pop('recon_loss', None)
+        if not self._has_cls:
+            res.pop('class_loss', None)
+            res.pop('class_acc', None)
         return res
 
     def prepare_for_start_of_epoch(self):
@@ -102,13 +108,16 @@ class Transformer(BaseModel):
         pad, n = self._pad_batch(inp_seq)
         self.engine.encode(pad)
         self.engine.synchronize()
-        return {'enc_output': self.engine.buffer('enc_output').view(self.engine.cfg.batch, self.seq_len, -1)[:n].cpu().numpy(),
-                'embedding': self.engine.buffer('embedding')[:n].cpu().numpy(),
-                'class': self.engine.buffer('class_probs')[:n].cpu().numpy()}
+        B = self.engine.cfg.batch
+        enc = self.engine.buffer('enc_output').view(B, self.seq_len, -1)[:n].cpu().numpy()
+        emb = self.engine.buffer('embedding')[:n].cpu().numpy() if self.hps['lowerdim'] else enc
+        return {'enc_output': enc, 'embedding': emb,
+                'class': self.engine.buffer('class_probs')[:n].cpu().numpy() if self._has_cls else None}
 
     def predict_class(self, inp_seq):
         out = self.encode_from_seq(inp_seq)
-        out['class'] = out['class'].argmax(-1).astype(np.int32)
+        if self._has_cls:
+            out['class'] = out['class'].argmax(-1).astype(np.int32)
         return out
 
     def make_dummy_input(self, expected_len, nattn, batch_size):
@@ -132,12 +141,12 @@ class Transformer(BaseModel):
         if not self.hps['do_reconstruction']:
             raise ValueError("do_reconstruction is off")
         emb = np.asarray(emb, dtype=np.float32)
-        if emb.ndim == 1:
+        if emb.ndim == (1 if self.hps['lowerdim'] else 2):     # one embedding: (E,) - or (L, d) without a bottleneck
             emb = emb[None]
         n, B = emb.shape[0], self.engine.cfg.batch
         if n > B:
             raise ValueError("at most batch_size=%d embeddings per call" % B)
-        pad = np.zeros((B, emb.shape[1]), dtype=np.float32)
+        pad = np.zeros((B,) + emb.shape[1:], dtype=np.float32)
         pad[:n] = emb
         tok = self.dataset.tokenizer
         if self.hps['blind_decoder_mask']:
@@ -146,14 +155,14 @@ class Transformer(BaseModel):
                                           sos=getattr(tok, 'SOS', 0) if tok is not None else 0,
                                           eos=getattr(tok, 'EOS', 0) if tok is not None else 0)
         out = {'recon': recon, 'attn_weights': None}
-        if self.hps['do_classification']:
+        if self._has_cls:
             out['class'] = self.engine.buffer('class_probs')[:n].cpu().numpy().argmax(-1).astype(np.int32)
         return out
 
     def predict(self, inp_seq):
         """models/sketchformer.py:201-221."""
         out = self.encode_from_seq(inp_seq)
-        if self.hps['do_classification']:
+        if self._has_cls:
             out['class'] = out['class'].argmax(-1).astype(np.int32)
         if self.hps['do_reconstruction']:
             x = np.asarray(inp_seq)

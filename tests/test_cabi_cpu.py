@@ -64,6 +64,22 @@ def test_layout_names_match_oracle(lib):
     assert got == want
 
 
+@pytest.mark.parametrize("kw", [dict(do_classification=False), dict(do_reconstruction=False),
+                                dict(lowerdim=0, do_classification=False), dict(do_reconstruction=False, attn_version=2, lowerdim=64)])
+def test_structural_variant_layouts_match_oracle(lib, kw):
+    """do_classification / do_reconstruction off, lowerdim=0 (models/sketchformer.py:76-108): the variable set shrinks."""
+    import oracle
+    from sketchformer_amd import engine
+    base = dict(num_layers=2, d_model=64, dff=128, num_heads=4, lowerdim=32, vocab_size=52, n_classes=7, seq_len=24)
+    base.update(kw)
+    ocfg = oracle.Config(**base)
+    cfg = engine.make_config(batch=4, **base)
+    want = [(n, s) for n, s, _ in oracle.param_specs(ocfg)]
+    got = [(e["name"], engine.logical_shape(e)) for e in engine.param_entries(cfg)]
+    assert dict(got) == dict(want)
+    assert [n for n, _ in got if "/mha" not in n] == [n for n, _ in want if "/mha" not in n]
+
+
 @pytest.mark.parametrize("attn_version,cbuf", [(2, 0), (1, 2), (2, 1)])
 def test_variant_layout_names_match_oracle(lib, attn_version, cbuf):
     """SelfAttnV2 (builders/layers/transformer.py:76-131: W (d,d), Dense(lowerdim) -> embedding width = lowerdim, which is
@@ -83,9 +99,13 @@ def test_variant_layout_names_match_oracle(lib, attn_version, cbuf):
 
 def test_unsupported_configs_fail_loudly(lib):
     from sketchformer_amd import engine
-    cfg = engine.make_config(batch=4, lowerdim=0)
-    assert lib.skf_config_validate(C.byref(cfg)) == -2
+    cfg = engine.make_config(batch=4, lowerdim=0)                       # class head without a bottleneck: the reference fails too
+    assert lib.skf_config_validate(C.byref(cfg)) == -1
     assert b"lowerdim" in lib.skf_last_error()
+    assert lib.skf_config_validate(C.byref(engine.make_config(batch=4, lowerdim=0, do_classification=False))) == 0
+    assert lib.skf_config_validate(C.byref(engine.make_config(batch=4, do_reconstruction=False))) == 0
+    assert lib.skf_config_validate(C.byref(engine.make_config(batch=4, do_reconstruction=False, do_classification=False))) == -1
+    assert lib.skf_config_validate(C.byref(engine.make_config(batch=4, d_model=96))) == -2        # unsupported width
     assert lib.skf_config_validate(C.byref(engine.make_config(batch=4, attn_version=3))) == -1
     assert lib.skf_config_validate(C.byref(engine.make_config(batch=4, attn_version=2, lowerdim=100))) == -2
     assert lib.skf_config_validate(C.byref(engine.make_config(batch=4, attn_version=2, class_buffer_layers=2, optimizer="sgd"))) == 0

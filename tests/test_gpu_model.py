@@ -22,7 +22,9 @@ def _mk(batch, rate=0.0, use_graph=False, blind=True, **kw):
                          vocab_size=small["vocab_size"], n_classes=small["n_classes"], seq_len=small["seq_len"],
                          blind_decoder_mask=blind, attn_version=small.get("attn_version", 1),
                          class_buffer_layers=small.get("class_buffer_layers", 0),
-                         class_dropout=small.get("class_dropout", 0.1), optimizer=small.get("optimizer", "adam").lower())
+                         class_dropout=small.get("class_dropout", 0.1), optimizer=small.get("optimizer", "adam").lower(),
+                         do_classification=small.get("do_classification", True),
+                         do_reconstruction=small.get("do_reconstruction", True))
     eng = engine.TrainEngine(cfg, init_seed=1)
     # make biases / LN parameters non-trivial
     rng = np.random.RandomState(9)
@@ -440,3 +442,65 @@ def test_bucketed_apply_gradients_equals_plain():
         res.append((eng.params.clone(), eng.adam_m.clone(), eng.adam_v.clone()))
     for a, b in zip(*res):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)                   # embedding-gradient atomics reorder sums
+
+
+# ------------------------------------------------------------------ structural variants (models/sketchformer.py:76-108)
+@pytest.mark.parametrize("kw", [dict(do_classification=False), dict(do_reconstruction=False),
+                                dict(lowerdim=0, do_classification=False), dict(lowerdim=0, do_classification=False, blind=False),
+                                dict(do_reconstruction=False, class_buffer_layers=1, attn_version=2, lowerdim=64)],
+                         ids=["no_class_head", "no_decoder", "no_bottleneck", "no_bottleneck_masked", "classifier_only_v2"])
+@pytest.mark.parametrize("rate", [0.0, 0.1])
+def test_structural_variants_losses_gradients_and_inference(kw, rate):
+    B = 5
+    kw = dict(kw)
+    blind = kw.pop("blind", True)
+    if rate == 0.0:
+        kw["class_dropout"] = 0.0
+    eng, ocfg = _mk(B, rate=rate, blind=blind, **kw)
+    x, y = synthetic.token_batch(B, ocfg.seq_len, ocfg.vocab_size, ocfg.n_classes, seed=17)
+    x[3, 6:] = 0
+    P = {k: v.astype(np.float64) for k, v in eng.state_dict_numpy().items()}
+    assert set(P) == {n for n, _, _ in oracle.param_specs(ocfg)}
+    eng.forward_backward(x, None, y)
+    torch.cuda.synchronize()
+    drops = _drops_from_engine(eng, ocfg, B) if rate > 0 else None
+    losses, out, G = oracle.loss_and_grads(P, ocfg, x, x, y, drops)
+    m = eng.step_metrics()
+    for k in ("recon_loss", "class_loss", "total_loss"):
+        want = losses.get(k, 0.0)                      # an absent head contributes 0 (sum(all_losses))
+        assert abs(m[k] - want) < 1e-5 * max(1.0, abs(want)), (k, m[k], want)
+    got = eng.state_dict_numpy("grads")
+    floor = 1e-3 * np.median([np.abs(G[k]).max() for k in G])
+    rel = {k: np.abs(got[k].astype(np.float64) - G[k]).max() / max(np.abs(G[k]).max(), floor) for k in G}
+    worst = max((v, k) for k, v in rel.items())
+    assert worst[0] < 1e-3, worst
+    # one optimizer step over the (shorter) flat buffer, buckets consistent with the layout
+    buckets = eng.grad_buckets()
+    assert sum(c for _, c in buckets) == eng.n_floats and len(buckets) == (2 if ocfg.do_reconstruction else 1)
+    eng.state[0] = 2000
+    eng.apply_gradients(bucketed=True)
+    torch.cuda.synchronize()
+    assert eng.iterations == 2001 and torch.isfinite(eng.params).all()
+    eng.load_numpy({k: v.astype(np.float32) for k, v in P.items()})
+    # inference
+    enc = oracle.encode_from_seq(P, ocfg, x)
+    eng.encode(x)
+    torch.cuda.synchronize()
+    emb = eng.buffer("embedding").cpu().numpy()
+    if ocfg.lowerdim == 0:
+        assert emb.shape == (B * ocfg.seq_len, ocfg.d_model)
+        assert _rel(emb.reshape(B, ocfg.seq_len, -1), enc["embedding"]) < 1e-4
+    else:
+        assert _rel(emb, enc["embedding"]) < 1e-4
+    if ocfg.has_classifier:
+        assert _rel(eng.buffer("class_probs").cpu().numpy(), enc["class"]) < 1e-4
+    if ocfg.do_reconstruction:
+        sos, eos = ocfg.vocab_size - 2, ocfg.vocab_size - 1
+        want = oracle.predict(P, ocfg, x, sos, eos)["recon"]
+        tlen = None if blind else np.sum(x > 0, axis=-1)
+        assert np.array_equal(eng.greedy_decode(None, expected_len=tlen, sos=sos, eos=eos), want)
+        if ocfg.lowerdim == 0:          # explicit (B, L, d) embedding
+            assert np.array_equal(eng.greedy_decode(emb.reshape(B, ocfg.seq_len, -1), expected_len=tlen, sos=sos, eos=eos), want)
+    else:
+        with pytest.raises(Exception):
+            eng.greedy_decode(None)

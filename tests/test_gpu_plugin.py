@@ -167,3 +167,29 @@ def test_builders_front_ends_against_oracle():
     assert np.abs(got_x.cpu().numpy() - want_x).max() < 1e-4
     with pytest.raises(NotImplementedError):
         enc(tok, True, enc_m)
+
+
+@pytest.mark.parametrize("extra,keys", [("do_reconstruction=False", ["class_acc", "class_loss", "total_loss"]),
+                                        ("do_classification=False", ["recon_acc", "recon_loss", "total_loss"]),
+                                        ("lowerdim=0,do_classification=False", ["recon_acc", "recon_loss", "total_loss"])])
+def test_plugin_structural_hparams(tmp_path, extra, keys):
+    """models/sketchformer.py:76-108: only the heads that exist register losses / metrics; predict returns what exists."""
+    from sketchformer_amd import models, dataloaders
+    Model = models.get_model_by_name("sketch-transformer-tf2")
+    Loader = dataloaders.get_dataloader_by_name("stroke3-synthetic")
+    dataset = Loader(Loader.parse_hparams(DATA), None)
+    small = SMALL.replace("lowerdim=32,", "") if "lowerdim" in extra else SMALL       # an hparam may be assigned once
+    model = Model(Model.parse_hparams(base="batch_size=8,num_epochs=1,log_every=4", specific=small + "," + extra), dataset,
+                  str(tmp_path), "v")
+    x, y = next(dataset.batch_iterator("train", 8, False))
+    res = model.train_on_batch((x, y))
+    assert sorted(res) == keys and all(np.isfinite(v) for v in res.values())
+    out = model.predict(x[:3])
+    assert ("recon" in out) == model.hps["do_reconstruction"]
+    if model.hps["do_reconstruction"]:
+        assert out["recon"].shape[0] == 3 and out["recon"][:, 0].tolist() == [dataset.tokenizer.SOS] * 3
+    if not model.hps["lowerdim"]:
+        assert out["embedding"].shape == (3, 24, 64)
+    with pytest.raises(ValueError):
+        Model(Model.parse_hparams(base="batch_size=8", specific=SMALL.replace("lowerdim=32", "lowerdim=0")), dataset,
+              str(tmp_path), "bad")

@@ -7,8 +7,8 @@ from sketchformer_amd import synthetic
 import witness_torch
 
 
-def _tiny(continuous=False, attn_version=1, blind=True, class_buffer_layers=0):
-    return oracle.Config(num_layers=2, d_model=16, dff=32, num_heads=4, dropout_rate=0.1, lowerdim=8,
+def _tiny(continuous=False, attn_version=1, blind=True, class_buffer_layers=0, **kw):
+    return oracle.Config(**kw, num_layers=2, d_model=16, dff=32, num_heads=4, dropout_rate=0.1, lowerdim=8,
                          attn_version=attn_version, vocab_size=24, n_classes=5, seq_len=12,
                          continuous=continuous, blind_decoder_mask=blind, max_pos=32,
                          class_buffer_layers=class_buffer_layers, class_dropout=0.2)
@@ -53,6 +53,52 @@ def test_oracle_matches_autograd(continuous, attn_version, blind, cbuf):
     for k in ("recon_loss", "class_loss", "total_loss"):
         assert abs(losses[k] - wl[k]) < 1e-12
     np.testing.assert_allclose(out["recon"], wo["recon"], rtol=0, atol=1e-11)
+
+
+@pytest.mark.parametrize("kw", [dict(do_classification=False), dict(do_reconstruction=False),
+                                dict(lowerdim=0, do_classification=False, blind_decoder_mask=False),
+                                dict(lowerdim=0, do_classification=False, continuous=True)],
+                         ids=["no_class_head", "no_decoder", "no_bottleneck_masked", "no_bottleneck_continuous"])
+def test_structural_variants_match_autograd(kw):
+    """do_classification / do_reconstruction off and lowerdim=0 (models/sketchformer.py:76-108,149-181): the variable
+    set shrinks accordingly and the remaining losses / gradients agree with autograd."""
+    kw = dict(kw)
+    continuous = kw.pop("continuous", False)
+    blind = kw.pop("blind_decoder_mask", True)
+    base = dict(num_layers=2, d_model=16, dff=32, num_heads=4, dropout_rate=0.1, lowerdim=8, vocab_size=24, n_classes=5,
+                seq_len=12, continuous=continuous, blind_decoder_mask=blind, max_pos=32)
+    base.update(kw)
+    cfg = oracle.Config(**base)
+    B = 3
+    if continuous:
+        x, y = synthetic.continuous_batch(B, cfg.seq_len, cfg.n_classes, seed=3)
+        x = x.astype(np.float64)
+        x[0, 6:, :] = [0, 0, 0, 0, 1]
+    else:
+        x, y = synthetic.token_batch(B, cfg.seq_len, cfg.vocab_size, cfg.n_classes, seed=3)
+        x[0, 6:] = 0
+    P = oracle.init_params(cfg, seed=0)
+    names = set(P)
+    assert ("classify/kernel" in names) == cfg.has_classifier
+    assert ("output/kernel" in names) == cfg.do_reconstruction
+    assert ("bottleneck/W_attn" in names) == cfg.has_bottleneck
+    assert ("expand/kernel" in names) == (cfg.has_bottleneck and cfg.do_reconstruction)
+    rng = np.random.RandomState(5)
+    for k in P:
+        if k.endswith(("bias", "beta", "b_attn")):
+            P[k] = rng.normal(0, 0.1, P[k].shape)
+    drops = _drops(cfg, B)
+    losses, out, G = oracle.loss_and_grads(P, cfg, x, x, y, drops)
+    wl, wo, WG = witness_torch.loss_and_grads(P, cfg, x, x, y, drops)
+    assert ("recon_loss" in losses) == cfg.do_reconstruction and ("class_loss" in losses) == cfg.has_classifier
+    for k in losses:
+        assert abs(losses[k] - wl[k]) < 1e-12, k
+    assert set(G) == set(P)
+    for k in P:
+        assert WG[k] is not None, k
+        np.testing.assert_allclose(G[k], WG[k], rtol=0, atol=1e-11, err_msg=k)
+    res, _, _, _ = oracle.train_step(oracle.TrainState.create({k: v.copy() for k, v in P.items()}), cfg, x, x, y, drops)
+    assert ("recon_loss" in res) == cfg.do_reconstruction and ("class_acc" in res) == cfg.has_classifier
     assert set(G) == set(P)
     for k in P:
         assert WG[k] is not None, k

@@ -84,43 +84,52 @@ def loss_and_grads(params_np, cfg, inp, tar, labels, drops=None):
         o1 = _ln(P, p + "/layernorm1", x + a)
         f = _drop(_ffn(P, p + "/ffn", o1), drops.get(p + "/dropout2"), rate)
         x = _ln(P, p + "/layernorm2", o1 + f)
-    u = torch.tanh(x @ P["bottleneck/W_attn"] + P["bottleneck/b_attn"])
-    a = torch.softmax(u @ P["bottleneck/V_attn"], dim=1)
-    emb = (x * a).sum(1)
-    if cfg.attn_version != 1:
-        emb = emb @ P["bottleneck/embeding_layer/kernel"] + P["bottleneck/embeding_layer/bias"]
-    fc = emb
-    for i in range(getattr(cfg, "class_buffer_layers", 0)):
-        fc = torch.relu(fc @ P["class_buffer/%d/kernel" % i] + P["class_buffer/%d/bias" % i])
-        fc = _drop(fc, drops.get("class_dropout/%d" % i), cfg.class_dropout if rate > 0 else 0.0)
-    cls_logits = fc @ P["classify/kernel"] + P["classify/bias"]
-    pre = emb[:, None, :] * P["expand/kernel"][0][None, :, None] + P["expand/bias"][None, :, None]
-
-    y = _embed(P, "decoder/embedding", tar_inp, cfg, pos, drops.get("decoder/dropout"), rate)
-    for i in range(cfg.num_layers):
-        p = "decoder/layer%d" % i
-        a1 = _drop(_mha(P, p + "/mha1", y, y, y, comb, H), drops.get(p + "/dropout1"), rate)
-        o1 = _ln(P, p + "/layernorm1", a1 + y)
-        a2 = _drop(_mha(P, p + "/mha2", pre, pre, o1, cross, H), drops.get(p + "/dropout2"), rate)
-        o2 = _ln(P, p + "/layernorm2", a2 + o1)
-        f = _drop(_ffn(P, p + "/ffn", o2), drops.get(p + "/dropout3"), rate)
-        y = _ln(P, p + "/layernorm3", f + o2)
-    logits = y @ P["output/kernel"] + P["output/bias"]
-
-    if cfg.continuous:
-        real = torch.tensor(tar_real, dtype=dtype)
-        mask = (real[..., -1] != 1).to(dtype)
-        loc = ((real[..., :2] - logits[..., :2]) ** 2).mean(-1)
-        meta = F.cross_entropy(logits[..., 2:].reshape(-1, 3), real[..., 2:].argmax(-1).reshape(-1))
-        recon = cfg.recon_weight * ((loc + meta) * mask).mean()
+    has_bott = cfg.lowerdim > 0
+    has_cls = has_bott and getattr(cfg, "do_classification", True)
+    do_recon = getattr(cfg, "do_reconstruction", True)
+    if has_bott:
+        u = torch.tanh(x @ P["bottleneck/W_attn"] + P["bottleneck/b_attn"])
+        a = torch.softmax(u @ P["bottleneck/V_attn"], dim=1)
+        emb = (x * a).sum(1)
+        if cfg.attn_version != 1:
+            emb = emb @ P["bottleneck/embeding_layer/kernel"] + P["bottleneck/embeding_layer/bias"]
     else:
-        real = torch.tensor(tar_real)
-        per = F.cross_entropy(logits.reshape(-1, logits.shape[-1]), real.reshape(-1), reduction="none")
-        recon = cfg.recon_weight * (per * (real.reshape(-1) != 0).to(dtype)).mean()
-    clas = cfg.class_weight * F.cross_entropy(cls_logits, torch.tensor(labels).reshape(-1))
+        emb = x
+    recon = clas = torch.zeros((), dtype=dtype)
+    logits = cls_logits = None
+    if has_cls:
+        fc = emb
+        for i in range(getattr(cfg, "class_buffer_layers", 0)):
+            fc = torch.relu(fc @ P["class_buffer/%d/kernel" % i] + P["class_buffer/%d/bias" % i])
+            fc = _drop(fc, drops.get("class_dropout/%d" % i), cfg.class_dropout if rate > 0 else 0.0)
+        cls_logits = fc @ P["classify/kernel"] + P["classify/bias"]
+        clas = cfg.class_weight * F.cross_entropy(cls_logits, torch.tensor(labels).reshape(-1))
+    if do_recon:
+        pre = emb[:, None, :] * P["expand/kernel"][0][None, :, None] + P["expand/bias"][None, :, None] if has_bott else emb
+        y = _embed(P, "decoder/embedding", tar_inp, cfg, pos, drops.get("decoder/dropout"), rate)
+        for i in range(cfg.num_layers):
+            p = "decoder/layer%d" % i
+            a1 = _drop(_mha(P, p + "/mha1", y, y, y, comb, H), drops.get(p + "/dropout1"), rate)
+            o1 = _ln(P, p + "/layernorm1", a1 + y)
+            a2 = _drop(_mha(P, p + "/mha2", pre, pre, o1, cross, H), drops.get(p + "/dropout2"), rate)
+            o2 = _ln(P, p + "/layernorm2", a2 + o1)
+            f = _drop(_ffn(P, p + "/ffn", o2), drops.get(p + "/dropout3"), rate)
+            y = _ln(P, p + "/layernorm3", f + o2)
+        logits = y @ P["output/kernel"] + P["output/bias"]
+        if cfg.continuous:
+            real = torch.tensor(tar_real, dtype=dtype)
+            mask = (real[..., -1] != 1).to(dtype)
+            loc = ((real[..., :2] - logits[..., :2]) ** 2).mean(-1)
+            meta = F.cross_entropy(logits[..., 2:].reshape(-1, 3), real[..., 2:].argmax(-1).reshape(-1))
+            recon = cfg.recon_weight * ((loc + meta) * mask).mean()
+        else:
+            real = torch.tensor(tar_real)
+            per = F.cross_entropy(logits.reshape(-1, logits.shape[-1]), real.reshape(-1), reduction="none")
+            recon = cfg.recon_weight * (per * (real.reshape(-1) != 0).to(dtype)).mean()
     total = recon + clas
     total.backward()
     grads = {k: (v.grad.numpy() if v.grad is not None else None) for k, v in P.items()}
     return ({"recon_loss": recon.item(), "class_loss": clas.item(), "total_loss": total.item()},
-            {"recon": logits.detach().numpy(), "class_logits": cls_logits.detach().numpy(),
+            {"recon": None if logits is None else logits.detach().numpy(),
+             "class_logits": None if cls_logits is None else cls_logits.detach().numpy(),
              "embedding": emb.detach().numpy()}, grads)
