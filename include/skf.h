@@ -176,29 +176,40 @@ int skf_adam_step(float* w, const float* g, float* m, float* v, size_t n, const 
 /* tf.keras.optimizers.SGD(lr_schedule, momentum), nesterov=False: velocity = momentum*velocity - lr*g*grad_scale; w += velocity */
 int skf_sgd_momentum_step(float* w, const float* g, float* velocity, size_t n, const void* step_state, float grad_scale,
                           float momentum, skf_stream_t stream);
-/* host helper for parity tests: the keep-mask the kernels derive for (drop_key, site) */
 /* y = inverted dropout of x (n floats, y may alias x) with the mask of (step key, site, element index);
  * applied to an upstream gradient it is the backward.  rate 0 = copy. */
 int skf_dropout(const float* x, float* y, size_t n, float rate, unsigned site, const void* step_state, skf_stream_t stream);
+/* host helper for parity tests: the keep-mask the kernels derive for (drop_key, site) */
 int skf_dropout_keep_mask(unsigned drop_key, unsigned site, float rate, size_t n, unsigned char* out_host);
 
 /* ---- single-query attention + token selection of the KV-cached greedy decode ----
  * skf_attention_decode: scaled_dot_product_attention (builders/utils.py:71-105) for ONE query row per (sample, head):
  *   Q (B, H*dh) row stride ldq; K/V rows of sample b start at K + b*kv_batch_stride, row stride ld_kv, Lk rows used;
  *   key_mask (B, key_mask_ld) bytes, 1 = masked (additive -1e9); keys >= key_limit[b] (or key_limit_all if > 0) masked.
- * skf_decode_init: column 0 of the output = SOS (tokens) or (0,0,1,0,0) (continuous); clears the flags.
+ *   Graph-replayable form: step_dev (device int) non-NULL and K_new/V_new (B, ld_new) given -> the number of keys is
+ *   *step_dev + 1 (Lk = cache capacity), the newest key/value row is read from K_new/V_new and appended to the cache at
+ *   row *step_dev; limit_from_step: keys >= *step_dev + 1 are masked where key_limit is NULL or negative.
+ * skf_decode_init: column 0 of the output = SOS (tokens) or (0,0,1,0,0) (continuous); clears the flags (and *step_dev).
+ * skf_decode_embed: decoder input of position *step_dev: table[token] (or Dense(5->d) of the stroke-5 row) * sqrt(d) + pos.
  * skf_decode_select_tokens / _continuous: models/sketchformer.py:285-301 - append argmax (first index on ties) or
- *   (x, y, softmax(pen)); maintain the target padding mask, the sticky EOS flags and done_step (-1 until the stop test holds). */
+ *   (x, y, softmax(pen)); maintain the target padding mask, the sticky EOS flags and done_step (-1 until the stop test
+ *   holds).  With step_dev/dyn non-NULL the step, n_valid (dyn[0]) and eos (dyn[1]) are read from device memory and
+ *   *step_dev is incremented, so that one captured launch sequence serves every step. */
 int skf_attention_decode(const float* Q, int ldq, const float* K, const float* V, int ld_kv, long long kv_batch_stride,
                          const unsigned char* key_mask, int key_mask_ld, const int* key_limit, int key_limit_all, int B,
-                         int H, int Lk, int dh, float* O, int ldo, skf_stream_t stream);
+                         int H, int Lk, int dh, float* O, int ldo, const int* step_dev, const float* K_new,
+                         const float* V_new, int ld_new, int limit_from_step, skf_stream_t stream);
 int skf_decode_init(long long* tokens, int tok_ld, float* cont, int cont_ld_rows, unsigned char* selfmask, int mask_ld,
-                    int* eos_seen, int* done_step, int B, long long sos, skf_stream_t stream);
+                    int* eos_seen, int* done_step, int B, long long sos, int* step_dev, skf_stream_t stream);
+int skf_decode_embed(const long long* tokens, const float* cont, int ld, int B, const float* table, int vocab,
+                     const float* W, const float* bias, int d, const float* pos, const int* step_dev, float* out,
+                     skf_stream_t stream);
 int skf_decode_select_tokens(const float* logits, int ld, int B, int V, int n_valid, int step, long long eos,
                              long long* tokens, int tok_ld, unsigned char* selfmask, int mask_ld, int* eos_seen,
-                             int* done_step, skf_stream_t stream);
+                             int* done_step, int* step_dev, const long long* dyn, skf_stream_t stream);
 int skf_decode_select_continuous(const float* pred, int ld, int B, int n_valid, int step, float* out, int out_ld_rows,
-                                 unsigned char* selfmask, int mask_ld, int* done_step, skf_stream_t stream);
+                                 unsigned char* selfmask, int mask_ld, int* done_step, int* step_dev,
+                                 const long long* dyn, skf_stream_t stream);
 
 /* ------------------------------------------------------------------ the train step
  * Transformer.build_model / call / model_trainer, models/sketchformer.py:63-147, 313-349. */

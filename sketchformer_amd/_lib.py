@@ -87,10 +87,12 @@ SIGNATURES = {
     "skf_sgd_momentum_step": (_I, [_P, _P, _P, _Z, _P, _F, _F, _P]),
     "skf_dropout": (_I, [_P, _P, _Z, _F, _U, _P, _P]),
     "skf_dropout_keep_mask": (_I, [_U, _U, _F, _Z, _P]),
-    "skf_attention_decode": (_I, [_P, _I, _P, _P, _I, C.c_longlong, _P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _P]),
-    "skf_decode_init": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _I, C.c_longlong, _P]),
-    "skf_decode_select_tokens": (_I, [_P, _I, _I, _I, _I, _I, C.c_longlong, _P, _I, _P, _I, _P, _P, _P]),
-    "skf_decode_select_continuous": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P]),
+    "skf_attention_decode": (_I, [_P, _I, _P, _P, _I, C.c_longlong, _P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I,
+                                  _I, _P]),
+    "skf_decode_init": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _I, C.c_longlong, _P, _P]),
+    "skf_decode_embed": (_I, [_P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P]),
+    "skf_decode_select_tokens": (_I, [_P, _I, _I, _I, _I, _I, C.c_longlong, _P, _I, _P, _I, _P, _P, _P, _P, _P]),
+    "skf_decode_select_continuous": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P]),
     "skf_config_validate": (_I, [C.POINTER(SkfConfig)]),
     "skf_model_param_floats": (_Z, [C.POINTER(SkfConfig)]),
     "skf_model_param_entries": (_I, [C.POINTER(SkfConfig), C.POINTER(SkfParamEntry), _I]),

@@ -14,6 +14,11 @@ struct AttnDecodeParams {
   const int* key_limit; int key_limit_all;                      // keys >= limit are masked (per sample / all samples; 0 = none)
   int B, H, Lk;
   float* O; int ldo;
+  // graph-replayable decode: the step index lives in device memory
+  const int* step_dev;            // non-null: Lk = *step_dev + 1 (the Lk field is the cache capacity)
+  const float* K_new; const float* V_new; int ld_new;   // non-null: row Lk-1 comes from here and is appended to the cache
+  float* K_cache; float* V_cache;                       // writable aliases of K / V for the append
+  int limit_from_step;            // cross attention without per-sample limits: keys >= step + 1 are masked
 };
 
 // One wave per (sample, head): lane j owns keys j, j+64, ... (Lk <= 64*MAXJ).
@@ -25,6 +30,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
   const int bh = blockIdx.x * 4 + wave;
   if (bh >= p.B * p.H) return;
   const int b = bh / p.H, h = bh % p.H;
+  const int step = p.step_dev ? *p.step_dev : 0;
+  const int Lk = p.K_new ? step + 1 : p.Lk;            // self attention over the cache grows with the step
   float q[DH];
 #pragma unroll
   for (int c4 = 0; c4 < DH / 4; ++c4) {
@@ -33,7 +40,18 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
   }
   const float* Kb = p.K + (size_t)b * p.kv_bs + h * DH;
   const float* Vb = p.V + (size_t)b * p.kv_bs + h * DH;
-  const int limit = p.key_limit ? p.key_limit[b] : (p.key_limit_all > 0 ? p.key_limit_all : 0x7fffffff);
+  int limit = p.key_limit ? p.key_limit[b] : (p.key_limit_all > 0 ? p.key_limit_all : 0x7fffffff);
+  if (p.limit_from_step && (!p.key_limit || limit < 0)) limit = step + 1;   // make_dummy_input(nattn = i + 1)
+  // the newest key / value row: taken from the projection output (no read-after-write through the cache) and appended
+  const int jn = p.K_new ? Lk - 1 : -1;
+  if (p.K_new && lane < DH / 4) {
+    const f32x4 kn = *reinterpret_cast<const f32x4*>(p.K_new + (size_t)b * p.ld_new + h * DH + 4 * lane);
+    const f32x4 vn = *reinterpret_cast<const f32x4*>(p.V_new + (size_t)b * p.ld_new + h * DH + 4 * lane);
+    *reinterpret_cast<f32x4*>(p.K_cache + (size_t)b * p.kv_bs + (size_t)jn * p.ld_kv + h * DH + 4 * lane) = kn;
+    *reinterpret_cast<f32x4*>(p.V_cache + (size_t)b * p.kv_bs + (size_t)jn * p.ld_kv + h * DH + 4 * lane) = vn;
+  }
+  const float* Kn = p.K_new ? p.K_new + (size_t)b * p.ld_new + h * DH : nullptr;
+  const float* Vn = p.V_new ? p.V_new + (size_t)b * p.ld_new + h * DH : nullptr;
   const float scale_div = sqrtf((float)DH);
   float s[MAXJ];
   float mx = -INFINITY;
@@ -41,8 +59,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
   for (int jj = 0; jj < MAXJ; ++jj) {
     const int j = lane + 64 * jj;
     float v = -INFINITY;
-    if (j < p.Lk) {
-      const float* kr = Kb + (size_t)j * p.ld_kv;
+    if (j < Lk) {
+      const float* kr = j == jn ? Kn : Kb + (size_t)j * p.ld_kv;
       float dot = 0.f;
 #pragma unroll
       for (int c4 = 0; c4 < DH / 4; ++c4) {
@@ -67,9 +85,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
 #pragma unroll
   for (int jj = 0; jj < MAXJ; ++jj) {
     const int j = lane + 64 * jj;
-    if (j < p.Lk) {
+    if (j < Lk) {
       const float pj = s[jj] * rinv;
-      const float* vr = Vb + (size_t)j * p.ld_kv;
+      const float* vr = j == jn ? Vn : Vb + (size_t)j * p.ld_kv;
 #pragma unroll
       for (int c4 = 0; c4 < DH / 4; ++c4) {
         const f32x4 vv = *reinterpret_cast<const f32x4*>(vr + 4 * c4);
@@ -94,8 +112,10 @@ __global__ __launch_bounds__(1024) void decode_select_tokens_kernel(const float*
                                                                      int n_valid, int step, long long eos,
                                                                      long long* __restrict__ tokens, int tok_ld,
                                                                      unsigned char* __restrict__ selfmask, int mask_ld,
-                                                                     int* __restrict__ eos_seen, int* __restrict__ done_step) {
+                                                                     int* __restrict__ eos_seen, int* __restrict__ done_step,
+                                                                     int* __restrict__ step_dev, const long long* __restrict__ dyn) {
   __shared__ int cnt[16];
+  if (step_dev) { step = *step_dev; n_valid = (int)dyn[0]; eos = dyn[1]; }   // graph replay: per-call values in device memory
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int seen = 0;
   for (int b = wave; b < B; b += 16) {
@@ -124,6 +144,7 @@ __global__ __launch_bounds__(1024) void decode_select_tokens_kernel(const float*
     int t = 0;
     for (int k = 0; k < 16; ++k) t += cnt[k];
     if (t >= n_valid && *done_step < 0) *done_step = step;
+    if (step_dev) *step_dev = step + 1;
   }
 }
 
@@ -132,8 +153,10 @@ __global__ __launch_bounds__(1024) void decode_select_tokens_kernel(const float*
 __global__ __launch_bounds__(256) void decode_select_continuous_kernel(const float* __restrict__ pred, int ld, int B,
                                                                         int n_valid, int step, float* __restrict__ out,
                                                                         int out_ld_rows, unsigned char* __restrict__ selfmask,
-                                                                        int mask_ld, int* __restrict__ done_step) {
+                                                                        int mask_ld, int* __restrict__ done_step,
+                                                                        int* __restrict__ step_dev, const long long* __restrict__ dyn) {
   __shared__ int cnt[256];
+  if (step_dev) { step = *step_dev; n_valid = (int)dyn[0]; }
   int fin = 0;
   for (int b = threadIdx.x; b < B; b += 256) {
     const float* x = pred + (size_t)b * ld;
@@ -152,11 +175,37 @@ __global__ __launch_bounds__(256) void decode_select_continuous_kernel(const flo
     int t = 0;
     for (int k = 0; k < 256; ++k) t += cnt[k];
     if (t >= n_valid && *done_step < 0) *done_step = step;
+    if (step_dev) *step_dev = step + 1;
+  }
+}
+
+// Decoder input of the current step (builders/layers/transformer.py:325-334, dropout off): embedding of the newest
+// token (or Dense(5->d) of the newest stroke-5 row) * sqrt(d) + pos[step]; the step index is read from device memory.
+__global__ __launch_bounds__(256) void decode_embed_kernel(const long long* __restrict__ tokens, const float* __restrict__ cont,
+                                                           int ld, int B, const float* __restrict__ table, int vocab,
+                                                           const float* __restrict__ W, const float* __restrict__ bias, int d,
+                                                           const float* __restrict__ pos, const int* __restrict__ step_dev,
+                                                           float* __restrict__ out) {
+  const int step = *step_dev;
+  const float sq = sqrtf((float)d);
+  const float* pe = pos + (size_t)step * d;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < B * d; e += gridDim.x * 256) {
+    const int b = e / d, c = e % d;
+    float v;
+    if (tokens) {
+      long long tk = tokens[(size_t)b * ld + step];
+      if (tk < 0 || tk >= vocab) tk = 0;
+      v = table[(size_t)tk * d + c];
+    } else {
+      const float* x = cont + ((size_t)b * ld + step) * 5;
+      v = x[0] * W[c] + x[1] * W[d + c] + x[2] * W[2 * d + c] + x[3] * W[3 * d + c] + x[4] * W[4 * d + c] + bias[c];
+    }
+    out[e] = v * sq + pe[c];
   }
 }
 
 __global__ void decode_init_kernel(long long* tokens, int tok_ld, float* cont, int cont_ld_rows, unsigned char* selfmask,
-                                   int mask_ld, int* eos_seen, int* done_step, int B, long long sos) {
+                                   int mask_ld, int* eos_seen, int* done_step, int B, long long sos, int* step_dev) {
   for (int b = threadIdx.x; b < B; b += blockDim.x) {
     if (tokens) { tokens[(size_t)b * tok_ld] = sos; selfmask[(size_t)b * mask_ld] = sos == 0 ? 1 : 0; }
     if (cont) {
@@ -166,7 +215,7 @@ __global__ void decode_init_kernel(long long* tokens, int tok_ld, float* cont, i
     }
     eos_seen[b] = 0;
   }
-  if (threadIdx.x == 0) *done_step = -1;
+  if (threadIdx.x == 0) { *done_step = -1; if (step_dev) *step_dev = 0; }
 }
 
 }  // namespace
@@ -174,13 +223,19 @@ __global__ void decode_init_kernel(long long* tokens, int tok_ld, float* cont, i
 extern "C" int skf_attention_decode(const float* Q, int ldq, const float* K, const float* V, int ld_kv,
                                     long long kv_batch_stride, const unsigned char* key_mask, int key_mask_ld,
                                     const int* key_limit, int key_limit_all, int B, int H, int Lk, int dh, float* O,
-                                    int ldo, skf_stream_t stream) {
+                                    int ldo, const int* step_dev, const float* K_new, const float* V_new, int ld_new,
+                                    int limit_from_step, skf_stream_t stream) {
   SKF_CHECK_ARG(Q && K && V && O, "null operand");
   SKF_CHECK_ARG(B > 0 && H > 0 && Lk > 0 && Lk <= 512, "need 0 < Lk <= 512");
   SKF_CHECK_ARG(dh == 16 || dh == 32 || dh == 64, "head size must be 16, 32 or 64");
   SKF_CHECK_ARG((ldq & 3) == 0 && (ld_kv & 3) == 0 && (kv_batch_stride & 3) == 0 &&
                 (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) == 0, "Q/K/V must allow 16-byte row loads");
-  AttnDecodeParams p{Q, ldq, K, V, ld_kv, kv_batch_stride, key_mask, key_mask_ld, key_limit, key_limit_all, B, H, Lk, O, ldo};
+  SKF_CHECK_ARG((K_new == nullptr) == (V_new == nullptr), "K_new and V_new go together");
+  SKF_CHECK_ARG(!K_new || (step_dev && (ld_new & 3) == 0 && (((uintptr_t)K_new | (uintptr_t)V_new) & 15) == 0),
+                "appending needs the device step index and 16-byte aligned new rows");
+  SKF_CHECK_ARG(!limit_from_step || step_dev, "limit_from_step needs the device step index");
+  AttnDecodeParams p{Q, ldq, K, V, ld_kv, kv_batch_stride, key_mask, key_mask_ld, key_limit, key_limit_all, B, H, Lk, O, ldo,
+                     step_dev, K_new, V_new, ld_new, const_cast<float*>(K), const_cast<float*>(V), limit_from_step};
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(skf_cdiv(B * H, 4)), block(256);
   SkfProfScope ps(st, "attn_decode", 4.0 * B * H * (double)Lk * dh, 8.0 * B * H * (double)Lk * dh);
@@ -194,32 +249,47 @@ extern "C" int skf_attention_decode(const float* Q, int ldq, const float* K, con
 }
 
 extern "C" int skf_decode_init(long long* tokens, int tok_ld, float* cont, int cont_ld_rows, unsigned char* selfmask,
-                               int mask_ld, int* eos_seen, int* done_step, int B, long long sos, skf_stream_t stream) {
+                               int mask_ld, int* eos_seen, int* done_step, int B, long long sos, int* step_dev,
+                               skf_stream_t stream) {
   SKF_CHECK_ARG((tokens || cont) && selfmask && eos_seen && done_step && B > 0, "bad argument");
   hipLaunchKernelGGL(decode_init_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, tokens, tok_ld, cont, cont_ld_rows,
-                     selfmask, mask_ld, eos_seen, done_step, B, sos);
+                     selfmask, mask_ld, eos_seen, done_step, B, sos, step_dev);
+  SKF_LAUNCH_CHECK();
+  return SKF_OK;
+}
+
+extern "C" int skf_decode_embed(const long long* tokens, const float* cont, int ld, int B, const float* table, int vocab,
+                                const float* W, const float* bias, int d, const float* pos, const int* step_dev, float* out,
+                                skf_stream_t stream) {
+  SKF_CHECK_ARG((tokens != nullptr) != (cont != nullptr), "exactly one of tokens / cont");
+  SKF_CHECK_ARG((tokens ? table != nullptr : (W && bias)) && pos && step_dev && out && B > 0 && d > 0, "null operand");
+  hipLaunchKernelGGL(decode_embed_kernel, dim3(skf_cdiv(B * d, 256)), dim3(256), 0, (hipStream_t)stream, tokens, cont, ld, B,
+                     table, vocab, W, bias, d, pos, step_dev, out);
   SKF_LAUNCH_CHECK();
   return SKF_OK;
 }
 
 extern "C" int skf_decode_select_tokens(const float* logits, int ld, int B, int V, int n_valid, int step, long long eos,
                                         long long* tokens, int tok_ld, unsigned char* selfmask, int mask_ld,
-                                        int* eos_seen, int* done_step, skf_stream_t stream) {
+                                        int* eos_seen, int* done_step, int* step_dev, const long long* dyn,
+                                        skf_stream_t stream) {
   SKF_CHECK_ARG(logits && tokens && selfmask && eos_seen && done_step, "null operand");
-  SKF_CHECK_ARG(B > 0 && V > 0 && n_valid > 0 && n_valid <= B && step >= 0 && step + 1 < tok_ld && step + 1 < mask_ld, "bad shape");
+  SKF_CHECK_ARG((step_dev == nullptr) == (dyn == nullptr), "step_dev and dyn go together");
+  SKF_CHECK_ARG(B > 0 && V > 0 && (step_dev || (n_valid > 0 && n_valid <= B && step >= 0 && step + 1 < tok_ld && step + 1 < mask_ld)), "bad shape");
   hipLaunchKernelGGL(decode_select_tokens_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, ld, B, V, n_valid,
-                     step, eos, tokens, tok_ld, selfmask, mask_ld, eos_seen, done_step);
+                     step, eos, tokens, tok_ld, selfmask, mask_ld, eos_seen, done_step, step_dev, dyn);
   SKF_LAUNCH_CHECK();
   return SKF_OK;
 }
 
 extern "C" int skf_decode_select_continuous(const float* pred, int ld, int B, int n_valid, int step, float* out,
                                             int out_ld_rows, unsigned char* selfmask, int mask_ld, int* done_step,
-                                            skf_stream_t stream) {
+                                            int* step_dev, const long long* dyn, skf_stream_t stream) {
   SKF_CHECK_ARG(pred && out && selfmask && done_step, "null operand");
-  SKF_CHECK_ARG(B > 0 && n_valid > 0 && n_valid <= B && step >= 0 && step + 1 < out_ld_rows && step + 1 < mask_ld, "bad shape");
+  SKF_CHECK_ARG((step_dev == nullptr) == (dyn == nullptr), "step_dev and dyn go together");
+  SKF_CHECK_ARG(B > 0 && (step_dev || (n_valid > 0 && n_valid <= B && step >= 0 && step + 1 < out_ld_rows && step + 1 < mask_ld)), "bad shape");
   hipLaunchKernelGGL(decode_select_continuous_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pred, ld, B, n_valid,
-                     step, out, out_ld_rows, selfmask, mask_ld, done_step);
+                     step, out, out_ld_rows, selfmask, mask_ld, done_step, step_dev, dyn);
   SKF_LAUNCH_CHECK();
   return SKF_OK;
 }

@@ -263,6 +263,7 @@ struct Plan {
   // KV-cached greedy decode (inference): per-layer self-attention K|V cache (B, L, 2d) + one-row-per-sample step buffers
   std::vector<size_t> dc_cache;
   size_t dc_x[2], dc_q, dc_o, dc_z, dc_out1, dc_out2, dc_h, dc_logits, dc_stats, dc_mask, dc_flags, dc_limit;
+  size_t dc_tok, dc_cont, dc_kvnew, dc_dyn;   // internal (B, L+1) output image, newest K|V rows, per-call scalars + step index
 };
 
 size_t wgrad_ws(int in, int out, int rows) {
@@ -345,6 +346,8 @@ Plan build_plan(const SkfConfig& c) {
   P.dc_z = b.take(B * d * f); P.dc_out1 = b.take(B * d * f); P.dc_out2 = b.take(B * d * f); P.dc_h = b.take(B * F * f);
   P.dc_logits = b.take(B * Vout * f); P.dc_stats = b.take(B * 2 * f); P.dc_mask = b.take(B * (L + 1));
   P.dc_flags = b.take((B + 16) * sizeof(int)); P.dc_limit = b.take(B * sizeof(int));
+  P.dc_tok = b.take(B * (L + 1) * 8); P.dc_cont = b.take(B * (L + 1) * 5 * f); P.dc_kvnew = b.take(B * 2 * d * f);
+  P.dc_dyn = b.take(64);
   P.bytes = b.off;
   return P;
 }
@@ -359,7 +362,8 @@ struct SkfModel {
   const float* pos = nullptr;
   char* ws = nullptr;
   void* state = nullptr;
-  hipGraphExec_t g_fb = nullptr, g_opt = nullptr;
+  hipGraphExec_t g_fb = nullptr, g_opt = nullptr, g_dec = nullptr;   // g_dec: one greedy-decode step
+  long long dec_dyn_host[2] = {0, 0};
   float g_opt_scale = 0.f;
   // weight-gradient GEMMs run on a side stream, off the dgrad critical path
   hipStream_t side = nullptr;
@@ -912,14 +916,21 @@ int run_greedy_decode(SkfModel* M, const float* embedding, const int* expected_l
   }
   int* eos_seen = M->at<int>(P.dc_flags);
   int* done_step = eos_seen + B;
+  long long* dyn = M->at<long long>(P.dc_dyn);          // [0] n_valid, [1] eos  (read by the selection kernel)
+  int* step_dev = reinterpret_cast<int*>(dyn + 4);      // index of the position being decoded
   unsigned char* selfmask = M->at<unsigned char>(P.dc_mask);
-  long long* tokens = c.continuous ? nullptr : (long long*)out;
-  float* cont = c.continuous ? (float*)out : nullptr;
-  SKF_TRY(skf_decode_init(tokens, T, cont, T, selfmask, Le + 1, eos_seen, done_step, B, sos, s));
-  int* limit = nullptr;
-  if (!c.blind_decoder_mask && expected_len_host) {
+  // the running output lives in an internal (B, Le+1) image so that the captured step has constant arguments
+  const int Ti = Le + 1;
+  long long* tokens = c.continuous ? nullptr : M->at<long long>(P.dc_tok);
+  float* cont = c.continuous ? M->at<float>(P.dc_cont) : nullptr;
+  SKF_TRY(skf_decode_init(tokens, Ti, cont, Ti, selfmask, Le + 1, eos_seen, done_step, B, sos, step_dev, s));
+  M->dec_dyn_host[0] = n_valid; M->dec_dyn_host[1] = eos;
+  SKF_HIP(hipMemcpyAsync(dyn, M->dec_dyn_host, 2 * sizeof(long long), hipMemcpyHostToDevice, s));
+  int* limit = nullptr;                                  // per-sample key limit of the cross attention (non-blind only)
+  if (!c.blind_decoder_mask) {
     limit = M->at<int>(P.dc_limit);
-    SKF_HIP(hipMemcpyAsync(limit, expected_len_host, (size_t)B * sizeof(int), hipMemcpyHostToDevice, s));
+    if (expected_len_host) SKF_HIP(hipMemcpyAsync(limit, expected_len_host, (size_t)B * sizeof(int), hipMemcpyHostToDevice, s));
+    else SKF_HIP(hipMemsetAsync(limit, 0xff, (size_t)B * sizeof(int), s));        // -1: nattn = step + 1
   }
   // pre_decoder and the cross-attention K/V of every layer: once
   if (bott)
@@ -935,32 +946,32 @@ int run_greedy_decode(SkfModel* M, const float* embedding, const int* expected_l
   float* q = M->at<float>(P.dc_q); float* o = M->at<float>(P.dc_o); float* z = M->at<float>(P.dc_z);
   float* out1 = M->at<float>(P.dc_out1); float* out2 = M->at<float>(P.dc_out2); float* hbuf = M->at<float>(P.dc_h);
   float* stats = M->at<float>(P.dc_stats); float* logits = M->at<float>(P.dc_logits);
-  int done = -1, steps_run = 0;
-  for (int i = 0; i < max_steps; ++i) {
+  float* kvnew = M->at<float>(P.dc_kvnew);
+  // One decode step.  Every argument is the same for every step and every call (the step index, n_valid and eos are
+  // read from device memory), so the ~50 small launches are captured once into a hipGraph and replayed.
+  auto issue_step = [&]() -> int {
     float* x = M->at<float>(P.dc_x[0]);
     float* xn = M->at<float>(P.dc_x[1]);
-    if (c.continuous)
-      SKF_TRY(skf_embed_continuous_fwd(cont + (size_t)i * 5, T, B, 1, M->P(L.dec_embd.w), M->P(L.dec_embd.b), d,
-                                       M->pos + (size_t)i * d, x, 0.f, 0, M->state, s));
-    else
-      SKF_TRY(skf_embed_fwd(tokens + i, T, B, 1, M->P(L.dec_emb), c.vocab_size, d, M->pos + (size_t)i * d, x, 0.f, 0,
-                            M->state, s));
+    SKF_TRY(skf_decode_embed(tokens, cont, Ti, B, c.continuous ? nullptr : M->P(L.dec_emb), c.vocab_size,
+                             c.continuous ? M->P(L.dec_embd.w) : nullptr, c.continuous ? M->P(L.dec_embd.b) : nullptr, d,
+                             M->pos, step_dev, x, s));
     for (int l = 0; l < N; ++l) {
       const DecLayerP& w = L.dec[l];
-      float* cache = M->at<float>(P.dc_cache[l]);                       // (B, Le, 2d): K | V of positions 0..i
+      float* cache = M->at<float>(P.dc_cache[l]);                       // (B, Le, 2d): K | V of the positions so far
       const DenseP wq{w.mha1.qkv.w, w.mha1.qkv.b, d, d, w.mha1.qkv.ld};
       const DenseP wkv{w.mha1.qkv.w + d, w.mha1.qkv.b + d, d, 2 * d, w.mha1.qkv.ld};
       SKF_TRY(dense_fwd_ld(M, wq, x, d, B, q, d, 0, s));
-      SKF_TRY(dense_fwd_ld(M, wkv, x, d, B, cache + (size_t)i * 2 * d, Le * 2 * d, 0, s));
+      SKF_TRY(dense_fwd_ld(M, wkv, x, d, B, kvnew, 2 * d, 0, s));
+      // keys 0..step: the cache plus the row just projected (which the kernel also appends to the cache)
       SKF_TRY(skf_attention_decode(q, d, cache, cache + d, 2 * d, (long long)Le * 2 * d, selfmask, Le + 1, nullptr, 0, B, H,
-                                   i + 1, dh, o, d, s));
+                                   Le, dh, o, d, step_dev, kvnew, kvnew + d, 2 * d, 0, s));
       SKF_TRY(dense_fwd(M, w.mha1.o, o, B, z, 0, s));
       SKF_TRY(skf_layernorm_residual_fwd(x, z, M->P(w.ln1.g), M->P(w.ln1.b), out1, stats, B, d, 0.f, 0, M->state, s));
       const float* kv2 = M->at<float>(P.dec[l].kv2);
       SKF_TRY(dense_fwd(M, w.mha2.q, out1, B, q, 0, s));
-      // cross mask (models/sketchformer.py:172,279-283): none when blind, else keys >= nattn (expected length or i+1)
-      SKF_TRY(skf_attention_decode(q, d, kv2, kv2 + d, 2 * d, (long long)Le * 2 * d, nullptr, 0, limit,
-                                   (c.blind_decoder_mask || limit) ? 0 : i + 1, B, H, Le, dh, o, d, s));
+      // cross mask (models/sketchformer.py:172,279-283): none when blind, else keys >= nattn (expected length or step+1)
+      SKF_TRY(skf_attention_decode(q, d, kv2, kv2 + d, 2 * d, (long long)Le * 2 * d, nullptr, 0, limit, 0, B, H, Le, dh, o, d,
+                                   step_dev, nullptr, nullptr, 0, c.blind_decoder_mask ? 0 : 1, s));
       SKF_TRY(dense_fwd(M, w.mha2.o, o, B, z, 0, s));
       SKF_TRY(skf_layernorm_residual_fwd(out1, z, M->P(w.ln2.g), M->P(w.ln2.b), out2, stats, B, d, 0.f, 0, M->state, s));
       SKF_TRY(dense_fwd(M, w.f1, out2, B, hbuf, 1, s));
@@ -970,10 +981,27 @@ int run_greedy_decode(SkfModel* M, const float* embedding, const int* expected_l
     }
     SKF_TRY(dense_fwd(M, L.out, x, B, logits, 0, s));
     if (c.continuous)
-      SKF_TRY(skf_decode_select_continuous(logits, Vout, B, n_valid, i, cont, T, selfmask, Le + 1, done_step, s));
-    else
-      SKF_TRY(skf_decode_select_tokens(logits, Vout, B, Vout, n_valid, i, eos, tokens, T, selfmask, Le + 1, eos_seen,
-                                       done_step, s));
+      return skf_decode_select_continuous(logits, Vout, B, 0, 0, cont, Ti, selfmask, Le + 1, done_step, step_dev, dyn, s);
+    return skf_decode_select_tokens(logits, Vout, B, Vout, 0, 0, 0, tokens, Ti, selfmask, Le + 1, eos_seen, done_step,
+                                    step_dev, dyn, s);
+  };
+  static const bool use_graph = !(getenv("SKF_DECODE_GRAPH") && getenv("SKF_DECODE_GRAPH")[0] == '0');
+  if (use_graph && !M->g_dec) {
+    hipGraph_t graph = nullptr;
+    SKF_HIP(hipStreamSynchronize(s));        // nothing of the setup above may end up inside the captured step
+    SKF_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    const int rc = issue_step();
+    hipError_t e = hipStreamEndCapture(s, &graph);
+    if (rc != SKF_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) { skf_set_error("hipStreamEndCapture (decode step): %s", hipGetErrorString(e)); return SKF_EHIP; }
+    e = hipGraphInstantiate(&M->g_dec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) { skf_set_error("hipGraphInstantiate (decode step): %s", hipGetErrorString(e)); M->g_dec = nullptr; return SKF_EHIP; }
+  }
+  int done = -1, steps_run = 0;
+  for (int i = 0; i < max_steps; ++i) {
+    if (use_graph) SKF_HIP(hipGraphLaunch(M->g_dec, s));
+    else SKF_TRY(issue_step());
     steps_run = i + 1;
     if ((i & 7) == 7 || i + 1 == max_steps) {            // the reference syncs every token; every 8th is enough here
       SKF_HIP(hipMemcpyAsync(&done, done_step, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -981,7 +1009,12 @@ int run_greedy_decode(SkfModel* M, const float* embedding, const int* expected_l
       if (done >= 0) break;
     }
   }
-  if (out_len_host) *out_len_host = (done >= 0 ? done + 1 : steps_run) + 1;   // start symbol + emitted positions
+  const int ncols = (done >= 0 ? done + 1 : steps_run) + 1;     // start symbol + emitted positions
+  if (out_len_host) *out_len_host = ncols;
+  // hand the valid columns to the caller's (B, max_steps + 1[, 5]) buffer
+  const size_t esz = c.continuous ? 5 * sizeof(float) : sizeof(long long);
+  SKF_HIP(hipMemcpy2DAsync(out, (size_t)T * esz, c.continuous ? (const void*)cont : (const void*)tokens, (size_t)Ti * esz,
+                           (size_t)ncols * esz, B, hipMemcpyDeviceToDevice, s));
   return SKF_OK;
 }
 
@@ -1118,6 +1151,7 @@ extern "C" void skf_model_destroy(SkfModel* m) {
   if (!m) return;
   if (m->g_fb) (void)hipGraphExecDestroy(m->g_fb);
   if (m->g_opt) (void)hipGraphExecDestroy(m->g_opt);
+  if (m->g_dec) (void)hipGraphExecDestroy(m->g_dec);
   for (hipEvent_t e : m->events) (void)hipEventDestroy(e);
   for (int i = 0; i < 2; ++i) if (m->bucket_ready[i]) (void)hipEventDestroy(m->bucket_ready[i]);
   if (m->side) (void)hipStreamDestroy(m->side);
@@ -1134,6 +1168,7 @@ extern "C" int skf_model_bind(SkfModel* m, float* params, float* grads, float* a
   m->ws = (char*)workspace; m->metrics = metrics; m->state = step_state;
   if (m->g_fb) { (void)hipGraphExecDestroy(m->g_fb); m->g_fb = nullptr; }
   if (m->g_opt) { (void)hipGraphExecDestroy(m->g_opt); m->g_opt = nullptr; }
+  if (m->g_dec) { (void)hipGraphExecDestroy(m->g_dec); m->g_dec = nullptr; }
   m->descs.clear(); m->descs_uploaded = false;
   return SKF_OK;
 }

@@ -91,7 +91,8 @@ def attention_fwd(q, k, v, num_heads, key_mask=None, causal=False):
     return o, stats
 
 
-def attention_decode(q, k, v, num_heads, n_keys=None, key_mask=None, key_limit=None, key_limit_all=0):
+def attention_decode(q, k, v, num_heads, n_keys=None, key_mask=None, key_limit=None, key_limit_all=0, step=None,
+                     k_new=None, v_new=None, limit_from_step=False):
     """One query row per (sample, head): q (B,d), k/v (B,Lcap,d) cache views with unit inner stride, the first
     n_keys rows of each sample are used -> o (B,d)."""
     B, d = q.shape
@@ -100,7 +101,8 @@ def attention_decode(q, k, v, num_heads, n_keys=None, key_mask=None, key_limit=N
     o = torch.empty(B, d, dtype=torch.float32, device=q.device)
     _lib.call("skf_attention_decode", _p(q), q.stride(0), _p(k), _p(v), k.stride(1), k.stride(0), _p(key_mask),
               key_mask.stride(0) if key_mask is not None else 0, _p(key_limit), int(key_limit_all), B, num_heads, Lk,
-              d // num_heads, _p(o), o.stride(0), _stream())
+              d // num_heads, _p(o), o.stride(0), _p(step), _p(k_new), _p(v_new), k_new.stride(0) if k_new is not None else 0,
+              int(limit_from_step), _stream())
     return o
 
 

@@ -362,3 +362,33 @@ def test_attention_decode_single_query(ops, dh, Lk, cap):
         want, _, _ = oracle.sdpa_fwd(sp(q[:, None, :], 1), sp(cache[:, :Lk, :d], Lk), sp(cache[:, :Lk, d:], Lk), m)
         want = want.transpose(0, 2, 1, 3).reshape(B, d)
         _close(o, want, 3e-5, "attention_decode mask=%s limit=%s" % (use_mask, use_limit))
+
+
+def test_attention_decode_appends_new_row_and_reads_step_from_device(ops):
+    """Graph-replayable form: the number of keys is *step + 1, the newest K/V row comes from the projection output and is
+    appended to the cache at row *step; limit_from_step masks keys >= step + 1 of a full-length cross cache."""
+    B, H, dh, cap = 3, 4, 16, 24
+    d = H * dh
+    rng = np.random.RandomState(7)
+    cache = rng.randn(B, cap, 2 * d).astype(np.float32)
+    ct = torch.from_numpy(cache.copy()).cuda()
+    step = torch.zeros(1, dtype=torch.int32, device="cuda")
+    sp = lambda t, n: t.reshape(B, n, H, dh).transpose(0, 2, 1, 3).astype(np.float32)  # noqa: E731
+    for i in (0, 5, 23):
+        step.fill_(i)
+        q = rng.randn(B, d).astype(np.float32)
+        kvn = rng.randn(B, 2 * d).astype(np.float32)
+        kvt = torch.from_numpy(kvn).cuda()
+        o = ops.attention_decode(torch.from_numpy(q).cuda(), ct[:, :, :d], ct[:, :, d:], H, n_keys=cap, step=step,
+                                 k_new=kvt[:, :d], v_new=kvt[:, d:])
+        cache[:, i] = kvn                                        # what the kernel must have appended
+        want, _, _ = oracle.sdpa_fwd(sp(q[:, None, :], 1), sp(cache[:, :i + 1, :d], i + 1), sp(cache[:, :i + 1, d:], i + 1), None)
+        _close(o, want.transpose(0, 2, 1, 3).reshape(B, d), 3e-5, "append step %d" % i)
+        assert np.array_equal(ct[:, i].cpu().numpy(), kvn)
+        # cross attention over the whole cache with keys >= step + 1 masked
+        o2 = ops.attention_decode(torch.from_numpy(q).cuda(), ct[:, :, :d], ct[:, :, d:], H, n_keys=cap, step=step,
+                                  limit_from_step=True)
+        m = (np.arange(cap)[None, None, None, :] > i).astype(np.float32)
+        cur = ct.cpu().numpy()
+        want2, _, _ = oracle.sdpa_fwd(sp(q[:, None, :], 1), sp(cur[:, :, :d], cap), sp(cur[:, :, d:], cap), m)
+        _close(o2, want2.transpose(0, 2, 1, 3).reshape(B, d), 3e-5, "limit_from_step %d" % i)
