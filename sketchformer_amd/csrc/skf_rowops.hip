@@ -140,6 +140,62 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   }
 }
 
+// Same, D = 4*LPR <= 256: a row is read by LPR lanes with 16-byte loads, 64/LPR rows per wave instruction and two
+// such groups in flight per iteration (the kernel is bound by bytes in flight, not by arithmetic).
+template <int LPR>
+__global__ __launch_bounds__(256) void ln_fwd_v4_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float* __restrict__ out, float* __restrict__ stats, int rows,
+                                                        float rate, uint32_t site, const SkfStepState* st) {
+  constexpr int D = 4 * LPR, RPW = 64 / LPR, UR = 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % LPR, rsel = lane / LPR;
+  const uint32_t thresh = skf_drop_thresh(rate);
+  const float inv_keep = 1.0f / (1.0f - rate);
+  const uint32_t sk = rate > 0.f ? skf_site_key(st->drop_key, site) : 0u;
+  const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + 4 * sub), bt = *reinterpret_cast<const f32x4*>(beta + 4 * sub);
+  const int stride = gridDim.x * 4 * RPW * UR;
+  for (int row0 = (blockIdx.x * 4 + wave) * RPW * UR; row0 < rows; row0 += stride) {
+    f32x4 xv[UR], yv[UR];
+    size_t off[UR];
+    bool ok[UR];
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      const int row = row0 + u * RPW + rsel;
+      ok[u] = row < rows;
+      off[u] = (size_t)(ok[u] ? row : rows - 1) * D + 4 * sub;
+      xv[u] = *reinterpret_cast<const f32x4*>(x + off[u]);
+      yv[u] = *reinterpret_cast<const f32x4*>(y + off[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      f32x4 z;
+      float sum = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float yy = yv[u][e];
+        if (rate > 0.f) yy *= skf_keep(sk, (uint32_t)off[u] + e, thresh) ? inv_keep : 0.f;
+        z[e] = xv[u][e] + yy;
+        sum += z[e];
+      }
+#pragma unroll
+      for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+      const float mean = sum * (1.0f / D);
+      float sq = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float c = z[e] - mean; sq += c * c; }
+#pragma unroll
+      for (int o = LPR / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+      const float rstd = rsqrtf(sq * (1.0f / D) + 1e-6f);
+      if (ok[u]) {
+        *reinterpret_cast<f32x4*>(y + off[u]) = z;
+        *reinterpret_cast<f32x4*>(out + off[u]) = (z - mean) * rstd * gm + bt;
+        if (sub == 0) { const size_t row = off[u] / D; stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+      }
+    }
+  }
+}
+
 // dz = LN'(dout); dy = dz * dropmask (written to dy when dy != null, i.e. rate > 0);
 // partial dgamma/dbeta per workgroup -> part[block][2][D].
 template <int VPL>
@@ -200,6 +256,79 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   }
 #pragma unroll
   for (int v = 0; v < VPL; ++v) { red[wave][0][lane * VPL + v] = dg[v]; red[wave][1][lane * VPL + v] = db[v]; }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 2 * D; e += 256) {
+    const int w = e / D, c = e % D;
+    part[(size_t)blockIdx.x * 2 * D + e] = red[0][w][c] + red[1][w][c] + red[2][w][c] + red[3][w][c];
+  }
+}
+
+// Same, D = 4*LPR <= 256: 16-byte loads, 64/LPR rows per wave instruction, two groups in flight (see ln_fwd_v4_kernel).
+template <int LPR>
+__global__ __launch_bounds__(256) void ln_bwd_v4_kernel(const float* __restrict__ dout, const float* __restrict__ z,
+                                                        const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                        float* __restrict__ dz, float* __restrict__ dy,
+                                                        float* __restrict__ part, int rows, float rate, uint32_t site,
+                                                        const SkfStepState* st) {
+  constexpr int D = 4 * LPR, RPW = 64 / LPR, UR = 2;
+  __shared__ float red[4][2][D];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % LPR, rsel = lane / LPR;
+  const uint32_t thresh = skf_drop_thresh(rate);
+  const float inv_keep = 1.0f / (1.0f - rate);
+  const uint32_t sk = rate > 0.f ? skf_site_key(st->drop_key, site) : 0u;
+  const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + 4 * sub);
+  f32x4 dg = {0.f, 0.f, 0.f, 0.f}, db = dg;
+  const int stride = gridDim.x * 4 * RPW * UR;
+  for (int row0 = (blockIdx.x * 4 + wave) * RPW * UR; row0 < rows; row0 += stride) {
+    f32x4 dv[UR], zv[UR];
+    float mean[UR], rstd[UR];
+    size_t off[UR];
+    bool ok[UR];
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      const int row = row0 + u * RPW + rsel;
+      ok[u] = row < rows;
+      const int rr = ok[u] ? row : rows - 1;
+      off[u] = (size_t)rr * D + 4 * sub;
+      mean[u] = stats[2 * (size_t)rr]; rstd[u] = stats[2 * (size_t)rr + 1];
+      dv[u] = *reinterpret_cast<const f32x4*>(dout + off[u]);
+      zv[u] = *reinterpret_cast<const f32x4*>(z + off[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      const float live = ok[u] ? 1.f : 0.f;                 // rows past the end: loads were clamped, contribute nothing
+      const f32x4 xh = (zv[u] - mean[u]) * rstd[u];
+      const f32x4 gg = dv[u] * gm;
+      dg += (dv[u] * xh) * live;
+      db += dv[u] * live;
+      float s1 = (gg[0] + gg[1]) + (gg[2] + gg[3]);
+      float s2 = (gg[0] * xh[0] + gg[1] * xh[1]) + (gg[2] * xh[2] + gg[3] * xh[3]);
+#pragma unroll
+      for (int o = LPR / 2; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+      s1 *= (1.0f / D); s2 *= (1.0f / D);
+      const f32x4 g = rstd[u] * (gg - s1 - xh * s2);
+      if (ok[u]) {
+        *reinterpret_cast<f32x4*>(dz + off[u]) = g;
+        if (dy) {
+          f32x4 gy;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) gy[e] = g[e] * (skf_keep(sk, (uint32_t)off[u] + e, thresh) ? inv_keep : 0.f);
+          *reinterpret_cast<f32x4*>(dy + off[u]) = gy;
+        }
+      }
+    }
+  }
+  // fold the 64/LPR row groups of the wave, then the 4 waves
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) { dg[e] += __shfl_xor(dg[e], o, 64); db[e] += __shfl_xor(db[e], o, 64); }
+  }
+  if (rsel == 0) {
+    *reinterpret_cast<f32x4*>(&red[wave][0][4 * sub]) = dg;
+    *reinterpret_cast<f32x4*>(&red[wave][1][4 * sub]) = db;
+  }
   __syncthreads();
   for (int e = threadIdx.x; e < 2 * D; e += 256) {
     const int w = e / D, c = e % D;
@@ -629,6 +758,17 @@ extern "C" int skf_layernorm_residual_fwd(const float* x, float* y_inout_z, cons
   dim3 grid(grid_for_rows(rows)), block(256);
   hipStream_t s = (hipStream_t)stream;
   SkfProfScope ps(s, "ln_fwd", 0.0, 16.0 * rows * d);
+  static const bool v4 = !(getenv("SKF_LN_V4") && getenv("SKF_LN_V4")[0] == '0');
+  const bool al = ((((uintptr_t)x | (uintptr_t)y_inout_z | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0);
+  if (v4 && al && (d == 64 || d == 128 || d == 256)) {
+    const int rpi = (64 / (d / 4)) * 2 * 4;                       // rows per workgroup iteration
+    int g = skf_cdiv(rows, rpi); if (g > kMaxGrid) g = kMaxGrid;
+    if (d == 64) hipLaunchKernelGGL(ln_fwd_v4_kernel<16>, dim3(g), block, 0, s, x, y_inout_z, gamma, beta, out, stats, rows, rate, site, st);
+    else if (d == 128) hipLaunchKernelGGL(ln_fwd_v4_kernel<32>, dim3(g), block, 0, s, x, y_inout_z, gamma, beta, out, stats, rows, rate, site, st);
+    else hipLaunchKernelGGL(ln_fwd_v4_kernel<64>, dim3(g), block, 0, s, x, y_inout_z, gamma, beta, out, stats, rows, rate, site, st);
+    SKF_LAUNCH_CHECK();
+    return SKF_OK;
+  }
   switch (d) {
     case 128: hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, block, 0, s, x, y_inout_z, gamma, beta, out, stats, rows, rate, site, st); break;
     case 256: hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, block, 0, s, x, y_inout_z, gamma, beta, out, stats, rows, rate, site, st); break;
@@ -660,6 +800,12 @@ extern "C" int skf_layernorm_residual_bwd(const float* dout, const float* z, con
   float* part = (float*)workspace;
   float* dyp = (dy && (rate > 0.f || dy != dz)) ? dy : nullptr;   // rate 0 with a separate dy buffer: dy = dz
   SkfProfScope ps(s, "ln_bwd", 0.0, (rate > 0.f ? 16.0 : 12.0) * rows * d);
+  static const bool v4 = !(getenv("SKF_LN_V4") && getenv("SKF_LN_V4")[0] == '0');
+  const bool al = ((((uintptr_t)dout | (uintptr_t)z | (uintptr_t)dz | (uintptr_t)dyp | (uintptr_t)gamma) & 15) == 0);
+  if (v4 && al && d == 64) hipLaunchKernelGGL(ln_bwd_v4_kernel<16>, grid, block, 0, s, dout, z, stats, gamma, dz, dyp, part, rows, rate, site, st);
+  else if (v4 && al && d == 128) hipLaunchKernelGGL(ln_bwd_v4_kernel<32>, grid, block, 0, s, dout, z, stats, gamma, dz, dyp, part, rows, rate, site, st);
+  else if (v4 && al && d == 256) hipLaunchKernelGGL(ln_bwd_v4_kernel<64>, grid, block, 0, s, dout, z, stats, gamma, dz, dyp, part, rows, rate, site, st);
+  else
   switch (d) {
     case 128: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, 0, s, dout, z, stats, gamma, dz, dyp, part, rows, rate, site, st); break;
     case 256: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, s, dout, z, stats, gamma, dz, dyp, part, rows, rate, site, st); break;
