@@ -147,6 +147,10 @@ class BaseModel(object, metaclass=ABCMeta):
                 print("[Checkpoint] Not found")
                 return
             checkpoint = self._safety[-1]
+        if os.path.exists(checkpoint + '.index'):       # a TensorFlow checkpoint prefix written by the reference
+            self.load_reference_checkpoint(checkpoint)
+            print("[Checkpoint] Restored reference (TensorFlow) checkpoint, step #{}".format(self.current_step))
+            return
         state = torch.load(checkpoint, map_location='cpu', weights_only=False)
         self.load_state_dict(state)
         self.current_step = int(state['current_step'])

@@ -177,6 +177,23 @@ class Transformer(BaseModel):
             out['attn_weights'] = dec['attn_weights']
         return out
 
+    def load_reference_checkpoint(self, prefix):
+        """Weights (+ Adam slots, optimizer.iterations, current_step) from a checkpoint written by the reference's
+        tf.train.Checkpoint(transformer=..., optimizer=...) (core/models.py:321-344), read without TensorFlow."""
+        import torch
+        from ..utils import tf_checkpoint
+        params, m, v, scalars = tf_checkpoint.load_reference_checkpoint(prefix, self.engine.entries)
+        e = self.engine
+        e.load_numpy(params)
+        e.adam_m.zero_()
+        e.adam_v.zero_()
+        e.load_numpy(m, "adam_m")
+        e.load_numpy(v, "adam_v")
+        if 'iterations' in scalars:
+            e.state[0] = int(scalars['iterations'])
+        self.current_step = int(scalars.get('current_step', scalars.get('iterations', 0)))
+        torch.cuda.synchronize()
+
     # ---- checkpoint payload
     def state_dict(self):
         e = self.engine

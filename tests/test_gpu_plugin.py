@@ -193,3 +193,37 @@ def test_plugin_structural_hparams(tmp_path, extra, keys):
     with pytest.raises(ValueError):
         Model(Model.parse_hparams(base="batch_size=8", specific=SMALL.replace("lowerdim=32", "lowerdim=0")), dataset,
               str(tmp_path), "bad")
+
+
+def test_restore_from_reference_style_tensorflow_checkpoint(tmp_path):
+    """--resume <prefix> with a TensorBundle laid out like the reference's tf.train.Checkpoint: weights, Adam slots and
+    step counters land in the flat buffers (read without TensorFlow), and the model computes with them."""
+    from sketchformer_amd.utils import tf_checkpoint as tfc
+    model, dataset = _build(tmp_path, "tf")
+    ocfg = oracle.Config(num_layers=2, d_model=64, dff=128, num_heads=4, lowerdim=32, vocab_size=52, n_classes=7, seq_len=24)
+    P = oracle.init_params(ocfg, seed=9, dtype=np.float32)
+    keymap = tfc.reference_variable_keys(list(P))
+    rng = np.random.RandomState(2)
+    tensors = {}
+    for n, a in P.items():
+        tensors[keymap[n] + tfc.SUFFIX] = a
+        tensors[keymap[n] + "/.OPTIMIZER_SLOT/optimizer/m" + tfc.SUFFIX] = (1e-3 * rng.randn(*a.shape)).astype(np.float32)
+        tensors[keymap[n] + "/.OPTIMIZER_SLOT/optimizer/v" + tfc.SUFFIX] = (1e-6 * rng.rand(*a.shape)).astype(np.float32)
+    tensors["optimizer/iter" + tfc.SUFFIX] = np.array(7000, dtype=np.int64)
+    tensors["transformer/current_step" + tfc.SUFFIX] = np.array(6999, dtype=np.int64)
+    prefix = str(tmp_path / "ckpt-3")
+    tfc.write_tensor_bundle(prefix, tensors)
+    model.restore_checkpoint_if_exists(prefix)
+    assert model.current_step == 6999 and model.engine.iterations == 7000
+    got = model.engine.state_dict_numpy()
+    assert all(np.array_equal(got[n], P[n]) for n in P)
+    m = model.engine.state_dict_numpy("adam_m")
+    assert np.array_equal(m["output/kernel"], tensors[keymap["output/kernel"] + "/.OPTIMIZER_SLOT/optimizer/m" + tfc.SUFFIX])
+    x, y = next(dataset.batch_iterator("valid", 8, True))
+    ref, _ = oracle.forward({k: v.astype(np.float64) for k, v in P.items()}, ocfg, x, x[:, :-1], training=False)
+    model.engine.forward(x, training=False)
+    torch.cuda.synchronize()
+    logits = model.engine.buffer("logits").cpu().numpy().reshape(8, 23, -1)
+    assert np.abs(logits - ref["recon"]).max() < 1e-4 * np.abs(ref["recon"]).max()
+    res = model.train_on_batch((x, y))                     # and training goes on from step 7000
+    assert model.engine.iterations == 7001 and np.isfinite(res["total_loss"])
