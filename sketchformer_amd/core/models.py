@@ -43,6 +43,7 @@ class BaseModel(object, metaclass=ABCMeta):
         self.config_filepath = self.get_config_filepath(outdir, self.experiment_id)
         self.current_step = 0
         self.epoch = 0
+        self._metric_inputs = {}
         self.build_model()
         self.prepare_checkpointing()
 
@@ -120,6 +121,82 @@ class BaseModel(object, metaclass=ABCMeta):
         return log
 
     # ---- checkpoints (core/models.py:321-358; own on-disk format)
+    # ---- slow metrics (core/models.py:218-296 of the reference): computed on demand (evaluate-metrics.py) or by
+    # train() when hps['notify_every'] asks for it; plotting = one PNG per call, no Slack
+    def build_slow_metrics(self, names=None):
+        from .. import metrics
+        names = list(self.slow_metrics) if names is None else names
+        built = {m: metrics.build_metric_by_name(m, self.hps) for m in names}
+        for m in built:
+            if m in self.slow_metrics:
+                self.slow_metrics[m] = built[m]
+        return built
+
+    def gather_data_for_metric(self, data_type):
+        if data_type not in self._metric_inputs:
+            gather = getattr(self, "compute_{}".format(data_type), None)
+            if gather is None:
+                raise AttributeError("One of your metrics requires a compute_{} method".format(data_type))
+            self._metric_inputs[data_type] = gather()
+        return self._metric_inputs[data_type]
+
+    def compute_metrics_from(self, chosen_metrics):
+        self._metric_inputs = {}
+        for metric in chosen_metrics.values():
+            metric.computation_worker(self.gather_data_for_metric(metric.input_type))
+        self._metric_inputs = {}
+
+    def compute_all_metrics(self):
+        self._metric_inputs = {}
+        for m in [m for m, v in self.slow_metrics.items() if v is None]:
+            self.build_slow_metrics([m])
+        for metric in self.slow_metrics.values():
+            metric.compute_in_parallel(self.gather_data_for_metric(metric.input_type))
+        self._metric_inputs = {}
+
+    def plot_metrics(self, metrics_dict, filename):
+        """One PNG with every quick-metric history and every ready slow metric (utils/plots.PlotManager in the reference)."""
+        import matplotlib
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+        import numpy as np
+        panels = [(m, 'lines', q.history) for m, q in self.quick_metrics.items() if len(q.history) > 1]
+        panels += [(m, v.plot_type, v.get_data_for_plot()) for m, v in metrics_dict.items() if v is not None and v.is_ready_for_plot()]
+        if not panels:
+            return None
+        cols = min(3, len(panels))
+        rows = (len(panels) + cols - 1) // cols
+        fig, axes = plt.subplots(rows, cols, figsize=(5 * cols, 4 * rows), squeeze=False)
+        for ax in axes.reshape(-1)[len(panels):]:
+            ax.axis("off")
+        for ax, (name, kind, data) in zip(axes.reshape(-1), panels):
+            ax.set_title(name)
+            if kind == 'lines':
+                ax.plot(np.asarray(data, dtype=np.float64))
+            elif kind == 'scatter':
+                d = np.asarray(data, dtype=np.float64)
+                ax.scatter(d[:, 0], d[:, 1], c=d[:, 2], s=6, cmap="tab10")
+            elif kind == 'hist':
+                ax.hist(np.asarray(data, dtype=np.float64).reshape(-1), bins=30)
+            elif kind == 'image':
+                ax.imshow(plt.imread(data))
+                ax.axis("off")
+        path = os.path.join(self.plots_out_dir, filename)
+        fig.savefig(path, dpi=70)
+        plt.close(fig)
+        return path
+
+    def plot_and_send_notification_for(self, metrics_list):
+        for metric in metrics_list.values():
+            metric.wait()
+        return self.plot_metrics(metrics_list, "evaluation_plots.png")
+
+    def clean_up_tmp_dir(self):
+        for name in os.listdir(self.tmp_out_dir):
+            path = os.path.join(self.tmp_out_dir, name)
+            if os.path.isfile(path):
+                os.unlink(path)
+
     def prepare_checkpointing(self):
         self._safety = sorted(glob.glob(os.path.join(self.wgt_out_dir, 'ckpt-*.pt')),
                               key=lambda p: int(os.path.basename(p)[5:-3]))

@@ -6,10 +6,11 @@ import numpy as np
 
 from .. import builders
 from ..core.models import BaseModel
+from .evaluation_mixin import TransformerMetricsMixin
 from ..utils.hparams import HParams
 
 
-class Transformer(BaseModel):
+class Transformer(BaseModel, TransformerMetricsMixin):
     name = 'sketch-transformer-tf2'
     quick_metrics = ['recon_loss', 'recon_acc', 'class_loss', 'class_acc', 'total_loss']
     slow_metrics = ["sketch-reconstruction", "val-clas-acc", "tsne", "tsne-predicted"]

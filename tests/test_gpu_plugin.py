@@ -227,3 +227,42 @@ def test_restore_from_reference_style_tensorflow_checkpoint(tmp_path):
     assert np.abs(logits - ref["recon"]).max() < 1e-4 * np.abs(ref["recon"]).max()
     res = model.train_on_batch((x, y))                     # and training goes on from step 7000
     assert model.engine.iterations == 7001 and np.isfinite(res["total_loss"])
+
+
+def test_slow_metrics_and_extract_embeddings(tmp_path):
+    """the evaluation plug-ins run end to end on the device model - predictions_on_validation_set
+    (greedy reconstructions + class predictions + embeddings), val-clas-acc, t-SNE / PCA projections, the reconstruction
+    grid, the evaluation plot, and the extract-embeddings experiment."""
+    from sketchformer_amd import experiments, metrics
+    model, dataset = _build(tmp_path, "ev")
+    assert set(model.slow_metrics) <= set(metrics.metrics_by_name)
+    data = model.compute_predictions_on_validation_set()
+    x, all_y, pred_x, pred_y, pred_z, tokenizer, plot_fp, tmp_fp, is_cont = data
+    n_valid = len(dataset.get_all_data_from("valid")[0])
+    assert x.shape == (32, 24) and pred_x.shape == (32, 25) and pred_y.shape == (n_valid,) and pred_z.shape == (n_valid, 64)
+    assert all_y.shape == (n_valid,) and not is_cont and tokenizer is dataset.tokenizer
+    chosen = {m: metrics.build_metric_by_name(m, model.hps) for m in ("val-clas-acc", "tsne", "tsne-predicted", "pca", "sketch-reconstruction")}
+    model.compute_metrics_from(chosen)
+    acc = chosen["val-clas-acc"].last_value
+    assert acc == pytest.approx(float(np.mean(pred_y == all_y))) and 0.0 <= acc <= 1.0
+    for m in ("tsne", "tsne-predicted", "pca"):
+        proj = chosen[m].get_data_for_plot()
+        assert proj.ndim == 2 and proj.shape[1] == 3 and np.isfinite(proj).all() and len(proj) > 10
+    import os
+    assert os.path.exists(chosen["sketch-reconstruction"].get_data_for_plot())
+    plot = model.plot_and_send_notification_for(chosen)
+    assert plot.endswith("evaluation_plots.png") and os.path.getsize(plot) > 1000
+    model.clean_up_tmp_dir()
+    # a failing metric is reported and swallowed, like in the reference
+    class Broken(metrics.metrics_by_name["val-clas-acc"]):
+        name = None
+        def compute(self, input_data):
+            raise RuntimeError("boom")
+    b = Broken(model.hps)
+    b.computation_worker(data)
+    assert b.last_value == 0 and b.history == [0]
+    Exp = experiments.get_experiment_by_name("extract-embeddings")
+    exp = Exp(Exp.parse_hparams("n_samples_to_reconstruct=6"), "e0", str(tmp_path))
+    out = np.load(exp.compute(model), allow_pickle=True)
+    assert out["embeddings"].shape == (n_valid, 64) and out["pred_y"].shape == (n_valid,) and out["y"].shape == (n_valid,)
+    assert len(out["sketches"]) == 6 and len(out["recon_sketches"]) == 6 and out["sketches"][0].shape[1] == 3
