@@ -431,7 +431,6 @@ extern "C" int skf_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K,
   p.tiles_m = skf_cdiv(M, 128); p.tiles_n = skf_cdiv(N, 128);
   { const char* ab = getenv("SKF_GEMM_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }
   { const char* xr = getenv("SKF_WS_XCD"); p.xcd_remap = xr ? atoi(xr) : 0; }
-  { const char* ds = getenv("SKF_WS_DIRECT"); p.direct_store = ds ? atoi(ds) : 0; }
   { const char* db = getenv("SKF_GEMM_DBG"); p.dbg = db ? (long long*)strtoull(db, nullptr, 0) : nullptr; }
   SKF_CHECK_ARG(!bias_grad || !b_kcontig, "bias_grad needs B as [K][N]");
   {

@@ -21,8 +21,7 @@ struct GemmParams {
   int tiles_m, tiles_n;
   long long* dbg;          // diagnostics only: per-phase s_memtime stamps of a few workgroups (env SKF_GEMM_DBG)
   int xcd_remap;           // ws kernel: XCD-contiguous logical ids (env SKF_WS_XCD, A/B knob)
-  int direct_store;        // ws kernel: store C straight from the MFMA layout (env SKF_WS_DIRECT, A/B knob)
-  int ablate;              // diagnostics only (env SKF_GEMM_ABLATE): 1 no MFMA, 2 no C store, 3 no global reload
+  int ablate;              // generic kernel, diagnostics only (env SKF_GEMM_ABLATE): 1 no MFMA, 2 no C store, 3 no global reload
 };
 
 // weight-stationary fast path; sets *handled when it launched the problem
