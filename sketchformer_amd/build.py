@@ -21,12 +21,26 @@ def _hipcc():
     return "hipcc"
 
 
+STAMP = LIB + ".stamp"
+
+
+def _source_digest():
+    """sha256 over every file the library is built from + the compiler flags (file times do not survive a snapshot copy)."""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [os.path.join(HERE, "..", "include", "skf.h")]
+    for path in files:
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def needs_build():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "skf.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(STAMP) as f:
+        return f.read().strip() != _source_digest()
 
 
 def build_library(force=False, verbose=True):
@@ -57,6 +71,8 @@ def build_library(force=False, verbose=True):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(_source_digest())
     return LIB
 
 
