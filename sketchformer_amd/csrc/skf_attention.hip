@@ -285,12 +285,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
 
   const unsigned char* km = p.key_mask ? p.key_mask + (size_t)b * p.key_mask_ld : nullptr;
   // skipping fully look-ahead-masked tiles is exact only if key 0 is visible (see forward)
-  const bool can_skip = p.causal && !(km && km[0]);
+  const bool can_skip = CAUSAL && !(km && km[0]);      // CAUSAL == p.causal (dispatch)
   // trailing all-padding key tiles have P == 0 exactly: their dK/dV are 0 and they add nothing to dQ (see forward)
   const int lastk = max(max(last_valid[0], last_valid[1]), max(last_valid[2], last_valid[3]));
-  const int nkt_eff = (lastk >= 0 && (!p.causal || can_skip)) ? (lastk >> 4) + 1 : nkt;
+  const int nkt_eff = (lastk >= 0 && (!CAUSAL || can_skip)) ? (lastk >> 4) + 1 : nkt;
   const float inv_sqrt = 1.0f / sqrtf((float)DH);
-  const bool pow4 = (DH == 16 || DH == 64);
   const float c2 = 1.44269504088896340736f / sqrtf((float)DH);
   float* tr = Tr + wave * 16 * TLD;
   f32x4 dK_shared[NC], dV_shared[NC];
@@ -307,14 +306,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
     // A-operand (transposed) fragments (lane = d 16c+i, contraction key = k0+4g+s)
     float4 kb[KTW][NC], vb[KTW][NC];
     float kT[KTW][NC][4];
-    float kadd[KTW], kvalid[KTW];
+    float kadd[KTW];
     f32x4 dKt[KTW][NC], dVt[KTW][NC];
 #pragma unroll
     for (int j = 0; j < KTW; ++j) {
       const int ktj = (share && j == KTW - 1) ? nkt - 1 : kt0 + 4 * j;
       const int k0 = ktj * 16, krow = k0 + i;
       const bool kok = krow < p.Lk;
-      kvalid[j] = kok ? 1.f : 0.f;
       // keys past Lk get -inf (never -1e9): with a fully padded sample the row max itself is -1e9 and exp(x - max) would overflow
       kadd[j] = kok ? ((km && km[krow]) ? -1e9f : 0.f) : -INFINITY;
 #pragma unroll
@@ -327,7 +325,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const int kr = k0 + g * 4 + s;
-          kT[j][c][s] = kr < p.Lk ? p.K[(size_t)(b * p.Lk + kr) * p.ldk + h * DH + c * 16 + i] : 0.f;
+          // pre-scaled by 1/sqrt(dh): dQ = (P o (dP - delta)) . K / sqrt(dh) without a multiply per score
+          kT[j][c][s] = kr < p.Lk ? p.K[(size_t)(b * p.Lk + kr) * p.ldk + h * DH + c * 16 + i] * inv_sqrt : 0.f;
         }
         dKt[j][c] = (f32x4){0.f, 0.f, 0.f, 0.f}; dVt[j][c] = dKt[j][c];
       }
@@ -346,7 +345,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
         da[c] = *reinterpret_cast<const float4*>(&dOs[(q0 + i) * LD + c * 16 + g * 4]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          qT[c][r] = Qs[(q0 + g * 4 + r) * LD + c * 16 + i];
+          qT[c][r] = Qs[(q0 + g * 4 + r) * LD + c * 16 + i] * inv_sqrt;   // likewise for dK = dS^T . Q / sqrt(dh)
           dT[c][r] = dOs[(q0 + g * 4 + r) * LD + c * 16 + i];
         }
       }
@@ -386,12 +385,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int q = q0 + g * 4 + r;
-          const float m = fminf(kadd[j], (p.causal && krow > q) ? -1e9f : 0.f);
-          const float v = m < 0.f ? m : sacc[r] * c2;             // base-2 logits, masked ones SET (see forward)
-          const float pv = __builtin_amdgcn_exp2f(v - mxr[r]) * (rir[r] * kvalid[j]);
+          // base-2 logits, masked ones SET (see forward); keys >= Lk carry -inf, so their p is exactly 0
+          const float m = CAUSAL ? fminf(kadd[j], krow > q ? -1e9f : 0.f) : kadd[j];
+          const float v = m < 0.f ? m : sacc[r] * c2;
+          const float pv = __builtin_amdgcn_exp2f(v - mxr[r]) * rir[r];
           pr[r] = pv;
-          const float d = pv * (dpacc[r] - dlr[r]);
-          ds[r] = pow4 ? d * inv_sqrt : d / sqrtf((float)DH);
+          ds[r] = pv * (dpacc[r] - dlr[r]);                       // the 1/sqrt(dh) factor sits in qT / kT
         }
         // dV^T[d][k] += sum_q dO[q][d] P[q][k];  dK^T[d][k] += sum_q Q[q][d] dS[q][k]
 #pragma unroll
