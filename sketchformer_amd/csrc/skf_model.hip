@@ -627,6 +627,19 @@ int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s, bool 
     SKF_TRY(skf_embed_fwd(tar, Le, B, Ld, M->P(L.dec_emb), c.vocab_size, d, M->pos, M->at<float>(P.dec[0].x_in), rate,
                           site_dec_embed(N), M->state, s));
   const unsigned char* cross_mask = c.blind_decoder_mask ? nullptr : emask;
+  // The cross-attention K|V projections of ALL decoder layers only depend on pre_decoder: on the eager path they run
+  // on the side stream under the first layer's self-attention block (one event pair) instead of on the critical path.
+  hipEvent_t kv_done = nullptr;
+  if (M->side) {
+    M->next_event = 0;
+    hipEvent_t pre_ready = M->new_event();
+    kv_done = M->new_event();
+    SKF_CHECK_ARG(pre_ready && kv_done, "event allocation failed");
+    SKF_HIP(hipEventRecord(pre_ready, s));
+    SKF_HIP(hipStreamWaitEvent(M->side, pre_ready, 0));
+    for (int i = 0; i < N; ++i) SKF_TRY(dense_fwd(M, L.dec[i].mha2.kv, pre, Me, M->at<float>(P.dec[i].kv2), 0, M->side));
+    SKF_HIP(hipEventRecord(kv_done, M->side));
+  }
   for (int i = 0; i < N; ++i) {
     const DecLayerP& w = L.dec[i];
     const DecAct& a = P.dec[i];
@@ -640,7 +653,8 @@ int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s, bool 
                                        M->at<float>(a.st1), Md, d, rate, site_dec(N, i, 0), M->state, s));
     float* kv2 = M->at<float>(a.kv2);
     SKF_TRY(dense_fwd(M, w.mha2.q, M->at<float>(a.out1), Md, M->at<float>(a.q2), 0, s));
-    SKF_TRY(dense_fwd(M, w.mha2.kv, pre, Me, kv2, 0, s));
+    if (!kv_done) SKF_TRY(dense_fwd(M, w.mha2.kv, pre, Me, kv2, 0, s));
+    else if (i == 0) SKF_HIP(hipStreamWaitEvent(s, kv_done, 0));
     SKF_TRY(skf_attention_fwd(M->at<float>(a.q2), d, kv2, 2 * d, kv2 + d, 2 * d, cross_mask, Le, 0, B, H, Ld, Le, dh,
                               M->at<float>(a.o2), d, M->at<float>(a.astats2), s));
     SKF_TRY(dense_fwd(M, w.mha2.o, M->at<float>(a.o2), Md, M->at<float>(a.z2), 0, s));
