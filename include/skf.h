@@ -52,6 +52,13 @@ int skf_profiler_report(char* buf_host, size_t len);
  *   act: 0 none, 1 relu, 2 tanh;  relu_src (optional, ld_relu): C = 0 where relu_src <= 0
  *   splits > 1 (or bias_grad != NULL): split-K through `workspace`; bias_grad[n] = sum_k B[k][n]
  *   (the bias gradient of a wgrad call, B stored [K][N]); no fused epilogue on that path. */
+/* Arithmetic of the Dense matmuls (process-wide): 0 = v_mfma_f32_16x16x4_f32 on the fp32 operands;
+ * 6 = every fp32 operand split exactly into three bf16 pieces, the six largest piece products summed in fp32 on
+ *     the bf16 matrix cores (dropped terms <= 2^-23 |a||b| per product: the size of one fp32 rounding);
+ * 3 = two pieces / three products (dropped terms <= 2^-15 |a||b|).  Initial value: env SKF_GEMM_PRECISION
+ * (f32 | bf16x6 | bf16x3), default f32.  Results stay fp32 tensors in every mode. */
+int skf_set_gemm_precision(int mode);
+int skf_get_gemm_precision(void);
 size_t skf_gemm_workspace_bytes(int M, int N, int K, int splits, int with_bias_grad);
 int skf_gemm_default_splits(int M, int N, int K);
 int skf_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K, const float* A, int lda, const float* B, int ldb,

@@ -52,6 +52,8 @@ SIGNATURES = {
     "skf_version": (_I, []),
     "skf_device_info": (_I, [C.c_char_p, _Z, C.POINTER(_I)]),
     "skf_profiler_enable": (_I, [_I]),
+    "skf_set_gemm_precision": (_I, [_I]),
+    "skf_get_gemm_precision": (_I, []),
     "skf_profiler_report": (_I, [C.c_char_p, _Z]),
     "skf_gemm_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "skf_gemm_default_splits": (_I, [_I, _I, _I]),

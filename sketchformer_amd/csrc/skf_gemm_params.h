@@ -26,6 +26,8 @@ struct GemmParams {
 
 // weight-stationary fast path; sets *handled when it launched the problem
 int skf_gemm_ws_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, hipStream_t st, int* handled);
+// the same problem on the bf16 matrix cores with split fp32 operands (pieces = 3: six products, 2: three products)
+int skf_gemm_wsx_launch(const GemmParams& p, int b_kcontig, int pieces, hipStream_t st);
 // wgrad (X^T.dY) fast path writing the split-K slab; sets *handled when it launched the problem
 int skf_gemm_wgrad_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, int splits, hipStream_t st, int* handled);
 // small-problem path (M*N*K <= 2^25): any layout, all epilogues, optional bias gradient (column sums of B) in the same launch

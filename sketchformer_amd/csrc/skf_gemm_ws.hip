@@ -16,6 +16,7 @@
 // MFMA: v_mfma_f32_16x16x4_f32 (A: lane (i=l&15,g=l>>4) holds A[i][k=g], B[k=g][j=i]; C: col=i,row=4g+r).
 #include "skf_common.h"
 #include "skf_gemm_params.h"
+#include <string.h>
 
 namespace {
 
@@ -318,6 +319,22 @@ int launch_ws(const GemmParams& p, int b_kc, hipStream_t st) {
 
 }  // namespace
 
+// GEMM arithmetic of the Dense kernels: 0 = fp32 MFMA, 6 / 3 = fp32 operands split into 3 / 2 bf16 pieces on the
+// bf16 matrix cores (skf_gemm_wsx.hip).  Process-wide; initial value from SKF_GEMM_PRECISION (f32 | bf16x6 | bf16x3).
+static int g_gemm_precision = -1;
+extern "C" int skf_get_gemm_precision(void) {
+  if (g_gemm_precision < 0) {
+    const char* e = getenv("SKF_GEMM_PRECISION");
+    g_gemm_precision = (e && !strcmp(e, "bf16x6")) ? 6 : (e && !strcmp(e, "bf16x3")) ? 3 : 0;
+  }
+  return g_gemm_precision;
+}
+extern "C" int skf_set_gemm_precision(int mode) {
+  SKF_CHECK_ARG(mode == 0 || mode == 3 || mode == 6, "mode must be 0 (fp32 MFMA), 6 (bf16x6) or 3 (bf16x3)");
+  g_gemm_precision = mode;
+  return SKF_OK;
+}
+
 // Returns SKF_OK and sets *handled = 1 when the weight-stationary path applies.
 int skf_gemm_ws_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, hipStream_t st, int* handled) {
   *handled = 0;
@@ -330,6 +347,7 @@ int skf_gemm_ws_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, hipS
   if (!b_kcontig && ((p.ldb & 1) || ((uintptr_t)p.B & 7))) return SKF_OK;   // NB-wide loads along n
   if (p.relu_src && ((p.ld_relu & 3) || ((uintptr_t)p.relu_src & 15))) return SKF_OK;
   *handled = 1;
+  if (const int prec = skf_get_gemm_precision()) return skf_gemm_wsx_launch(p, b_kcontig, prec == 3 ? 2 : 3, st);
   switch (p.K) {
     case 128: return launch_ws<128, 2>(p, b_kcontig, st);
     case 256: return launch_ws<256, 2>(p, b_kcontig, st);

@@ -1,0 +1,356 @@
+// Weight-stationary fp32 GEMM on the bf16 matrix cores: every fp32 operand is split EXACTLY into P bf16 pieces
+// (x = x0 + x1 + x2, 8 significand bits each, by truncation and exact fp32 subtraction) and the product is
+// evaluated as the sum of the piece products a_i.b_j with i + j < P in fp32 accumulators:
+//   P = 3 -> 6 MFMA products, dropped terms <= 2^-23 |a||b| per product (the size of one fp32 rounding),
+//   P = 2 -> 3 MFMA products, dropped terms <= 2^-15 |a||b|.
+// Why: gfx950 issues v_mfma_f32_16x16x4_f32 (2048 FLOP) in 32 cycles but v_mfma_f32_16x16x32_bf16 (16384 FLOP)
+// in 16, so six bf16 products cost 96 cycles for the work of 256 cycles of fp32 MFMA - the Dense shapes of this
+// model (K = 128..512, M = 25k rows) turn from MFMA-bound into HBM-stream-bound.
+//
+// Structure = skf_gemm_ws.hip (persistent workgroups, weight slice in registers, A tiles global -> registers ->
+// LDS two tiles ahead, C fragments stored straight from registers through buffer descriptors), except:
+//   * A is split when it is handed to LDS (P planes of bf16 per tile, 8-byte ds_writes), so each element is
+//     split once per workgroup, not once per wave;
+//   * the weight slice is split once in the prologue: P x (K/32) x NB operands of 8 bf16 per lane;
+//   * one MFMA step covers k = 32s + 8g + e (lane group g, e < 8): A fragments are one ds_read_b128 per
+//     (step, piece), conflict-free with a 16-byte row pad.
+// Small products go to their own accumulator (added to the a0.b0 sum at the end).
+#include "skf_common.h"
+#include "skf_gemm_params.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+constexpr int TR = 16;   // rows per tile
+
+template <int N> struct VecOfX;
+template <> struct VecOfX<1> { typedef float type; typedef unsigned utype; };
+template <> struct VecOfX<2> { typedef float __attribute__((ext_vector_type(2))) type; typedef u32x2 utype; };
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wsx_rows_rsrc(const float* base, int ld, int M, int row0) {
+  long long rem = ((long long)M - row0) * ld * 4;
+  rem = rem < 0 ? 0 : (rem > 0xffffffffLL ? 0xffffffffLL : rem);
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + (long long)row0 * ld), 0, (unsigned)rem, 0x00020000);
+}
+template <int NB>
+__device__ __forceinline__ typename VecOfX<NB>::type wsx_buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+  typedef typename VecOfX<NB>::type vecn;
+  if constexpr (NB == 1) return __builtin_bit_cast(vecn, __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
+  else return __builtin_bit_cast(vecn, __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0));
+}
+template <int NB>
+__device__ __forceinline__ void wsx_buf_store(typename VecOfX<NB>::type v, __amdgpu_buffer_rsrc_t r, unsigned voff) {
+  typedef typename VecOfX<NB>::utype uvec;
+  if constexpr (NB == 1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uvec, v), r, voff, 0, 0);
+  else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uvec, v), r, voff, 0, 0);
+}
+
+// (x, y) -> P dwords; dword q = bf16 piece q of x in the low half, of y in the high half.  Pieces are the top
+// 16 bits of the running remainder (truncation), remainders are exact: x = x0 + x1 + x2 for every finite fp32.
+template <int P>
+__device__ __forceinline__ void split2(float x, float y, unsigned (&out)[P]) {
+#pragma unroll
+  for (int q = 0; q < P; ++q) {
+    const unsigned ux = __builtin_bit_cast(unsigned, x), uy = __builtin_bit_cast(unsigned, y);
+    out[q] = __builtin_amdgcn_perm(uy, ux, 0x07060302u);   // (uy & 0xffff0000) | (ux >> 16)
+    if (q + 1 < P) {
+      x -= __builtin_bit_cast(float, ux & 0xffff0000u);
+      y -= __builtin_bit_cast(float, uy & 0xffff0000u);
+    }
+  }
+}
+
+template <int K>
+__device__ __forceinline__ void wsx_load_tile(const float* __restrict__ A, int lda, int M, int tile,
+                                              const unsigned (&a_voff)[TR * K / 1024], f32x4 (&ra)[TR * K / 1024]) {
+  const __amdgpu_buffer_rsrc_t r = wsx_rows_rsrc(A, lda, M, tile * TR);
+#pragma unroll
+  for (int v = 0; v < TR * K / 1024; ++v)
+    ra[v] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, a_voff[v], 0, 0));
+}
+
+// one A tile (registers, fp32) -> P bf16 planes in LDS; PITCH = bytes per row
+template <int K, int P, int PITCH>
+__device__ __forceinline__ void wsx_store_tile(char* __restrict__ dst, const f32x4 (&ra)[TR * K / 1024]) {
+#pragma unroll
+  for (int v = 0; v < TR * K / 1024; ++v) {
+    const int e = threadIdx.x + v * 256, row = e / (K / 4), c4 = (e % (K / 4)) * 4;
+    unsigned lo[P], hi[P];
+    split2<P>(ra[v][0], ra[v][1], lo);
+    split2<P>(ra[v][2], ra[v][3], hi);
+#pragma unroll
+    for (int q = 0; q < P; ++q)
+      *reinterpret_cast<u32x2*>(dst + (q * TR + row) * PITCH + c4 * 2) = (u32x2){lo[q], hi[q]};
+  }
+}
+
+template <int K, int NB, int P, bool B_KC, bool EXTRA>
+__global__ __launch_bounds__(256, (K <= 256 ? 2 : 1)) void gemm_wsx_kernel(GemmParams p, int groups, int workers) {
+  constexpr int CW = 16 * NB;            // columns per wave
+  constexpr int NKS = K / 32;            // MFMA k-steps per tile
+  constexpr int NF = NKS * P;            // A fragments (ds_read_b128) per tile
+  constexpr bool EARLY = K == 128;       // every fragment of a tile in registers: barrier inside the MFMA stream
+  constexpr int PF = EARLY ? NF : (NF < 6 ? NF : 6);
+  constexpr int NACC = NB == 1 ? 3 : 2;  // accumulators per column block: [0] = a0.b0, the others = small products
+  constexpr int PITCH = 2 * K + 16;      // bytes per LDS row: the 16 rows of a ds_read_b128 group hit 16 different bank quads
+  constexpr int TILE_B = P * TR * PITCH; // bytes per LDS tile buffer
+  constexpr int NV = TR * K / 1024;      // float4 per thread per A tile
+  constexpr unsigned OOB = 0x7ffffff0u;
+  typedef typename VecOfX<NB>::type vecn;
+  extern __shared__ __attribute__((aligned(16))) char smem_x[];
+  char* As = smem_x;                     // [2][P][TR][PITCH]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, g = lane >> 4;
+  const int logical = p.xcd_remap ? skf_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int group = logical % groups, worker = logical / groups;
+  const int n_lane = group * 4 * CW + wave * CW + NB * i;
+  const bool nok = n_lane < p.N;
+  const int n_ld = nok ? n_lane : p.N - NB;
+  const int ntiles = (p.M + TR - 1) / TR;
+
+  long long* dbg = (p.dbg && lane == 0 && wave == 0 && (blockIdx.x % 97) == 0 && blockIdx.x / 97 < 8) ? p.dbg + (blockIdx.x / 97) * 32 : nullptr;
+  int dbi = 0;
+#if SKF_WS_STAMPS   // per-phase s_memtime stamps (tools/ws_timeline.py); off by default
+#define SKF_STAMP() do { if (dbg && dbi < 32) dbg[dbi++] = clock64(); } while (0)
+#else
+#define SKF_STAMP() do { (void)dbg; (void)dbi; } while (0)
+#endif
+  SKF_STAMP();
+  unsigned a_voff[NV], c_voff[4], h_voff[4];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int e = tid + v * 256, row = e / (K / 4), c4 = (e % (K / 4)) * 4;
+    a_voff[v] = (unsigned)(row * p.lda + c4) * 4u;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    c_voff[r] = nok ? (unsigned)((4 * g + r) * p.ldc + n_lane) * 4u : OOB;
+    h_voff[r] = nok ? (unsigned)((4 * g + r) * p.ld_relu + n_lane) * 4u : OOB;
+  }
+  f32x4 ra0[NV], ra1[NV];
+  int tile = worker;
+  wsx_load_tile<K>(p.A, p.lda, p.M, tile, a_voff, ra0);
+  wsx_load_tile<K>(p.A, p.lda, p.M, tile + workers, a_voff, ra1);
+
+  // ---- weight slice -> split bf16 operands (once): bq[nb][s][q] = pieces q of B[k = 32s + 8g + e][n_lane + nb], e < 8
+  u32x4 bq[NB][NKS][P];
+#pragma unroll
+  for (int s = 0; s < NKS; ++s) {
+    float f[NB][8];
+    if (B_KC) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(p.B + (size_t)(n_ld + nb) * p.ldb + 32 * s + 8 * g + 4 * h);
+          f[nb][4 * h + 0] = v[0]; f[nb][4 * h + 1] = v[1]; f[nb][4 * h + 2] = v[2]; f[nb][4 * h + 3] = v[3];
+        }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const vecn v = *reinterpret_cast<const vecn*>(p.B + (size_t)(32 * s + 8 * g + e) * p.ldb + n_ld);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) f[nb][e] = reinterpret_cast<const float*>(&v)[nb];
+      }
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        unsigned pc[P];
+        split2<P>(f[nb][2 * d], f[nb][2 * d + 1], pc);
+#pragma unroll
+        for (int q = 0; q < P; ++q) bq[nb][s][q][d] = pc[q];
+      }
+  }
+  float bias_r[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) bias_r[nb] = p.bias ? p.bias[n_ld + nb] : 0.f;
+
+  SKF_STAMP();   // weight slice loaded + split
+  wsx_store_tile<K, P, PITCH>(As, ra0);
+  __syncthreads();
+  wsx_load_tile<K>(p.A, p.lda, p.M, tile + 2 * workers, a_voff, ra0);
+  SKF_STAMP();   // first A tile in LDS
+
+  vecn cprev[4], hsrc[4], oacc[4];
+  int prev_tile = ntiles;
+  const bool has_relu = EXTRA && p.relu_src != nullptr;
+  auto store_prev = [&]() {
+    const __amdgpu_buffer_rsrc_t rc = wsx_rows_rsrc(p.C, p.ldc, p.M, prev_tile * TR);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      vecn v = cprev[r];
+      if (EXTRA) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          reinterpret_cast<float*>(&v)[nb] = (!has_relu || reinterpret_cast<const float*>(&hsrc[r])[nb] > 0.f) ? reinterpret_cast<const float*>(&v)[nb] : 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) reinterpret_cast<float*>(&v)[nb] += reinterpret_cast<const float*>(&oacc[r])[nb];
+      }
+      wsx_buf_store<NB>(v, rc, c_voff[r]);
+    }
+  };
+
+  const int frag_off = i * PITCH + 16 * g;   // byte offset of this lane's fragment inside (plane, step 0)
+  u32x4 afA[PF], afB[PF];
+  if (EARLY) {
+#pragma unroll
+    for (int f = 0; f < PF; ++f) afA[f] = *reinterpret_cast<const u32x4*>(As + (f % P) * TR * PITCH + frag_off + 64 * (f / P));
+  }
+
+  auto do_tile = [&](int cur, f32x4 (&rn)[NV], u32x4 (&af)[PF], u32x4 (&afn)[PF]) {
+    const char* At = As + cur * TILE_B + frag_off;
+    if (!EARLY) {
+#pragma unroll
+      for (int f = 0; f < PF; ++f) af[f] = *reinterpret_cast<const u32x4*>(At + (f % P) * TR * PITCH + 64 * (f / P));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    store_prev();
+    __builtin_amdgcn_sched_barrier(0);
+    SKF_STAMP();   // previous C tile stored
+    f32x4 acc[NB][NACC];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int c = 0; c < NACC; ++c) {
+        const float b0 = c == 0 ? bias_r[nb] : 0.f;
+        acc[nb][c] = (f32x4){b0, b0, b0, b0};
+      }
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+      u32x4 a[P];
+#pragma unroll
+      for (int q = 0; q < P; ++q) {
+        const int f = s * P + q;
+        if (f < PF) a[q] = af[f]; else a[q] = *reinterpret_cast<const u32x4*>(At + q * TR * PITCH + 64 * s);
+      }
+      int c = 0;
+#pragma unroll
+      for (int d = 0; d < P; ++d)            // d = qa + qb: products of equal magnitude together
+#pragma unroll
+        for (int qa = 0; qa <= d; ++qa) {
+          const int qb = d - qa;
+          const int ai = c == 0 ? 0 : (NACC == 2 ? 1 : 1 + (c & 1));
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[nb][ai] = mfma_bf16(a[qa], bq[nb][s][qb], acc[nb][ai]);
+          ++c;
+        }
+      if (s == NKS / 2 - 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        wsx_store_tile<K, P, PITCH>(As + (cur ^ 1) * TILE_B, rn);
+        wsx_load_tile<K>(p.A, p.lda, p.M, tile + 3 * workers, a_voff, rn);
+        if (EXTRA) {
+          const __amdgpu_buffer_rsrc_t rh = wsx_rows_rsrc(has_relu ? p.relu_src : p.C, p.ld_relu, has_relu ? p.M : 0, tile * TR);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) hsrc[r] = wsx_buf_load<NB>(rh, h_voff[r]);
+          const __amdgpu_buffer_rsrc_t ro = wsx_rows_rsrc(p.C, p.ldc, p.accumulate ? p.M : 0, tile * TR);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) oacc[r] = wsx_buf_load<NB>(ro, c_voff[r]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (EARLY && s == (3 * NKS) / 4 - 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        const char* An = As + (cur ^ 1) * TILE_B + frag_off;
+#pragma unroll
+        for (int f = 0; f < PF; ++f) afn[f] = *reinterpret_cast<const u32x4*>(An + (f % P) * TR * PITCH + 64 * (f / P));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    SKF_STAMP();   // MFMAs issued
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        float small = acc[nb][1][r];
+        if (NACC == 3) small += acc[nb][2][r];
+        reinterpret_cast<float*>(&cprev[r])[nb] = acc[nb][0][r] + small;
+      }
+    if (p.act == 1) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) reinterpret_cast<float*>(&cprev[r])[nb] = fmaxf(reinterpret_cast<float*>(&cprev[r])[nb], 0.f);
+    } else if (p.act == 2) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) reinterpret_cast<float*>(&cprev[r])[nb] = tanhf(reinterpret_cast<float*>(&cprev[r])[nb]);
+    }
+    prev_tile = tile;
+    if (!EARLY) __syncthreads();
+    SKF_STAMP();   // tile done
+  };
+  while (tile < ntiles) {
+    do_tile(0, ra1, afA, afB);
+    tile += workers;
+    if (tile >= ntiles) break;
+    do_tile(1, ra0, afB, afA);
+    tile += workers;
+  }
+  store_prev();
+  SKF_STAMP();
+#undef SKF_STAMP
+}
+
+template <int K, int NB, int P>
+int launch_wsx(const GemmParams& p, int b_kc, hipStream_t st) {
+  constexpr int CW = 16 * NB;
+  const int groups = skf_cdiv(p.N, 4 * CW);
+  static const int wg_target = getenv("SKF_WS_WGS") ? atoi(getenv("SKF_WS_WGS")) : (K <= 256 ? 512 : 256);
+  int workers = wg_target / groups;
+  if (workers < 1) workers = 1;
+  const int ntiles = skf_cdiv(p.M, TR);
+  if (workers > ntiles) workers = ntiles;
+  const size_t smem = (size_t)2 * P * TR * (2 * K + 16);
+  dim3 grid(groups * workers), block(256);
+  static const std::string tag = "gemm_wsx<K" + std::to_string(K) + ",CW" + std::to_string(CW) + ",bf16x" + std::to_string(P * (P + 1) / 2) + ">";
+  SkfProfScope ps(st, tag.c_str(), 2.0 * p.M * p.N * p.K,
+                  4.0 * ((double)p.M * p.K + (double)p.K * p.N + (double)p.M * p.N * (p.accumulate ? 2 : 1)));
+  const bool extra = p.relu_src || p.accumulate;
+#define SKF_WSX_LAUNCH(BKC, EX)                                                                                    \
+  do {                                                                                                             \
+    static bool attr_done = false;                                                                                 \
+    if (!attr_done) {                                                                                              \
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wsx_kernel<K, NB, P, BKC, EX>),                      \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                                  \
+      attr_done = true;                                                                                            \
+    }                                                                                                              \
+    hipLaunchKernelGGL((gemm_wsx_kernel<K, NB, P, BKC, EX>), grid, block, smem, st, p, groups, workers);           \
+  } while (0)
+  if (b_kc && extra) SKF_WSX_LAUNCH(true, true);
+  else if (b_kc) SKF_WSX_LAUNCH(true, false);
+  else if (extra) SKF_WSX_LAUNCH(false, true);
+  else SKF_WSX_LAUNCH(false, false);
+#undef SKF_WSX_LAUNCH
+  SKF_LAUNCH_CHECK();
+  return SKF_OK;
+}
+
+template <int P>
+int launch_wsx_k(const GemmParams& p, int b_kc, hipStream_t st) {
+  switch (p.K) {
+    case 128: return launch_wsx<128, 2, P>(p, b_kc, st);
+    case 256: return launch_wsx<256, 1, P>(p, b_kc, st);
+    case 384: return launch_wsx<384, 1, P>(p, b_kc, st);
+    default:  return launch_wsx<512, 1, P>(p, b_kc, st);
+  }
+}
+
+}  // namespace
+
+// pieces = 3 (six products, fp32-equivalent) or 2 (three products); same applicability rules as skf_gemm_ws_dispatch
+int skf_gemm_wsx_launch(const GemmParams& p, int b_kcontig, int pieces, hipStream_t st) {
+  return pieces == 2 ? launch_wsx_k<2>(p, b_kcontig, st) : launch_wsx_k<3>(p, b_kcontig, st);
+}
