@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_f32_16x16x32_bf16 / 32x32x16)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -70,6 +71,11 @@ def cpu_baseline(seconds_budget=25.0):
                       % (len(times), med, os.cpu_count() or 1)}
 
 
+def _gemm_precision():
+    from sketchformer_amd import _lib
+    return int(_lib.load().skf_get_gemm_precision())
+
+
 def pmc_traffic(tag):
     """HBM bytes per launch of the kernel behind a profiler tag, from the committed rocprofv3 PMC passes
     (profiles/*pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate runs, gfx950 corrections applied)."""
@@ -79,9 +85,9 @@ def pmc_traffic(tag):
     if not files:
         return None
     table = json.load(open(files[-1]))
-    m = re.match(r"gemm_ws<K(\d+),CW(\d+)>", tag)
+    m = re.match(r"gemm_ws(x?)<K(\d+),CW(\d+)", tag)
     if m:   # kernel template is <K, columns per lane = CW/16, ...>
-        prefix = "gemm_ws_kernel<%s, %d," % (m.group(1), int(m.group(2)) // 16)
+        prefix = "gemm_ws%s_kernel<%s, %d," % (m.group(1), m.group(2), int(m.group(3)) // 16)
     else:
         prefix = {"wgrad<64x64>": "wgrad_kernel", "attn_bwd<dh16>": "attn_bwd_kernel<16", "attn_fwd<dh16>": "attn_fwd_kernel<16",
                   "ln_fwd": "ln_fwd_kernel", "ln_bwd": "ln_bwd_kernel"}.get(tag)
@@ -201,6 +207,9 @@ def main():
                                ("cfg2: sketch-transformer-tf2 4L/8H/d128/dff512 L=200 V=1004 C=345 dropout=0.1, "
                                 "fwd+bwd+Adam(WarmupDecay)"), "global_batch": B * world, "per_gpu_batch": B,
                    "seq_len": L, "parallelism": "dp%d" % world, "hip_graph": args.graph,
+                   "dense_gemm_arithmetic": {0: "fp32 MFMA", 6: "fp32 operands split exactly into 3 bf16 pieces, 6 products on the bf16 "
+                                                "matrix cores, fp32 accumulate (error below the fp32-MFMA kernel's)",
+                                             3: "bf16x3 (opt-in fast mode)"}[_gemm_precision()],
                    "pad_fraction": float((xs[..., 4] == 1).mean() if cont else (xs == 0).mean())},
         "step_mfma_frac": f_step / (elapsed / args.steps) / (PEAK_F32_MFMA_TFLOPS * 1e12),
         "step_tflops": f_step / (elapsed / args.steps) / 1e12,
@@ -219,6 +228,10 @@ def main():
             ach = top["bytes"] / (top["ms"] * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
                     "traffic": None}
+        if "bf16x" in top["tag"]:   # split-operand kernel: fp32-equivalent FLOPs priced against the fp32 MFMA peak (the dtype of
+            n_prod = int(top["tag"].split("bf16x")[1].rstrip(">"))   # the path); the bf16 matrix cores execute n_prod x as many
+            roof["issued_bf16_tflops"] = ach * n_prod
+            roof["issued_frac_of_bf16_peak"] = ach * n_prod / PEAK_BF16_MFMA_TFLOPS
         roof["traffic"] = pmc_traffic(top["tag"])
         roof["algorithmic_per_launch"] = (top["flops"] if is_mfma else top["bytes"]) / top["count"]
         roof.update({"kernel": top["tag"], "launches_per_step": top["count"] // 3, "avg_launch_us": top["avg_us"],

@@ -56,7 +56,9 @@ int skf_profiler_report(char* buf_host, size_t len);
  * 6 = every fp32 operand split exactly into three bf16 pieces, the six largest piece products summed in fp32 on
  *     the bf16 matrix cores (dropped terms <= 2^-23 |a||b| per product: the size of one fp32 rounding);
  * 3 = two pieces / three products (dropped terms <= 2^-15 |a||b|).  Initial value: env SKF_GEMM_PRECISION
- * (f32 | bf16x6 | bf16x3), default f32.  Results stay fp32 tensors in every mode. */
+ * (f32 | bf16x6 | bf16x3), default bf16x6 (against float64 its error is below the fp32-MFMA kernel's: the piece
+ * products are exact and the small ones are summed before the large ones).  Operands and results are fp32 tensors in
+ * every mode; mode 3 is an opt-in fast mode, never a default. */
 int skf_set_gemm_precision(int mode);
 int skf_get_gemm_precision(void);
 size_t skf_gemm_workspace_bytes(int M, int N, int K, int splits, int with_bias_grad);

@@ -30,6 +30,15 @@ __device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
 
 constexpr int TR = 16;   // rows per tile
 
+// gfx950 hides about one VALU / LDS / VMEM instruction per v_mfma_f32_16x16x32_bf16 of the SAME wave and almost none
+// of another wave's (tools/micro/mfma_bf16_valu_overlap.hip), so the tile body is left to the scheduler as one region
+// (no fences between its phases) unless SKF_WSX_FENCES is defined.
+#ifdef SKF_WSX_FENCES
+#define SKF_WSX_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#else
+#define SKF_WSX_SCHED_BARRIER() do { } while (0)
+#endif
+
 template <int N> struct VecOfX;
 template <> struct VecOfX<1> { typedef float type; typedef unsigned utype; };
 template <> struct VecOfX<2> { typedef float __attribute__((ext_vector_type(2))) type; typedef u32x2 utype; };
@@ -60,6 +69,9 @@ __device__ __forceinline__ void split2(float x, float y, unsigned (&out)[P]) {
   for (int q = 0; q < P; ++q) {
     const unsigned ux = __builtin_bit_cast(unsigned, x), uy = __builtin_bit_cast(unsigned, y);
     out[q] = __builtin_amdgcn_perm(uy, ux, 0x07060302u);   // (uy & 0xffff0000) | (ux >> 16)
+#ifdef SKF_WSX_ABLATE_SPLIT   // diagnostics: wrong results, no remainder arithmetic
+    continue;
+#endif
     if (q + 1 < P) {
       x -= __builtin_bit_cast(float, ux & 0xffff0000u);
       y -= __builtin_bit_cast(float, uy & 0xffff0000u);
@@ -70,6 +82,9 @@ __device__ __forceinline__ void split2(float x, float y, unsigned (&out)[P]) {
 template <int K>
 __device__ __forceinline__ void wsx_load_tile(const float* __restrict__ A, int lda, int M, int tile,
                                               const unsigned (&a_voff)[TR * K / 1024], f32x4 (&ra)[TR * K / 1024]) {
+#ifdef SKF_WSX_ABLATE_LOAD   // diagnostics: every A tile load hits the same (cached) rows
+  tile &= 7;
+#endif
   const __amdgpu_buffer_rsrc_t r = wsx_rows_rsrc(A, lda, M, tile * TR);
 #pragma unroll
   for (int v = 0; v < TR * K / 1024; ++v)
@@ -96,12 +111,13 @@ __global__ __launch_bounds__(256, (K <= 256 ? 2 : 1)) void gemm_wsx_kernel(GemmP
   constexpr int CW = 16 * NB;            // columns per wave
   constexpr int NKS = K / 32;            // MFMA k-steps per tile
   constexpr int NF = NKS * P;            // A fragments (ds_read_b128) per tile
-  constexpr bool EARLY = K == 128;       // every fragment of a tile in registers: barrier inside the MFMA stream
+  constexpr bool EARLY = K == 128 && P == 2;   // every fragment of a tile in registers: barrier inside the MFMA stream
   constexpr int PF = EARLY ? NF : (NF < 6 ? NF : 6);
-  constexpr int NACC = NB == 1 ? 3 : 2;  // accumulators per column block: [0] = a0.b0, the others = small products
+  constexpr int NCH = NB == 1 ? 2 : 1;   // accumulator chains per column block
   constexpr int PITCH = 2 * K + 16;      // bytes per LDS row: the 16 rows of a ds_read_b128 group hit 16 different bank quads
   constexpr int TILE_B = P * TR * PITCH; // bytes per LDS tile buffer
   constexpr int NV = TR * K / 1024;      // float4 per thread per A tile
+  constexpr int R = K == 128 ? 4 : 2;   // A tiles in flight in registers
   constexpr unsigned OOB = 0x7ffffff0u;
   typedef typename VecOfX<NB>::type vecn;
   extern __shared__ __attribute__((aligned(16))) char smem_x[];
@@ -117,12 +133,15 @@ __global__ __launch_bounds__(256, (K <= 256 ? 2 : 1)) void gemm_wsx_kernel(GemmP
   const int n_ld = nok ? n_lane : p.N - NB;
   const int ntiles = (p.M + TR - 1) / TR;
 
-  long long* dbg = (p.dbg && lane == 0 && wave == 0 && (blockIdx.x % 97) == 0 && blockIdx.x / 97 < 8) ? p.dbg + (blockIdx.x / 97) * 32 : nullptr;
+  long long* dbg = (p.dbg && lane == 0 && wave == 0 && (blockIdx.x % 64) == 0 && blockIdx.x / 64 < 8) ? p.dbg + (blockIdx.x / 64) * 32 : nullptr;   // same XCD: comparable clocks
   int dbi = 0;
 #if SKF_WS_STAMPS   // per-phase s_memtime stamps (tools/ws_timeline.py); off by default
-#define SKF_STAMP() do { if (dbg && dbi < 32) dbg[dbi++] = clock64(); } while (0)
+#define SKF_STAMP() do { if (dbg && dbi < 30) dbg[dbi++] = clock64(); } while (0)
 #else
 #define SKF_STAMP() do { (void)dbg; (void)dbi; } while (0)
+#endif
+#if SKF_WS_STAMPS
+  const long long wall0 = wall_clock64(), cyc0 = clock64();   // 100 MHz constant clock vs shader clock
 #endif
   SKF_STAMP();
   unsigned a_voff[NV], c_voff[4], h_voff[4];
@@ -136,10 +155,12 @@ __global__ __launch_bounds__(256, (K <= 256 ? 2 : 1)) void gemm_wsx_kernel(GemmP
     c_voff[r] = nok ? (unsigned)((4 * g + r) * p.ldc + n_lane) * 4u : OOB;
     h_voff[r] = nok ? (unsigned)((4 * g + r) * p.ld_relu + n_lane) * 4u : OOB;
   }
-  f32x4 ra0[NV], ra1[NV];
+  // Register ring of R A tiles ahead of the one in LDS: with the MFMAs 2.7x shorter than in the fp32 kernel a tile
+  // takes ~1.2k cycles, and a global load under a busy chip 3-4k.
+  f32x4 ra[R][NV];
   int tile = worker;
-  wsx_load_tile<K>(p.A, p.lda, p.M, tile, a_voff, ra0);
-  wsx_load_tile<K>(p.A, p.lda, p.M, tile + workers, a_voff, ra1);
+#pragma unroll
+  for (int j = 0; j < R; ++j) wsx_load_tile<K>(p.A, p.lda, p.M, tile + j * workers, a_voff, ra[j]);
 
   // ---- weight slice -> split bf16 operands (once): bq[nb][s][q] = pieces q of B[k = 32s + 8g + e][n_lane + nb], e < 8
   u32x4 bq[NB][NKS][P];
@@ -177,9 +198,9 @@ __global__ __launch_bounds__(256, (K <= 256 ? 2 : 1)) void gemm_wsx_kernel(GemmP
   for (int nb = 0; nb < NB; ++nb) bias_r[nb] = p.bias ? p.bias[n_ld + nb] : 0.f;
 
   SKF_STAMP();   // weight slice loaded + split
-  wsx_store_tile<K, P, PITCH>(As, ra0);
+  wsx_store_tile<K, P, PITCH>(As, ra[0]);
   __syncthreads();
-  wsx_load_tile<K>(p.A, p.lda, p.M, tile + 2 * workers, a_voff, ra0);
+  wsx_load_tile<K>(p.A, p.lda, p.M, tile + R * workers, a_voff, ra[0]);
   SKF_STAMP();   // first A tile in LDS
 
   vecn cprev[4], hsrc[4], oacc[4];
@@ -197,6 +218,9 @@ __global__ __launch_bounds__(256, (K <= 256 ? 2 : 1)) void gemm_wsx_kernel(GemmP
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) reinterpret_cast<float*>(&v)[nb] += reinterpret_cast<const float*>(&oacc[r])[nb];
       }
+#ifdef SKF_WSX_ABLATE_STORE   // diagnostics: only the first tile's stores reach memory
+      if (prev_tile < workers)
+#endif
       wsx_buf_store<NB>(v, rc, c_voff[r]);
     }
   };
@@ -214,41 +238,64 @@ __global__ __launch_bounds__(256, (K <= 256 ? 2 : 1)) void gemm_wsx_kernel(GemmP
 #pragma unroll
       for (int f = 0; f < PF; ++f) af[f] = *reinterpret_cast<const u32x4*>(At + (f % P) * TR * PITCH + 64 * (f / P));
     }
-    __builtin_amdgcn_sched_barrier(0);
+    SKF_WSX_SCHED_BARRIER();
     store_prev();
-    __builtin_amdgcn_sched_barrier(0);
+    SKF_WSX_SCHED_BARRIER();
     SKF_STAMP();   // previous C tile stored
-    f32x4 acc[NB][NACC];
+    // One accumulator chain per column block (two for NB = 1: a dependent MFMA straight behind its producer stalls):
+    // the small products first, the a0.b0 products last - small-to-large summation, no separate add.
+    f32x4 acc[NB][NCH];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-      for (int c = 0; c < NACC; ++c) {
+      for (int c = 0; c < NCH; ++c) {
         const float b0 = c == 0 ? bias_r[nb] : 0.f;
         acc[nb][c] = (f32x4){b0, b0, b0, b0};
       }
+    auto frag = [&](int s, int q) -> u32x4 {
+      const int f = s * P + q;
+      if (f < PF) return af[f];
+      return *reinterpret_cast<const u32x4*>(At + q * TR * PITCH + 64 * s);
+    };
+    // K <= 256: all small products of the tile first, its a0.b0 products last (their A fragments stay in registers);
+    // longer K: the a0.b0 product closes each k-step (no room to keep K/32 fragments, and no second LDS read).
+    constexpr bool TWO_PHASE = K <= 256;
+    u32x4 a0keep[TWO_PHASE ? NKS : 1];
+    int c = 0;
 #pragma unroll
     for (int s = 0; s < NKS; ++s) {
       u32x4 a[P];
 #pragma unroll
-      for (int q = 0; q < P; ++q) {
-        const int f = s * P + q;
-        if (f < PF) a[q] = af[f]; else a[q] = *reinterpret_cast<const u32x4*>(At + q * TR * PITCH + 64 * s);
-      }
-      int c = 0;
+      for (int q = 0; q < P; ++q) a[q] = frag(s, q);
+      if (TWO_PHASE) a0keep[s] = a[0];
 #pragma unroll
-      for (int d = 0; d < P; ++d)            // d = qa + qb: products of equal magnitude together
+      for (int d = 1; d < P; ++d)            // d = qa + qb: products of equal magnitude together
 #pragma unroll
         for (int qa = 0; qa <= d; ++qa) {
           const int qb = d - qa;
-          const int ai = c == 0 ? 0 : (NACC == 2 ? 1 : 1 + (c & 1));
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb) acc[nb][ai] = mfma_bf16(a[qa], bq[nb][s][qb], acc[nb][ai]);
+          for (int nb = 0; nb < NB; ++nb) {
+#ifdef SKF_WSX_ABLATE_MFMA   // diagnostics: wrong results; keeps every operand live with one VALU op per 4 MFMAs
+            if ((c & 3) == 0 && nb == 0) acc[nb][c % NCH][0] += __builtin_bit_cast(float, a[qa][0] ^ bq[nb][s][qb][0]);
+#else
+            acc[nb][c % NCH] = mfma_bf16(a[qa], bq[nb][s][qb], acc[nb][c % NCH]);
+#endif
+          }
           ++c;
         }
+      if (!TWO_PHASE) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+#ifndef SKF_WSX_ABLATE_MFMA
+          acc[nb][c % NCH] = mfma_bf16(a[0], bq[nb][s][0], acc[nb][c % NCH]);
+#endif
+        }
+        ++c;
+      }
       if (s == NKS / 2 - 1) {
-        __builtin_amdgcn_sched_barrier(0);
+        SKF_WSX_SCHED_BARRIER();
         wsx_store_tile<K, P, PITCH>(As + (cur ^ 1) * TILE_B, rn);
-        wsx_load_tile<K>(p.A, p.lda, p.M, tile + 3 * workers, a_voff, rn);
+        wsx_load_tile<K>(p.A, p.lda, p.M, tile + (R + 1) * workers, a_voff, rn);
         if (EXTRA) {
           const __amdgpu_buffer_rsrc_t rh = wsx_rows_rsrc(has_relu ? p.relu_src : p.C, p.ld_relu, has_relu ? p.M : 0, tile * TR);
 #pragma unroll
@@ -257,7 +304,7 @@ __global__ __launch_bounds__(256, (K <= 256 ? 2 : 1)) void gemm_wsx_kernel(GemmP
 #pragma unroll
           for (int r = 0; r < 4; ++r) oacc[r] = wsx_buf_load<NB>(ro, c_voff[r]);
         }
-        __builtin_amdgcn_sched_barrier(0);
+        SKF_WSX_SCHED_BARRIER();
       }
       if (EARLY && s == (3 * NKS) / 4 - 1) {
         __builtin_amdgcn_sched_barrier(0);
@@ -268,39 +315,57 @@ __global__ __launch_bounds__(256, (K <= 256 ? 2 : 1)) void gemm_wsx_kernel(GemmP
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    if (TWO_PHASE) {
+#pragma unroll
+      for (int s = 0; s < NKS; ++s) {        // the a0.b0 products
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+#ifndef SKF_WSX_ABLATE_MFMA
+          acc[nb][c % NCH] = mfma_bf16(a0keep[s], bq[nb][s][0], acc[nb][c % NCH]);
+#endif
+        }
+        ++c;
+      }
+    }
     SKF_STAMP();   // MFMAs issued
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        float small = acc[nb][1][r];
-        if (NACC == 3) small += acc[nb][2][r];
-        reinterpret_cast<float*>(&cprev[r])[nb] = acc[nb][0][r] + small;
+        float v = acc[nb][0][r];
+        if (NCH == 2) v += acc[nb][1][r];
+        reinterpret_cast<float*>(&cprev[r])[nb] = v;
       }
     if (p.act == 1) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) reinterpret_cast<float*>(&cprev[r])[nb] = fmaxf(reinterpret_cast<float*>(&cprev[r])[nb], 0.f);
-    } else if (p.act == 2) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) reinterpret_cast<float*>(&cprev[r])[nb] = tanhf(reinterpret_cast<float*>(&cprev[r])[nb]);
+        for (int nb = 0; nb < NB; ++nb) reinterpret_cast<float*>(&cprev[r])[nb] = __builtin_amdgcn_fmed3f(reinterpret_cast<float*>(&cprev[r])[nb], 0.f, __builtin_inff());   // one op (fmaxf = canonicalise + max)
     }
     prev_tile = tile;
     if (!EARLY) __syncthreads();
     SKF_STAMP();   // tile done
   };
-  while (tile < ntiles) {
-    do_tile(0, ra1, afA, afB);
-    tile += workers;
-    if (tile >= ntiles) break;
-    do_tile(1, ra0, afB, afA);
-    tile += workers;
+  constexpr int U = (R & 1) ? 2 * R : R;   // unroll: LDS buffer parity x ring position (written out: a `for` with
+                                           // a break is not unrolled and would index the ring dynamically)
+#define SKF_WSX_STEP(u)                                              \
+  {                                                                  \
+    if ((u) & 1) do_tile(1, ra[((u) + 1) % R], afB, afA);            \
+    else do_tile(0, ra[((u) + 1) % R], afA, afB);                    \
+    tile += workers;                                                 \
+    if (tile >= ntiles) break;                                       \
   }
+  while (tile < ntiles) {
+    SKF_WSX_STEP(0) SKF_WSX_STEP(1)
+    if constexpr (U > 2) { SKF_WSX_STEP(2) SKF_WSX_STEP(3) }
+    if constexpr (U > 4) { SKF_WSX_STEP(4) SKF_WSX_STEP(5) }
+  }
+#undef SKF_WSX_STEP
   store_prev();
   SKF_STAMP();
+#if SKF_WS_STAMPS
+  if (dbg) { dbg[30] = wall_clock64() - wall0; dbg[31] = clock64() - cyc0; }
+#endif
 #undef SKF_STAMP
 }
 
@@ -323,7 +388,7 @@ int launch_wsx(const GemmParams& p, int b_kc, hipStream_t st) {
   do {                                                                                                             \
     static bool attr_done = false;                                                                                 \
     if (!attr_done) {                                                                                              \
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wsx_kernel<K, NB, P, BKC, EX>),                      \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wsx_kernel<K, NB, P, BKC, EX>),                    \
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                                  \
       attr_done = true;                                                                                            \
     }                                                                                                              \

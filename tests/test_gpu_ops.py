@@ -83,6 +83,38 @@ def test_gemm_weight_stationary_path(ops, M, N, K):
     _close(out, c0 + x @ w, name="ws dgrad accumulate")
 
 
+@pytest.mark.parametrize("M,N,K,bkc", [(2000, 128, 128, False), (1100, 384, 128, False), (1500, 128, 512, True),
+                                       (1030, 256, 256, False), (1025, 1004, 128, False), (3001, 128, 384, True)])
+def test_gemm_arithmetic_modes(ops, M, N, K, bkc):
+    """skf_set_gemm_precision: 0 = fp32 MFMA, 6 = fp32 operands split exactly into three bf16 pieces (six products on
+    the bf16 matrix cores), 3 = two pieces.  Against float64: bf16x6 is at least as accurate as the fp32-MFMA kernel,
+    bf16x3 stays inside 1e-4 of sum|a||b| (north_star tolerance: 1e-3 relative)."""
+    from sketchformer_amd import _lib
+    lib = _lib.load()
+    rng = np.random.RandomState(M + N + K)
+    x = rng.randn(M, K) * np.exp(rng.randn(M, 1))          # rows of very different magnitude
+    w = rng.randn(N, K) if bkc else rng.randn(K, N)
+    b = rng.randn(N)
+    xf, wf, bf = x.astype(np.float32), w.astype(np.float32), b.astype(np.float32)
+    wm = wf.T.astype(np.float64) if bkc else wf.astype(np.float64)
+    want = xf.astype(np.float64) @ wm + bf
+    scale = np.abs(xf).astype(np.float64) @ np.abs(wm)
+    start = lib.skf_get_gemm_precision()
+    err = {}
+    try:
+        for mode in (0, 6, 3):
+            assert lib.skf_set_gemm_precision(mode) == 0 and lib.skf_get_gemm_precision() == mode
+            y = ops.gemm(_dev(xf), _dev(wf), b_kcontig=bkc, bias=_dev(bf)).cpu().numpy().astype(np.float64)
+            err[mode] = np.abs(y - want) / scale
+        assert lib.skf_set_gemm_precision(5) != 0            # rejected, mode unchanged
+        assert lib.skf_get_gemm_precision() == 3
+    finally:
+        lib.skf_set_gemm_precision(start)
+    assert err[0].max() < 2e-6, err[0].max()
+    assert err[6].max() < 2e-6 and err[6].mean() <= 1.25 * err[0].mean(), (err[6].max(), err[6].mean(), err[0].mean())
+    assert err[3].max() < 1e-4, err[3].max()
+
+
 def test_gemm_strided_views(ops):
     """fused QKV layout: W stored [d][3d]; outputs written into a (rows, 3d) buffer at a column offset."""
     rng = np.random.RandomState(5)
