@@ -123,6 +123,147 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(GemmParams p) {
     p.colsum_slab[(size_t)split * p.N + b0 + tid] = cs[tid] + cs[64 + tid] + cs[128 + tid] + cs[192 + tid];
 }
 
+// ---- the same block decomposition on the bf16 matrix cores (see skf_gemm_wsx.hip for the exact three-piece split):
+// one step = 32 rows.  Lane (i, g) loads X[m0 + 8g + j][a0 + 4i .. 4i+3] and dY[m0 + 8g + j][b0 + 4i .. 4i+3], j < 8
+// (dwordx4, 256 contiguous bytes per 16 lanes); operand e of v_mfma_f32_16x16x32_bf16 is the column e of those
+// eight rows, split in registers - still no LDS in the loop.  Rows outside [kb, ke) and columns outside the matrix
+// come back as exact zeros from the buffer range check, so there is no masking arithmetic.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int P>
+__device__ __forceinline__ void wg_split2(float x, float y, unsigned (&out)[P]) {
+#pragma unroll
+  for (int q = 0; q < P; ++q) {
+    const unsigned ux = __builtin_bit_cast(unsigned, x), uy = __builtin_bit_cast(unsigned, y);
+    out[q] = __builtin_amdgcn_perm(uy, ux, 0x07060302u);
+    if (q + 1 < P) {
+      x -= __builtin_bit_cast(float, ux & 0xffff0000u);
+      y -= __builtin_bit_cast(float, uy & 0xffff0000u);
+    }
+  }
+}
+// column e of eight row vectors -> P operands of 8 bf16
+template <int P>
+__device__ __forceinline__ void wg_split_col(const f32x4 (&rows)[8], int e, u32x4 (&out)[P]) {
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    unsigned pc[P];
+    wg_split2<P>(rows[2 * d][e], rows[2 * d + 1][e], pc);
+#pragma unroll
+    for (int q = 0; q < P; ++q) out[q][d] = pc[q];
+  }
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wg_rows_rsrc(const float* base, int ld, int row0, int row_end) {
+  long long rem = ((long long)row_end - row0) * ld * 4;
+  rem = rem < 0 ? 0 : (rem > 0xffffffffLL ? 0xffffffffLL : rem);
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + (long long)row0 * ld), 0, (unsigned)rem, 0x00020000);
+}
+
+template <int P>
+__global__ __launch_bounds__(256, 2) void wgrad_x_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [4 waves][64][64] + [4][64] column sums
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, g = lane >> 4;
+  const int ntile = p.tiles_m * p.tiles_n;
+  const int logical = skf_xcd_remap(blockIdx.x, gridDim.x);
+  const int split = logical / ntile, tile = logical % ntile;
+  const int tile_m = tile / p.tiles_n, tile_n = tile % p.tiles_n;
+  const int a0 = tile_m * 64, b0 = tile_n * 64;
+  const int kb = split * p.k_chunk, ke = min(p.K, kb + p.k_chunk);
+  const bool aok = a0 + 4 * i < p.M, bok = b0 + 4 * i < p.N;
+  const bool do_colsum = p.colsum_slab != nullptr && tile_m == 0;
+  constexpr unsigned OOB = 0x7ffffff0u;
+  // per-lane byte offsets of the eight rows of a step (row 32*wave + 8g + j of a 128-row iteration)
+  unsigned xo[8], yo[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    xo[j] = aok ? (unsigned)((32 * wave + 8 * g + j) * p.lda + a0 + 4 * i) * 4u : OOB;
+    yo[j] = bok ? (unsigned)((32 * wave + 8 * g + j) * p.ldb + b0 + 4 * i) * 4u : OOB;
+  }
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int f = 0; f < 4; ++f) acc[e][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+
+  const int niter = (ke - kb + 127) / 128;
+  f32x4 xa[8], yb[8];
+  auto load_step = [&](int it) {
+    const __amdgpu_buffer_rsrc_t rx = wg_rows_rsrc(p.A, p.lda, kb + 128 * it, ke);
+    const __amdgpu_buffer_rsrc_t ry = wg_rows_rsrc(p.B, p.ldb, kb + 128 * it, ke);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      xa[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xo[j], 0, 0));
+      yb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, yo[j], 0, 0));
+    }
+  };
+  load_step(0);
+  for (int it = 0; it < niter; ++it) {
+    u32x4 ax[4][P];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wg_split_col<P>(xa, e, ax[e]);
+    f32x4 yc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) yc[j] = yb[j];
+    load_step(it + 1);                               // past the end: empty descriptor, zeros, never used
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      u32x4 by[P];
+      wg_split_col<P>(yc, f, by);
+#pragma unroll
+      for (int d = P - 1; d >= 0; --d)               // small products first
+#pragma unroll
+        for (int qa = 0; qa <= d; ++qa)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc[e][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ax[e][qa]),
+                                                                __builtin_bit_cast(bf16x8, by[d - qa]), acc[e][f], 0, 0, 0);
+    }
+    if (do_colsum) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) csum += yc[j];
+    }
+  }
+
+  float* mine = smem + wave * 4096;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * g + 4 * r + e;
+      *reinterpret_cast<f32x4*>(&mine[row * 64 + 4 * i]) =
+          (f32x4){acc[e][0][r], acc[e][1][r], acc[e][2][r], acc[e][3][r]};
+    }
+  float* cs = smem + 4 * 4096;
+  if (do_colsum) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float v = csum[c];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      csum[c] = v;
+    }
+    if (g == 0) *reinterpret_cast<f32x4*>(&cs[wave * 64 + 4 * i]) = csum;
+  }
+  __syncthreads();
+  float* slab = p.slab + (size_t)split * p.M * p.N;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int e4 = tid + v * 256, row = e4 >> 4, c4 = (e4 & 15) * 4;
+    const f32x4 s = *reinterpret_cast<const f32x4*>(&smem[row * 64 + c4]) +
+                    *reinterpret_cast<const f32x4*>(&smem[4096 + row * 64 + c4]) +
+                    *reinterpret_cast<const f32x4*>(&smem[8192 + row * 64 + c4]) +
+                    *reinterpret_cast<const f32x4*>(&smem[12288 + row * 64 + c4]);
+    if (a0 + row < p.M && b0 + c4 < p.N)
+      *reinterpret_cast<f32x4*>(&slab[(size_t)(a0 + row) * p.N + b0 + c4]) = s;
+  }
+  if (do_colsum && tid < 64 && b0 + tid < p.N)
+    p.colsum_slab[(size_t)split * p.N + b0 + tid] = cs[tid] + cs[64 + tid] + cs[128 + tid] + cs[192 + tid];
+}
+
 }  // namespace
 
 // wgrad fast path: A = X stored [K=rows][M=Kin], B = dY stored [K=rows][N=Nout]; writes the split-K slab
@@ -142,6 +283,20 @@ int skf_gemm_wgrad_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, i
   if (!attr_done) {
     SKF_HIP(hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr_done = true;
+  }
+  const int prec = skf_get_gemm_precision();
+  if (prec) {
+    static bool attr_x = false;
+    if (!attr_x) {
+      SKF_HIP(hipFuncSetAttribute((const void*)wgrad_x_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      SKF_HIP(hipFuncSetAttribute((const void*)wgrad_x_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      attr_x = true;
+    }
+    SkfProfScope ps(st, prec == 3 ? "wgrad<64x64,bf16x3>" : "wgrad<64x64,bf16x6>", 2.0 * p.M * p.N * p.K, 4.0 * (double)p.K * (p.M + p.N));
+    if (prec == 3) hipLaunchKernelGGL(wgrad_x_kernel<2>, dim3(q.tiles_m * q.tiles_n * splits), dim3(256), smem, st, q);
+    else hipLaunchKernelGGL(wgrad_x_kernel<3>, dim3(q.tiles_m * q.tiles_n * splits), dim3(256), smem, st, q);
+    SKF_LAUNCH_CHECK();
+    return SKF_OK;
   }
   SkfProfScope ps(st, "wgrad<64x64>", 2.0 * p.M * p.N * p.K, 4.0 * (double)p.K * (p.M + p.N));
   hipLaunchKernelGGL(wgrad_kernel, dim3(q.tiles_m * q.tiles_n * splits), dim3(256), smem, st, q);
