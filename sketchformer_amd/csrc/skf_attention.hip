@@ -56,10 +56,24 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 // the mask work is only done on key tiles that contain a masked key (or the diagonal tile of a causal row), the
 // 1/sum normalisation is applied to the 16 x dh output instead of the L scores, V sits transposed in LDS so that
 // one ds_read_b128 feeds four MFMAs.
-template <int DH, int MAXT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
+// SPLIT (dh = 16 only): S^T = K.Q^T on the bf16 matrix cores.  Both operands are split exactly into three bf16 pieces
+// (skf_split2) and the contraction is only 16 deep, so the 32-deep v_mfma_f32_16x16x32_bf16 takes TWO piece products per
+// instruction: [k1|k0].[q1|q2], [k1|k2].[q0|q0], [k0|k0].[q0|q1] = all six products of the fp32-equivalent sum in
+// 3 x 16 cycles instead of 4 x 32 for v_mfma_f32_16x16x4_f32 (lane group g supplies dh 8(g&1)..+7 of the first (g < 2)
+// or second (g >= 2) operand of each pair).  K sits in LDS as three bf16 planes of 48-byte rows.
+typedef __bf16 attn_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned attn_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned attn_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 mfma_bf16(attn_u32x4 a, attn_u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(attn_bf16x8, a), __builtin_bit_cast(attn_bf16x8, b), c, 0, 0, 0);
+}
+constexpr int KPP = 48;   // bytes per key row of a bf16 K plane (32 + 16 pad: 16-byte aligned rows, the 16 rows of a ds_read_b128 hit 16 bank quads; a 40-byte pitch breaks the alignment: 1.6x slower)
+
+template <int DH, int MAXT, bool SPLIT>
+__global__ __launch_bounds__(256, MAXT <= 13 ? 4 : 1) void attn_fwd_kernel(AttnParams p) {   // <= 128 VGPRs: 1024 (sample, head) workgroups = one round of 4 per CU
+  static_assert(!SPLIT || DH == 16, "split S^T path is written for dh = 16");
   constexpr int NC = DH / 16;
-  constexpr int LD = DH + 4;
+  constexpr int LD = SPLIT ? 3 * KPP / 4 : DH + 4;   // floats per key row of the K image (SPLIT: three 48-byte plane rows)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // A head is a 64..256-byte slice of every activation row, i.e. half (or less) of each 128-byte line it touches; the
   // other half belongs to the neighbouring head.  XCD-contiguous ids put all heads of a sample on ONE XCD (one L2),
@@ -76,6 +90,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: loop bounds stay scalar
   const int i = lane & 15, g = lane >> 4;
 
+  // Query rows of a tile: loaded one tile ahead (the first before the K/V staging) - a global load under a busy chip
+  // takes 2-4k cycles and nothing else of a tile can start without them.  Rows past Lq read row Lq-1 and are zeroed.
+  constexpr int NQ = SPLIT ? 2 : NC;
+  float4 qnext[NQ];
+  auto load_q = [&](int qt_, float4 (&dst)[NQ]) {
+    const int row = qt_ * 16 + i, rc = row < p.Lq ? row : p.Lq - 1;
+    const float* qp = p.Q + (size_t)(b * p.Lq + rc) * p.ldq + h * DH;
+#pragma unroll
+    for (int c = 0; c < NQ; ++c) {
+      const float4 v = *reinterpret_cast<const float4*>(qp + (SPLIT ? (g & 1) * 8 + 4 * c : c * 16 + g * 4));
+      dst[c] = row < p.Lq ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  load_q((wave + bh) & 3, qnext);
   // ---- stage K, V^T (zero-filled tail rows) and the key mask
   for (int e = tid; e < nkt * 16 * (DH / 4); e += 256) {
     const int row = e / (DH / 4), c4 = (e % (DH / 4)) * 4;
@@ -84,7 +112,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
       kv = *reinterpret_cast<const float4*>(p.K + (size_t)(b * p.Lk + row) * p.ldk + h * DH + c4);
       vv = *reinterpret_cast<const float4*>(p.V + (size_t)(b * p.Lk + row) * p.ldv + h * DH + c4);
     }
-    *reinterpret_cast<float4*>(&Ks[row * LD + c4]) = kv;
+    if constexpr (SPLIT) {
+      unsigned lo[3], hi[3];
+      skf_split2<3>(kv.x, kv.y, lo);
+      skf_split2<3>(kv.z, kv.w, hi);
+      char* kp = reinterpret_cast<char*>(Ks);
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        *reinterpret_cast<attn_u32x2*>(kp + (size_t)q * nkt * 16 * KPP + row * KPP + c4 * 2) = (attn_u32x2){lo[q], hi[q]};
+    } else {
+      *reinterpret_cast<float4*>(&Ks[row * LD + c4]) = kv;
+    }
     Vt[(c4 + 0) * VP + row] = vv.x; Vt[(c4 + 1) * VP + row] = vv.y; Vt[(c4 + 2) * VP + row] = vv.z; Vt[(c4 + 3) * VP + row] = vv.w;
   }
   {
@@ -120,14 +158,32 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   // Query tiles are dealt to the waves round-robin starting at a per-workgroup offset: with 13 tiles one wave gets 4 and
   // the others 3, and wave w always runs on SIMD w - without the rotation SIMD 0 of every CU carries the extra tile of
   // every resident workgroup.
+  // SPLIT: per-lane plane bases of the three A operands ([k1|k0], [k1|k2], [k0|k0]) inside the K image
+  const char* kp = reinterpret_cast<const char*>(Ks);
+  const int plane_b = nkt * 16 * KPP, lane_k = i * KPP + (g & 1) * 16;
+  const char* ka3 = kp + (g < 2 ? plane_b : 0) + lane_k;
+  const char* ka2 = kp + (g < 2 ? plane_b : 2 * plane_b) + lane_k;
+  const char* ka1 = kp + lane_k;
   for (int qt = (wave + bh) & 3; qt < nqt; qt += 4) {
     const int q0 = qt * 16, qrow = q0 + i;
     const bool qok = qrow < p.Lq;
-    float4 qf[NC];
+    float4 qcur[NQ];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      qf[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (qok) qf[c] = *reinterpret_cast<const float4*>(p.Q + (size_t)(b * p.Lq + qrow) * p.ldq + h * DH + c * 16 + g * 4);
+    for (int c = 0; c < NQ; ++c) qcur[c] = qnext[c];
+    load_q(qt + 4, qnext);                // the next tile's rows travel during this tile's MFMAs
+    float4 qf[NC];
+    attn_u32x4 qb1, qb2, qb3;             // SPLIT: B operands [q0|q1], [q0|q0], [q1|q2]
+    if constexpr (SPLIT) {
+      const float4 qa = qcur[0], qc = qcur[1];
+      unsigned d0[3], d1[3], d2[3], d3[3];
+      skf_split2<3>(qa.x, qa.y, d0); skf_split2<3>(qa.z, qa.w, d1);
+      skf_split2<3>(qc.x, qc.y, d2); skf_split2<3>(qc.z, qc.w, d3);
+      const attn_u32x4 p0 = {d0[0], d1[0], d2[0], d3[0]}, p1 = {d0[1], d1[1], d2[1], d3[1]}, p2 = {d0[2], d1[2], d2[2], d3[2]};
+      const bool first = g < 2;
+      qb1 = first ? p0 : p1; qb2 = p0; qb3 = first ? p1 : p2;
+    } else {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) qf[c] = qcur[c];
     }
     const int nt = min(can_skip ? qt + 1 : nkt, nkt_eff);
     float s[MAXT][4];
@@ -136,13 +192,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     for (int kt = 0; kt < MAXT; ++kt) {
       if (kt < nt) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (SPLIT) {
+          const attn_u32x4 a3 = *reinterpret_cast<const attn_u32x4*>(ka3 + kt * 16 * KPP);
+          const attn_u32x4 a2 = *reinterpret_cast<const attn_u32x4*>(ka2 + kt * 16 * KPP);
+          const attn_u32x4 a1 = *reinterpret_cast<const attn_u32x4*>(ka1 + kt * 16 * KPP);
+          acc = mfma_bf16(a3, qb3, acc);      // k1.q1 + k0.q2   (smallest first)
+          acc = mfma_bf16(a2, qb2, acc);      // k1.q0 + k2.q0
+          acc = mfma_bf16(a1, qb1, acc);      // k0.q0 + k0.q1
+        } else {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-          const float4 kf = *reinterpret_cast<const float4*>(&Ks[(kt * 16 + i) * LD + c * 16 + g * 4]);
-          acc = mfma16(kf.x, qf[c].x, acc);
-          acc = mfma16(kf.y, qf[c].y, acc);
-          acc = mfma16(kf.z, qf[c].z, acc);
-          acc = mfma16(kf.w, qf[c].w, acc);
+          for (int c = 0; c < NC; ++c) {
+            const float4 kf = *reinterpret_cast<const float4*>(&Ks[(kt * 16 + i) * LD + c * 16 + g * 4]);
+            acc = mfma16(kf.x, qf[c].x, acc);
+            acc = mfma16(kf.y, qf[c].y, acc);
+            acc = mfma16(kf.z, qf[c].z, acc);
+            acc = mfma16(kf.w, qf[c].w, acc);
+          }
         }
         // wave-uniform: does this tile need any masking at all?
         const bool need_mask = __builtin_amdgcn_readfirstlane(Tf[kt]) != 0 || (p.causal && kt >= qt);
@@ -484,9 +549,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
   }
 }
 
-size_t fwd_smem(int DH, int Lk) {
+size_t fwd_smem(int DH, int Lk, bool split) {
   const size_t n16 = (size_t)(Lk + 15) / 16 * 16;
-  return (n16 * (DH + 4) + (size_t)DH * (n16 + 4) + n16 + n16 / 16 + 4) * sizeof(float);
+  const size_t krow = split ? 3 * KPP / 4 : DH + 4;   // floats per key row of the K image
+  return (n16 * krow + (size_t)DH * (n16 + 4) + n16 + n16 / 16 + 4) * sizeof(float);
 }
 size_t bwd_smem(int DH, int Lq) {
   const size_t QR = (size_t)(Lq + 15) / 16 * 16;
@@ -520,13 +586,18 @@ extern "C" int skf_attention_fwd(const float* Q, int ldq, const float* K, int ld
   if (rc) return rc;
   SKF_CHECK_ARG(Q && K && V && O, "null operand");
   SKF_CHECK_ARG(Lk <= 512, "Lk > 512 not supported");
-  const size_t smem = fwd_smem(dh, Lk);
+  // The split S^T path is opt-in (SKF_ATTN_SPLIT=1): it removes 26 % of the kernel's MFMA cycles and changes nothing in its
+  // time (41.9 vs 40.2 us) - the forward is wait-bound (45 % of the wave cycles parked on s_waitcnt, PMC), and the bf16 K
+  // planes cost the fourth resident workgroup per CU.
+  static const bool split_env = getenv("SKF_ATTN_SPLIT") && getenv("SKF_ATTN_SPLIT")[0] == '1';
+  const bool split = dh == 16 && split_env;
+  const size_t smem = fwd_smem(dh, Lk, split);
   SKF_CHECK_ARG(smem <= 160 * 1024, "K/V of one head do not fit in LDS");
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(B * H), block(256);
-#define SKF_ATTN_FWD(DHV, MT)                                   \
+#define SKF_ATTN_FWD(DHV, MT, SP)                               \
   {                                                             \
-    auto kfn = attn_fwd_kernel<DHV, MT>;                        \
+    auto kfn = attn_fwd_kernel<DHV, MT, SP>;                    \
     if ((rc = set_smem(kfn, smem))) return rc;                  \
     hipLaunchKernelGGL(kfn, grid, block, smem, st, p);          \
   }
@@ -534,9 +605,10 @@ extern "C" int skf_attention_fwd(const float* Q, int ldq, const float* K, int ld
   SkfProfScope ps(st, tags[dh == 16 ? 0 : dh == 32 ? 1 : 2], 4.0 * B * H * (double)Lq * Lk * dh,
                   4.0 * B * H * dh * (2.0 * Lq + 2.0 * Lk));
   const bool small = Lk <= 208;
-  if (dh == 16) { if (small) SKF_ATTN_FWD(16, 13) else SKF_ATTN_FWD(16, 32) }
-  else if (dh == 32) { if (small) SKF_ATTN_FWD(32, 13) else SKF_ATTN_FWD(32, 32) }
-  else { if (small) SKF_ATTN_FWD(64, 13) else SKF_ATTN_FWD(64, 32) }
+  if (dh == 16 && split) { if (small) SKF_ATTN_FWD(16, 13, true) else SKF_ATTN_FWD(16, 32, true) }
+  else if (dh == 16) { if (small) SKF_ATTN_FWD(16, 13, false) else SKF_ATTN_FWD(16, 32, false) }
+  else if (dh == 32) { if (small) SKF_ATTN_FWD(32, 13, false) else SKF_ATTN_FWD(32, 32, false) }
+  else { if (small) SKF_ATTN_FWD(64, 13, false) else SKF_ATTN_FWD(64, 32, false) }
 #undef SKF_ATTN_FWD
   SKF_LAUNCH_CHECK();
   return SKF_OK;

@@ -67,6 +67,32 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// (x, y) -> P dwords; dword q = bf16 piece q of x in the low half, of y in the high half.  Pieces are the top 16 bits
+// of the running remainder (truncation), remainders are exact: x = x0 + x1 + x2 for every finite fp32 (24 significand
+// bits = 3 x 8).  The remainder x - x_q is one v_dot2c_f32_bf16 (x += piece . (-1, 0)) instead of a mask and a subtract.
+typedef __bf16 skf_bf16x2 __attribute__((ext_vector_type(2)));
+template <int P>
+__device__ __forceinline__ void skf_split2(float x, float y, unsigned (&out)[P]) {
+#pragma unroll
+  for (int q = 0; q < P; ++q) {
+    out[q] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, y), __builtin_bit_cast(unsigned, x), 0x07060302u);   // (y & 0xffff0000) | (x >> 16)
+    if (q + 1 < P) {
+#ifdef SKF_SPLIT_NO_DOT2
+      x -= __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & 0xffff0000u);
+      y -= __builtin_bit_cast(float, __builtin_bit_cast(unsigned, y) & 0xffff0000u);
+#else
+      // the (-1, 0) / (0, -1) selectors are kept opaque in SGPRs: folded into an inline constant "-1.0" the
+      // instruction subtracted the wrong half on gfx950
+      unsigned sel_lo = 0x0000bf80u, sel_hi = 0xbf800000u;
+      asm volatile("" : "+s"(sel_lo), "+s"(sel_hi));
+      const skf_bf16x2 pc = __builtin_bit_cast(skf_bf16x2, out[q]);
+      x = __builtin_amdgcn_fdot2_f32_bf16(pc, __builtin_bit_cast(skf_bf16x2, sel_lo), x, false);
+      y = __builtin_amdgcn_fdot2_f32_bf16(pc, __builtin_bit_cast(skf_bf16x2, sel_hi), y, false);
+#endif
+    }
+  }
+}
+
 // Counter-based dropout RNG: one 32-bit hash per element, keyed on
 // (key = f(seed, step), site, flat element index).  Deterministic, stateless,
 // identical on host (skf_dropout_keep_mask) and device.

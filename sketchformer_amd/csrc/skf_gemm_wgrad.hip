@@ -131,18 +131,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(GemmParams p) {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <int P>
-__device__ __forceinline__ void wg_split2(float x, float y, unsigned (&out)[P]) {
-#pragma unroll
-  for (int q = 0; q < P; ++q) {
-    const unsigned ux = __builtin_bit_cast(unsigned, x), uy = __builtin_bit_cast(unsigned, y);
-    out[q] = __builtin_amdgcn_perm(uy, ux, 0x07060302u);
-    if (q + 1 < P) {
-      x -= __builtin_bit_cast(float, ux & 0xffff0000u);
-      y -= __builtin_bit_cast(float, uy & 0xffff0000u);
-    }
-  }
-}
+template <int P> __device__ __forceinline__ void wg_split2(float x, float y, unsigned (&out)[P]) { skf_split2<P>(x, y, out); }
 // column e of eight row vectors -> P operands of 8 bf16
 template <int P>
 __device__ __forceinline__ void wg_split_col(const f32x4 (&rows)[8], int e, u32x4 (&out)[P]) {
@@ -160,9 +149,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t wg_rows_rsrc(const float* base
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + (long long)row0 * ld), 0, (unsigned)rem, 0x00020000);
 }
 
-template <int P>
-__global__ __launch_bounds__(256, 2) void wgrad_x_kernel(GemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];   // [4 waves][64][64] + [4][64] column sums
+template <int P, int NW>   // NW waves per workgroup = intra-workgroup split of the row range
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void wgrad_x_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [NW waves][64][64] + [NW][64] column sums
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, g = lane >> 4;
@@ -189,11 +178,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_x_kernel(GemmParams p) {
     for (int f = 0; f < 4; ++f) acc[e][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
   f32x4 csum = {0.f, 0.f, 0.f, 0.f};
 
-  const int niter = (ke - kb + 127) / 128;
+  constexpr int RI = 32 * NW;                       // rows per iteration of the workgroup
+  const int niter = (ke - kb + RI - 1) / RI;
   f32x4 xa[8], yb[8];
   auto load_step = [&](int it) {
-    const __amdgpu_buffer_rsrc_t rx = wg_rows_rsrc(p.A, p.lda, kb + 128 * it, ke);
-    const __amdgpu_buffer_rsrc_t ry = wg_rows_rsrc(p.B, p.ldb, kb + 128 * it, ke);
+    const __amdgpu_buffer_rsrc_t rx = wg_rows_rsrc(p.A, p.lda, kb + RI * it, ke);
+    const __amdgpu_buffer_rsrc_t ry = wg_rows_rsrc(p.B, p.ldb, kb + RI * it, ke);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       xa[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xo[j], 0, 0));
@@ -237,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_x_kernel(GemmParams p) {
       *reinterpret_cast<f32x4*>(&mine[row * 64 + 4 * i]) =
           (f32x4){acc[e][0][r], acc[e][1][r], acc[e][2][r], acc[e][3][r]};
     }
-  float* cs = smem + 4 * 4096;
+  float* cs = smem + NW * 4096;
   if (do_colsum) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -251,17 +241,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_x_kernel(GemmParams p) {
   __syncthreads();
   float* slab = p.slab + (size_t)split * p.M * p.N;
 #pragma unroll
-  for (int v = 0; v < 4; ++v) {
-    const int e4 = tid + v * 256, row = e4 >> 4, c4 = (e4 & 15) * 4;
-    const f32x4 s = *reinterpret_cast<const f32x4*>(&smem[row * 64 + c4]) +
-                    *reinterpret_cast<const f32x4*>(&smem[4096 + row * 64 + c4]) +
-                    *reinterpret_cast<const f32x4*>(&smem[8192 + row * 64 + c4]) +
-                    *reinterpret_cast<const f32x4*>(&smem[12288 + row * 64 + c4]);
+  for (int v = 0; v < 16 / NW; ++v) {
+    const int e4 = tid + v * 64 * NW, row = e4 >> 4, c4 = (e4 & 15) * 4;
+    f32x4 s = *reinterpret_cast<const f32x4*>(&smem[row * 64 + c4]);
+#pragma unroll
+    for (int w = 1; w < NW; ++w) s += *reinterpret_cast<const f32x4*>(&smem[w * 4096 + row * 64 + c4]);
     if (a0 + row < p.M && b0 + c4 < p.N)
       *reinterpret_cast<f32x4*>(&slab[(size_t)(a0 + row) * p.N + b0 + c4]) = s;
   }
-  if (do_colsum && tid < 64 && b0 + tid < p.N)
-    p.colsum_slab[(size_t)split * p.N + b0 + tid] = cs[tid] + cs[64 + tid] + cs[128 + tid] + cs[192 + tid];
+  if (do_colsum && tid < 64 && b0 + tid < p.N) {
+    float v = cs[tid];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) v += cs[w * 64 + tid];
+    p.colsum_slab[(size_t)split * p.N + b0 + tid] = v;
+  }
 }
 
 }  // namespace
@@ -286,15 +279,26 @@ int skf_gemm_wgrad_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, i
   }
   const int prec = skf_get_gemm_precision();
   if (prec) {
+    // 4 waves per workgroup; 8 (two per SIMD, 128 KB of LDS for the reduction) measured the same: the loop is issue-bound
+    // (6 MFMAs + ~14 VALU per operand pair), not latency-bound.  SKF_WGRAD_WAVES=8 selects it.
+    static const int nw_env = getenv("SKF_WGRAD_WAVES") ? atoi(getenv("SKF_WGRAD_WAVES")) : 0;
+    const int nwg = q.tiles_m * q.tiles_n * splits;
+    const int nw = nw_env == 8 ? 8 : 4;
+    const size_t smem_x = (size_t)nw * (4096 + 64) * sizeof(float);
     static bool attr_x = false;
     if (!attr_x) {
-      SKF_HIP(hipFuncSetAttribute((const void*)wgrad_x_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-      SKF_HIP(hipFuncSetAttribute((const void*)wgrad_x_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      SKF_HIP(hipFuncSetAttribute((const void*)wgrad_x_kernel<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (4096 + 64) * 4));
+      SKF_HIP(hipFuncSetAttribute((const void*)wgrad_x_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (4096 + 64) * 4));
+      SKF_HIP(hipFuncSetAttribute((const void*)wgrad_x_kernel<3, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * (4096 + 64) * 4));
+      SKF_HIP(hipFuncSetAttribute((const void*)wgrad_x_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * (4096 + 64) * 4));
       attr_x = true;
     }
     SkfProfScope ps(st, prec == 3 ? "wgrad<64x64,bf16x3>" : "wgrad<64x64,bf16x6>", 2.0 * p.M * p.N * p.K, 4.0 * (double)p.K * (p.M + p.N));
-    if (prec == 3) hipLaunchKernelGGL(wgrad_x_kernel<2>, dim3(q.tiles_m * q.tiles_n * splits), dim3(256), smem, st, q);
-    else hipLaunchKernelGGL(wgrad_x_kernel<3>, dim3(q.tiles_m * q.tiles_n * splits), dim3(256), smem, st, q);
+    const dim3 grid(nwg), block(64 * nw);
+    if (prec == 3 && nw == 8) hipLaunchKernelGGL((wgrad_x_kernel<2, 8>), grid, block, smem_x, st, q);
+    else if (prec == 3) hipLaunchKernelGGL((wgrad_x_kernel<2, 4>), grid, block, smem_x, st, q);
+    else if (nw == 8) hipLaunchKernelGGL((wgrad_x_kernel<3, 8>), grid, block, smem_x, st, q);
+    else hipLaunchKernelGGL((wgrad_x_kernel<3, 4>), grid, block, smem_x, st, q);
     SKF_LAUNCH_CHECK();
     return SKF_OK;
   }

@@ -61,23 +61,7 @@ __device__ __forceinline__ void wsx_buf_store(typename VecOfX<NB>::type v, __amd
   else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uvec, v), r, voff, 0, 0);
 }
 
-// (x, y) -> P dwords; dword q = bf16 piece q of x in the low half, of y in the high half.  Pieces are the top
-// 16 bits of the running remainder (truncation), remainders are exact: x = x0 + x1 + x2 for every finite fp32.
-template <int P>
-__device__ __forceinline__ void split2(float x, float y, unsigned (&out)[P]) {
-#pragma unroll
-  for (int q = 0; q < P; ++q) {
-    const unsigned ux = __builtin_bit_cast(unsigned, x), uy = __builtin_bit_cast(unsigned, y);
-    out[q] = __builtin_amdgcn_perm(uy, ux, 0x07060302u);   // (uy & 0xffff0000) | (ux >> 16)
-#ifdef SKF_WSX_ABLATE_SPLIT   // diagnostics: wrong results, no remainder arithmetic
-    continue;
-#endif
-    if (q + 1 < P) {
-      x -= __builtin_bit_cast(float, ux & 0xffff0000u);
-      y -= __builtin_bit_cast(float, uy & 0xffff0000u);
-    }
-  }
-}
+template <int P> __device__ __forceinline__ void split2(float x, float y, unsigned (&out)[P]) { skf_split2<P>(x, y, out); }
 
 template <int K>
 __device__ __forceinline__ void wsx_load_tile(const float* __restrict__ A, int lda, int M, int tile,
@@ -384,6 +368,10 @@ int launch_wsx(const GemmParams& p, int b_kc, hipStream_t st) {
   SkfProfScope ps(st, tag.c_str(), 2.0 * p.M * p.N * p.K,
                   4.0 * ((double)p.M * p.K + (double)p.K * p.N + (double)p.M * p.N * (p.accumulate ? 2 : 1)));
   const bool extra = p.relu_src || p.accumulate;
+  GemmParams q = p;
+  // K >= 384 (N = 128): the two column groups of a worker read the same A tiles - XCD-contiguous ids keep the second read
+  // in the L2 (PMC: 132 -> ~80 MB per launch); with one or two groups of short tiles (K <= 256) the remap only costs
+  if (!getenv("SKF_WS_XCD")) q.xcd_remap = K >= 384 && groups > 1;
 #define SKF_WSX_LAUNCH(BKC, EX)                                                                                    \
   do {                                                                                                             \
     static bool attr_done = false;                                                                                 \
@@ -392,7 +380,7 @@ int launch_wsx(const GemmParams& p, int b_kc, hipStream_t st) {
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                                  \
       attr_done = true;                                                                                            \
     }                                                                                                              \
-    hipLaunchKernelGGL((gemm_wsx_kernel<K, NB, P, BKC, EX>), grid, block, smem, st, p, groups, workers);           \
+    hipLaunchKernelGGL((gemm_wsx_kernel<K, NB, P, BKC, EX>), grid, block, smem, st, q, groups, workers);           \
   } while (0)
   if (b_kc && extra) SKF_WSX_LAUNCH(true, true);
   else if (b_kc) SKF_WSX_LAUNCH(true, false);
