@@ -270,8 +270,11 @@ __global__ __launch_bounds__(256, MAXT <= 13 ? 4 : 1) void attn_fwd_kernel(AttnP
 // consecutive key tiles, and when nkt = 4*(KTW-1)+1 (L = 193..208 at dh=16) the odd 13th key tile is SHARED: every wave
 // holds its fragments and processes it for the query tiles with (qt & 3) == wave; the four partial dK/dV are summed
 // through LDS at the end (work per wave 42.25 pairs instead of 52 / 39 / 39 / 39).
+#ifndef SKF_ATTN_BWD_WAVES
+#define SKF_ATTN_BWD_WAVES 2   // waves per SIMD the register allocation aims at (3 = 168 VGPRs)
+#endif
 template <int DH, int KTW, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, SKF_ATTN_BWD_WAVES) void attn_bwd_kernel(AttnParams p) {
   constexpr int NC = DH / 16;
   constexpr int LD = DH + 4;
   constexpr int TLD = 20;

@@ -42,6 +42,7 @@ constexpr int TR = 16;   // rows per tile
 template <int N> struct VecOfX;
 template <> struct VecOfX<1> { typedef float type; typedef unsigned utype; };
 template <> struct VecOfX<2> { typedef float __attribute__((ext_vector_type(2))) type; typedef u32x2 utype; };
+template <> struct VecOfX<4> { typedef f32x4 type; typedef u32x4 utype; };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t wsx_rows_rsrc(const float* base, int ld, int M, int row0) {
   long long rem = ((long long)M - row0) * ld * 4;
@@ -52,13 +53,15 @@ template <int NB>
 __device__ __forceinline__ typename VecOfX<NB>::type wsx_buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff) {
   typedef typename VecOfX<NB>::type vecn;
   if constexpr (NB == 1) return __builtin_bit_cast(vecn, __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
-  else return __builtin_bit_cast(vecn, __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0));
+  else if constexpr (NB == 2) return __builtin_bit_cast(vecn, __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0));
+  else return __builtin_bit_cast(vecn, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
 }
 template <int NB>
 __device__ __forceinline__ void wsx_buf_store(typename VecOfX<NB>::type v, __amdgpu_buffer_rsrc_t r, unsigned voff) {
   typedef typename VecOfX<NB>::utype uvec;
   if constexpr (NB == 1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uvec, v), r, voff, 0, 0);
-  else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uvec, v), r, voff, 0, 0);
+  else if constexpr (NB == 2) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uvec, v), r, voff, 0, 0);
+  else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uvec, v), r, voff, 0, 0);
 }
 
 template <int P> __device__ __forceinline__ void split2(float x, float y, unsigned (&out)[P]) { skf_split2<P>(x, y, out); }
@@ -91,11 +94,11 @@ __device__ __forceinline__ void wsx_store_tile(char* __restrict__ dst, const f32
 }
 
 template <int K, int NB, int P, bool B_KC, bool EXTRA>
-__global__ __launch_bounds__(256, (K <= 256 ? 2 : 1)) void gemm_wsx_kernel(GemmParams p, int groups, int workers) {
+__global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_kernel(GemmParams p, int groups, int workers) {
   constexpr int CW = 16 * NB;            // columns per wave
   constexpr int NKS = K / 32;            // MFMA k-steps per tile
   constexpr int NF = NKS * P;            // A fragments (ds_read_b128) per tile
-  constexpr bool EARLY = K == 128 && P == 2;   // every fragment of a tile in registers: barrier inside the MFMA stream
+  constexpr bool EARLY = K == 128 && (P == 2 || NB == 4);   // every fragment of a tile in registers: barrier inside the MFMA stream
   constexpr int PF = EARLY ? NF : (NF < 6 ? NF : 6);
   constexpr int NCH = NB == 1 ? 2 : 1;   // accumulator chains per column block
   constexpr int PITCH = 2 * K + 16;      // bytes per LDS row: the 16 rows of a ds_read_b128 group hit 16 different bank quads
@@ -357,7 +360,7 @@ template <int K, int NB, int P>
 int launch_wsx(const GemmParams& p, int b_kc, hipStream_t st) {
   constexpr int CW = 16 * NB;
   const int groups = skf_cdiv(p.N, 4 * CW);
-  static const int wg_target = getenv("SKF_WS_WGS") ? atoi(getenv("SKF_WS_WGS")) : (K <= 256 ? 512 : 256);
+  static const int wg_target = getenv("SKF_WS_WGS") ? atoi(getenv("SKF_WS_WGS")) : (K <= 256 && NB <= 2 ? 512 : 256);
   int workers = wg_target / groups;
   if (workers < 1) workers = 1;
   const int ntiles = skf_cdiv(p.M, TR);
@@ -394,6 +397,8 @@ int launch_wsx(const GemmParams& p, int b_kc, hipStream_t st) {
 template <int P>
 int launch_wsx_k(const GemmParams& p, int b_kc, hipStream_t st) {
   switch (p.K) {
+    // (four columns per lane = 64 per wave, one workgroup per CU, was measured for N >= 256: 30.8 vs 28.7 us at N = 512 -
+    //  one wave per SIMD loses more to exposed waits than the doubled MFMA : overhead ratio wins)
     case 128: return launch_wsx<128, 2, P>(p, b_kc, st);
     case 256: return launch_wsx<256, 1, P>(p, b_kc, st);
     case 384: return launch_wsx<384, 1, P>(p, b_kc, st);
