@@ -879,9 +879,14 @@ int run_backward(SkfModel* M, hipStream_t s) {
     float* dqkv = M->at<float>(gs.dqkv);
     SKF_TRY(ln_bwd(M, w.ln2, G, M->at<float>(a.z2), M->at<float>(a.st2), G2, dy2, Me, rate, site_enc(i, 1), s));
     SKF_TRY(ffn_bwd(M, w.f1, w.f2, M->at<float>(a.x1), M->at<float>(a.h), dy2, M->at<float>(gs.dh), G2, Me, s));
+    // last layer of the backward: nothing is left on the main stream to hide a whole layer's weight gradients behind
+    // (only the embedding gradient follows), so they go out per sublayer - the step's tail before Adam is one wgrad, not four
+    static const bool early_tail = !getenv("SKF_NO_EARLY_TAIL");
+    if (i == 0 && early_tail) SKF_TRY(issue_wgrads(M, s));
     SKF_TRY(ln_bwd(M, w.ln1, G2, M->at<float>(a.z1), M->at<float>(a.st1), G, dy1, Me, rate, site_enc(i, 0), s));
     SKF_TRY(dense_wgrad(M, w.mha.o, M->at<float>(a.o), d, dy1, d, Me, s));
     SKF_TRY(dense_dgrad(M, w.mha.o, dy1, d, Me, dO, d, 0, nullptr, 0, s));
+    if (i == 0 && early_tail) SKF_TRY(issue_wgrads(M, s));
     const float* qkv = M->at<float>(a.qkv);
     SKF_TRY(before_write(M, dqkv, s));
     SKF_TRY(skf_attention_bwd(qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, M->at<float>(a.o), d, dO, d,
