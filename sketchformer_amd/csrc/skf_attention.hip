@@ -67,7 +67,7 @@ typedef unsigned attn_u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x4 mfma_bf16(attn_u32x4 a, attn_u32x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(attn_bf16x8, a), __builtin_bit_cast(attn_bf16x8, b), c, 0, 0, 0);
 }
-constexpr int KPP = 48;   // bytes per key row of a bf16 K plane (32 + 16 pad: 16-byte aligned rows, the 16 rows of a ds_read_b128 hit 16 bank quads; a 40-byte pitch breaks the alignment: 1.6x slower)
+constexpr int KPP = 32;   // bytes per key row of a bf16 K plane: unpadded (2-way bank conflicts on the fragment reads) so that K planes + V^T of a 208-key head stay under 40 KB = four workgroups per CU; 40 bytes would break the 16-byte alignment of ds_read_b128 (1.6x slower)
 
 template <int DH, int MAXT, bool SPLIT>
 __global__ __launch_bounds__(256, MAXT <= 13 ? 4 : 1) void attn_fwd_kernel(AttnParams p) {   // <= 128 VGPRs: 1024 (sample, head) workgroups = one round of 4 per CU
@@ -589,11 +589,12 @@ extern "C" int skf_attention_fwd(const float* Q, int ldq, const float* K, int ld
   if (rc) return rc;
   SKF_CHECK_ARG(Q && K && V && O, "null operand");
   SKF_CHECK_ARG(Lk <= 512, "Lk > 512 not supported");
-  // The split S^T path is opt-in (SKF_ATTN_SPLIT=1): it removes 26 % of the kernel's MFMA cycles and changes nothing in its
-  // time (41.9 vs 40.2 us) - the forward is wait-bound (45 % of the wave cycles parked on s_waitcnt, PMC), and the bf16 K
-  // planes cost the fourth resident workgroup per CU.
-  static const bool split_env = getenv("SKF_ATTN_SPLIT") && getenv("SKF_ATTN_SPLIT")[0] == '1';
-  const bool split = dh == 16 && split_env;
+  // S^T on the bf16 pipe follows the Dense arithmetic switch (SKF_ATTN_SPLIT=0 turns it off).  With padded 48-byte plane
+  // rows it removed 26 % of the MFMA cycles and changed nothing (the forward is wait-bound: 45 % of the wave cycles parked,
+  // and the planes cost the fourth resident workgroup per CU); with unpadded rows (four workgroups per CU again, 2-way bank
+  // conflicts) it is 4-11 % faster than the fp32-MFMA tiles: 36.4 / 29.0 / 42.1 vs 39.2 / 30.2 / 47.2 us.
+  static const bool split_off = getenv("SKF_ATTN_SPLIT") && getenv("SKF_ATTN_SPLIT")[0] == '0';
+  const bool split = dh == 16 && !split_off && skf_get_gemm_precision() != 0;
   const size_t smem = fwd_smem(dh, Lk, split);
   SKF_CHECK_ARG(smem <= 160 * 1024, "K/V of one head do not fit in LDS");
   hipStream_t st = (hipStream_t)stream;
