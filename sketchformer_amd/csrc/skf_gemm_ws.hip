@@ -337,17 +337,7 @@ extern "C" int skf_set_gemm_precision(int mode) {
 }
 
 // Returns SKF_OK and sets *handled = 1 when the weight-stationary path applies.
-int skf_gemm_ws_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, hipStream_t st, int* handled) {
-  *handled = 0;
-  const char* off = getenv("SKF_GEMM_NO_WS");
-  if (off && off[0] == '1') return SKF_OK;
-  if (!a_kcontig || p.M < 1024) return SKF_OK;
-  if (!(p.K == 128 || p.K == 256 || p.K == 384 || p.K == 512)) return SKF_OK;
-  if ((p.N & 3) || (p.lda & 3) || (p.ldc & 3) || ((uintptr_t)p.A & 15) || ((uintptr_t)p.C & 15)) return SKF_OK;
-  if (b_kcontig && ((p.ldb & 3) || ((uintptr_t)p.B & 15))) return SKF_OK;
-  if (!b_kcontig && ((p.ldb & 1) || ((uintptr_t)p.B & 7))) return SKF_OK;   // NB-wide loads along n
-  if (p.relu_src && ((p.ld_relu & 3) || ((uintptr_t)p.relu_src & 15))) return SKF_OK;
-  *handled = 1;
+static int ws_launch_one(const GemmParams& p, int b_kcontig, hipStream_t st) {
   if (const int prec = skf_get_gemm_precision(); prec && p.act != 2) return skf_gemm_wsx_launch(p, b_kcontig, prec == 3 ? 2 : 3, st);
   switch (p.K) {
     case 128: return launch_ws<128, 2>(p, b_kcontig, st);
@@ -357,4 +347,35 @@ int skf_gemm_ws_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, hipS
     case 384: return launch_ws<384, 1>(p, b_kcontig, st);
     default:  return launch_ws<512, 1>(p, b_kcontig, st);
   }
+}
+
+int skf_gemm_ws_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, hipStream_t st, int* handled) {
+  *handled = 0;
+  const char* off = getenv("SKF_GEMM_NO_WS");
+  if (off && off[0] == '1') return SKF_OK;
+  if (!a_kcontig || p.M < 1024) return SKF_OK;
+  // K in {128,256,384,512} = one launch; longer K (a multiple of 128 up to 2048: dff = 1024 / 2048, the 3d-wide qkv dgrad
+  // at d = 256) = a chain of <= 512-deep launches over column slices of A / row slices of B, every launch after the first
+  // accumulating into C - only without an epilogue that must see the complete sum (activation, relu mask)
+  const bool single = p.K == 128 || p.K == 256 || p.K == 384 || p.K == 512;
+  const bool chain = !single && p.K > 512 && p.K <= 2048 && (p.K & 127) == 0 && p.act == 0 && !p.relu_src;
+  if (!single && !chain) return SKF_OK;
+  if ((p.N & 3) || (p.lda & 3) || (p.ldc & 3) || ((uintptr_t)p.A & 15) || ((uintptr_t)p.C & 15)) return SKF_OK;
+  if (b_kcontig && ((p.ldb & 3) || ((uintptr_t)p.B & 15))) return SKF_OK;
+  if (!b_kcontig && ((p.ldb & 1) || ((uintptr_t)p.B & 7))) return SKF_OK;   // NB-wide loads along n
+  if (p.relu_src && ((p.ld_relu & 3) || ((uintptr_t)p.relu_src & 15))) return SKF_OK;
+  *handled = 1;
+  if (single) return ws_launch_one(p, b_kcontig, st);
+  for (int k0 = 0; k0 < p.K;) {
+    const int left = p.K - k0, kc = left >= 512 ? 512 : left;       // left is a multiple of 128 below 512: 128 / 256 / 384
+    GemmParams q = p;
+    q.K = kc;
+    q.A = p.A + k0;
+    q.B = b_kcontig ? p.B + k0 : p.B + (size_t)k0 * p.ldb;
+    if (k0 > 0) { q.bias = nullptr; q.accumulate = 1; }
+    const int rc = ws_launch_one(q, b_kcontig, st);
+    if (rc != SKF_OK) return rc;
+    k0 += kc;
+  }
+  return SKF_OK;
 }

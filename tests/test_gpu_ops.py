@@ -115,6 +115,20 @@ def test_gemm_arithmetic_modes(ops, M, N, K, bkc):
     assert err[3].max() < 1e-4, err[3].max()
 
 
+@pytest.mark.parametrize("M,N,K,bkc", [(1500, 256, 1024, False), (1200, 256, 768, True), (1100, 128, 2048, False), (1030, 256, 640, True)])
+def test_gemm_long_k_chain(ops, M, N, K, bkc):
+    """K = a multiple of 128 in (512, 2048]: chained <= 512-deep weight-stationary launches (bias in the first, every
+    later one accumulating), with and without an initial accumulate."""
+    rng = np.random.RandomState(M + N + K)
+    x, w, b, c0 = rng.randn(M, K), rng.randn(K, N) / np.sqrt(K), rng.randn(N), rng.randn(M, N)
+    wd = _dev(np.ascontiguousarray(w.T)) if bkc else _dev(w)
+    _close(ops.gemm(_dev(x), wd, b_kcontig=bkc, bias=_dev(b)), x @ w + b, name="chain")
+    out = _dev(c0)
+    ops.gemm(_dev(x), wd, b_kcontig=bkc, out=out, accumulate=True)
+    _close(out, c0 + x @ w, name="chain accumulate")
+    _close(ops.gemm(_dev(x), wd, b_kcontig=bkc, bias=_dev(b), act=1), np.maximum(x @ w + b, 0), name="relu: generic kernel")
+
+
 def test_gemm_strided_views(ops):
     """fused QKV layout: W stored [d][3d]; outputs written into a (rows, 3d) buffer at a column offset."""
     rng = np.random.RandomState(5)
