@@ -370,7 +370,9 @@ struct SkfModel {
   std::vector<hipEvent_t> events;
   size_t next_event = 0;
   std::map<const void*, hipEvent_t> pending_readers;   // buffer -> completion event of its last side-stream reader
-  struct QueuedWgrad { DenseP w; const float* x; int ldx; const float* dy; int lddy; int rows; };
+  // kind 0: dW = X^T dY (+ bias grad); kind 1: an input gradient nobody on the main stream needs soon (dx (+)= dY W^T)
+  struct QueuedWgrad { DenseP w; const float* x; int ldx; const float* dy; int lddy; int rows; int kind = 0; float* dx = nullptr; int lddx = 0; int accumulate = 0; };
+  std::map<const void*, hipEvent_t> pending_writers;   // buffers a side-stream dgrad still writes
   std::vector<QueuedWgrad> wq;                         // wgrads of the current layer, not yet issued
   bool side_used = false;
   std::vector<SkfReduceDesc> descs;     // one per wgrad of the step, in launch order
@@ -439,6 +441,16 @@ int dense_wgrad(SkfModel* M, const DenseP& w, const float* x, int ldx, const flo
   M->wq.push_back({w, x, ldx, dy, lddy, rows});
   return SKF_OK;
 }
+// Main-stream kernels that read `buf` first wait for the side-stream dgrad that writes it.
+int before_read(SkfModel* M, const void* buf, hipStream_t s) {
+  for (const auto& q : M->wq)
+    if (q.kind == 1 && q.dx == buf) { SKF_TRY(issue_wgrads(M, s)); break; }
+  auto it = M->pending_writers.find(buf);
+  if (it == M->pending_writers.end()) return SKF_OK;
+  SKF_HIP(hipStreamWaitEvent(s, it->second, 0));
+  M->pending_writers.erase(it);
+  return SKF_OK;
+}
 // Issue the queued wgrads on the side stream: ONE ready event (everything queued on `s` so far is complete before they
 // start) and ONE done event for the whole group; they are serialized among themselves and joined before the optimizer.
 int issue_wgrads(SkfModel* M, hipStream_t s) {
@@ -449,8 +461,19 @@ int issue_wgrads(SkfModel* M, hipStream_t s) {
   SKF_CHECK_ARG(ready && done, "event allocation failed");
   SKF_HIP(hipEventRecord(ready, s));
   SKF_HIP(hipStreamWaitEvent(M->side, ready, 0));
+  // deferred input gradients first, with their own completion event: their reader must not wait for the weight gradients
+  hipEvent_t dgrad_done = nullptr;
+  for (const auto& q : group) {
+    if (q.kind != 1) continue;
+    const DenseP& w = q.w;
+    SKF_TRY(skf_gemm_f32(1, 1, q.rows, w.in, w.out, q.dy, q.lddy, M->P(w.w), w.ld, q.dx, q.lddx, nullptr, 0, nullptr, 0,
+                         q.accumulate, 1, nullptr, 0, nullptr, 0, M->side));
+    if (!dgrad_done) { dgrad_done = M->new_event(); SKF_CHECK_ARG(dgrad_done, "event allocation failed"); }
+  }
+  if (dgrad_done) SKF_HIP(hipEventRecord(dgrad_done, M->side));
   for (const auto& q : group) {
     const DenseP& w = q.w;
+    if (q.kind == 1) continue;
     if ((double)w.in * w.out * q.rows <= 33554432.0) {
       // batch-sized problems (classifier, class buffers, SelfAttnV2 projection): one small-GEMM launch, no split-K slab
       SKF_TRY(dense_wgrad_on(M, w, q.x, q.ldx, q.dy, q.lddy, q.rows, M->side));
@@ -476,7 +499,11 @@ int issue_wgrads(SkfModel* M, hipStream_t s) {
     M->desc_cursor += 1;
   }
   SKF_HIP(hipEventRecord(done, M->side));
-  for (const auto& q : group) { M->pending_readers[q.dy] = done; M->pending_readers[q.x] = done; }
+  for (const auto& q : group) {
+    M->pending_readers[q.dy] = done;
+    if (q.x) M->pending_readers[q.x] = done;
+    if (q.kind == 1) M->pending_writers[q.dx] = dgrad_done;
+  }
   M->side_used = true;
   return SKF_OK;
 }
@@ -513,6 +540,7 @@ int flush_wgrads(SkfModel* M, hipStream_t s, int bucket, bool final) {
   M->reduce_blocks = 0;                 // block numbering of the next batch starts again at 0
   if (final) {
     M->pending_readers.clear();
+    M->pending_writers.clear();
     M->side_used = false;
   }
   return SKF_OK;
@@ -522,6 +550,19 @@ int dense_dgrad(SkfModel* M, const DenseP& w, const float* dy, int lddy, int row
   SKF_TRY(before_write(M, dx, s));
   return skf_gemm_f32(1, 1, rows, w.in, w.out, dy, lddy, M->P(w.w), w.ld, dx, lddx, nullptr, 0, relu_src, ld_relu,
                       accumulate, 1, nullptr, 0, nullptr, 0, s);
+}
+
+// dx (+)= dY W^T for a dx that the main stream reads much later (the encoder-output gradient sent back by the decoder's
+// cross-attention K/V projections): queued behind this layer's weight gradients on the side stream; the reader calls
+// before_read(dx).  Successive deferred writers of one dx stay in order (one side stream).
+int dense_dgrad_deferred(SkfModel* M, const DenseP& w, const float* dy, int lddy, int rows, float* dx, int lddx, int accumulate,
+                         hipStream_t s) {
+  static const bool off = getenv("SKF_NO_DEFERRED_DGRAD") != nullptr;
+  if (!M->side || off) return dense_dgrad(M, w, dy, lddy, rows, dx, lddx, accumulate, nullptr, 0, s);
+  SkfModel::QueuedWgrad q{w, nullptr, 0, dy, lddy, rows};
+  q.kind = 1; q.dx = dx; q.lddx = lddx; q.accumulate = accumulate;
+  M->wq.push_back(q);
+  return SKF_OK;
 }
 
 // site ids follow oracle.dropout_sites()
@@ -794,7 +835,11 @@ int run_backward(SkfModel* M, hipStream_t s) {
     SKF_TRY(dense_wgrad(M, w.mha2.q, M->at<float>(a.out1), d, dq2, d, Md, s));
     SKF_TRY(dense_dgrad(M, w.mha2.q, dq2, d, Md, G, d, 1, nullptr, 0, s));
     SKF_TRY(dense_wgrad(M, w.mha2.kv, pre, L.E, dkv2, 2 * d, Me, s));
-    SKF_TRY(dense_dgrad(M, w.mha2.kv, dkv2, 2 * d, Me, dpre, L.E, i != N - 1, nullptr, 0, s));
+    // (the last layer of the loop runs it on the main stream: its reader follows too soon to gain anything)
+    if (i == 0) {
+      SKF_TRY(before_read(M, dpre, s));   // the side-stream writers of the layers above have finished accumulating
+      SKF_TRY(dense_dgrad(M, w.mha2.kv, dkv2, 2 * d, Me, dpre, L.E, i != N - 1, nullptr, 0, s));
+    } else SKF_TRY(dense_dgrad_deferred(M, w.mha2.kv, dkv2, 2 * d, Me, dpre, L.E, i != N - 1, s));
     // out1 = LN1(x + drop(mha1(x,x,x)))
     SKF_TRY(ln_bwd(M, w.ln1, G, M->at<float>(a.z1), M->at<float>(a.st1), G2, dy1, Md, rate, site_dec(N, i, 0), s));
     SKF_TRY(dense_wgrad(M, w.mha1.o, M->at<float>(a.o1), d, dy1, d, Md, s));
@@ -819,6 +864,7 @@ int run_backward(SkfModel* M, hipStream_t s) {
   }
   // every gradient of [decoder embedding .. output layer] is issued: first bucket of the flat buffer
   if (M->n_buckets == 2) SKF_TRY(flush_wgrads(M, s, 0, false));
+  SKF_TRY(before_read(M, dpre, s));     // the deferred K/V-projection input gradients (side stream) are complete
   }   // recon
   const int E = L.E, Ua = L.Ua, U = c.lowerdim, NB = c.class_buffer_layers;
   if (bott) {
