@@ -86,6 +86,7 @@ __global__ __launch_bounds__(256, MAXT <= 13 ? 4 : 1) void attn_fwd_kernel(AttnP
   float* Ms = Vt + DH * VP;               // [nkt*16] key mask: 0, -1e9 (padded key) or -inf (key >= Lk)
   int* Tf = reinterpret_cast<int*>(Ms + nkt * 16);   // [nkt] 1 = the key tile holds a masked key
   int* last_valid = Tf + nkt;             // [4]: per-wave index of the last un-padded key
+  const SkfSplitSel sel = skf_split_sel();
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: loop bounds stay scalar
   const int i = lane & 15, g = lane >> 4;
@@ -114,8 +115,8 @@ __global__ __launch_bounds__(256, MAXT <= 13 ? 4 : 1) void attn_fwd_kernel(AttnP
     }
     if constexpr (SPLIT) {
       unsigned lo[3], hi[3];
-      skf_split2<3>(kv.x, kv.y, lo);
-      skf_split2<3>(kv.z, kv.w, hi);
+      skf_split2<3>(kv.x, kv.y, lo, sel);
+      skf_split2<3>(kv.z, kv.w, hi, sel);
       char* kp = reinterpret_cast<char*>(Ks);
 #pragma unroll
       for (int q = 0; q < 3; ++q)
@@ -176,8 +177,8 @@ __global__ __launch_bounds__(256, MAXT <= 13 ? 4 : 1) void attn_fwd_kernel(AttnP
     if constexpr (SPLIT) {
       const float4 qa = qcur[0], qc = qcur[1];
       unsigned d0[3], d1[3], d2[3], d3[3];
-      skf_split2<3>(qa.x, qa.y, d0); skf_split2<3>(qa.z, qa.w, d1);
-      skf_split2<3>(qc.x, qc.y, d2); skf_split2<3>(qc.z, qc.w, d3);
+      skf_split2<3>(qa.x, qa.y, d0, sel); skf_split2<3>(qa.z, qa.w, d1, sel);
+      skf_split2<3>(qc.x, qc.y, d2, sel); skf_split2<3>(qc.z, qc.w, d3, sel);
       const attn_u32x4 p0 = {d0[0], d1[0], d2[0], d3[0]}, p1 = {d0[1], d1[1], d2[1], d3[1]}, p2 = {d0[2], d1[2], d2[2], d3[2]};
       const bool first = g < 2;
       qb1 = first ? p0 : p1; qb2 = p0; qb3 = first ? p1 : p2;

@@ -71,8 +71,16 @@ __device__ __forceinline__ float wave_max(float v) {
 // of the running remainder (truncation), remainders are exact: x = x0 + x1 + x2 for every finite fp32 (24 significand
 // bits = 3 x 8).  The remainder x - x_q is one v_dot2c_f32_bf16 (x += piece . (-1, 0)) instead of a mask and a subtract.
 typedef __bf16 skf_bf16x2 __attribute__((ext_vector_type(2)));
+// the (-1, 0) / (0, -1) selectors of the remainder dot products, kept opaque in SGPRs (folded into the inline constant
+// "-1.0" the instruction subtracted the wrong half on gfx950).  Create ONCE per kernel: the asm is not hoisted.
+struct SkfSplitSel { unsigned lo, hi; };
+__device__ __forceinline__ SkfSplitSel skf_split_sel() {
+  SkfSplitSel r{0x0000bf80u, 0xbf800000u};
+  asm volatile("" : "+s"(r.lo), "+s"(r.hi));
+  return r;
+}
 template <int P>
-__device__ __forceinline__ void skf_split2(float x, float y, unsigned (&out)[P]) {
+__device__ __forceinline__ void skf_split2(float x, float y, unsigned (&out)[P], const SkfSplitSel& sel) {
 #pragma unroll
   for (int q = 0; q < P; ++q) {
     out[q] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, y), __builtin_bit_cast(unsigned, x), 0x07060302u);   // (y & 0xffff0000) | (x >> 16)
@@ -81,13 +89,9 @@ __device__ __forceinline__ void skf_split2(float x, float y, unsigned (&out)[P])
       x -= __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & 0xffff0000u);
       y -= __builtin_bit_cast(float, __builtin_bit_cast(unsigned, y) & 0xffff0000u);
 #else
-      // the (-1, 0) / (0, -1) selectors are kept opaque in SGPRs: folded into an inline constant "-1.0" the
-      // instruction subtracted the wrong half on gfx950
-      unsigned sel_lo = 0x0000bf80u, sel_hi = 0xbf800000u;
-      asm volatile("" : "+s"(sel_lo), "+s"(sel_hi));
       const skf_bf16x2 pc = __builtin_bit_cast(skf_bf16x2, out[q]);
-      x = __builtin_amdgcn_fdot2_f32_bf16(pc, __builtin_bit_cast(skf_bf16x2, sel_lo), x, false);
-      y = __builtin_amdgcn_fdot2_f32_bf16(pc, __builtin_bit_cast(skf_bf16x2, sel_hi), y, false);
+      x = __builtin_amdgcn_fdot2_f32_bf16(pc, __builtin_bit_cast(skf_bf16x2, sel.lo), x, false);
+      y = __builtin_amdgcn_fdot2_f32_bf16(pc, __builtin_bit_cast(skf_bf16x2, sel.hi), y, false);
 #endif
     }
   }

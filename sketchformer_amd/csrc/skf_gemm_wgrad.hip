@@ -131,14 +131,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(GemmParams p) {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <int P> __device__ __forceinline__ void wg_split2(float x, float y, unsigned (&out)[P]) { skf_split2<P>(x, y, out); }
 // column e of eight row vectors -> P operands of 8 bf16
 template <int P>
-__device__ __forceinline__ void wg_split_col(const f32x4 (&rows)[8], int e, u32x4 (&out)[P]) {
+__device__ __forceinline__ void wg_split_col(const f32x4 (&rows)[8], int e, u32x4 (&out)[P], const SkfSplitSel& sel) {
 #pragma unroll
   for (int d = 0; d < 4; ++d) {
     unsigned pc[P];
-    wg_split2<P>(rows[2 * d][e], rows[2 * d + 1][e], pc);
+    skf_split2<P>(rows[2 * d][e], rows[2 * d + 1][e], pc, sel);
 #pragma unroll
     for (int q = 0; q < P; ++q) out[q][d] = pc[q];
   }
@@ -150,8 +149,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t wg_rows_rsrc(const float* base
 }
 
 template <int P, int NW>   // NW waves per workgroup = intra-workgroup split of the row range
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void wgrad_x_kernel(GemmParams p) {
+__global__ __launch_bounds__(64 * NW, 1) void wgrad_x_kernel(GemmParams p) {   // grids are ~one workgroup per CU: registers before occupancy
   extern __shared__ __attribute__((aligned(16))) float smem[];   // [NW waves][64][64] + [NW][64] column sums
+  const SkfSplitSel sel = skf_split_sel();
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, g = lane >> 4;
@@ -180,8 +180,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void wgrad_x_kernel(GemmP
 
   constexpr int RI = 32 * NW;                       // rows per iteration of the workgroup
   const int niter = (ke - kb + RI - 1) / RI;
-  f32x4 xa[8], yb[8];
-  auto load_step = [&](int it) {
+  // two register sets of operand rows, used alternately (no copies: the split works in place on the rows)
+  f32x4 xa0[8], yb0[8], xa1[8], yb1[8];
+  auto load_step = [&](int it, f32x4 (&xa)[8], f32x4 (&yb)[8]) {
     const __amdgpu_buffer_rsrc_t rx = wg_rows_rsrc(p.A, p.lda, kb + RI * it, ke);
     const __amdgpu_buffer_rsrc_t ry = wg_rows_rsrc(p.B, p.ldb, kb + RI * it, ke);
 #pragma unroll
@@ -190,19 +191,18 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void wgrad_x_kernel(GemmP
       yb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, yo[j], 0, 0));
     }
   };
-  load_step(0);
-  for (int it = 0; it < niter; ++it) {
+  auto step = [&](const f32x4 (&xa)[8], const f32x4 (&yb)[8]) {
     u32x4 ax[4][P];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) wg_split_col<P>(xa, e, ax[e]);
-    f32x4 yc[8];
+    for (int e = 0; e < 4; ++e) wg_split_col<P>(xa, e, ax[e], sel);
+    if (do_colsum) {                                 // before the split: v_dot2c works in place, the rows die with it
 #pragma unroll
-    for (int j = 0; j < 8; ++j) yc[j] = yb[j];
-    load_step(it + 1);                               // past the end: empty descriptor, zeros, never used
+      for (int j = 0; j < 8; ++j) csum += yb[j];
+    }
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
       u32x4 by[P];
-      wg_split_col<P>(yc, f, by);
+      wg_split_col<P>(yb, f, by, sel);
 #pragma unroll
       for (int d = P - 1; d >= 0; --d)               // small products first
 #pragma unroll
@@ -212,10 +212,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void wgrad_x_kernel(GemmP
             acc[e][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ax[e][qa]),
                                                                 __builtin_bit_cast(bf16x8, by[d - qa]), acc[e][f], 0, 0, 0);
     }
-    if (do_colsum) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) csum += yc[j];
-    }
+  };
+  load_step(0, xa0, yb0);
+  for (int it = 0; it < niter; it += 2) {
+    load_step(it + 1, xa1, yb1);                     // past the end: empty descriptor, zeros
+    step(xa0, yb0);
+    if (it + 1 >= niter) break;
+    load_step(it + 2, xa0, yb0);
+    step(xa1, yb1);
   }
 
   float* mine = smem + wave * 4096;

@@ -64,7 +64,7 @@ __device__ __forceinline__ void wsx_buf_store(typename VecOfX<NB>::type v, __amd
   else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uvec, v), r, voff, 0, 0);
 }
 
-template <int P> __device__ __forceinline__ void split2(float x, float y, unsigned (&out)[P]) { skf_split2<P>(x, y, out); }
+template <int P> __device__ __forceinline__ void split2(float x, float y, unsigned (&out)[P], const SkfSplitSel& sel) { skf_split2<P>(x, y, out, sel); }
 
 template <int K>
 __device__ __forceinline__ void wsx_load_tile(const float* __restrict__ A, int lda, int M, int tile,
@@ -80,13 +80,13 @@ __device__ __forceinline__ void wsx_load_tile(const float* __restrict__ A, int l
 
 // one A tile (registers, fp32) -> P bf16 planes in LDS; PITCH = bytes per row
 template <int K, int P, int PITCH>
-__device__ __forceinline__ void wsx_store_tile(char* __restrict__ dst, const f32x4 (&ra)[TR * K / 1024]) {
+__device__ __forceinline__ void wsx_store_tile(char* __restrict__ dst, const f32x4 (&ra)[TR * K / 1024], const SkfSplitSel& sel) {
 #pragma unroll
   for (int v = 0; v < TR * K / 1024; ++v) {
     const int e = threadIdx.x + v * 256, row = e / (K / 4), c4 = (e % (K / 4)) * 4;
     unsigned lo[P], hi[P];
-    split2<P>(ra[v][0], ra[v][1], lo);
-    split2<P>(ra[v][2], ra[v][3], hi);
+    split2<P>(ra[v][0], ra[v][1], lo, sel);
+    split2<P>(ra[v][2], ra[v][3], hi, sel);
 #pragma unroll
     for (int q = 0; q < P; ++q)
       *reinterpret_cast<u32x2*>(dst + (q * TR + row) * PITCH + c4 * 2) = (u32x2){lo[q], hi[q]};
@@ -110,6 +110,7 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
   extern __shared__ __attribute__((aligned(16))) char smem_x[];
   char* As = smem_x;                     // [2][P][TR][PITCH]
 
+  const SkfSplitSel sel = skf_split_sel();
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, g = lane >> 4;
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
         unsigned pc[P];
-        split2<P>(f[nb][2 * d], f[nb][2 * d + 1], pc);
+        split2<P>(f[nb][2 * d], f[nb][2 * d + 1], pc, sel);
 #pragma unroll
         for (int q = 0; q < P; ++q) bq[nb][s][q][d] = pc[q];
       }
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
   for (int nb = 0; nb < NB; ++nb) bias_r[nb] = p.bias ? p.bias[n_ld + nb] : 0.f;
 
   SKF_STAMP();   // weight slice loaded + split
-  wsx_store_tile<K, P, PITCH>(As, ra[0]);
+  wsx_store_tile<K, P, PITCH>(As, ra[0], sel);
   __syncthreads();
   wsx_load_tile<K>(p.A, p.lda, p.M, tile + R * workers, a_voff, ra[0]);
   SKF_STAMP();   // first A tile in LDS
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
       }
       if (s == NKS / 2 - 1) {
         SKF_WSX_SCHED_BARRIER();
-        wsx_store_tile<K, P, PITCH>(As + (cur ^ 1) * TILE_B, rn);
+        wsx_store_tile<K, P, PITCH>(As + (cur ^ 1) * TILE_B, rn, sel);
         wsx_load_tile<K>(p.A, p.lda, p.M, tile + (R + 1) * workers, a_voff, rn);
         if (EXTRA) {
           const __amdgpu_buffer_rsrc_t rh = wsx_rows_rsrc(has_relu ? p.relu_src : p.C, p.ld_relu, has_relu ? p.M : 0, tile * TR);
