@@ -199,10 +199,14 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_x_kernel(GemmParams p) {   /
 #pragma unroll
       for (int j = 0; j < 8; ++j) csum += yb[j];
     }
+    // the split of dY column f+1 is independent of the MFMAs of column f: written next to them so that the scheduler can
+    // fill MFMA issue gaps with it (27.5 / 31.9 / 50.5 us instead of 29.1 / 33.8 / 54.4 for 128x384 / 128x512 / 128x1004;
+    // also splitting the NEXT step's X operands there was slower again: 28.6 / 33.0 / 51.6)
+    u32x4 by[4][P];
+    wg_split_col<P>(yb, 0, by[0], sel);
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
-      u32x4 by[P];
-      wg_split_col<P>(yb, f, by, sel);
+      if (f < 3) wg_split_col<P>(yb, f + 1, by[f + 1], sel);
 #pragma unroll
       for (int d = P - 1; d >= 0; --d)               // small products first
 #pragma unroll
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_x_kernel(GemmParams p) {   /
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             acc[e][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ax[e][qa]),
-                                                                __builtin_bit_cast(bf16x8, by[d - qa]), acc[e][f], 0, 0, 0);
+                                                                __builtin_bit_cast(bf16x8, by[f][d - qa]), acc[e][f], 0, 0, 0);
     }
   };
   load_step(0, xa0, yb0);
@@ -283,25 +287,20 @@ int skf_gemm_wgrad_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, i
   }
   const int prec = skf_get_gemm_precision();
   if (prec) {
-    // 4 waves per workgroup; 8 (two per SIMD, 128 KB of LDS for the reduction) measured the same: the loop is issue-bound
-    // (6 MFMAs + ~14 VALU per operand pair), not latency-bound.  SKF_WGRAD_WAVES=8 selects it.
-    static const int nw_env = getenv("SKF_WGRAD_WAVES") ? atoi(getenv("SKF_WGRAD_WAVES")) : 0;
+    // 4 waves per workgroup, one workgroup per CU (~256 workgroups): 8 waves (two per SIMD, 128 KB of LDS for the
+    // reduction) measured the same - the loop is issue-bound (6 MFMAs + ~14 VALU per operand pair), not latency-bound -
+    // and would halve the register budget the pipelined splits need
     const int nwg = q.tiles_m * q.tiles_n * splits;
-    const int nw = nw_env == 8 ? 8 : 4;
-    const size_t smem_x = (size_t)nw * (4096 + 64) * sizeof(float);
+    const size_t smem_x = (size_t)4 * (4096 + 64) * sizeof(float);
     static bool attr_x = false;
     if (!attr_x) {
-      SKF_HIP(hipFuncSetAttribute((const void*)wgrad_x_kernel<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (4096 + 64) * 4));
-      SKF_HIP(hipFuncSetAttribute((const void*)wgrad_x_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (4096 + 64) * 4));
-      SKF_HIP(hipFuncSetAttribute((const void*)wgrad_x_kernel<3, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * (4096 + 64) * 4));
-      SKF_HIP(hipFuncSetAttribute((const void*)wgrad_x_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * (4096 + 64) * 4));
+      SKF_HIP(hipFuncSetAttribute((const void*)wgrad_x_kernel<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_x));
+      SKF_HIP(hipFuncSetAttribute((const void*)wgrad_x_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_x));
       attr_x = true;
     }
     SkfProfScope ps(st, prec == 3 ? "wgrad<64x64,bf16x3>" : "wgrad<64x64,bf16x6>", 2.0 * p.M * p.N * p.K, 4.0 * (double)p.K * (p.M + p.N));
-    const dim3 grid(nwg), block(64 * nw);
-    if (prec == 3 && nw == 8) hipLaunchKernelGGL((wgrad_x_kernel<2, 8>), grid, block, smem_x, st, q);
-    else if (prec == 3) hipLaunchKernelGGL((wgrad_x_kernel<2, 4>), grid, block, smem_x, st, q);
-    else if (nw == 8) hipLaunchKernelGGL((wgrad_x_kernel<3, 8>), grid, block, smem_x, st, q);
+    const dim3 grid(nwg), block(256);
+    if (prec == 3) hipLaunchKernelGGL((wgrad_x_kernel<2, 4>), grid, block, smem_x, st, q);
     else hipLaunchKernelGGL((wgrad_x_kernel<3, 4>), grid, block, smem_x, st, q);
     SKF_LAUNCH_CHECK();
     return SKF_OK;
