@@ -129,6 +129,33 @@ def test_gemm_long_k_chain(ops, M, N, K, bkc):
     _close(ops.gemm(_dev(x), wd, b_kcontig=bkc, bias=_dev(b), act=1), np.maximum(x @ w + b, 0), name="relu: generic kernel")
 
 
+@pytest.mark.parametrize("rows,inf,outf", [(25600, 128, 128), (6000, 128, 512), (5000, 512, 128)])
+def test_wgrad_arithmetic_modes(ops, rows, inf, outf):
+    """Weight gradient dW = X^T dY in the fp32-MFMA and the bf16x6 arithmetic against float64: the split kernel is at
+    least as accurate (exact piece products, small-to-large accumulation)."""
+    from sketchformer_amd import _lib
+    lib = _lib.load()
+    rng = np.random.RandomState(rows + inf + outf)
+    x = (rng.randn(rows, inf) * np.exp(rng.randn(rows, 1))).astype(np.float32)
+    dy = (rng.randn(rows, outf) * np.exp(rng.randn(1, outf))).astype(np.float32)
+    want = x.astype(np.float64).T @ dy.astype(np.float64)
+    scale = np.abs(x).astype(np.float64).T @ np.abs(dy).astype(np.float64)
+    splits = lib.skf_gemm_default_splits(inf, outf, rows)
+    start = lib.skf_get_gemm_precision()
+    err = {}
+    try:
+        for mode in (0, 6):
+            lib.skf_set_gemm_precision(mode)
+            bg = torch.empty(outf, dtype=torch.float32, device="cuda")
+            dw = ops.gemm(_dev(x), _dev(dy), a_kcontig=False, b_kcontig=False, splits=splits, bias_grad=bg)
+            err[mode] = np.abs(dw.cpu().numpy().astype(np.float64) - want) / scale
+            np.testing.assert_allclose(bg.cpu().numpy(), dy.astype(np.float64).sum(0), rtol=1e-4, atol=1e-3 * np.abs(dy).sum(0).max() / rows ** 0.5)
+    finally:
+        lib.skf_set_gemm_precision(start)
+    assert err[0].max() < 2e-6 and err[6].max() < 2e-6, (err[0].max(), err[6].max())
+    assert err[6].mean() <= 1.25 * err[0].mean(), (err[6].mean(), err[0].mean())
+
+
 def test_gemm_strided_views(ops):
     """fused QKV layout: W stored [d][3d]; outputs written into a (rows, 3d) buffer at a column offset."""
     rng = np.random.RandomState(5)
