@@ -293,7 +293,8 @@ __global__ __launch_bounds__(256, SKF_ATTN_BWD_WAVES) void attn_bwd_kernel(AttnP
   float* Mx = Red + 2 * 4 * 16 * RLD; // [QR]
   float* Ri = Mx + QR;                // [QR]
   float* Dl = Ri + QR;                // [QR]  delta = sum_d dO*O
-  float* Tr = Dl + QR;                // [4 waves][16][TLD]
+  float* Tr = Dl + QR;                // [4 waves][KTW][16][TLD]: one transpose patch per key tile of the wave, so the
+                                      // key tiles of a query tile are independent chains the scheduler may interleave
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, g = lane >> 4;
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(256, SKF_ATTN_BWD_WAVES) void attn_bwd_kernel(AttnP
       }
     }
   }
-  int* last_valid = reinterpret_cast<int*>(Tr + 4 * 16 * TLD);   // [4]: per-wave index of the last un-padded key
+  int* last_valid = reinterpret_cast<int*>(Tr + 4 * KTW * 16 * TLD);   // [4]: per-wave index of the last un-padded key
   {
     int lv = -1;
     for (int key = tid; key < p.Lk; key += 256)
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(256, SKF_ATTN_BWD_WAVES) void attn_bwd_kernel(AttnP
   const int nkt_eff = (lastk >= 0 && (!CAUSAL || can_skip)) ? (lastk >> 4) + 1 : nkt;
   const float inv_sqrt = 1.0f / sqrtf((float)DH);
   const float c2 = 1.44269504088896340736f / sqrtf((float)DH);
-  float* tr = Tr + wave * 16 * TLD;
+  float* tr0 = Tr + wave * KTW * 16 * TLD;
   f32x4 dK_shared[NC], dV_shared[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) { dK_shared[c] = (f32x4){0.f, 0.f, 0.f, 0.f}; dV_shared[c] = dK_shared[c]; }
@@ -470,11 +471,11 @@ __global__ __launch_bounds__(256, SKF_ATTN_BWD_WAVES) void attn_bwd_kernel(AttnP
             dKt[j][c] = mfma16(qT[c][r], ds[r], dKt[j][c]);
           }
         // transpose dS through the wave-private scratch: write [q][k], read [q=i][k=4g..4g+3]
+        float* tr = tr0 + j * 16 * TLD;
 #pragma unroll
         for (int r = 0; r < 4; ++r) tr[(g * 4 + r) * TLD + i] = ds[r];
-        __builtin_amdgcn_wave_barrier();
+        // (no fence: the LDS executes one wave's instructions in order, and the patch is private to (wave, j))
         const float4 dst = *reinterpret_cast<const float4*>(&tr[i * TLD + g * 4]);
-        __builtin_amdgcn_wave_barrier();
         // dQ^T[d][q] += sum_k K[k][d] dS[q][k]   (lane: d = 16c+4g+r, q = q0+i)
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -560,7 +561,7 @@ size_t fwd_smem(int DH, int Lk, bool split) {
 }
 size_t bwd_smem(int DH, int Lq) {
   const size_t QR = (size_t)(Lq + 15) / 16 * 16;
-  return (2 * QR * (DH + 4) + (size_t)2 * 4 * 16 * (DH + 1) + 3 * QR + 4 * 16 * 20 + 4) * sizeof(float);
+  return (2 * QR * (DH + 4) + (size_t)2 * 4 * 16 * (DH + 1) + 3 * QR + (size_t)4 * (64 / DH) * 16 * 20 + 4) * sizeof(float);
 }
 
 template <typename K>
