@@ -142,10 +142,12 @@ __device__ __forceinline__ void wg_split_col(const f32x4 (&rows)[8], int e, u32x
     for (int q = 0; q < P; ++q) out[q][d] = pc[q];
   }
 }
+// rows [row0, row_end) of a row-major matrix; 32-bit byte arithmetic (the launcher checks rows * ld * 4 < 2^31)
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t wg_rows_rsrc(const float* base, int ld, int row0, int row_end) {
-  long long rem = ((long long)row_end - row0) * ld * 4;
-  rem = rem < 0 ? 0 : (rem > 0xffffffffLL ? 0xffffffffLL : rem);
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + (long long)row0 * ld), 0, (unsigned)rem, 0x00020000);
+  const int rows_left = row_end - row0 > 0 ? row_end - row0 : 0;
+  const unsigned rem = (unsigned)rows_left * (unsigned)ld * 4u;
+  const unsigned off = rows_left > 0 ? (unsigned)row0 * (unsigned)ld * 4u : 0u;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(base) + off), 0, rem, 0x00020000);
 }
 
 template <int P, int NW>   // NW waves per workgroup = intra-workgroup split of the row range
@@ -286,7 +288,8 @@ int skf_gemm_wgrad_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, i
     attr_done = true;
   }
   const int prec = skf_get_gemm_precision();
-  if (prec) {
+  const bool fits32 = (double)p.K * p.lda * 4 < 2147483648.0 && (double)p.K * p.ldb * 4 < 2147483648.0;
+  if (prec && fits32) {
     // 4 waves per workgroup, one workgroup per CU (~256 workgroups): 8 waves (two per SIMD, 128 KB of LDS for the
     // reduction) measured the same - the loop is issue-bound (6 MFMAs + ~14 VALU per operand pair), not latency-bound -
     // and would halve the register budget the pipelined splits need

@@ -44,10 +44,14 @@ template <> struct VecOfX<1> { typedef float type; typedef unsigned utype; };
 template <> struct VecOfX<2> { typedef float __attribute__((ext_vector_type(2))) type; typedef u32x2 utype; };
 template <> struct VecOfX<4> { typedef f32x4 type; typedef u32x4 utype; };
 
+// Descriptor over the rows [row0, M) of a row-major matrix.  The launcher guarantees M * ld * 4 < 2^31 (checked on the
+// host), so the byte counts are 32-bit SALU arithmetic: 8 scalar instructions per descriptor instead of 23 with the
+// 64-bit clamps (two to four descriptors per tile).
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t wsx_rows_rsrc(const float* base, int ld, int M, int row0) {
-  long long rem = ((long long)M - row0) * ld * 4;
-  rem = rem < 0 ? 0 : (rem > 0xffffffffLL ? 0xffffffffLL : rem);
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + (long long)row0 * ld), 0, (unsigned)rem, 0x00020000);
+  const int rows_left = M - row0 > 0 ? M - row0 : 0;
+  const unsigned rem = (unsigned)rows_left * (unsigned)ld * 4u;
+  const unsigned off = rows_left > 0 ? (unsigned)row0 * (unsigned)ld * 4u : 0u;   // empty descriptor: any valid base
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(base) + off), 0, rem, 0x00020000);
 }
 template <int NB>
 __device__ __forceinline__ typename VecOfX<NB>::type wsx_buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff) {
@@ -411,5 +415,6 @@ int launch_wsx_k(const GemmParams& p, int b_kc, hipStream_t st) {
 
 // pieces = 3 (six products, fp32-equivalent) or 2 (three products); same applicability rules as skf_gemm_ws_dispatch
 int skf_gemm_wsx_launch(const GemmParams& p, int b_kcontig, int pieces, hipStream_t st) {
+  // 32-bit byte offsets inside the kernels (callers fall back to the fp32 kernels otherwise: skf_gemm_wsx_fits)
   return pieces == 2 ? launch_wsx_k<2>(p, b_kcontig, st) : launch_wsx_k<3>(p, b_kcontig, st);
 }
