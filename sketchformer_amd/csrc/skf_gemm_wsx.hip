@@ -29,6 +29,9 @@ __device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
 }
 
 constexpr int TR = 16;   // rows per tile
+#ifndef SKF_WSX_EARLY3
+#define SKF_WSX_EARLY3 0   // 1: K = 128 keeps two full fragment sets also in the three-piece mode (register ring of 2)
+#endif
 
 // gfx950 hides about one VALU / LDS / VMEM instruction per v_mfma_f32_16x16x32_bf16 of the SAME wave and almost none
 // of another wave's (tools/micro/mfma_bf16_valu_overlap.hip), so the tile body is left to the scheduler as one region
@@ -102,13 +105,13 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
   constexpr int CW = 16 * NB;            // columns per wave
   constexpr int NKS = K / 32;            // MFMA k-steps per tile
   constexpr int NF = NKS * P;            // A fragments (ds_read_b128) per tile
-  constexpr bool EARLY = K == 128 && (P == 2 || NB == 4);   // every fragment of a tile in registers: barrier inside the MFMA stream
+  constexpr bool EARLY = K == 128 && (P == 2 || NB == 4 || SKF_WSX_EARLY3);   // every fragment of a tile in registers: barrier inside the MFMA stream
   constexpr int PF = EARLY ? NF : (NF < 6 ? NF : 6);
   constexpr int NCH = NB == 1 ? 2 : 1;   // accumulator chains per column block
   constexpr int PITCH = 2 * K + 16;      // bytes per LDS row: the 16 rows of a ds_read_b128 group hit 16 different bank quads
   constexpr int TILE_B = P * TR * PITCH; // bytes per LDS tile buffer
   constexpr int NV = TR * K / 1024;      // float4 per thread per A tile
-  constexpr int R = K == 128 ? 4 : 2;   // A tiles in flight in registers
+  constexpr int R = (K == 128 && !EARLY) ? 4 : 2;   // A tiles in flight in registers
   constexpr unsigned OOB = 0x7ffffff0u;
   typedef typename VecOfX<NB>::type vecn;
   extern __shared__ __attribute__((aligned(16))) char smem_x[];
