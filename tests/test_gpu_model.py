@@ -228,6 +228,36 @@ def test_full_size_training_agrees_between_dense_arithmetic_modes():
         assert np.abs(w6 - w0).max() <= bound, (name, np.abs(w6 - w0).max(), np.abs(w0).max())
 
 
+def test_full_size_forward_argmax_between_dense_arithmetic_modes():
+    """north_star bar at the bench size: forward logits within 1e-3 relative and token argmax identical - here between the
+    fp32-MFMA and the bf16x6 evaluation of the same weights (inference mode, cfg 2).  Argmax may only differ where the
+    top-2 logit margin is below the fp32 noise of either evaluation (1e-4 of the logit scale)."""
+    from sketchformer_amd import engine, _lib
+    lib = _lib.load()
+    start = lib.skf_get_gemm_precision()
+    B, L, V, C = 128, 200, 1004, 345
+    xs, _ = synthetic.token_batch(B, L, V, C, seed=5)
+    eng = engine.TrainEngine(engine.make_config(batch=B, dropout_rate=0.1, use_graph=False, seed=3), init_seed=0)
+    out = {}
+    try:
+        for mode in (0, 6):
+            lib.skf_set_gemm_precision(mode)
+            eng.forward(torch.from_numpy(xs).cuda(), training=False)
+            eng.synchronize()
+            out[mode] = eng.buffer("logits").cpu().numpy().astype(np.float64)
+    finally:
+        lib.skf_set_gemm_precision(start)
+    l0, l6 = out[0], out[6]
+    scale = np.abs(l0).max()
+    assert np.abs(l6 - l0).max() / scale < 1e-4, np.abs(l6 - l0).max() / scale      # bar: 1e-3
+    a0, a6 = l0.argmax(1), l6.argmax(1)
+    top2 = np.sort(l0, axis=1)[:, -2:]
+    margin = (top2[:, 1] - top2[:, 0]) / scale
+    differ = a0 != a6
+    assert np.all(margin[differ] < 1e-4), (differ.sum(), margin[differ].max() if differ.any() else 0)
+    assert differ.mean() < 1e-3
+
+
 def test_full_size_c1_class_head_k3():
     """K3 / cfg 1: one class -> class loss 0, class_acc 1 and zero gradient from that head."""
     from sketchformer_amd import engine
