@@ -104,6 +104,15 @@ int skf_embed_fwd(const long long* tokens, int tok_ld, int B, int L, const float
 /* dtable (vocab,d) must be zeroed by the caller; receives the dense embedding gradient. */
 int skf_embed_bwd(const long long* tokens, int tok_ld, int B, int L, const float* dx, int vocab, int d, float* dtable,
                   float rate, unsigned site, const void* step_state, skf_stream_t stream);
+/* The same gradient without pre-zeroed table and (almost) without atomics, in two launches: skf_embed_sort depends on the
+ * tokens only (counting sort of the B*L positions by id into `ws`, one workgroup; rows of ids that need more than one
+ * 256-position chunk are zeroed in `zero_table` when it is not NULL), skf_embed_bwd_sorted then writes EVERY row of
+ * dtable (zeros for unused ids). */
+size_t skf_embed_sort_workspace_bytes(int B, int L, int vocab);
+int skf_embed_sort(const long long* tokens, int tok_ld, int B, int L, int vocab, float* zero_table, int d, void* ws,
+                   size_t ws_bytes, skf_stream_t stream);
+int skf_embed_bwd_sorted(const void* ws, int B, int L, const float* dx, int vocab, int d, float* dtable, float rate,
+                         unsigned site, const void* step_state, skf_stream_t stream);
 /* key padding mask bytes (create_padding_mask, builders/utils.py:35-43): out[b][t] = tokens[b][t]==0 */
 int skf_padding_mask(const long long* tokens, int tok_ld, int B, int L, unsigned char* out, skf_stream_t stream);
 

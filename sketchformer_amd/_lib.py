@@ -66,6 +66,9 @@ SIGNATURES = {
                                _P, _I, _P, _I, _P, _I, _P]),
     "skf_embed_fwd": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _P, _F, _U, _P, _P]),
     "skf_embed_bwd": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _F, _U, _P, _P]),
+    "skf_embed_sort_workspace_bytes": (_Z, [_I, _I, _I]),
+    "skf_embed_sort": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _Z, _P]),
+    "skf_embed_bwd_sorted": (_I, [_P, _I, _I, _P, _I, _I, _P, _F, _U, _P, _P]),
     "skf_padding_mask": (_I, [_P, _I, _I, _I, _P, _P]),
     "skf_layernorm_residual_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _U, _P, _P]),
     "skf_layernorm_bwd_workspace_bytes": (_Z, [_I, _I]),

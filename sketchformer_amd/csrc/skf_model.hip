@@ -258,6 +258,7 @@ struct Plan {
   // layer after next starts (every cross-stream event costs ~5 us of dead time on the main stream).
   struct GradSet { size_t dy[3], dh, dq2, dkv2, dqkv; } gs[2];
   size_t gemm_ws, gemm_ws_bytes, small_ws, small_ws_bytes;
+  size_t emb_sort[2] = {0, 0}, emb_sort_bytes = 0;         // token positions sorted by id (encoder, decoder): skf_embed_sort
   size_t slab_arena, slab_arena_bytes, descs, n_wgrads;   // deferred split-K reduction (eager path)
   size_t ln_part, ln_part_stride;                          // per-LayerNorm dgamma|dbeta partials [5N][g][2d], reduced in the same batch
   // KV-cached greedy decode (inference): per-layer self-attention K|V cache (B, L, 2d) + one-row-per-sample step buffers
@@ -341,6 +342,10 @@ Plan build_plan(const SkfConfig& c) {
   if (2 * B * L * f > s) s = 2 * B * L * f;
   if (c.continuous && skf_embed_continuous_bwd_workspace_bytes((int)Me, (int)d) > s) s = skf_embed_continuous_bwd_workspace_bytes((int)Me, (int)d);
   P.small_ws_bytes = s; P.small_ws = b.take(s);
+  if (!c.continuous && c.vocab_size <= 12288 && !getenv("SKF_NO_EMBED_SORT")) {
+    P.emb_sort_bytes = (skf_embed_sort_workspace_bytes((int)B, (int)L, c.vocab_size) + 255) & ~(size_t)255;
+    P.emb_sort[0] = b.take(P.emb_sort_bytes); P.emb_sort[1] = b.take(P.emb_sort_bytes);
+  }
   for (int i = 0; i < c.num_layers; ++i) P.dc_cache.push_back(b.take(B * L * 2 * d * f));
   P.dc_x[0] = b.take(B * d * f); P.dc_x[1] = b.take(B * d * f); P.dc_q = b.take(B * d * f); P.dc_o = b.take(B * d * f);
   P.dc_z = b.take(B * d * f); P.dc_out1 = b.take(B * d * f); P.dc_out2 = b.take(B * d * f); P.dc_h = b.take(B * F * f);
@@ -859,8 +864,13 @@ int run_backward(SkfModel* M, hipStream_t s) {
     SKF_TRY(skf_embed_continuous_bwd(M->at<float>(P.tar), Le, B, Ld, G, d, M->G(L.dec_embd.w), M->G(L.dec_embd.b), rate,
                                      site_dec_embed(N), M->state, M->at<char>(P.small_ws), P.small_ws_bytes, s));
   } else {
-    SKF_HIP(hipMemsetAsync(M->G(L.dec_emb), 0, (size_t)c.vocab_size * d * sizeof(float), s));
-    SKF_TRY(skf_embed_bwd(tar, Le, B, Ld, G, c.vocab_size, d, M->G(L.dec_emb), rate, site_dec_embed(N), M->state, s));
+    if (P.emb_sort_bytes) {
+      SKF_TRY(skf_embed_bwd_sorted(M->at<char>(P.emb_sort[1]), B, Ld, G, c.vocab_size, d, M->G(L.dec_emb), rate, site_dec_embed(N),
+                                   M->state, s));
+    } else {
+      SKF_HIP(hipMemsetAsync(M->G(L.dec_emb), 0, (size_t)c.vocab_size * d * sizeof(float), s));
+      SKF_TRY(skf_embed_bwd(tar, Le, B, Ld, G, c.vocab_size, d, M->G(L.dec_emb), rate, site_dec_embed(N), M->state, s));
+    }
   }
   // every gradient of [decoder embedding .. output layer] is issued: first bucket of the flat buffer
   if (M->n_buckets == 2) SKF_TRY(flush_wgrads(M, s, 0, false));
@@ -946,8 +956,13 @@ int run_backward(SkfModel* M, hipStream_t s) {
     SKF_TRY(skf_embed_continuous_bwd(M->at<float>(P.inp), Le, B, Le, G, d, M->G(L.enc_embd.w), M->G(L.enc_embd.b), rate,
                                      site_enc_embed(), M->state, M->at<char>(P.small_ws), P.small_ws_bytes, s));
   } else {
-    SKF_HIP(hipMemsetAsync(M->G(L.enc_emb), 0, (size_t)c.vocab_size * d * sizeof(float), s));
-    SKF_TRY(skf_embed_bwd(inp, Le, B, Le, G, c.vocab_size, d, M->G(L.enc_emb), rate, site_enc_embed(), M->state, s));
+    if (P.emb_sort_bytes) {
+      SKF_TRY(skf_embed_bwd_sorted(M->at<char>(P.emb_sort[0]), B, Le, G, c.vocab_size, d, M->G(L.enc_emb), rate, site_enc_embed(),
+                                   M->state, s));
+    } else {
+      SKF_HIP(hipMemsetAsync(M->G(L.enc_emb), 0, (size_t)c.vocab_size * d * sizeof(float), s));
+      SKF_TRY(skf_embed_bwd(inp, Le, B, Le, G, c.vocab_size, d, M->G(L.enc_emb), rate, site_enc_embed(), M->state, s));
+    }
   }
   return flush_wgrads(M, s, M->n_buckets - 1, true);
 }
@@ -1266,6 +1281,31 @@ extern "C" int skf_model_greedy_decode(SkfModel* m, const float* embedding, cons
                            (hipStream_t)stream);
 }
 
+// The embedding gradients' counting sorts depend on the staged tokens only.  Eager path with a decoder: side stream, under
+// the forward (the main stream joins the side stream at the first cross-attention, long before the backward reads the
+// sorted positions); otherwise (hipGraph capture, encoder-only configurations) in place on the main stream.
+int issue_embed_sorts(SkfModel* M, hipStream_t s) {
+  const SkfConfig& c = M->cfg;
+  const Layout& L = M->lay;
+  const Plan& P = M->plan;
+  if (!P.emb_sort_bytes) return SKF_OK;
+  const int B = c.batch, Le = c.seq_len, Ld = c.seq_len - 1, d = c.d_model;
+  hipStream_t ss = s;
+  if (M->side && do_recon(c)) {
+    hipEvent_t staged = M->new_event();
+    SKF_CHECK_ARG(staged, "event allocation failed");
+    SKF_HIP(hipEventRecord(staged, s));
+    SKF_HIP(hipStreamWaitEvent(M->side, staged, 0));
+    ss = M->side;
+  }
+  SKF_TRY(skf_embed_sort(M->at<long long>(P.inp), Le, B, Le, c.vocab_size, M->G(L.enc_emb), d, M->at<char>(P.emb_sort[0]),
+                         P.emb_sort_bytes, ss));
+  if (do_recon(c))
+    SKF_TRY(skf_embed_sort(M->at<long long>(P.tar), Le, B, Ld, c.vocab_size, M->G(L.dec_emb), d, M->at<char>(P.emb_sort[1]),
+                           P.emb_sort_bytes, ss));
+  return SKF_OK;
+}
+
 extern "C" int skf_model_forward_backward(SkfModel* m, const void* inp, const void* tar, int tar_ld,
                                           const long long* labels, skf_stream_t stream) {
   SKF_CHECK_ARG(m && m->ws, "model not bound");
@@ -1274,6 +1314,7 @@ extern "C" int skf_model_forward_backward(SkfModel* m, const void* inp, const vo
   SKF_TRY(stage_inputs(m, inp, tar, tar_ld, labels, s));
   return capture_or_run(m, &m->g_fb, s, [&]() -> int {
     SKF_TRY(prologue(m, s));
+    SKF_TRY(issue_embed_sorts(m, s));
     SKF_TRY(run_forward(m, true, true, s));
     return run_backward(m, s);
   });

@@ -98,6 +98,149 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* __restr
   }
 }
 
+// Atomic-light embedding gradient in two launches.
+//  (1) embed_sort_kernel (ONE workgroup; depends on the tokens only, so the train step runs it on the side stream under the
+//      forward): counting sort of the B*L token positions by id -> order[], and a chunk list {id, first, count, single}:
+//      every id gets ceil(count / 256) chunks, at least one (count 0 = "store zeros"), so the gradient kernel never needs a
+//      pre-zeroed table except for the few ids with more than one chunk (PAD, frequent tokens) - those rows are zeroed here.
+//  (2) embed_bwd_sorted_kernel: one workgroup per chunk (a wave per 64 positions, summed through LDS) sums the dx rows of its positions (512-byte coalesced rows, dropout mask
+//      and sqrt(d) as in embed_bwd_kernel) and STORES the table row (single chunk) or adds it atomically (split ids).
+// Global float atomics run at ~25 G/s on this part: the ballot-grouping kernel above spends 46 us on ~1.4 M of them.
+constexpr int kEmbChunk = 256;   // positions per chunk = per workgroup of the gradient kernel (4 waves x 64)
+struct EmbChunk { int id, first, count, single; };
+
+__global__ __launch_bounds__(1024) void embed_sort_kernel(const long long* __restrict__ tok, int tok_ld, int Lrows, int rows,
+                                                          int vocab, int* __restrict__ hdr, EmbChunk* __restrict__ chunks,
+                                                          int* __restrict__ order, float* __restrict__ zero_table, int d) {
+  extern __shared__ int smem_i[];
+  int* cnt = smem_i;                     // [vocab]      positions per id -> later the write cursor of the id
+  int* pst = smem_i + vocab;             // [vocab]      first position of the id in order[]
+  int* cst = smem_i + 2 * vocab;         // [vocab + 1]  first chunk of the id (exclusive scan; [vocab] = number of chunks)
+  __shared__ int part_tok[1024], part_chk[1024];
+  const int tid = threadIdx.x;
+  for (int v = tid; v < vocab; v += 1024) cnt[v] = 0;
+  __syncthreads();
+  for (int r = tid; r < rows; r += 1024) {
+    const long long tk = tok[(size_t)(r / Lrows) * tok_ld + (r % Lrows)];
+    if (tk >= 0 && tk < vocab) atomicAdd(&cnt[(int)tk], 1);
+  }
+  __syncthreads();
+  // exclusive scans over ids: positions and chunks.  Thread t owns ids [t*per, (t+1)*per)
+  const int per = (vocab + 1023) / 1024;
+  int st = 0, sc = 0;
+  for (int k = 0; k < per; ++k) {
+    const int v = tid * per + k;
+    if (v < vocab) { const int c = cnt[v]; st += c; sc += c == 0 ? 1 : (c + kEmbChunk - 1) / kEmbChunk; }
+  }
+  part_tok[tid] = st; part_chk[tid] = sc;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {      // Hillis-Steele inclusive scan (two arrays)
+    const int a = tid >= off ? part_tok[tid - off] : 0, b = tid >= off ? part_chk[tid - off] : 0;
+    __syncthreads();
+    part_tok[tid] += a; part_chk[tid] += b;
+    __syncthreads();
+  }
+  int pos = part_tok[tid] - st, chk = part_chk[tid] - sc;
+  const int nchunks = part_chk[1023];
+  if (tid == 1023) { hdr[0] = nchunks; hdr[1] = part_tok[1023]; cst[vocab] = nchunks; }
+  for (int k = 0; k < per; ++k) {
+    const int v = tid * per + k;
+    if (v >= vocab) break;
+    const int c = cnt[v];
+    pst[v] = pos; cst[v] = chk;
+    pos += c; chk += c == 0 ? 1 : (c + kEmbChunk - 1) / kEmbChunk;
+  }
+  __syncthreads();
+  // chunk descriptors, one per thread and round: the id of chunk ci = last v with cst[v] <= ci (binary search)
+  for (int ci = tid; ci < nchunks; ci += 1024) {
+    int lo = 0, hi = vocab - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (cst[mid] <= ci) lo = mid; else hi = mid - 1; }
+    const int v = lo, j = ci - cst[v], c = cnt[v];
+    const int left = c - j * kEmbChunk;
+    chunks[ci] = EmbChunk{v, pst[v] + j * kEmbChunk, left < kEmbChunk ? (left > 0 ? left : 0) : kEmbChunk, cst[v + 1] - cst[v] == 1};
+    // rows of ids with several chunks are accumulated atomically: zero them now (a handful of rows; the first chunk does it)
+    if (zero_table && j == 0 && cst[v + 1] - cst[v] > 1)
+      for (int cc = 0; cc < d; ++cc) zero_table[(size_t)v * d + cc] = 0.f;
+  }
+  __syncthreads();
+  for (int v = tid; v < vocab; v += 1024) cnt[v] = pst[v];      // counts -> write cursors
+  __syncthreads();
+  for (int r = tid; r < rows; r += 1024) {
+    const long long tk = tok[(size_t)(r / Lrows) * tok_ld + (r % Lrows)];
+    if (tk >= 0 && tk < vocab) order[atomicAdd(&cnt[(int)tk], 1)] = r;
+  }
+}
+
+__global__ __launch_bounds__(256) void embed_bwd_sorted_kernel(const int* __restrict__ hdr, const EmbChunk* __restrict__ chunks,
+                                                               const int* __restrict__ order, const float* __restrict__ dx, int d,
+                                                               float* __restrict__ dtable, float rate, uint32_t site,
+                                                               const SkfStepState* st) {
+  extern __shared__ float emb_red[];       // [3 waves][d] partial rows of waves 1..3
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ci = blockIdx.x;
+  if (ci >= hdr[0]) return;
+  const EmbChunk ch = chunks[ci];
+  const float sq = sqrtf((float)d);
+  const uint32_t thresh = skf_drop_thresh(rate);
+  const float inv_keep = 1.0f / (1.0f - rate);
+  const uint32_t sk = rate > 0.f ? skf_site_key(st->drop_key, site) : 0u;
+  // wave w owns positions [64w, 64w + 64) of the chunk; lane j holds one of them
+  const int wfirst = ch.first + 64 * wave;
+  const int wcount = ch.count - 64 * wave < 0 ? 0 : (ch.count - 64 * wave > 64 ? 64 : ch.count - 64 * wave);
+  int mine = lane < wcount ? order[wfirst + lane] : 0x7fffffff;
+  // The scatter of the sort is unordered (LDS atomics): sort the wave's positions (bitonic network over the 64 lanes) so
+  // that the summation order - and with it the result of every id with at most 64 positions - does not change between runs.
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1)
+#pragma unroll
+    for (int j2 = k >> 1; j2 > 0; j2 >>= 1) {
+      const int other = __shfl_xor(mine, j2, 64);
+      const bool up = (lane & k) == 0, lower = (lane & j2) == 0;
+      mine = (lower == up) ? min(mine, other) : max(mine, other);
+    }
+  for (int c0 = 0; c0 < d; c0 += 128) {              // uniform trip count: every lane takes part in the shuffles
+    const int c = c0 + lane * 2;
+    const bool on = c < d;
+    const int cc = on ? c : 0;
+    float2 acc0 = make_float2(0.f, 0.f), acc1 = acc0;
+    // eight rows in flight per round (a wave's share is a latency chain of up to 64 row reads otherwise); rows past its
+    // count re-read its first row with weight 0
+    for (int j = 0; j < wcount; j += 8) {
+      int r[8];
+      float2 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int src = j + u < wcount ? j + u : 0;
+        r[u] = __shfl(mine, src, 64);
+        v[u] = *reinterpret_cast<const float2*>(dx + (size_t)r[u] * d + cc);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        float wx = j + u < wcount ? 1.f : 0.f, wy = wx;
+        if (rate > 0.f) {
+          const uint32_t i0 = (uint32_t)r[u] * (uint32_t)d + cc;
+          wx *= skf_keep(sk, i0, thresh) ? inv_keep : 0.f;
+          wy *= skf_keep(sk, i0 + 1, thresh) ? inv_keep : 0.f;
+        }
+        if (u & 1) { acc1.x += v[u].x * wx; acc1.y += v[u].y * wy; }
+        else { acc0.x += v[u].x * wx; acc0.y += v[u].y * wy; }
+      }
+    }
+    if (on && wave > 0) *reinterpret_cast<float2*>(&emb_red[(wave - 1) * d + c]) = make_float2(acc0.x + acc1.x, acc0.y + acc1.y);
+    __syncthreads();
+    if (on && wave == 0) {
+      float gx = acc0.x + acc1.x, gy = acc0.y + acc1.y;
+#pragma unroll
+      for (int w = 0; w < 3; ++w) { const float2 t = *reinterpret_cast<const float2*>(&emb_red[w * d + c]); gx += t.x; gy += t.y; }
+      gx *= sq; gy *= sq;
+      float* dst = dtable + (size_t)ch.id * d + c;
+      if (ch.single) *reinterpret_cast<float2*>(dst) = make_float2(gx, gy);
+      else { atomicAdd(dst, gx); atomicAdd(dst + 1, gy); }
+    }
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------ layernorm
 // out = LayerNorm(x + Dropout(y)), eps=1e-6, biased variance
 // (builders/layers/transformer.py:217-222, 247-260).  z = x + drop(y) is written
@@ -744,6 +887,46 @@ extern "C" int skf_embed_bwd(const long long* tokens, int tok_ld, int B, int L, 
   int grid = skf_cdiv(rows, 256);
   SkfProfScope ps((hipStream_t)stream, "embed_bwd", 0.0, 8.0 * rows * d);
   hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, tokens, tok_ld, L, rows, dx, vocab,
+                     d, dtable, rate, site, (const SkfStepState*)step_state);
+  SKF_LAUNCH_CHECK();
+  return SKF_OK;
+}
+
+extern "C" size_t skf_embed_sort_workspace_bytes(int B, int L, int vocab) {
+  const size_t rows = (size_t)B * L, maxc = (size_t)vocab + rows / kEmbChunk + 1;
+  return 16 + maxc * sizeof(EmbChunk) + rows * sizeof(int);
+}
+extern "C" int skf_embed_sort(const long long* tokens, int tok_ld, int B, int L, int vocab, float* zero_table, int d,
+                              void* ws, size_t ws_bytes, skf_stream_t stream) {
+  SKF_CHECK_ARG(tokens && ws, "null operand");
+  SKF_CHECK_ARG(ws_bytes >= skf_embed_sort_workspace_bytes(B, L, vocab) && (((uintptr_t)ws) & 15) == 0, "workspace too small or misaligned");
+  SKF_CHECK_ARG(vocab > 0 && vocab <= 12288, "vocabulary does not fit the sort kernel's LDS tables");
+  const int rows = B * L;
+  const size_t maxc = (size_t)vocab + (size_t)rows / kEmbChunk + 1;
+  int* hdr = (int*)ws;
+  EmbChunk* chunks = (EmbChunk*)((char*)ws + 16);
+  int* order = (int*)((char*)ws + 16 + maxc * sizeof(EmbChunk));
+  const size_t smem = ((size_t)3 * vocab + 1) * sizeof(int);
+  static bool attr_done = false;
+  if (!attr_done) { SKF_HIP(hipFuncSetAttribute((const void*)embed_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (3 * 12288 + 1) * 4)); attr_done = true; }
+  SkfProfScope ps((hipStream_t)stream, "embed_sort", 0.0, 12.0 * rows);
+  hipLaunchKernelGGL(embed_sort_kernel, dim3(1), dim3(1024), smem, (hipStream_t)stream, tokens, tok_ld, L, rows, vocab, hdr, chunks,
+                     order, zero_table, d);
+  SKF_LAUNCH_CHECK();
+  return SKF_OK;
+}
+extern "C" int skf_embed_bwd_sorted(const void* ws, int B, int L, const float* dx, int vocab, int d, float* dtable, float rate,
+                                    unsigned site, const void* step_state, skf_stream_t stream) {
+  SKF_CHECK_ARG(ws && dx && dtable, "null operand");
+  SKF_CHECK_ARG((d & 1) == 0, "d_model must be even");
+  SKF_CHECK_ARG(rate == 0.f || step_state, "dropout needs the step state");
+  const int rows = B * L;
+  const size_t maxc = (size_t)vocab + (size_t)rows / kEmbChunk + 1;
+  const int* hdr = (const int*)ws;
+  const EmbChunk* chunks = (const EmbChunk*)((const char*)ws + 16);
+  const int* order = (const int*)((const char*)ws + 16 + maxc * sizeof(EmbChunk));
+  SkfProfScope ps((hipStream_t)stream, "embed_bwd_sorted", 0.0, 4.0 * rows * d + 4.0 * (double)vocab * d);
+  hipLaunchKernelGGL(embed_bwd_sorted_kernel, dim3((unsigned)maxc), dim3(256), (size_t)3 * d * sizeof(float), (hipStream_t)stream, hdr, chunks, order, dx,
                      d, dtable, rate, site, (const SkfStepState*)step_state);
   SKF_LAUNCH_CHECK();
   return SKF_OK;

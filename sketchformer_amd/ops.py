@@ -145,6 +145,20 @@ def embed_bwd(tokens, dx, vocab, L=None, rate=0.0, site=0, state=None):
     return dtable
 
 
+def embed_bwd_sorted(tokens, dx, vocab, L=None, rate=0.0, site=0, state=None, prefill=None):
+    """The two-launch form (skf_embed_sort + skf_embed_bwd_sorted); dtable starts as `prefill` (garbage is fine: every row is
+    written) to show that no pre-zeroed table is needed."""
+    B, ld = tokens.shape
+    L = L or ld
+    d = dx.shape[-1]
+    dtable = torch.full((vocab, d), float("nan") if prefill is None else prefill, dtype=torch.float32, device=dx.device)
+    nbytes = _lib.load().skf_embed_sort_workspace_bytes(B, L, vocab)
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=dx.device)
+    _lib.call("skf_embed_sort", _p(tokens), ld, B, L, vocab, _p(dtable), d, _p(ws), nbytes, _stream())
+    _lib.call("skf_embed_bwd_sorted", _p(ws), B, L, _p(dx), vocab, d, _p(dtable), rate, site, _p(state), _stream())
+    return dtable
+
+
 def layernorm_residual_fwd(x, y, gamma, beta, rate=0.0, site=0, state=None):
     """-> out, z (= x + drop(y), written over a copy of y), stats."""
     d = x.shape[-1]

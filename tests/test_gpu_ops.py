@@ -293,6 +293,32 @@ def test_embed_fwd_bwd_with_dropout(ops):
     _close(got, want, rtol=5e-5, name="embed bwd")
 
 
+@pytest.mark.parametrize("B,L,V,d,rate", [(5, 33, 52, 128, 0.1), (128, 200, 1004, 128, 0.1), (16, 199, 10004, 64, 0.0), (3, 7, 5, 256, 0.0)])
+def test_embed_bwd_sorted(ops, B, L, V, d, rate):
+    """Sorted two-launch embedding gradient: equals the scatter-add definition, writes every table row (the table starts as
+    NaN), handles ids split over several 64-position chunks (PAD), out-of-range ids, unused ids, d != 128."""
+    site = 2
+    rng = np.random.RandomState(B + L + V)
+    tok = rng.randint(0, V, size=(B, L + 1))
+    tok[:, (2 * L) // 3:] = 0                         # PAD tail: one id with hundreds of positions
+    tok[0, 0] = V + 7                                  # out of range: ignored
+    st = ops.new_step_state("cuda", iterations=3)
+    ops.step_prologue(st, seed=5)
+    key = ops.read_step_state(st)["drop_key"]
+    keep = ops.dropout_keep_mask(key, site, rate, B * L * d).reshape(B, L, d) if rate > 0 else np.ones((B, L, d))
+    dx = rng.randn(B, L, d)
+    want = np.zeros((V, d))
+    tk = tok[:, :L].reshape(-1)
+    ok = tk < V
+    np.add.at(want, tk[ok], (dx * keep / (1 - rate) * np.sqrt(np.float64(d))).reshape(-1, d)[ok])
+    got = ops.embed_bwd_sorted(_dev(tok, torch.int64), _dev(dx), V, L=L, rate=rate, site=site, state=st)
+    assert torch.isfinite(got).all()
+    _close(got, want, rtol=5e-5, name="embed bwd sorted")
+    ref = ops.embed_bwd(_dev(np.where(tok < V, tok, 0) * (tok < V), torch.int64), _dev(dx * (tok[:, :L] < V)[..., None]), V, L=L,
+                        rate=rate, site=site, state=st)
+    _close(got, ref.cpu().numpy(), rtol=5e-5, name="embed bwd sorted vs atomic kernel")
+
+
 @pytest.mark.parametrize("d,rate", [(128, 0.0), (128, 0.1), (256, 0.1), (64, 0.0), (512, 0.0)])
 def test_layernorm_residual_fwd_bwd(ops, d, rate):
     rows = 1031
