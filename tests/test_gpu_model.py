@@ -511,6 +511,24 @@ def test_bucketed_apply_gradients_equals_plain():
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)                   # embedding-gradient atomics reorder sums
 
 
+def test_small_batch_steps_are_bit_reproducible():
+    """No atomics and no run-dependent summation order on the whole step as long as every token id has at most 64 positions
+    in the batch (embedding gradient: sorted positions per id): two runs from the same state give identical bits."""
+    B = 4
+    runs = []
+    for _ in range(2):
+        eng, ocfg = _mk(B, rate=0.1)
+        eng.state[0] = 2000
+        for step in range(3):
+            x, y = synthetic.token_batch(B, ocfg.seq_len, ocfg.vocab_size, ocfg.n_classes, seed=70 + step)
+            eng.forward_backward(x, None, y)
+            eng.apply_gradients()
+        torch.cuda.synchronize()
+        runs.append((eng.params.clone(), eng.adam_m.clone(), eng.adam_v.clone(), eng.grads.clone()))
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
+
+
 # ------------------------------------------------------------------ structural variants (models/sketchformer.py:76-108)
 @pytest.mark.parametrize("kw", [dict(do_classification=False), dict(do_reconstruction=False),
                                 dict(lowerdim=0, do_classification=False), dict(lowerdim=0, do_classification=False, blind=False),
