@@ -7,8 +7,17 @@
 
 namespace {
 
-constexpr int kMaxGrid = 2048;
-constexpr int kLnBwdGrid = 512;    // workgroups of the LayerNorm backward (each leaves one [2][d] partial for the column sums)
+#ifndef SKF_LN_FWD_GRID
+#define SKF_LN_FWD_GRID 2048
+#endif
+#ifndef SKF_LN_BWD_GRID
+#define SKF_LN_BWD_GRID 640    // more workgroups shorten the kernel (15.4 -> 14.7 us) but lengthen the batched reduction of their partials
+#endif
+#ifndef SKF_LN_UR
+#define SKF_LN_UR 1            // row groups in flight per wave iteration (2 measured 0.3-0.5 us slower per launch in the step)
+#endif
+constexpr int kMaxGrid = SKF_LN_FWD_GRID;
+constexpr int kLnBwdGrid = SKF_LN_BWD_GRID;    // workgroups of the LayerNorm backward (each leaves one [2][d] partial for the column sums)
 
 __global__ void padding_mask_kernel(const long long* __restrict__ tok, int tok_ld, int B, int L,
                                     unsigned char* __restrict__ out) {
@@ -290,7 +299,7 @@ __global__ __launch_bounds__(256) void ln_fwd_v4_kernel(const float* __restrict_
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float* __restrict__ out, float* __restrict__ stats, int rows,
                                                         float rate, uint32_t site, const SkfStepState* st) {
-  constexpr int D = 4 * LPR, RPW = 64 / LPR, UR = 2;
+  constexpr int D = 4 * LPR, RPW = 64 / LPR, UR = SKF_LN_UR;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane % LPR, rsel = lane / LPR;
   const uint32_t thresh = skf_drop_thresh(rate);
@@ -406,14 +415,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   }
 }
 
-// Same, D = 4*LPR <= 256: 16-byte loads, 64/LPR rows per wave instruction, two groups in flight (see ln_fwd_v4_kernel).
+// Same, D = 4*LPR <= 256: 16-byte loads, 64/LPR rows per wave instruction, SKF_LN_UR groups in flight (see ln_fwd_v4_kernel).
 template <int LPR>
 __global__ __launch_bounds__(256) void ln_bwd_v4_kernel(const float* __restrict__ dout, const float* __restrict__ z,
                                                         const float* __restrict__ stats, const float* __restrict__ gamma,
                                                         float* __restrict__ dz, float* __restrict__ dy,
                                                         float* __restrict__ part, int rows, float rate, uint32_t site,
                                                         const SkfStepState* st) {
-  constexpr int D = 4 * LPR, RPW = 64 / LPR, UR = 2;
+  constexpr int D = 4 * LPR, RPW = 64 / LPR, UR = SKF_LN_UR;
   __shared__ float red[4][2][D];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane % LPR, rsel = lane / LPR;
@@ -944,7 +953,7 @@ extern "C" int skf_layernorm_residual_fwd(const float* x, float* y_inout_z, cons
   static const bool v4 = !(getenv("SKF_LN_V4") && getenv("SKF_LN_V4")[0] == '0');
   const bool al = ((((uintptr_t)x | (uintptr_t)y_inout_z | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0);
   if (v4 && al && (d == 64 || d == 128 || d == 256)) {
-    const int rpi = (64 / (d / 4)) * 2 * 4;                       // rows per workgroup iteration
+    const int rpi = (64 / (d / 4)) * SKF_LN_UR * 4;               // rows per workgroup iteration
     int g = skf_cdiv(rows, rpi); if (g > kMaxGrid) g = kMaxGrid;
     if (d == 64) hipLaunchKernelGGL(ln_fwd_v4_kernel<16>, dim3(g), block, 0, s, x, y_inout_z, gamma, beta, out, stats, rows, rate, site, st);
     else if (d == 128) hipLaunchKernelGGL(ln_fwd_v4_kernel<32>, dim3(g), block, 0, s, x, y_inout_z, gamma, beta, out, stats, rows, rate, site, st);
