@@ -329,7 +329,8 @@ extern "C" size_t skf_gemm_workspace_bytes(int M, int N, int K, int splits, int 
 extern "C" int skf_gemm_default_splits(int M, int N, int K) {
   const int tiles = skf_cdiv(M, 64) * skf_cdiv(N, 64);
   if (K <= 512) return 1;
-  int splits = 256 / tiles;
+  static const int wgs = getenv("SKF_WGRAD_WGS") ? atoi(getenv("SKF_WGRAD_WGS")) : 256;
+  int splits = wgs / tiles;
   const int max_splits = skf_cdiv(K, 8 * BK);   // at least 8 slabs per split
   if (splits > max_splits) splits = max_splits;
   return splits < 1 ? 1 : splits;
