@@ -108,7 +108,9 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
   constexpr bool EARLY = K == 128 && (P == 2 || NB == 4 || SKF_WSX_EARLY3);   // every fragment of a tile in registers: barrier inside the MFMA stream
   constexpr int PF = EARLY ? NF : (NF < 6 ? NF : 6);
   constexpr int NCH = NB == 1 ? 2 : 1;   // accumulator chains per column block
-  constexpr int PITCH = 2 * K + 16;      // bytes per LDS row: the 16 rows of a ds_read_b128 group hit 16 different bank quads
+  constexpr int PITCH = 2 * K + 32;      // bytes per LDS row.  ds_read_b128 is served in four groups of 16 lanes that MIX the lane
+                                         // groups g (lanes {0-3,12-15,20-27}, ...): with quad(i, g) = 2i + g (pitch = 32 mod 256) every
+                                         // group hits 16 different bank quads; +16 (quad = i + g) had a 2-way conflict in each group
   constexpr int TILE_B = P * TR * PITCH; // bytes per LDS tile buffer
   constexpr int NV = TR * K / 1024;      // float4 per thread per A tile
   constexpr int R = (K == 128 && !EARLY) ? 4 : 2;   // A tiles in flight in registers
@@ -373,7 +375,7 @@ int launch_wsx(const GemmParams& p, int b_kc, hipStream_t st) {
   if (workers < 1) workers = 1;
   const int ntiles = skf_cdiv(p.M, TR);
   if (workers > ntiles) workers = ntiles;
-  const size_t smem = (size_t)2 * P * TR * (2 * K + 16);
+  const size_t smem = (size_t)2 * P * TR * (2 * K + 32);
   dim3 grid(groups * workers), block(256);
   static const std::string tag = "gemm_wsx<K" + std::to_string(K) + ",CW" + std::to_string(CW) + ",bf16x" + std::to_string(P * (P + 1) / 2) + ">";
   SkfProfScope ps(st, tag.c_str(), 2.0 * p.M * p.N * p.K,
