@@ -80,7 +80,8 @@ __global__ __launch_bounds__(256, MAXT <= 13 ? 4 : 1) void attn_fwd_kernel(AttnP
   // consecutively in time, so the neighbour's half is an L2 hit instead of a second HBM fetch of the same line.
   const int bh = p.xcd_remap ? skf_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x, b = bh / p.H, h = bh % p.H;
   const int nkt = (p.Lk + 15) >> 4, nqt = (p.Lq + 15) >> 4;
-  const int VP = nkt * 16 + 4;            // pitch of the transposed V image
+  const int VP = nkt * 16 + 8;            // pitch of the transposed V image: (VP / 4) mod 4 == 2 keeps the ds_read_b128 of the PV
+                                          // operands free of bank conflicts (the four 16-lane groups of the instruction mix lane groups g)
   float* Ks = smem;                       // [nkt*16][LD]
   float* Vt = smem + nkt * 16 * LD;       // [DH][VP]   V transposed: Vt[d][key]
   float* Ms = Vt + DH * VP;               // [nkt*16] key mask: 0, -1e9 (padded key) or -inf (key >= Lk)
@@ -557,7 +558,7 @@ __global__ __launch_bounds__(256, SKF_ATTN_BWD_WAVES) void attn_bwd_kernel(AttnP
 size_t fwd_smem(int DH, int Lk, bool split) {
   const size_t n16 = (size_t)(Lk + 15) / 16 * 16;
   const size_t krow = split ? 3 * KPP / 4 : DH + 4;   // floats per key row of the K image
-  return (n16 * krow + (size_t)DH * (n16 + 4) + n16 + n16 / 16 + 4) * sizeof(float);
+  return (n16 * krow + (size_t)DH * (n16 + 8) + n16 + n16 / 16 + 4) * sizeof(float);
 }
 size_t bwd_smem(int DH, int Lq) {
   const size_t QR = (size_t)(Lq + 15) / 16 * 16;
