@@ -69,7 +69,7 @@ __device__ __forceinline__ void ws_store_tile(float* __restrict__ dst, const f32
 #pragma unroll
   for (int v = 0; v < TR * K / 1024; ++v) {
     const int e = threadIdx.x + v * 256, row = e / (K / 4), c4 = (e % (K / 4)) * 4;
-    *reinterpret_cast<f32x4*>(&dst[row * (K + 4) + c4]) = ra[v];
+    *reinterpret_cast<f32x4*>(&dst[row * (K + 8) + c4]) = ra[v];
   }
 }
 
@@ -95,7 +95,8 @@ __global__ __launch_bounds__(256, (K * NB <= 512 ? 2 : 1)) void gemm_ws_kernel(G
   constexpr int NJ = KQ / 4;             // A fragments (ds_read_b128) per tile
   constexpr int PF = NJ <= 8 ? NJ : 4;   // fragments read ahead of the C stores
   constexpr int NACC = NB == 1 ? 2 : 1;  // independent accumulators per column block (dependent MFMA latency 40 > 32)
-  constexpr int LDA_S = K + 4;           // +16 B: the 16 rows of a ds_read_b128 group land on 16 different slots
+  constexpr int LDA_S = K + 8;           // +32 B: pitch/16 = 2 (mod 4) keeps the four 16-lane groups of ds_read_b128 (which mix the lane
+                                         // groups g) free of bank conflicts; +16 B left a 2-way conflict per group
   constexpr int NV = TR * K / 1024;      // float4 per thread per A tile
   constexpr unsigned OOB = 0x7ffffff0u;  // byte offset outside any descriptor: load -> 0, store -> dropped
   typedef typename VecOf<NB>::type vecn;
@@ -303,7 +304,7 @@ int launch_ws(const GemmParams& p, int b_kc, hipStream_t st) {
   if (workers < 1) workers = 1;
   const int ntiles = skf_cdiv(p.M, TR);
   if (workers > ntiles) workers = ntiles;
-  const size_t smem = (size_t)(2 * TR * (K + 4)) * sizeof(float);
+  const size_t smem = (size_t)(2 * TR * (K + 8)) * sizeof(float);
   dim3 grid(groups * workers), block(256);
   static const std::string tag = "gemm_ws<K" + std::to_string(K) + ",CW" + std::to_string(CW) + ">";
   SkfProfScope ps(st, tag.c_str(), 2.0 * p.M * p.N * p.K,
