@@ -341,7 +341,7 @@ extern "C" int skf_set_gemm_precision(int mode) {
 static int ws_launch_one(const GemmParams& p, int b_kcontig, hipStream_t st) {
   const bool fits32 = (double)p.M * p.lda * 4 < 2147483648.0 && (double)p.M * p.ldc * 4 < 2147483648.0 &&
                       (!p.relu_src || (double)p.M * p.ld_relu * 4 < 2147483648.0);   // the split kernels use 32-bit byte offsets
-  if (const int prec = skf_get_gemm_precision(); prec && p.act != 2 && fits32) return skf_gemm_wsx_launch(p, b_kcontig, prec == 3 ? 2 : 3, st);
+  if (const int prec = skf_get_gemm_precision(); prec && fits32) return skf_gemm_wsx_launch(p, b_kcontig, prec == 3 ? 2 : 3, st);
   switch (p.K) {
     case 128: return launch_ws<128, 2>(p, b_kcontig, st);
     case 256: return launch_ws<256, 2>(p, b_kcontig, st);

@@ -338,6 +338,11 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) reinterpret_cast<float*>(&cprev[r])[nb] = __builtin_amdgcn_fmed3f(reinterpret_cast<float*>(&cprev[r])[nb], 0.f, __builtin_inff());   // one op (fmaxf = canonicalise + max)
+    } else if (p.act == 2) {   // the bottleneck's tanh projection (one launch per step): a wave-uniform branch nobody else takes
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) reinterpret_cast<float*>(&cprev[r])[nb] = tanhf(reinterpret_cast<float*>(&cprev[r])[nb]);
     }
     prev_tile = tile;
     if (!EARLY) __syncthreads();
