@@ -73,7 +73,7 @@ def cpu_baseline(seconds_budget=25.0):
 
 def _gemm_precision():
     from sketchformer_amd import _lib
-    return int(_lib.load().skf_get_gemm_precision())
+    return int(_lib.default_precision())
 
 
 def pmc_traffic(tag):
@@ -218,19 +218,16 @@ def main():
     if rank == 0 and world == 1 and _gemm_precision() != 0 and not args.no_profile:
         # the same step with the Dense matmuls on v_mfma_f32_16x16x4_f32 (SKF_GEMM_PRECISION=f32), timed the same way on the
         # same engine after the headline region: reported beside it, never part of `value`
-        from sketchformer_amd import _lib
-        lib = _lib.load()
-        start_mode = _gemm_precision()
-        lib.skf_set_gemm_precision(0)
+        eng0 = engine.TrainEngine(engine.make_config(use_graph=args.graph, gemm_precision=0, **cfg_kwargs), init_seed=0)
         for _ in range(max(2, min(args.warmup, 5))):
-            eng.train_step(x, y)
+            eng0.train_step(x, y)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            eng.train_step(x, y)
+            eng0.train_step(x, y)
         torch.cuda.synchronize()
         e1 = time.perf_counter() - t1
-        lib.skf_set_gemm_precision(start_mode)
+        del eng0
         out["fp32_mfma_mode"] = {"ms_per_step": 1e3 * e1 / args.steps, "value": B * L * args.steps / e1,
                                  "step_mfma_frac": f_step / (e1 / args.steps) / (PEAK_F32_MFMA_TFLOPS * 1e12)}
     if rank == 0 and not args.no_profile:

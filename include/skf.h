@@ -12,7 +12,8 @@
  *  - the caller owns every buffer; kernels never allocate.  Scratch is passed as
  *    (workspace, workspace_bytes); sizes come from the *_workspace_bytes queries.
  *  - launches are asynchronous on `stream` (a hipStream_t cast to void*), re-entrant,
- *    and keep no global state besides a thread-local error string.
+ *    and keep no global state besides a thread-local error string (the opt-in launch
+ *    profiler below is a measurement facility of the calling process, off by default).
  *  - return 0 on success, negative on error (never throws across the ABI);
  *    skf_last_error() describes the last failure on the calling thread.
  */
@@ -52,21 +53,26 @@ int skf_profiler_report(char* buf_host, size_t len);
  *   act: 0 none, 1 relu, 2 tanh;  relu_src (optional, ld_relu): C = 0 where relu_src <= 0
  *   splits > 1 (or bias_grad != NULL): split-K through `workspace`; bias_grad[n] = sum_k B[k][n]
  *   (the bias gradient of a wgrad call, B stored [K][N]); no fused epilogue on that path. */
-/* Arithmetic of the Dense matmuls (process-wide): 0 = v_mfma_f32_16x16x4_f32 on the fp32 operands;
- * 6 = every fp32 operand split exactly into three bf16 pieces, the six largest piece products summed in fp32 on
- *     the bf16 matrix cores (dropped terms <= 2^-23 |a||b| per product: the size of one fp32 rounding);
- * 3 = two pieces / three products (dropped terms <= 2^-15 |a||b|).  Initial value: env SKF_GEMM_PRECISION
- * (f32 | bf16x6 | bf16x3), default bf16x6 (against float64 its error is below the fp32-MFMA kernel's: the piece
- * products are exact and the small ones are summed before the large ones).  Operands and results are fp32 tensors in
- * every mode; mode 3 is an opt-in fast mode, never a default. */
-int skf_set_gemm_precision(int mode);
-int skf_get_gemm_precision(void);
+/* `precision` - the arithmetic of a Dense matmul (an argument of every entry that multiplies, and a field of SkfConfig):
+ * SKF_PREC_F32 (0)    = v_mfma_f32_16x16x4_f32 on the fp32 operands (bit-for-bit a k-ordered fmaf chain);
+ * SKF_PREC_BF16X6 (6) = every fp32 operand split exactly into three bf16 pieces, the six largest piece products summed
+ *     in fp32 on the bf16 matrix cores (dropped terms <= 2^-23 |a||b| per product: the size of one fp32 rounding;
+ *     against float64 its error is below the fp32-MFMA kernel's: the piece products are exact and the small ones are
+ *     summed before the large ones);
+ * SKF_PREC_BF16X3 (3) = two pieces / three products (dropped terms <= 2^-15 |a||b|): opt-in fast mode, never a default.
+ * Operands and results are fp32 tensors in every mode.  Non-finite operands: an output element is non-finite in the
+ * split modes exactly where it is non-finite in mode 0 (an inf operand gives NaN there instead of +-inf: the remainder
+ * of inf is inf - inf); finite outputs are unaffected.  fp32 subnormal operands / pieces below the bf16 normal range are
+ * flushed by the bf16 matrix cores: absolute error <= 2^-126 per product (tests/test_gpu_ops.py). */
+#define SKF_PREC_F32 0
+#define SKF_PREC_BF16X3 3
+#define SKF_PREC_BF16X6 6
 size_t skf_gemm_workspace_bytes(int M, int N, int K, int splits, int with_bias_grad);
 int skf_gemm_default_splits(int M, int N, int K);
 int skf_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                  float* C, int ldc, const float* bias, int act, const float* relu_src, int ld_relu, int accumulate,
                  int splits, float* bias_grad, int bias_grad_accumulate, void* workspace, size_t workspace_bytes,
-                 skf_stream_t stream);
+                 int precision, skf_stream_t stream);
 
 /* wgrad split into its two phases so that a caller can run MANY wgrads and reduce all their slabs with one launch:
  * skf_gemm_wgrad_partial = the partial-tile kernel only (A = X [K][M], B = dY [K][N]; slab layout
@@ -77,7 +83,8 @@ typedef struct SkfReduceDesc {
   int32_t splits, M, N, ldc, block_begin, pad;
 } SkfReduceDesc;
 int skf_gemm_wgrad_partial(int M, int N, int K, const float* A, int lda, const float* B, int ldb, int splits,
-                           int with_bias_grad, float* slab, size_t slab_bytes, int* splits_used_host, skf_stream_t stream);
+                           int with_bias_grad, float* slab, size_t slab_bytes, int* splits_used_host, int precision,
+                           skf_stream_t stream);
 int skf_splitk_reduce_blocks(int M, int N);
 int skf_splitk_reduce_batch(const SkfReduceDesc* descs_dev, int ndesc, int total_blocks, skf_stream_t stream);
 
@@ -86,15 +93,16 @@ int skf_splitk_reduce_batch(const SkfReduceDesc* descs_dev, int ndesc, int total
  * builders/layers/transformer.py:160-186 + the masks of builders/utils.py:35-68.
  * Q (B,Lq,ldq) K,V (B,Lk,ld*) O (B,Lq,ldo); head h = columns [h*dh,(h+1)*dh).
  * key_mask: (B, key_mask_ld) bytes, 1 = padded key (create_padding_mask), may be NULL.
+ * precision != SKF_PREC_F32: the score products of the dh = 16 kernels run on the bf16 matrix cores with split operands.
  * causal: add the look-ahead mask (needs Lq == Lk).  stats: (B,H,Lq,2) row max of the base-2 logits
  * (q.k * log2(e)/sqrt(dh)) and 1/row-sum - opaque to the caller, kept for the backward.  dh in {16,32,64}. */
 int skf_attention_fwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
                       const unsigned char* key_mask, int key_mask_ld, int causal, int B, int H, int Lq, int Lk, int dh,
-                      float* O, int ldo, float* stats, skf_stream_t stream);
+                      float* O, int ldo, float* stats, int precision, skf_stream_t stream);
 int skf_attention_bwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* O, int ldo,
                       const float* dO, int lddo, const float* stats, const unsigned char* key_mask, int key_mask_ld,
                       int causal, int B, int H, int Lq, int Lk, int dh, float* dQ, int lddq, float* dK, int lddk,
-                      float* dV, int lddv, skf_stream_t stream);
+                      float* dV, int lddv, int precision, skf_stream_t stream);
 
 /* ------------------------------------------------------------------ embedding stage
  * Encoder.call / Decoder.call head, builders/layers/transformer.py:288-296, 325-334:
@@ -248,6 +256,7 @@ typedef struct SkfConfig {
   /* models/sketchformer.py:42,46,76-108: the class head needs lowerdim > 0 and do_classification; the decoder / output
    * layer / expander need do_reconstruction; lowerdim == 0 = no bottleneck, the decoder attends to the encoder output */
   int32_t do_classification, do_reconstruction;
+  int32_t gemm_precision; /* SKF_PREC_*: arithmetic of every Dense / attention matmul of the step (0 = fp32 MFMA) */
 } SkfConfig;
 
 typedef struct SkfParamEntry {

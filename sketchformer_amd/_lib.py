@@ -11,6 +11,19 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libskf.so")
 
 SKF_OK = 0
+PREC_F32, PREC_BF16X3, PREC_BF16X6 = 0, 3, 6          # SKF_PREC_* of include/skf.h
+
+
+def default_precision():
+    """Arithmetic of the Dense matmuls when the caller does not choose: bf16x6 (exact 3-way split of the fp32 operands on
+    the bf16 matrix cores - measured MORE accurate against float64 than the fp32-MFMA kernels, tests/test_gpu_ops.py);
+    env SKF_GEMM_PRECISION = f32 | bf16x6 | bf16x3 overrides.  Read here, on the Python side: the library itself keeps
+    no such state, every entry takes the mode as an argument / SkfConfig field."""
+    e = os.environ.get("SKF_GEMM_PRECISION", "bf16x6").lower()
+    try:
+        return {"f32": PREC_F32, "bf16x6": PREC_BF16X6, "bf16x3": PREC_BF16X3, "0": 0, "3": 3, "6": 6}[e]
+    except KeyError:
+        raise ValueError("SKF_GEMM_PRECISION must be f32, bf16x6 or bf16x3 (got %r)" % e)
 
 
 class SkfError(RuntimeError):
@@ -32,6 +45,7 @@ class SkfConfig(C.Structure):
         ("optimizer", C.c_int32), ("momentum", C.c_float),
         ("class_buffer_layers", C.c_int32), ("class_dropout", C.c_float),
         ("do_classification", C.c_int32), ("do_reconstruction", C.c_int32),
+        ("gemm_precision", C.c_int32),
     ]
 
 
@@ -52,18 +66,16 @@ SIGNATURES = {
     "skf_version": (_I, []),
     "skf_device_info": (_I, [C.c_char_p, _Z, C.POINTER(_I)]),
     "skf_profiler_enable": (_I, [_I]),
-    "skf_set_gemm_precision": (_I, [_I]),
-    "skf_get_gemm_precision": (_I, []),
     "skf_profiler_report": (_I, [C.c_char_p, _Z]),
     "skf_gemm_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "skf_gemm_default_splits": (_I, [_I, _I, _I]),
-    "skf_gemm_wgrad_partial": (_I, [_I, _I, _I, _P, _I, _P, _I, _I, _I, _P, _Z, _P, _P]),
+    "skf_gemm_wgrad_partial": (_I, [_I, _I, _I, _P, _I, _P, _I, _I, _I, _P, _Z, _P, _I, _P]),
     "skf_splitk_reduce_blocks": (_I, [_I, _I]),
     "skf_splitk_reduce_batch": (_I, [_P, _I, _I, _P]),
-    "skf_gemm_f32": (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _I, _P, _Z, _P]),
-    "skf_attention_fwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P]),
+    "skf_gemm_f32": (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _I, _P, _Z, _I, _P]),
+    "skf_attention_fwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P]),
     "skf_attention_bwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I,
-                               _P, _I, _P, _I, _P, _I, _P]),
+                               _P, _I, _P, _I, _P, _I, _I, _P]),
     "skf_embed_fwd": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _P, _F, _U, _P, _P]),
     "skf_embed_bwd": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _F, _U, _P, _P]),
     "skf_embed_sort_workspace_bytes": (_Z, [_I, _I, _I]),

@@ -22,9 +22,18 @@ class BaseModel(object, metaclass=ABCMeta):
             batch_size=128, num_epochs=10, save_every=1., safety_save=.5, autograph=True, log_every=100,
             notify_every=1000, slack_config='token.secret', goal='No description')
 
-    def __init__(self, hps, dataset, outdir, experiment_id):
+    def __init__(self, hps, dataset, outdir, experiment_id, process_group=None):
         self.hps = hps if isinstance(hps, dict) else dict(hps.values())
         self.dataset = dataset
+        # data parallelism (one process per GPU): every rank runs the same loop on its own shard; rank 0 alone
+        # prints, writes config / checkpoints / plots, the others only take part in the collectives
+        self.process_group = process_group
+        if process_group is not None:
+            import torch.distributed as dist
+            self.rank, self.world_size = dist.get_rank(process_group), dist.get_world_size(process_group)
+        else:
+            self.rank, self.world_size = 0, 1
+        self._pending_quick = []
         self.host = socket.gethostname()
         self.experiment_id = experiment_id
         self.batches_per_epoch = self.dataset.n_samples // self.hps['batch_size']
@@ -90,8 +99,14 @@ class BaseModel(object, metaclass=ABCMeta):
         pass
 
     # ---- the loop (core/models.py:163-197)
+    def _barrier(self):
+        if self.world_size > 1:
+            import torch.distributed as dist
+            dist.barrier(group=self.process_group)
+
     def train(self, max_steps=None):
-        print("*Training started on {}*\n*Goal:* {}\nParams:\n{}".format(self.host, self.hps['goal'], pprint.pformat(self.hps)))
+        if self.rank == 0:
+            print("*Training started on {}*\n*Goal:* {}\nParams:\n{}".format(self.host, self.hps['goal'], pprint.pformat(self.hps)))
         total_steps = self.batches_per_epoch * self.hps['num_epochs']
         if max_steps is not None:
             total_steps = min(total_steps, self.current_step + max_steps)
@@ -106,23 +121,41 @@ class BaseModel(object, metaclass=ABCMeta):
             if self.current_step // self.batches_per_epoch > self.epoch:
                 self.epoch = self.current_step // self.batches_per_epoch
                 self.status_report(end_of_epoch=True)
+        self.flush_quick_metrics()
 
     def update_quick_metrics_history(self, new_metrics):
+        """core/models.py:199-201.  A model may return a lazily read mapping (``resolve_all`` on its type: one device
+        read-back for many steps); those are queued and enter the histories, in order, when the loop next prints."""
+        if hasattr(type(new_metrics), 'resolve_all'):
+            self._pending_quick.append(new_metrics)
+            return
+        self.flush_quick_metrics()
         for name, value in new_metrics.items():
             self.quick_metrics[name].append_to_history(value)
 
+    def flush_quick_metrics(self):
+        pending, self._pending_quick = self._pending_quick, []
+        if not pending:
+            return
+        type(pending[0]).resolve_all(pending)
+        for res in pending:
+            for name, value in res.items():
+                self.quick_metrics[name].append_to_history(value)
+
     def status_report(self, end_of_epoch=False):
         cur_iter = self.current_step % self.batches_per_epoch
+        if not ((cur_iter % self.hps['log_every'] == 0) or (cur_iter % self.hps['notify_every'] == 0) or end_of_epoch):
+            return None                       # nothing is printed: the metrics stay on the device
+        self.flush_quick_metrics()            # (collective under data parallelism: every rank gets here at the same step)
         log = "Epoch {} Batch {}/{}".format(self.epoch, cur_iter, self.batches_per_epoch)
         for k, m in self.quick_metrics.items():
             log = "{}|{}={:4.4f}".format(log, k, m.last_value)
-        if (cur_iter % self.hps['log_every'] == 0) or (cur_iter % self.hps['notify_every'] == 0) or end_of_epoch:
+        if self.rank == 0:
             print(log)
         return log
 
-    # ---- checkpoints (core/models.py:321-358; own on-disk format)
-    # ---- slow metrics (core/models.py:218-296 of the reference): computed on demand (evaluate-metrics.py) or by
-    # train() when hps['notify_every'] asks for it; plotting = one PNG per call, no Slack
+    # ---- slow metrics (core/models.py:218-296 of the reference): computed on demand (evaluate-metrics.py /
+    # compute_all_metrics); the training loop itself never computes them here; plotting = one PNG per call, no Slack
     def build_slow_metrics(self, names=None):
         from .. import metrics
         names = list(self.slow_metrics) if names is None else names
@@ -209,11 +242,19 @@ class BaseModel(object, metaclass=ABCMeta):
     def load_state_dict(self, state):
         pass
 
+    # ---- checkpoints (core/models.py:321-358; own on-disk format).  Data parallel: the replicas are identical, so rank 0
+    # alone writes (temp file + atomic rename) and rotates; a barrier on each side keeps the other ranks from running
+    # ahead into the next collective while the file is written, and every rank restores from the same file.
     def _save(self, path):
         import torch
-        state = self.state_dict()
-        state['current_step'] = self.current_step
-        torch.save(state, path)
+        self._barrier()
+        if self.rank == 0:
+            state = self.state_dict()
+            state['current_step'] = self.current_step
+            tmp = path + '.tmp'
+            torch.save(state, tmp)
+            os.replace(tmp, path)
+        self._barrier()
 
     def restore_checkpoint_if_exists(self, checkpoint):
         import torch
@@ -221,17 +262,20 @@ class BaseModel(object, metaclass=ABCMeta):
             return
         if checkpoint == 'latest':
             if not self._safety:
-                print("[Checkpoint] Not found")
+                if self.rank == 0:
+                    print("[Checkpoint] Not found")
                 return
             checkpoint = self._safety[-1]
         if os.path.exists(checkpoint + '.index'):       # a TensorFlow checkpoint prefix written by the reference
             self.load_reference_checkpoint(checkpoint)
-            print("[Checkpoint] Restored reference (TensorFlow) checkpoint, step #{}".format(self.current_step))
+            if self.rank == 0:
+                print("[Checkpoint] Restored reference (TensorFlow) checkpoint, step #{}".format(self.current_step))
             return
         state = torch.load(checkpoint, map_location='cpu', weights_only=False)
         self.load_state_dict(state)
         self.current_step = int(state['current_step'])
-        print("[Checkpoint] Restored, step #{}".format(self.current_step))
+        if self.rank == 0:
+            print("[Checkpoint] Restored, step #{}".format(self.current_step))
 
     def save_checkpoint_if_its_time(self):
         safety_save = max(int(self.hps['safety_save'] * self.batches_per_epoch), 1)
@@ -242,9 +286,16 @@ class BaseModel(object, metaclass=ABCMeta):
             self._save(path)
             self._safety.append(path)
             while len(self._safety) > 2:          # CheckpointManager(max_to_keep=2)
-                os.remove(self._safety.pop(0))
-            print('Saving safety checkpoint for step {} at {}'.format(self.current_step + 1, path))
+                old = self._safety.pop(0)
+                if self.rank == 0:
+                    try:
+                        os.remove(old)
+                    except FileNotFoundError:
+                        pass
+            if self.rank == 0:
+                print('Saving safety checkpoint for step {} at {}'.format(self.current_step + 1, path))
         if (self.current_step + 1) % save_every == 0:
             path = "{}/step{}.pt".format(self.wgt_out_dir, self.current_step)
             self._save(path)
-            print('Saving fixed checkpoint for step {} at {}'.format(self.current_step + 1, path))
+            if self.rank == 0:
+                print('Saving fixed checkpoint for step {} at {}'.format(self.current_step + 1, path))

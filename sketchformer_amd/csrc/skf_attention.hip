@@ -583,7 +583,7 @@ int check_common(const AttnParams& p, int dh) {
 
 extern "C" int skf_attention_fwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
                                  const unsigned char* key_mask, int key_mask_ld, int causal, int B, int H, int Lq, int Lk,
-                                 int dh, float* O, int ldo, float* stats, skf_stream_t stream) {
+                                 int dh, float* O, int ldo, float* stats, int precision, skf_stream_t stream) {
   AttnParams p{};
   p.Q = Q; p.K = K; p.V = V; p.O = O; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
   p.key_mask = key_mask; p.key_mask_ld = key_mask_ld; p.causal = causal; p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.stats = stats;
@@ -597,7 +597,7 @@ extern "C" int skf_attention_fwd(const float* Q, int ldq, const float* K, int ld
   // and the planes cost the fourth resident workgroup per CU); with unpadded rows (four workgroups per CU again, 2-way bank
   // conflicts) it is 4-11 % faster than the fp32-MFMA tiles: 36.4 / 29.0 / 42.1 vs 39.2 / 30.2 / 47.2 us.
   static const bool split_off = getenv("SKF_ATTN_SPLIT") && getenv("SKF_ATTN_SPLIT")[0] == '0';
-  const bool split = dh == 16 && !split_off && skf_get_gemm_precision() != 0;
+  const bool split = dh == 16 && !split_off && precision != SKF_PREC_F32;
   const size_t smem = fwd_smem(dh, Lk, split);
   SKF_CHECK_ARG(smem <= 160 * 1024, "K/V of one head do not fit in LDS");
   hipStream_t st = (hipStream_t)stream;
@@ -624,7 +624,8 @@ extern "C" int skf_attention_fwd(const float* Q, int ldq, const float* K, int ld
 extern "C" int skf_attention_bwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
                                  const float* O, int ldo, const float* dO, int lddo, const float* stats,
                                  const unsigned char* key_mask, int key_mask_ld, int causal, int B, int H, int Lq, int Lk,
-                                 int dh, float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv, skf_stream_t stream) {
+                                 int dh, float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv, int precision, skf_stream_t stream) {
+  (void)precision;
   AttnParams p{};
   p.Q = Q; p.K = K; p.V = V; p.O = const_cast<float*>(O); p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
   p.key_mask = key_mask; p.key_mask_ld = key_mask_ld; p.causal = causal; p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk;

@@ -393,8 +393,9 @@ extern "C" int skf_splitk_reduce_batch(const SkfReduceDesc* descs_dev, int ndesc
 // ([splits][M][N] then [splits][N]); *splits_used receives the effective split count.  Needs M, N, lda, ldb % 4 == 0.
 extern "C" int skf_gemm_wgrad_partial(int M, int N, int K, const float* A, int lda, const float* B, int ldb, int splits,
                                       int with_bias_grad, float* slab, size_t slab_bytes, int* splits_used,
-                                      skf_stream_t stream) {
+                                      int precision, skf_stream_t stream) {
   SKF_CHECK_ARG(M > 0 && N > 0 && K > 0 && A && B && slab && splits_used, "bad argument");
+  SKF_CHECK_ARG(precision == SKF_PREC_F32 || precision == SKF_PREC_BF16X3 || precision == SKF_PREC_BF16X6, "precision must be 0 (fp32 MFMA), 6 (bf16x6) or 3 (bf16x3)");
   if (splits < 1) splits = 1;
   int chunk = skf_cdiv(K, splits);
   chunk = skf_cdiv(chunk, 64) * 64;
@@ -404,7 +405,7 @@ extern "C" int skf_gemm_wgrad_partial(int M, int N, int K, const float* A, int l
   p.A = A; p.B = B; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb;
   p.a_vec = ((lda & 3) == 0) && (((uintptr_t)A & 15) == 0);
   p.b_vec = ((ldb & 3) == 0) && (((uintptr_t)B & 15) == 0);
-  p.k_chunk = chunk; p.slab = slab;
+  p.k_chunk = chunk; p.slab = slab; p.precision = precision;
   p.colsum_slab = with_bias_grad ? slab + (size_t)splits * M * N : nullptr;
   p.tiles_m = skf_cdiv(M, 64); p.tiles_n = skf_cdiv(N, 64);
   *splits_used = splits;
@@ -418,8 +419,9 @@ extern "C" int skf_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K,
                             const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                             const float* bias, int act, const float* relu_src, int ld_relu, int accumulate,
                             int splits, float* bias_grad, int bias_grad_accumulate,
-                            void* workspace, size_t workspace_bytes, skf_stream_t stream) {
+                            void* workspace, size_t workspace_bytes, int precision, skf_stream_t stream) {
   SKF_CHECK_ARG(M > 0 && N > 0 && K > 0, "empty problem");
+  SKF_CHECK_ARG(precision == SKF_PREC_F32 || precision == SKF_PREC_BF16X3 || precision == SKF_PREC_BF16X6, "precision must be 0 (fp32 MFMA), 6 (bf16x6) or 3 (bf16x3)");
   SKF_CHECK_ARG(A && B && C, "null operand");
   SKF_CHECK_ARG(act >= 0 && act <= 2, "bad activation");
   hipStream_t st = (hipStream_t)stream;
@@ -427,6 +429,7 @@ extern "C" int skf_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K,
   p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.bias = bias; p.act = act; p.relu_src = relu_src; p.ld_relu = ld_relu; p.accumulate = accumulate;
+  p.precision = precision;
   p.a_vec = ((lda & 3) == 0) && (((uintptr_t)A & 15) == 0);
   p.b_vec = ((ldb & 3) == 0) && (((uintptr_t)B & 15) == 0);
   p.tiles_m = skf_cdiv(M, 128); p.tiles_n = skf_cdiv(N, 128);

@@ -21,6 +21,7 @@ struct GemmParams {
   int tiles_m, tiles_n;
   long long* dbg;          // diagnostics only: per-phase s_memtime stamps of a few workgroups (env SKF_GEMM_DBG)
   int xcd_remap;           // ws kernel: XCD-contiguous logical ids (env SKF_WS_XCD, A/B knob)
+  int precision;           // SKF_PREC_*: 0 fp32 MFMA, 6 / 3 = split fp32 operands on the bf16 matrix cores
   int ablate;              // generic kernel, diagnostics only (env SKF_GEMM_ABLATE): 1 no MFMA, 2 no C store, 3 no global reload
 };
 

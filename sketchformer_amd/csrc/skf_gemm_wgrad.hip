@@ -287,7 +287,7 @@ int skf_gemm_wgrad_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, i
     SKF_HIP(hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr_done = true;
   }
-  const int prec = skf_get_gemm_precision();
+  const int prec = p.precision;
   const bool fits32 = (double)p.K * p.lda * 4 < 2147483648.0 && (double)p.K * p.ldb * 4 < 2147483648.0;
   if (prec && fits32) {
     // 4 waves per workgroup, one workgroup per CU (~256 workgroups): 8 waves (two per SIMD, 128 KB of LDS for the

@@ -320,28 +320,12 @@ int launch_ws(const GemmParams& p, int b_kc, hipStream_t st) {
 
 }  // namespace
 
-// GEMM arithmetic of the Dense kernels: 0 = fp32 MFMA, 6 / 3 = fp32 operands split into 3 / 2 bf16 pieces on the
-// bf16 matrix cores (skf_gemm_wsx.hip).  Process-wide; initial value from SKF_GEMM_PRECISION (f32 | bf16x6 | bf16x3),
-// default bf16x6: measured against float64 it is MORE accurate than the fp32-MFMA kernel (tests/test_gpu_ops.py).
-static int g_gemm_precision = -1;
-extern "C" int skf_get_gemm_precision(void) {
-  if (g_gemm_precision < 0) {
-    const char* e = getenv("SKF_GEMM_PRECISION");
-    g_gemm_precision = (e && !strcmp(e, "f32")) ? 0 : (e && !strcmp(e, "bf16x3")) ? 3 : 6;
-  }
-  return g_gemm_precision;
-}
-extern "C" int skf_set_gemm_precision(int mode) {
-  SKF_CHECK_ARG(mode == 0 || mode == 3 || mode == 6, "mode must be 0 (fp32 MFMA), 6 (bf16x6) or 3 (bf16x3)");
-  g_gemm_precision = mode;
-  return SKF_OK;
-}
-
+// p.precision: 0 = fp32 MFMA, 6 / 3 = fp32 operands split into 3 / 2 bf16 pieces on the bf16 matrix cores (skf_gemm_wsx.hip).
 // Returns SKF_OK and sets *handled = 1 when the weight-stationary path applies.
 static int ws_launch_one(const GemmParams& p, int b_kcontig, hipStream_t st) {
   const bool fits32 = (double)p.M * p.lda * 4 < 2147483648.0 && (double)p.M * p.ldc * 4 < 2147483648.0 &&
                       (!p.relu_src || (double)p.M * p.ld_relu * 4 < 2147483648.0);   // the split kernels use 32-bit byte offsets
-  if (const int prec = skf_get_gemm_precision(); prec && fits32) return skf_gemm_wsx_launch(p, b_kcontig, prec == 3 ? 2 : 3, st);
+  if (const int prec = p.precision; prec && fits32) return skf_gemm_wsx_launch(p, b_kcontig, prec == 3 ? 2 : 3, st);
   switch (p.K) {
     case 128: return launch_ws<128, 2>(p, b_kcontig, st);
     case 256: return launch_ws<256, 2>(p, b_kcontig, st);

@@ -416,17 +416,17 @@ namespace {
 
 int dense_fwd(SkfModel* M, const DenseP& w, const float* x, int rows, float* y, int act, hipStream_t s) {
   return skf_gemm_f32(1, 0, rows, w.out, w.in, x, w.in, M->P(w.w), w.ld, y, w.out, M->P(w.b), act, nullptr, 0, 0, 1,
-                      nullptr, 0, nullptr, 0, s);
+                      nullptr, 0, nullptr, 0, M->cfg.gemm_precision, s);
 }
 // strided-input variant (x has row stride ldx)
 int dense_fwd_ld(SkfModel* M, const DenseP& w, const float* x, int ldx, int rows, float* y, int ldy, int act, hipStream_t s) {
   return skf_gemm_f32(1, 0, rows, w.out, w.in, x, ldx, M->P(w.w), w.ld, y, ldy, M->P(w.b), act, nullptr, 0, 0, 1,
-                      nullptr, 0, nullptr, 0, s);
+                      nullptr, 0, nullptr, 0, M->cfg.gemm_precision, s);
 }
 int dense_wgrad_on(SkfModel* M, const DenseP& w, const float* x, int ldx, const float* dy, int lddy, int rows, hipStream_t s) {
   const int splits = skf_gemm_default_splits(w.in, w.out, rows);
   return skf_gemm_f32(0, 0, w.in, w.out, rows, x, ldx, dy, lddy, M->G(w.w), w.ld, nullptr, 0, nullptr, 0, 0, splits,
-                      M->G(w.b), 0, M->at<char>(M->plan.gemm_ws), M->plan.gemm_ws_bytes, s);
+                      M->G(w.b), 0, M->at<char>(M->plan.gemm_ws), M->plan.gemm_ws_bytes, M->cfg.gemm_precision, s);
 }
 int issue_wgrads(SkfModel* M, hipStream_t s);
 // Main-stream kernels that overwrite `buf` must first wait for the side-stream wgrad that still reads it
@@ -472,7 +472,7 @@ int issue_wgrads(SkfModel* M, hipStream_t s) {
     if (q.kind != 1) continue;
     const DenseP& w = q.w;
     SKF_TRY(skf_gemm_f32(1, 1, q.rows, w.in, w.out, q.dy, q.lddy, M->P(w.w), w.ld, q.dx, q.lddx, nullptr, 0, nullptr, 0,
-                         q.accumulate, 1, nullptr, 0, nullptr, 0, M->side));
+                         q.accumulate, 1, nullptr, 0, nullptr, 0, M->cfg.gemm_precision, M->side));
     if (!dgrad_done) { dgrad_done = M->new_event(); SKF_CHECK_ARG(dgrad_done, "event allocation failed"); }
   }
   if (dgrad_done) SKF_HIP(hipEventRecord(dgrad_done, M->side));
@@ -490,7 +490,7 @@ int issue_wgrads(SkfModel* M, hipStream_t s) {
     SKF_CHECK_ARG(M->slab_cursor + bytes <= M->plan.slab_arena_bytes && M->desc_cursor < M->plan.n_wgrads, "slab arena exhausted");
     float* slab = M->at<float>(M->plan.slab_arena + M->slab_cursor);
     int used = 0;
-    SKF_TRY(skf_gemm_wgrad_partial(w.in, w.out, q.rows, q.x, q.ldx, q.dy, q.lddy, splits, 1, slab, bytes, &used, M->side));
+    SKF_TRY(skf_gemm_wgrad_partial(w.in, w.out, q.rows, q.x, q.ldx, q.dy, q.lddy, splits, 1, slab, bytes, &used, M->cfg.gemm_precision, M->side));
     SkfReduceDesc d;
     d.slab = slab; d.C = M->G(w.w); d.bias_grad = M->G(w.b); d.splits = used; d.M = w.in; d.N = w.out; d.ldc = w.ld;
     d.block_begin = M->reduce_blocks; d.pad = 0;
@@ -554,7 +554,7 @@ int dense_dgrad(SkfModel* M, const DenseP& w, const float* dy, int lddy, int row
                 const float* relu_src, int ld_relu, hipStream_t s) {
   SKF_TRY(before_write(M, dx, s));
   return skf_gemm_f32(1, 1, rows, w.in, w.out, dy, lddy, M->P(w.w), w.ld, dx, lddx, nullptr, 0, relu_src, ld_relu,
-                      accumulate, 1, nullptr, 0, nullptr, 0, s);
+                      accumulate, 1, nullptr, 0, nullptr, 0, M->cfg.gemm_precision, s);
 }
 
 // dx (+)= dY W^T for a dx that the main stream reads much later (the encoder-output gradient sent back by the decoder's
@@ -631,7 +631,7 @@ int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s, bool 
     float* qkv = M->at<float>(a.qkv);
     SKF_TRY(dense_fwd(M, w.mha.qkv, x, Me, qkv, 0, s));
     SKF_TRY(skf_attention_fwd(qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, emask, Le, 0, B, H, Le, Le, dh,
-                              M->at<float>(a.o), d, M->at<float>(a.astats), s));
+                              M->at<float>(a.o), d, M->at<float>(a.astats), M->cfg.gemm_precision, s));
     SKF_TRY(dense_fwd(M, w.mha.o, M->at<float>(a.o), Me, M->at<float>(a.z1), 0, s));
     SKF_TRY(skf_layernorm_residual_fwd(x, M->at<float>(a.z1), M->P(w.ln1.g), M->P(w.ln1.b), M->at<float>(a.x1),
                                        M->at<float>(a.st1), Me, d, rate, site_enc(i, 0), M->state, s));
@@ -693,7 +693,7 @@ int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s, bool 
     float* qkv = M->at<float>(a.qkv);
     SKF_TRY(dense_fwd(M, w.mha1.qkv, x, Md, qkv, 0, s));
     SKF_TRY(skf_attention_fwd(qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, dmask, Ld, 1, B, H, Ld, Ld, dh,
-                              M->at<float>(a.o1), d, M->at<float>(a.astats1), s));
+                              M->at<float>(a.o1), d, M->at<float>(a.astats1), M->cfg.gemm_precision, s));
     SKF_TRY(dense_fwd(M, w.mha1.o, M->at<float>(a.o1), Md, M->at<float>(a.z1), 0, s));
     SKF_TRY(skf_layernorm_residual_fwd(x, M->at<float>(a.z1), M->P(w.ln1.g), M->P(w.ln1.b), M->at<float>(a.out1),
                                        M->at<float>(a.st1), Md, d, rate, site_dec(N, i, 0), M->state, s));
@@ -702,7 +702,7 @@ int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s, bool 
     if (!kv_done) SKF_TRY(dense_fwd(M, w.mha2.kv, pre, Me, kv2, 0, s));
     else if (i == 0) SKF_HIP(hipStreamWaitEvent(s, kv_done, 0));
     SKF_TRY(skf_attention_fwd(M->at<float>(a.q2), d, kv2, 2 * d, kv2 + d, 2 * d, cross_mask, Le, 0, B, H, Ld, Le, dh,
-                              M->at<float>(a.o2), d, M->at<float>(a.astats2), s));
+                              M->at<float>(a.o2), d, M->at<float>(a.astats2), M->cfg.gemm_precision, s));
     SKF_TRY(dense_fwd(M, w.mha2.o, M->at<float>(a.o2), Md, M->at<float>(a.z2), 0, s));
     SKF_TRY(skf_layernorm_residual_fwd(M->at<float>(a.out1), M->at<float>(a.z2), M->P(w.ln2.g), M->P(w.ln2.b),
                                        M->at<float>(a.out2), M->at<float>(a.st2), Md, d, rate, site_dec(N, i, 1), M->state, s));
@@ -836,7 +836,7 @@ int run_backward(SkfModel* M, hipStream_t s) {
     SKF_TRY(before_write(M, dkv2, s));
     SKF_TRY(skf_attention_bwd(M->at<float>(a.q2), d, kv2, 2 * d, kv2 + d, 2 * d, M->at<float>(a.o2), d, dO, d,
                               M->at<float>(a.astats2), cross_mask, Le, 0, B, H, Ld, Le, dh, dq2, d, dkv2, 2 * d,
-                              dkv2 + d, 2 * d, s));
+                              dkv2 + d, 2 * d, M->cfg.gemm_precision, s));
     SKF_TRY(dense_wgrad(M, w.mha2.q, M->at<float>(a.out1), d, dq2, d, Md, s));
     SKF_TRY(dense_dgrad(M, w.mha2.q, dq2, d, Md, G, d, 1, nullptr, 0, s));
     SKF_TRY(dense_wgrad(M, w.mha2.kv, pre, L.E, dkv2, 2 * d, Me, s));
@@ -853,7 +853,7 @@ int run_backward(SkfModel* M, hipStream_t s) {
     SKF_TRY(before_write(M, dqkv, s));
     SKF_TRY(skf_attention_bwd(qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, M->at<float>(a.o1), d, dO, d,
                               M->at<float>(a.astats1), dmask, Ld, 1, B, H, Ld, Ld, dh, dqkv, 3 * d, dqkv + d, 3 * d,
-                              dqkv + 2 * d, 3 * d, s));
+                              dqkv + 2 * d, 3 * d, M->cfg.gemm_precision, s));
     SKF_TRY(dense_wgrad(M, w.mha1.qkv, M->at<float>(a.x_in), d, dqkv, 3 * d, Md, s));
     SKF_TRY(dense_dgrad(M, w.mha1.qkv, dqkv, 3 * d, Md, G2, d, 1, nullptr, 0, s));
     float* t = G; G = G2; G2 = t;
@@ -947,7 +947,7 @@ int run_backward(SkfModel* M, hipStream_t s) {
     SKF_TRY(before_write(M, dqkv, s));
     SKF_TRY(skf_attention_bwd(qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, M->at<float>(a.o), d, dO, d,
                               M->at<float>(a.astats), emask, Le, 0, B, H, Le, Le, dh, dqkv, 3 * d, dqkv + d, 3 * d,
-                              dqkv + 2 * d, 3 * d, s));
+                              dqkv + 2 * d, 3 * d, M->cfg.gemm_precision, s));
     SKF_TRY(dense_wgrad(M, w.mha.qkv, M->at<float>(a.x_in), d, dqkv, 3 * d, Me, s));
     SKF_TRY(dense_dgrad(M, w.mha.qkv, dqkv, 3 * d, Me, G, d, 1, nullptr, 0, s));
     SKF_TRY(issue_wgrads(M, s));
@@ -1162,6 +1162,8 @@ extern "C" int skf_config_validate(const SkfConfig* c) {
   SKF_CHECK_ARG(c->class_buffer_layers >= 0 && c->class_buffer_layers <= 8, "class_buffer_layers must be in [0, 8]");
   SKF_CHECK_ARG(c->class_dropout >= 0.f && c->class_dropout < 1.f, "class_dropout out of range");
   SKF_CHECK_ARG(c->optimizer == 0 || c->optimizer == 1, "optimizer must be 0 (Adam) or 1 (SGD with momentum)");
+  SKF_CHECK_ARG(c->gemm_precision == SKF_PREC_F32 || c->gemm_precision == SKF_PREC_BF16X3 || c->gemm_precision == SKF_PREC_BF16X6,
+                "gemm_precision must be 0 (fp32 MFMA), 6 (bf16x6) or 3 (bf16x3)");
   SKF_CHECK_ARG(c->n_classes > 0, "bad number of classes");
   if (!c->continuous) {
     SKF_CHECK_ARG(c->vocab_size > 0, "bad vocab size");

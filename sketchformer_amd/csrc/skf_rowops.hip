@@ -41,12 +41,16 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restr
   for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
     const int b = row / Lrows, t = row % Lrows;
     long long tk = tok[(size_t)b * tok_ld + t];
-    if (tk < 0 || tk >= vocab) tk = 0;   // tf.gather on GPU yields zeros for OOB; ids are validated on the host
+    // out-of-range ids: a zero embedding vector like tf.gather on a GPU (the backward kernels skip them, so the
+    // pair is consistent); TrainEngine rejects them on the host before they get here (engine._dev_tokens)
+    const bool oob = tk < 0 || tk >= vocab;
+    if (oob) tk = 0;
     const float* e = table + (size_t)tk * d;
     const float* pe = pos + (size_t)t * d;
     float* o = out + (size_t)row * d;
     for (int c = lane * 2; c < d; c += 128) {
       float2 v = *reinterpret_cast<const float2*>(e + c);
+      if (oob) v = make_float2(0.f, 0.f);
       const float2 pp = *reinterpret_cast<const float2*>(pe + c);
       v.x = v.x * sq + pp.x; v.y = v.y * sq + pp.y;
       if (rate > 0.f) {

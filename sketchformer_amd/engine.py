@@ -36,8 +36,11 @@ def make_config(batch, seq_len=200, d_model=128, num_heads=8, dff=512, num_layer
                 lowerdim=256, attn_version=1, continuous=False, blind_decoder_mask=True, dropout_rate=0.1,
                 recon_weight=1.0, class_weight=1.0, lr_scheduler="WarmupDecay", lr=0.01, seed=0, use_graph=True,
                 max_pos=1000, optimizer="Adam", class_buffer_layers=0, class_dropout=0.1, do_classification=True,
-                do_reconstruction=True):
+                do_reconstruction=True, gemm_precision=None):
+    """gemm_precision: SKF_PREC_* arithmetic of the Dense / attention matmuls (0 fp32 MFMA, 6 bf16x6, 3 bf16x3);
+    None = _lib.default_precision() (bf16x6 unless SKF_GEMM_PRECISION says otherwise)."""
     cfg = SkfConfig()
+    cfg.gemm_precision = _lib.default_precision() if gemm_precision is None else int(gemm_precision)
     cfg.batch, cfg.seq_len, cfg.d_model, cfg.num_heads, cfg.dff, cfg.num_layers = batch, seq_len, d_model, num_heads, dff, num_layers
     cfg.vocab_size, cfg.n_classes, cfg.lowerdim, cfg.attn_version = vocab_size or 0, n_classes, lowerdim, attn_version
     cfg.continuous, cfg.blind_decoder_mask, cfg.max_pos = int(continuous), int(blind_decoder_mask), max_pos
@@ -150,6 +153,11 @@ class TrainEngine:
         self._comm = None                # communication stream of the data-parallel gradient buckets
         self.pg = process_group
         self.world_size = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        self.rank = torch.distributed.get_rank(process_group) if process_group is not None else 0
+        # "bucketed": the flat gradient buffer is all-reduced in the pieces backward finishes (overlapping the rest of
+        # backward / the optimizer sweep of the previous piece); "single": ONE all-reduce of the whole buffer after
+        # backward (the literal north-star schedule) - bench.py --allreduce single|bucketed A/Bs the two
+        self.dp_mode = "bucketed"
 
     def __del__(self):
         h = getattr(self, "handle", None)
@@ -198,8 +206,16 @@ class TrainEngine:
             self.set(k, v, which)
 
     # ---- steps
-    def _dev_tokens(self, x):
+    def _dev_tokens(self, x, limit=None, what="token id"):
+        """int64 device copy.  Host inputs (the loader's numpy batches) are range-checked against ``limit`` here - a
+        tokenizer / vocab_size (or class count) mismatch must fail loudly instead of training on wrong rows; tensors
+        that already live on the device are trusted (checking them would cost a host sync per step)."""
         t = torch.as_tensor(x)
+        if limit is not None and not t.is_cuda and t.numel():
+            lo, hi = int(t.min()), int(t.max())
+            if lo < 0 or hi >= limit:
+                raise ValueError("%s out of range: values span [%d, %d], valid range is [0, %d) - tokenizer / dataset "
+                                 "does not match the model (vocab_size / n_classes)" % (what, lo, hi, limit))
         if t.dtype != torch.int64:
             t = t.to(torch.int64)
         return t.to(self.device, non_blocking=True).contiguous()
@@ -208,7 +224,7 @@ class TrainEngine:
         """(B,L) int64 tokens, or (B,L,5) float32 stroke-5 rows in continuous mode (the reference casts the
         loader's float64 to float32 at the tf.function boundary, models/sketchformer.py:317-319)."""
         if not self.cfg.continuous:
-            return self._dev_tokens(x)
+            return self._dev_tokens(x, self.cfg.vocab_size)
         t = torch.as_tensor(x)
         if t.dim() != 3 or t.shape[-1] != 5:
             raise ValueError("continuous mode expects (B, L, 5) stroke-5 input")
@@ -274,7 +290,8 @@ class TrainEngine:
     def forward_backward(self, inp, tar, labels):
         inp = self._dev_input(inp)
         tar = inp if tar is None else self._dev_input(tar)
-        labels = self._dev_tokens(labels)
+        labels = self._dev_tokens(labels, self.cfg.n_classes if self.cfg.do_classification and self.cfg.lowerdim else None,
+                                  "class label")
         self._enter()
         _lib.call("skf_model_forward_backward", self.handle, self._p(inp), self._p(tar), self._ld(tar), self._p(labels),
                   self._stream())
@@ -293,19 +310,27 @@ class TrainEngine:
         on a communication stream as soon as backward has finished it (bucket 0 = decoder part, overlaps the encoder
         backward; bucket 1 overlaps the optimizer sweep of bucket 0), then the optimizer runs per bucket with the 1/W
         factor fused.  ``bucketed=True`` forces that schedule without a process group (single-GPU test of the plumbing)."""
+        from . import parallel
         if bucketed is None:
-            bucketed = self.world_size > 1
+            bucketed = self.world_size > 1 and self.dp_mode == "bucketed"
         self._enter()
         if not bucketed:
-            _lib.call("skf_model_apply_gradients", self.handle, 1.0, self._stream())
+            scale = 1.0
+            if self.world_size > 1:       # one all-reduce of the whole flat buffer, ordered after backward on the step's stream
+                with torch.cuda.stream(self.stream):
+                    scale = parallel.allreduce_flat_gradients(self.grads, self.pg)
+            _lib.call("skf_model_apply_gradients", self.handle, scale, self._stream())
             self._leave()
             return
-        from . import parallel
         if self._comm is None:
             self._comm = torch.cuda.Stream(device=self.device)
         buckets = self.grad_buckets()
         scale = 1.0 / max(self.world_size, 1)
         works = []
+        if self.cfg.use_graph:
+            # a step replayed from a hipGraph records no per-bucket events (one bucket): the communication stream must be
+            # ordered after the whole captured forward/backward, or the all-reduce would race with the gradient writes
+            self._comm.wait_stream(self.stream)
         for i, (off, cnt) in enumerate(buckets):
             _lib.call("skf_model_wait_grad_bucket", self.handle, i, C.c_void_p(self._comm.cuda_stream))
             with torch.cuda.stream(self._comm):
@@ -345,6 +370,53 @@ class TrainEngine:
 
     def reset_metrics(self):
         self.metrics.zero_()
+
+    def metrics_snapshot(self):
+        """Device copy of the 32 metric floats as they stand after the steps queued so far (no host sync): what
+        ``train_on_batch`` hands back; ``resolve_metrics`` turns a list of them into floats with ONE read-back."""
+        with torch.cuda.stream(self.stream):
+            snap = self.metrics.clone()
+        return snap
+
+    def resolve_metrics(self, snaps):
+        """[snapshot] -> [running-metric dict].  One device->host copy for the whole list; under data parallelism the
+        (sum, count) accumulators are summed over the ranks first (all-reduce only when metrics are read),
+        so every rank must call this with the same number of snapshots."""
+        if not snaps:
+            return []
+        with torch.cuda.stream(self.stream):
+            m = torch.stack(list(snaps))
+            if self.world_size > 1:
+                acc = torch.cat([m[:, 8:13], m[:, 16:21]], dim=1).contiguous()
+                torch.distributed.all_reduce(acc, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+                m = m.clone()
+                m[:, 8:13], m[:, 16:21] = acc[:, :5], acc[:, 5:]
+        self.stream.synchronize()
+        rows = m.cpu().numpy()
+        return [{n: float(r[8 + i] / r[16 + i]) if r[16 + i] else 0.0 for i, n in enumerate(METRIC_NAMES)} for r in rows]
+
+    def assert_replicas_equal(self):
+        """Data parallelism keeps W copies of the parameters / optimizer state in step only if they start equal: compare
+        every rank's flat buffers with rank 0's (one broadcast each) and raise on any difference."""
+        if self.world_size <= 1:
+            return
+        import torch.distributed as dist
+        src = dist.get_global_rank(self.pg, 0) if self.pg is not None else 0
+        bad = torch.zeros(1, dtype=torch.int32, device=self.device)
+        for name in ("params", "adam_m", "adam_v"):
+            mine = getattr(self, name)
+            ref = mine.clone()
+            dist.broadcast(ref, src=src, group=self.pg)
+            if not torch.equal(ref, mine):
+                bad += 1
+        its = self.state[:1].clone()
+        dist.broadcast(its, src=src, group=self.pg)
+        if int(its.item()) != self.iterations:
+            bad += 1
+        dist.all_reduce(bad, op=dist.ReduceOp.SUM, group=self.pg)
+        if int(bad.item()):
+            raise _lib.SkfError("data-parallel replicas differ at start (parameters / optimizer state / iterations): "
+                                "every rank must build the model with the same init_seed and restore the same checkpoint")
 
     @property
     def iterations(self):

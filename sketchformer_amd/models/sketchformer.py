@@ -2,12 +2,56 @@
 TrainEngine (the C-ABI HIP train step).  Same registry name, hparams, ctor, ``train_on_batch`` contract
 and metric names; the arithmetic runs in libskf.so - there is no CPU / eager fallback.
 """
+import zlib
+from collections.abc import Mapping
+
 import numpy as np
 
 from .. import builders
 from ..core.models import BaseModel
 from .evaluation_mixin import TransformerMetricsMixin
 from ..utils.hparams import HParams
+
+
+class DeferredMetrics(Mapping):
+    """What ``train_on_batch`` returns: the reference's {metric name: float} dict (models/sketchformer.py:351-359), read
+    back from the device only when somebody looks.  The reference pays one host sync per step for ``.numpy()``
+    (builders/keras_metrics.py:41-42); here the step only snapshots the 32 device floats, ``BaseModel.train`` resolves
+    all pending snapshots with ONE copy when it prints (``log_every``), and a caller that indexes / iterates the mapping
+    right away gets the same floats the reference would have returned (one sync, like the reference).  Under data
+    parallelism resolving all-reduces the (sum, count) accumulators, so every rank has to read the same steps."""
+
+    def __init__(self, engine, snapshot, drop):
+        self._engine, self._snap, self._drop, self._vals = engine, snapshot, drop, None
+
+    def resolve_with(self, vals):
+        self._vals = {k: v for k, v in vals.items() if k not in self._drop}
+        self._snap = None
+
+    def _resolved(self):
+        if self._vals is None:
+            self.resolve_with(self._engine.resolve_metrics([self._snap])[0])
+        return self._vals
+
+    @staticmethod
+    def resolve_all(pending):
+        """One read-back (and, data parallel, one all-reduce) for a list of unresolved results of the same engine."""
+        todo = [p for p in pending if p._vals is None]
+        if todo:
+            for p, vals in zip(todo, todo[0]._engine.resolve_metrics([p._snap for p in todo])):
+                p.resolve_with(vals)
+
+    def __getitem__(self, k):
+        return self._resolved()[k]
+
+    def __iter__(self):
+        return iter(self._resolved())
+
+    def __len__(self):
+        return len(self._resolved())
+
+    def __repr__(self):
+        return repr(self._resolved())
 
 
 class Transformer(BaseModel, TransformerMetricsMixin):
@@ -32,7 +76,7 @@ class Transformer(BaseModel, TransformerMetricsMixin):
         self.vocab_size = dataset.tokenizer.VOCAB_SIZE if not dataset.hps['use_continuous_data'] else None
         self.seq_len = dataset.hps['max_seq_len']
         self._device, self._pg, self._init_seed = device, process_group, init_seed
-        super().__init__(hps, dataset, out_dir, experiment_id)
+        super().__init__(hps, dataset, out_dir, experiment_id, process_group=process_group)
 
     def build_model(self):
         from .. import engine
@@ -67,23 +111,29 @@ class Transformer(BaseModel, TransformerMetricsMixin):
             blind_decoder_mask=h['blind_decoder_mask'], dropout_rate=h['dropout_rate'], recon_weight=h['recon_weight'],
             class_weight=h['class_weight'], lr_scheduler=h['lr_scheduler'], lr=h['lr'], use_graph=False,
             optimizer=h['optimizer'], class_buffer_layers=h['class_buffer_layers'], class_dropout=h['class_dropout'],
-            do_classification=h['do_classification'], do_reconstruction=h['do_reconstruction'])
+            do_classification=h['do_classification'], do_reconstruction=h['do_reconstruction'],
+            # dropout key = hash(seed, iterations): the seed differs per experiment id and per rank (ranks must
+            # draw independent masks, or W ranks at B rows are not one step at W*B rows); the weight init seed does NOT
+            # depend on the rank - replicas start identical (checked below)
+            seed=(zlib.crc32(str(self.experiment_id).encode()) + 0x9e3779b1 * self.rank) & 0xffffffff)
         self.engine = engine.TrainEngine(cfg, device=self._device, init_seed=self._init_seed, process_group=self._pg)
+        self.engine.assert_replicas_equal()
         self.trainable_variables = [e["name"] for e in self.engine.entries]
+        drop = set()
+        if self.dataset.hps['use_continuous_data'] or not h['do_reconstruction']:
+            drop.add('recon_acc')
+        if not h['do_reconstruction']:
+            drop.add('recon_loss')
+        if not self._has_cls:
+            drop.update(('class_loss', 'class_acc'))
+        self._dropped_metrics = drop
 
     # ---- the train step (models/sketchformer.py:351-359)
     def train_on_batch(self, batch):
         data, labels = batch
         self.engine.train_step(data, labels)
-        res = self.engine.running_metrics()          # Keras running metrics, read back every step like the reference
-        if self.dataset.hps['use_continuous_data'] or not self.hps['do_reconstruction']:
-            res.pop('recon_acc', None)
-        if not self.hps['do_reconstruction']:
-            res.pop('recon_loss', None)
-        if not self._has_cls:
-            res.pop('class_loss', None)
-            res.pop('class_acc', None)
-        return res
+        # the Keras running metrics of this step, as a mapping that is read back lazily (no host sync here)
+        return DeferredMetrics(self.engine, self.engine.metrics_snapshot(), self._dropped_metrics)
 
     def prepare_for_start_of_epoch(self):
         pass
@@ -194,6 +244,7 @@ class Transformer(BaseModel, TransformerMetricsMixin):
             e.state[0] = int(scalars['iterations'])
         self.current_step = int(scalars.get('current_step', scalars.get('iterations', 0)))
         torch.cuda.synchronize()
+        e.assert_replicas_equal()
 
     # ---- checkpoint payload
     def state_dict(self):
@@ -209,3 +260,4 @@ class Transformer(BaseModel, TransformerMetricsMixin):
         e.adam_v.copy_(state['adam_v'])
         e.metrics.copy_(state['metrics'])
         e.state[0] = int(state['iterations'])
+        e.assert_replicas_equal()

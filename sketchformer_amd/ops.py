@@ -23,6 +23,10 @@ def _p(t):
     return C.c_void_p(t.data_ptr())
 
 
+def _prec(precision):
+    return _lib.default_precision() if precision is None else int(precision)
+
+
 def _f32(t, name):
     if t.dtype != torch.float32:
         raise TypeError("%s must be float32" % name)
@@ -60,8 +64,9 @@ def read_step_state(state):
 
 
 def gemm(a, b, a_kcontig=True, b_kcontig=False, bias=None, act=0, relu_src=None, out=None, accumulate=False,
-         splits=1, bias_grad=None):
-    """C[M,N] (+)= opA(a) . opB(b).  a: [M,K] (a_kcontig) or [K,M]; b: [K,N] or [N,K] (b_kcontig)."""
+         splits=1, bias_grad=None, precision=None):
+    """C[M,N] (+)= opA(a) . opB(b).  a: [M,K] (a_kcontig) or [K,M]; b: [K,N] or [N,K] (b_kcontig).
+    precision: SKF_PREC_* (0 fp32 MFMA, 6 bf16x6, 3 bf16x3); None = _lib.default_precision()."""
     _f32(a, "a"); _f32(b, "b")
     M, K = (a.shape[0], a.shape[1]) if a_kcontig else (a.shape[1], a.shape[0])
     N = b.shape[0] if b_kcontig else b.shape[1]
@@ -75,11 +80,11 @@ def gemm(a, b, a_kcontig=True, b_kcontig=False, bias=None, act=0, relu_src=None,
         ws = _ws(wsb, a.device)
     _lib.call("skf_gemm_f32", int(a_kcontig), int(b_kcontig), M, N, K, _p(a), a.stride(0), _p(b), b.stride(0),
               _p(out), out.stride(0), _p(bias), act, _p(relu_src), relu_src.stride(0) if relu_src is not None else 0,
-              int(accumulate), splits, _p(bias_grad), 0, _p(ws), wsb, _stream())
+              int(accumulate), splits, _p(bias_grad), 0, _p(ws), wsb, _prec(precision), _stream())
     return out
 
 
-def attention_fwd(q, k, v, num_heads, key_mask=None, causal=False):
+def attention_fwd(q, k, v, num_heads, key_mask=None, causal=False, precision=None):
     """q (B,Lq,d) k,v (B,Lk,d) views with unit inner stride -> o (B,Lq,d), stats (B,H,Lq,2)."""
     B, Lq, d = q.shape
     Lk = k.shape[1]
@@ -87,7 +92,7 @@ def attention_fwd(q, k, v, num_heads, key_mask=None, causal=False):
     stats = torch.empty(B, num_heads, Lq, 2, dtype=torch.float32, device=q.device)
     _lib.call("skf_attention_fwd", _p(q), q.stride(1), _p(k), k.stride(1), _p(v), v.stride(1), _p(key_mask),
               key_mask.stride(0) if key_mask is not None else 0, int(causal), B, num_heads, Lq, Lk, d // num_heads,
-              _p(o), o.stride(1), _p(stats), _stream())
+              _p(o), o.stride(1), _p(stats), _prec(precision), _stream())
     return o, stats
 
 
@@ -106,7 +111,7 @@ def attention_decode(q, k, v, num_heads, n_keys=None, key_mask=None, key_limit=N
     return o
 
 
-def attention_bwd(q, k, v, o, do, stats, num_heads, key_mask=None, causal=False):
+def attention_bwd(q, k, v, o, do, stats, num_heads, key_mask=None, causal=False, precision=None):
     B, Lq, d = q.shape
     Lk = k.shape[1]
     dq = torch.empty(B, Lq, d, dtype=torch.float32, device=q.device)
@@ -115,7 +120,7 @@ def attention_bwd(q, k, v, o, do, stats, num_heads, key_mask=None, causal=False)
     _lib.call("skf_attention_bwd", _p(q), q.stride(1), _p(k), k.stride(1), _p(v), v.stride(1), _p(o), o.stride(1),
               _p(do), do.stride(1), _p(stats), _p(key_mask), key_mask.stride(0) if key_mask is not None else 0,
               int(causal), B, num_heads, Lq, Lk, d // num_heads, _p(dq), dq.stride(1), _p(dk), dk.stride(1),
-              _p(dv), dv.stride(1), _stream())
+              _p(dv), dv.stride(1), _prec(precision), _stream())
     return dq, dk, dv
 
 

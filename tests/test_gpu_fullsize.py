@@ -1,0 +1,141 @@
+"""Model-level oracle parity at the REAL BASELINE dimensions (SURVEY 8(c) "Acceptance on GPU"):
+
+  cfg 1: 4L/8H/d128/dff512, L=200, V=1004, C=1      (models/sketchformer.py:27-52 defaults)
+  cfg 2: the same with C=345
+  cfg 3: 6L/8H/d256/dff1024, L=200, continuous stroke-5 input (use_continuous_data=True), C=345
+
+with a small batch so that the float64 oracle costs seconds, in both Dense arithmetic modes (0 = fp32 MFMA,
+6 = exact bf16x6 split).  Checked against the oracle on identical parameters and inputs
+(models/sketchformer.py:131-181 call, :325-349 model_trainer):
+  forward logits rel <= 1e-3 (north star; achieved value printed), token argmax identical wherever the oracle's
+  top-2 margin > 1e-4 (count below margin printed), losses <= 1e-5, every gradient <= 1e-3 (per-tensor max-norm),
+  and a 3-step Adam trajectory from iterations = 3000 (lr ~ 1e-3) incl. the running Keras metrics.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from sketchformer_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+CFGS = {
+    "cfg1": dict(kw=dict(seq_len=200, d_model=128, num_heads=8, dff=512, num_layers=4, vocab_size=1004, n_classes=1,
+                         lowerdim=256), continuous=False),
+    "cfg2": dict(kw=dict(seq_len=200, d_model=128, num_heads=8, dff=512, num_layers=4, vocab_size=1004, n_classes=345,
+                         lowerdim=256), continuous=False),
+    "cfg3": dict(kw=dict(seq_len=200, d_model=256, num_heads=8, dff=1024, num_layers=6, n_classes=345, lowerdim=256),
+                 continuous=True),
+}
+
+
+def _build(name, B, mode, rate=0.0, use_graph=False):
+    from sketchformer_amd import engine
+    spec = CFGS[name]
+    kw = dict(spec["kw"])
+    mk = dict(kw)
+    if spec["continuous"]:
+        mk.update(continuous=True, vocab_size=None)
+    cfg = engine.make_config(batch=B, dropout_rate=rate, use_graph=use_graph, seed=11, gemm_precision=mode, **mk)
+    eng = engine.TrainEngine(cfg, init_seed=1)
+    ocfg = oracle.Config(continuous=spec["continuous"], dropout_rate=rate, **kw)
+    rng = np.random.RandomState(9)
+    for e in eng.entries:                     # non-trivial biases / LayerNorm parameters
+        n = e["name"]
+        if n.endswith(("/bias", "/beta", "b_attn")):
+            eng.set(n, rng.normal(0, 0.1, engine.logical_shape(e)))
+        elif n.endswith("/gamma"):
+            eng.set(n, 1 + rng.normal(0, 0.1, engine.logical_shape(e)))
+    return eng, ocfg
+
+
+def _batch(name, B, ocfg, seed):
+    if CFGS[name]["continuous"]:
+        x, y = synthetic.continuous_batch(B, ocfg.seq_len, ocfg.n_classes, seed=seed)
+        x[0, 57:] = [0, 0, 0, 0, 1]
+        return x, y, x.astype(np.float64)
+    x, y = synthetic.token_batch(B, ocfg.seq_len, ocfg.vocab_size, ocfg.n_classes, seed=seed)
+    x[0, 57:] = 0                             # a short row beside whatever the generator drew
+    return x, y, x
+
+
+def _rel(got, want):
+    return np.abs(np.asarray(got, np.float64) - want).max() / max(np.abs(want).max(), 1e-30)
+
+
+@pytest.mark.parametrize("mode", [0, 6])
+@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg3"])
+def test_full_dims_forward_logits_argmax(name, mode):
+    B = 4
+    eng, ocfg = _build(name, B, mode)
+    x, y, xo = _batch(name, B, ocfg, seed=2)
+    P = {k: v.astype(np.float64) for k, v in eng.state_dict_numpy().items()}
+    out, _ = oracle.forward(P, ocfg, xo, xo[:, :-1], training=False)
+    eng.forward(x, training=False)
+    torch.cuda.synchronize()
+    want = out["recon"]
+    logits = eng.buffer("logits").cpu().numpy().reshape(want.shape)
+    r = _rel(logits, want)
+    r_emb = _rel(eng.buffer("embedding").cpu().numpy(), out["embedding"])
+    r_cls = _rel(eng.buffer("class_probs").cpu().numpy(), out["class"])
+    print("\n[%s mode %d] logits rel %.3e  embedding rel %.3e  class probs rel %.3e" % (name, mode, r, r_emb, r_cls))
+    assert r < 1e-3 and r_emb < 1e-3 and r_cls < 1e-3      # north star bar
+    assert r < 2e-4                                        # what the fp32 path actually achieves (regression guard)
+    if not CFGS[name]["continuous"]:
+        srt = np.sort(want, -1)
+        safe = (srt[..., -1] - srt[..., -2]) > 1e-4
+        print("[%s mode %d] argmax: %d of %d positions below the 1e-4 margin" % (name, mode, (~safe).sum(), safe.size))
+        assert safe.mean() > 0.99
+        assert np.array_equal(logits.argmax(-1)[safe], want.argmax(-1)[safe])
+
+
+@pytest.mark.parametrize("mode", [0, 6])
+@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg3"])
+def test_full_dims_losses_and_all_gradients(name, mode):
+    B = 4
+    eng, ocfg = _build(name, B, mode)
+    x, y, xo = _batch(name, B, ocfg, seed=3)
+    P = {k: v.astype(np.float64) for k, v in eng.state_dict_numpy().items()}
+    eng.forward_backward(x, None, y)
+    torch.cuda.synchronize()
+    losses, out, G = oracle.loss_and_grads(P, ocfg, xo, xo, y)
+    m = eng.step_metrics()
+    for k in ("recon_loss", "class_loss", "total_loss"):
+        assert abs(m[k] - losses[k]) < 1e-5 * max(1.0, abs(losses[k])), (k, m[k], losses[k])
+    got = eng.state_dict_numpy("grads")
+    floor = 1e-3 * np.median([np.abs(G[k]).max() for k in G])
+    rel = {k: np.abs(got[k].astype(np.float64) - G[k]).max() / max(np.abs(G[k]).max(), floor) for k in G}
+    worst = max((v, k) for k, v in rel.items())
+    print("\n[%s mode %d] worst gradient rel %.3e (%s), median %.3e over %d tensors" %
+          (name, mode, worst[0], worst[1], np.median(list(rel.values())), len(rel)))
+    assert worst[0] < 1e-3, worst
+    assert np.median(list(rel.values())) < 1e-4
+
+
+@pytest.mark.parametrize("mode", [0, 6])
+@pytest.mark.parametrize("name", ["cfg2", "cfg3"])
+def test_full_dims_adam_trajectory(name, mode):
+    B = 4
+    eng, ocfg = _build(name, B, mode, use_graph=(mode == 6))
+    P = {k: v.astype(np.float64) for k, v in eng.state_dict_numpy().items()}
+    st = oracle.TrainState.create(P)
+    st.iterations = 3000
+    eng.state[0] = 3000
+    for step in range(3):
+        x, y, xo = _batch(name, B, ocfg, seed=20 + step)
+        res, losses, _, _ = oracle.train_step(st, ocfg, xo, xo, y)
+        eng.train_step(x, y)
+        torch.cuda.synchronize()
+        m = eng.step_metrics()
+        assert abs(m["total_loss"] - losses["total_loss"]) < 1e-3 * abs(losses["total_loss"]), (step, m, losses)
+    assert eng.iterations == 3003
+    run = eng.running_metrics()
+    for k, v in res.items():
+        assert abs(run[k] - v) < 1e-3 * max(1.0, abs(v)), (k, run[k], v)
+    got = eng.state_dict_numpy()
+    # attention key biases have an analytically zero gradient: Adam turns their rounding noise into +-lr steps (in the
+    # reference too) and they cannot influence the loss - excluded, as in the small-size trajectory test
+    worst = max((np.abs(got[k] - st.params[k]).max(), k) for k in got if not k.endswith("wk/bias"))
+    print("\n[%s mode %d] 3-step trajectory: worst parameter abs diff %.3e (%s)" % (name, mode, worst[0], worst[1]))
+    assert worst[0] < 5e-4, worst

@@ -196,26 +196,21 @@ def test_full_size_training_agrees_between_dense_arithmetic_modes():
     bf16x6 split (the default) from the same initial weights and batches.  Both are fp32-accurate evaluations of the same
     step, so the loss curves agree to ~1e-4 and the trained weights stay within a few 1e-3 of each other (fp32 rounding
     differences amplified by 40 updates); the bf16x3 fast mode is NOT part of this bound."""
-    from sketchformer_amd import engine, _lib
-    lib = _lib.load()
-    start = lib.skf_get_gemm_precision()
+    from sketchformer_amd import engine
     B, L, V, C = 128, 200, 1004, 345
     batches = [synthetic.token_batch(B, L, V, C, seed=s) for s in range(4)]
     runs = {}
-    try:
-        for mode in (0, 6):
-            lib.skf_set_gemm_precision(mode)
-            eng = engine.TrainEngine(engine.make_config(batch=B, dropout_rate=0.1, use_graph=False, seed=3), init_seed=0)
-            losses = []
-            for it in range(40):
-                xs, ys = batches[it % 4]
-                eng.train_step(torch.from_numpy(xs).cuda(), torch.from_numpy(ys).cuda())
-                losses.append(eng.step_metrics()["total_loss"])
-            runs[mode] = (np.array(losses), {e["name"]: eng.get(e["name"]).astype(np.float64) for e in eng.entries[:40]})
-            del eng
-            torch.cuda.empty_cache()
-    finally:
-        lib.skf_set_gemm_precision(start)
+    for mode in (0, 6):
+        eng = engine.TrainEngine(engine.make_config(batch=B, dropout_rate=0.1, use_graph=False, seed=3, gemm_precision=mode),
+                                 init_seed=0)
+        losses = []
+        for it in range(40):
+            xs, ys = batches[it % 4]
+            eng.train_step(torch.from_numpy(xs).cuda(), torch.from_numpy(ys).cuda())
+            losses.append(eng.step_metrics()["total_loss"])
+        runs[mode] = (np.array(losses), {e["name"]: eng.get(e["name"]).astype(np.float64) for e in eng.entries[:40]})
+        del eng
+        torch.cuda.empty_cache()
     l0, l6 = runs[0][0], runs[6][0]
     assert np.all(np.isfinite(l0)) and np.all(np.isfinite(l6))
     assert l0[-1] < l0[5], "loss does not go down"          # lr = 0 on the first update, warm-up after
@@ -232,21 +227,18 @@ def test_full_size_forward_argmax_between_dense_arithmetic_modes():
     """north_star bar at the bench size: forward logits within 1e-3 relative and token argmax identical - here between the
     fp32-MFMA and the bf16x6 evaluation of the same weights (inference mode, cfg 2).  Argmax may only differ where the
     top-2 logit margin is below the fp32 noise of either evaluation (1e-4 of the logit scale)."""
-    from sketchformer_amd import engine, _lib
-    lib = _lib.load()
-    start = lib.skf_get_gemm_precision()
+    from sketchformer_amd import engine
     B, L, V, C = 128, 200, 1004, 345
     xs, _ = synthetic.token_batch(B, L, V, C, seed=5)
-    eng = engine.TrainEngine(engine.make_config(batch=B, dropout_rate=0.1, use_graph=False, seed=3), init_seed=0)
     out = {}
-    try:
-        for mode in (0, 6):
-            lib.skf_set_gemm_precision(mode)
-            eng.forward(torch.from_numpy(xs).cuda(), training=False)
-            eng.synchronize()
-            out[mode] = eng.buffer("logits").cpu().numpy().astype(np.float64)
-    finally:
-        lib.skf_set_gemm_precision(start)
+    for mode in (0, 6):          # same init seed = same weights
+        eng = engine.TrainEngine(engine.make_config(batch=B, dropout_rate=0.1, use_graph=False, seed=3, gemm_precision=mode),
+                                 init_seed=0)
+        eng.forward(torch.from_numpy(xs).cuda(), training=False)
+        eng.synchronize()
+        out[mode] = eng.buffer("logits").cpu().numpy().astype(np.float64)
+        del eng
+        torch.cuda.empty_cache()
     l0, l6 = out[0], out[6]
     scale = np.abs(l0).max()
     assert np.abs(l6 - l0).max() / scale < 1e-4, np.abs(l6 - l0).max() / scale      # bar: 1e-3

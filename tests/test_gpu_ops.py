@@ -86,11 +86,10 @@ def test_gemm_weight_stationary_path(ops, M, N, K):
 @pytest.mark.parametrize("M,N,K,bkc", [(2000, 128, 128, False), (1100, 384, 128, False), (1500, 128, 512, True),
                                        (1030, 256, 256, False), (1025, 1004, 128, False), (3001, 128, 384, True)])
 def test_gemm_arithmetic_modes(ops, M, N, K, bkc):
-    """skf_set_gemm_precision: 0 = fp32 MFMA, 6 = fp32 operands split exactly into three bf16 pieces (six products on
+    """The `precision` argument: 0 = fp32 MFMA, 6 = fp32 operands split exactly into three bf16 pieces (six products on
     the bf16 matrix cores), 3 = two pieces.  Against float64: bf16x6 is at least as accurate as the fp32-MFMA kernel,
     bf16x3 stays inside 1e-4 of sum|a||b| (north_star tolerance: 1e-3 relative)."""
     from sketchformer_amd import _lib
-    lib = _lib.load()
     rng = np.random.RandomState(M + N + K)
     x = rng.randn(M, K) * np.exp(rng.randn(M, 1))          # rows of very different magnitude
     w = rng.randn(N, K) if bkc else rng.randn(K, N)
@@ -99,17 +98,12 @@ def test_gemm_arithmetic_modes(ops, M, N, K, bkc):
     wm = wf.T.astype(np.float64) if bkc else wf.astype(np.float64)
     want = xf.astype(np.float64) @ wm + bf
     scale = np.abs(xf).astype(np.float64) @ np.abs(wm)
-    start = lib.skf_get_gemm_precision()
     err = {}
-    try:
-        for mode in (0, 6, 3):
-            assert lib.skf_set_gemm_precision(mode) == 0 and lib.skf_get_gemm_precision() == mode
-            y = ops.gemm(_dev(xf), _dev(wf), b_kcontig=bkc, bias=_dev(bf)).cpu().numpy().astype(np.float64)
-            err[mode] = np.abs(y - want) / scale
-        assert lib.skf_set_gemm_precision(5) != 0            # rejected, mode unchanged
-        assert lib.skf_get_gemm_precision() == 3
-    finally:
-        lib.skf_set_gemm_precision(start)
+    for mode in (0, 6, 3):
+        y = ops.gemm(_dev(xf), _dev(wf), b_kcontig=bkc, bias=_dev(bf), precision=mode).cpu().numpy().astype(np.float64)
+        err[mode] = np.abs(y - want) / scale
+    with pytest.raises(_lib.SkfError):                       # not a SKF_PREC_* value
+        ops.gemm(_dev(xf), _dev(wf), b_kcontig=bkc, bias=_dev(bf), precision=5)
     assert err[0].max() < 2e-6, err[0].max()
     assert err[6].max() < 2e-6 and err[6].mean() <= 1.25 * err[0].mean(), (err[6].max(), err[6].mean(), err[0].mean())
     assert err[3].max() < 1e-4, err[3].max()
@@ -141,19 +135,74 @@ def test_wgrad_arithmetic_modes(ops, rows, inf, outf):
     want = x.astype(np.float64).T @ dy.astype(np.float64)
     scale = np.abs(x).astype(np.float64).T @ np.abs(dy).astype(np.float64)
     splits = lib.skf_gemm_default_splits(inf, outf, rows)
-    start = lib.skf_get_gemm_precision()
     err = {}
-    try:
-        for mode in (0, 6):
-            lib.skf_set_gemm_precision(mode)
-            bg = torch.empty(outf, dtype=torch.float32, device="cuda")
-            dw = ops.gemm(_dev(x), _dev(dy), a_kcontig=False, b_kcontig=False, splits=splits, bias_grad=bg)
-            err[mode] = np.abs(dw.cpu().numpy().astype(np.float64) - want) / scale
-            np.testing.assert_allclose(bg.cpu().numpy(), dy.astype(np.float64).sum(0), rtol=1e-4, atol=1e-3 * np.abs(dy).sum(0).max() / rows ** 0.5)
-    finally:
-        lib.skf_set_gemm_precision(start)
+    for mode in (0, 6):
+        bg = torch.empty(outf, dtype=torch.float32, device="cuda")
+        dw = ops.gemm(_dev(x), _dev(dy), a_kcontig=False, b_kcontig=False, splits=splits, bias_grad=bg, precision=mode)
+        err[mode] = np.abs(dw.cpu().numpy().astype(np.float64) - want) / scale
+        np.testing.assert_allclose(bg.cpu().numpy(), dy.astype(np.float64).sum(0), rtol=1e-4, atol=1e-3 * np.abs(dy).sum(0).max() / rows ** 0.5)
     assert err[0].max() < 2e-6 and err[6].max() < 2e-6, (err[0].max(), err[6].max())
     assert err[6].mean() <= 1.25 * err[0].mean(), (err[6].mean(), err[0].mean())
+
+
+@pytest.mark.parametrize("kind", ["fwd", "dgrad", "wgrad"])
+def test_gemm_modes_extreme_operands(ops, kind):
+    """Robustness of the split arithmetic (mode 6) beside the fp32 MFMA (mode 0) on operands the randn tests never see:
+    rows / columns scaled over 1e+-30 (products up to 1e+-34, pieces far apart in exponent), fp32 subnormals, +-inf, NaN.
+    Defined behaviour (include/skf.h): finite results within one fp32 rounding of sum|a||b| plus the flush of pieces below
+    the bf16 normal range; an output is non-finite in mode 6 exactly where it is in mode 0 (and in float64 arithmetic on
+    the fp32 operands); the non-finite value itself may be NaN where mode 0 gives +-inf."""
+    rng = np.random.RandomState({"fwd": 1, "dgrad": 2, "wgrad": 3}[kind])
+    M, K, N = (1100, 128, 384) if kind != "wgrad" else (128, 4096, 384)        # wgrad: K = rows of the batch
+    a = rng.randn(M, K).astype(np.float32)
+    b = rng.randn(K, N).astype(np.float32)
+
+    def run(a, b, mode):
+        if kind == "fwd":
+            return ops.gemm(_dev(a), _dev(b), precision=mode).cpu().numpy()
+        if kind == "dgrad":
+            return ops.gemm(_dev(a), _dev(np.ascontiguousarray(b.T)), b_kcontig=True, precision=mode).cpu().numpy()
+        splits = 4
+        return ops.gemm(_dev(np.ascontiguousarray(a.T)), _dev(b), a_kcontig=False, b_kcontig=False, splits=splits,
+                        precision=mode).cpu().numpy()
+
+    # (1) huge dynamic range: rows of A scaled by 10^U(-30, 4), columns of B by 10^U(-4, 30) / 10^U(-30,-4) halves
+    ra = (10.0 ** rng.uniform(-30, 4, size=(M, 1))).astype(np.float32)
+    cb = (10.0 ** np.where(rng.rand(1, N) < 0.5, rng.uniform(-30, -4, size=(1, N)), rng.uniform(-4, 30, size=(1, N)))).astype(np.float32)
+    a1, b1 = a * ra, b * cb
+    want = a1.astype(np.float64) @ b1.astype(np.float64)
+    scale = np.abs(a1).astype(np.float64) @ np.abs(b1).astype(np.float64)
+    tiny = 2.0 ** -120 * K                                  # flushed sub-bf16-normal pieces / fp32 underflow of the products
+    for mode in (0, 6):
+        y = run(a1, b1, mode).astype(np.float64)
+        fin = np.isfinite(want.astype(np.float32))          # fp32 overflow of the exact result is legitimate
+        assert np.isfinite(y[fin & (np.abs(want) < 1e37)]).all(), mode
+        ok = fin & (np.abs(want) < 1e37)
+        err = np.abs(y - want)[ok] / (scale[ok] + tiny)
+        assert err.max() < 4e-6, (kind, mode, err.max())
+    # (2) fp32 subnormal operands beside normal ones: result error bounded by the flush (absolute), never NaN
+    a2 = a.copy(); a2[:, ::7] = (rng.randn(M, len(range(0, K, 7))) * 1e-41).astype(np.float32)
+    b2 = b.copy(); b2[::5, :] = (rng.randn(len(range(0, K, 5)), N) * 1e-42).astype(np.float32)
+    want = a2.astype(np.float64) @ b2.astype(np.float64)
+    scale = np.abs(a2).astype(np.float64) @ np.abs(b2).astype(np.float64)
+    for mode in (0, 6):
+        y = run(a2, b2, mode).astype(np.float64)
+        assert np.isfinite(y).all()
+        assert (np.abs(y - want) / (scale + 1e-30)).max() < 4e-6, (kind, mode)
+    # (3) non-finite operands: the same output positions are non-finite in both modes, finite ones agree
+    a3, b3 = a.copy(), b.copy()
+    a3[3, 5] = np.inf; a3[17, 100] = -np.inf; a3[40, 0] = np.nan
+    b3[9, 11] = np.inf; b3[77, 200] = np.nan
+    with np.errstate(invalid="ignore", over="ignore"):
+        want = a3.astype(np.float64) @ b3.astype(np.float64)
+    y0, y6 = run(a3, b3, 0), run(a3, b3, 6)
+    nf = ~np.isfinite(want)
+    assert nf.any() and (~nf).any()
+    assert np.array_equal(~np.isfinite(y0), nf), "mode 0: non-finite outputs differ from IEEE arithmetic"
+    assert np.array_equal(~np.isfinite(y6), nf), "mode 6: non-finite outputs differ from mode 0"
+    assert np.array_equal(np.isnan(y0), np.isnan(want.astype(np.float32)))     # the fp32 MFMA keeps inf vs NaN like IEEE
+    scale = np.abs(np.nan_to_num(a3, posinf=0, neginf=0)).astype(np.float64) @ np.abs(np.nan_to_num(b3, posinf=0, neginf=0)).astype(np.float64)
+    assert (np.abs(y6.astype(np.float64) - want)[~nf] / scale[~nf]).max() < 2e-6
 
 
 def test_gemm_strided_views(ops):

@@ -1,7 +1,10 @@
-"""Data-parallel train step end to end on ONE GPU: two processes share cuda:0 and all-reduce through gloo (RCCL refuses
-two ranks on one device; the schedule under test - gradient buckets, ready events, communication stream, per-bucket
-optimizer - is backend independent).  K6 of SURVEY 8(c) on the device path: W ranks x B_local rows == one engine at
-batch W*B_local."""
+"""Data-parallel train step end to end.  K6 of SURVEY 8(c) on the device path: W ranks x B_local rows == one engine
+at batch W*B_local, replicas stay bit-identical.
+  * one GPU visible: two processes share cuda:0 and all-reduce through gloo (RCCL refuses two ranks on one device; the
+    schedule under test - gradient buckets, ready events, communication stream, per-bucket optimizer - is backend
+    independent), eager and hipGraph-replayed steps, bucketed and single whole-buffer all-reduce;
+  * >= 2 GPUs visible: the same test on the real backend ("nccl" = RCCL over xGMI), one rank per device - skipped
+    otherwise (the driver's 8-GPU box runs it)."""
 import os
 import socket
 
@@ -22,17 +25,21 @@ def _batches(world):
     return [synthetic.token_batch(B_LOCAL * world, KW["seq_len"], KW["vocab_size"], KW["n_classes"], seed=70 + s) for s in range(STEPS)]
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, backend, use_graph, dp_mode):
+    local = rank if backend == "nccl" else 0
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK="0")
+                      LOCAL_RANK=str(local), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import faulthandler
-    faulthandler.dump_traceback_later(90, exit=True)      # a wedged collective must not hold the GPU box
+    faulthandler.dump_traceback_later(120, exit=True)     # a wedged collective must not hold the GPU box
     import torch.distributed as dist
     from sketchformer_amd import engine, parallel
-    torch.cuda.set_device(0)
-    _, _, _, pg = parallel.init_from_env(backend="gloo")
-    eng = engine.TrainEngine(engine.make_config(batch=B_LOCAL, **KW), init_seed=1, process_group=pg)
-    assert eng.world_size == world and len(eng.grad_buckets()) == 2
+    torch.cuda.set_device(local)
+    _, _, _, pg = parallel.init_from_env(backend=backend)
+    kw = dict(KW, use_graph=use_graph)
+    eng = engine.TrainEngine(engine.make_config(batch=B_LOCAL, **kw), init_seed=1, process_group=pg)
+    eng.dp_mode = dp_mode
+    assert eng.world_size == world and len(eng.grad_buckets()) == (1 if use_graph else 2)
+    eng.assert_replicas_equal()
     eng.state[0] = START
     for x, y in _batches(world):
         xs, ys = parallel.shard_batch(x, y, rank, world)
@@ -47,14 +54,19 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_ranks_equal_one_engine_at_double_batch(tmp_path):
+@pytest.mark.parametrize("backend,use_graph,dp_mode", [("gloo", False, "bucketed"), ("gloo", True, "bucketed"),
+                                                       ("gloo", False, "single"), ("nccl", False, "bucketed"),
+                                                       ("nccl", True, "bucketed"), ("nccl", False, "single")])
+def test_two_ranks_equal_one_engine_at_double_batch(tmp_path, backend, use_graph, dp_mode):
     from sketchformer_amd import engine
     world = 2
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("the RCCL run needs >= 2 visible GPUs (one rank per device)")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = str(tmp_path / "rank0.npz")
-    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, out, backend, use_graph, dp_mode), nprocs=world, join=True)
     res = np.load(out)
     flat, spread, iters = res["flat"], float(res["spread"]), int(res["iters"])
     assert spread == 0.0 and iters == START + STEPS          # replicas stay identical

@@ -41,11 +41,9 @@ for K, N, bkc in SHAPES:
     out = torch.empty(M, N, device=dev)
     line = "K=%3d N=%4d %s " % (K, N, "B[N][K]" if bkc else "B[K][N]")
     for mode in (0, 6, 3):
-        lib.skf_set_gemm_precision(mode)
-        fn = lambda: ops.gemm(ad, bd, True, bkc, bias=biasd, out=out)
+        fn = lambda mode=mode: ops.gemm(ad, bd, True, bkc, bias=biasd, out=out, precision=mode)
         fn()
         err = (out.cpu().double() - ref).abs()
         us = timeit(fn)
         line += "| %s %6.1f us err max %.1e mean %.1e " % ({0: "f32   ", 6: "bf16x6", 3: "bf16x3"}[mode], us, err.max().item(), err.mean().item())
     print(line, flush=True)
-lib.skf_set_gemm_precision(0)
