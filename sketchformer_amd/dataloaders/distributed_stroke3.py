@@ -22,6 +22,36 @@ def get_bounds(stroke3, factor=1.0):
     return xs.min(), xs.max(), ys.min(), ys.max()
 
 
+def augment_strokes(strokes, prob, urnd):
+    """utils/sketch.py:127-149 (random point dropping inside a stroke) without the Python loop.  ``urnd``: one uniform
+    draw per point, in order (the reference calls np.random.rand() once per point whether it is used or not).
+    The loop's state has a closed form: its `prev_stroke[2]` always equals the pen bit of the previous point (a dropped
+    point has pen 0 and so has the kept point it is merged into) and `count` is the distance to the last point where
+    either pen bit was 1 - so "dropped" is known per point, and the offsets of a run of dropped points are added, in
+    order and in the array's precision, to the kept point before them."""
+    s = np.asarray(strokes)
+    n = len(s)
+    if n == 0:
+        return np.array([])
+    pen = s[:, 2]
+    prev = np.concatenate([[1], pen[:-1]])
+    reset = (pen == 1) | (prev == 1)
+    idx = np.arange(n)
+    last_reset = np.maximum.accumulate(np.where(reset, idx, -1))        # index 0 always resets (prev = 1)
+    count = idx - last_reset
+    drop = (pen == 0) & (prev == 0) & (count > 2) & (np.asarray(urnd) < prob)
+    keep = ~drop
+    out = s[keep].copy()
+    if drop.any():
+        owner = np.cumsum(keep) - 1                  # kept point that absorbs a dropped one
+        run = idx - np.maximum.accumulate(np.where(keep, idx, -1))      # 1, 2, ... inside a run of dropped points
+        for k in range(1, int(run.max()) + 1):       # k-th dropped point of every run: sequential adds, like the loop
+            sel = drop & (run == k)
+            out[owner[sel], 0] += s[sel, 0]
+            out[owner[sel], 1] += s[sel, 1]
+    return out
+
+
 class DistributedStroke3DataLoader(BaseDataLoader):
     name = "stroke3-distributed"
 
@@ -80,27 +110,36 @@ class DistributedStroke3DataLoader(BaseDataLoader):
         """One block of sketches as padded (N, T) planes x / y / pen (reductions and scans run along the contiguous
         axis).  Every floating-point step repeats the per-sketch code's operations in the same order and precision."""
         L, N = self.hps["max_seq_len"], len(data)
+        do_aug = augment and self.hps["augment_stroke_prob"] > 0 and self.hps["use_continuous_data"]
+        if do_aug:
+            # scale + point dropping change the lengths: done per sketch (array operations inside a sketch, the random
+            # stream consumed in the per-sketch order: two draws, then one per point), the rest of the pipeline below
+            # runs on the block
+            data = [self._augment_sketch(np.array(np.clip(s, -self.limit, self.limit), dtype=np.float32)) for s in data]
+            if min(len(s) for s in data) == 0:
+                return self.preprocess_per_sketch_from(data)
         lens = np.fromiter((len(s) for s in data), dtype=np.int64, count=N)
         T = int(lens.max())
         rows = np.repeat(np.arange(N), lens)
         cols = np.arange(int(lens.sum())) - np.repeat(np.cumsum(lens) - lens, lens)
-        flat = np.clip(np.concatenate([np.asarray(s)[:, :3] for s in data], axis=0), -self.limit, self.limit).astype(np.float32)
+        flat = np.concatenate([np.asarray(s)[:, :3] for s in data], axis=0)
+        if not do_aug:                     # (augmented sketches were clamped before the augmentation, like the reference)
+            flat = np.clip(flat, -self.limit, self.limit)
+        flat = flat.astype(np.float32)
         X = np.zeros((N, T), dtype=np.float32); Y = np.zeros((N, T), dtype=np.float32); Pn = np.zeros((N, T), dtype=np.float32)
         X[rows, cols], Y[rows, cols], Pn[rows, cols] = flat[:, 0], flat[:, 1], flat[:, 2]
         ar = np.arange(T)[None, :]
         valid = ar < lens[:, None]
-        if augment and self.hps["augment_stroke_prob"] > 0 and self.hps["use_continuous_data"]:
-            e = self.hps["random_scale_factor"]
-            f = (np.random.random(size=(N, 2)) - 0.5) * 2 * e + 1.0      # same stream order as two draws per sketch
-            X *= f[:, 0:1].astype(np.float32)
-            Y *= f[:, 1:2].astype(np.float32)
-        # normalise by the larger side of the bounding box of the absolute path (origin included)
+        # normalise by the larger side of the bounding box of the absolute path (origin included): the bounds are summed in
+        # float64 (utils/sketch.py:41-44 converts every offset with float()), the division `sketch[:, :2] /= max_dim`
+        # (dataloaders/distributed_stroke3.py:103-104) is a float32 operation - the Python-float divisor is rounded to
+        # the array's precision first
         X64, Y64 = X.astype(np.float64), Y.astype(np.float64)
-        cx, cy = np.cumsum(X64, axis=1), np.cumsum(Y64, axis=1)          # sequential adds per row, like np.cumsum per sketch
+        cx, cy = np.cumsum(X64, axis=1), np.cumsum(Y64, axis=1)          # sequential adds per row, like the loop per sketch
         dx = np.maximum(cx.max(axis=1), 0.0) - np.minimum(cx.min(axis=1), 0.0)
         dy = np.maximum(cy.max(axis=1), 0.0) - np.minimum(cy.min(axis=1), 0.0)
-        div = np.maximum(np.maximum(dx, dy), 1.0)[:, None]
-        X, Y = (X64 / div).astype(np.float32), (Y64 / div).astype(np.float32)
+        div = np.maximum(np.maximum(dx, dy), 1.0)[:, None].astype(np.float32)
+        X, Y = X / div, Y / div
         if self.hps["use_continuous_data"]:
             n = np.minimum(lens, L)
             Tc = min(T, L)
@@ -115,14 +154,15 @@ class DistributedStroke3DataLoader(BaseDataLoader):
             return out
         tok = self.tokenizer
         if isinstance(tok, GridTokenizer):
-            cx = ((np.cumsum(X.astype(np.float64), axis=1) + 1) * tok.r).astype(np.int64)
-            cy = ((np.cumsum(Y.astype(np.float64), axis=1) + 1) * tok.r).astype(np.int64)
+            one, r32 = np.float32(1), np.float32(tok.r)               # float32 throughout, like GridTokenizer.encode
+            cx = ((np.cumsum(X, axis=1, dtype=np.float32) + one) * r32).astype(np.int64)
+            cy = ((np.cumsum(Y, axis=1, dtype=np.float32) + one) * r32).astype(np.int64)
             cx[cx == tok.resolution] = tok.resolution - 1
             cy[cy == tok.resolution] = tok.resolution - 1
             ids = cx + cy * tok.resolution + 1
         else:                                                            # k-means dictionary: nearest centre per offset
             ids = np.zeros((N, T), dtype=np.int64)
-            ids[rows, cols] = tok.nearest_center(X[rows, cols].astype(np.float64), Y[rows, cols].astype(np.float64)) + 1
+            ids[rows, cols] = tok.nearest_center(X[rows, cols], Y[rows, cols]) + 1
         lift = (Pn == 1) & valid
         nlift = lift.sum(axis=1)
         before = np.cumsum(lift, axis=1) - lift
@@ -147,13 +187,24 @@ class DistributedStroke3DataLoader(BaseDataLoader):
         return out
 
     def preprocess_per_sketch(self, data, augment=False):
+        """The reference's loop (dataloaders/distributed_stroke3.py:90-125), one sketch at a time."""
         out = []
         for sketch in data:
             sketch = np.array(np.clip(sketch, -self.limit, self.limit), dtype=np.float32)
             if augment:
                 sketch = self._augment_sketch(sketch)
+            out.append(sketch)
+        return self.preprocess_per_sketch_from(out)
+
+    def preprocess_per_sketch_from(self, data):
+        """Everything after clamping / augmentation, per sketch (float32 stroke-3 arrays in)."""
+        out = []
+        for sketch in data:
+            if len(sketch) == 0:        # augmentation cannot empty a sketch, an empty input fails like the reference
+                raise IndexError("empty sketch")
             min_x, max_x, min_y, max_y = get_bounds(sketch)
-            sketch[:, :2] /= max([max_x - min_x, max_y - min_y, 1])
+            # a float32 division: the reference's bounds are Python floats, which numpy rounds to the array's precision
+            sketch[:, :2] /= np.float32(max([max_x - min_x, max_y - min_y, 1]))
             if self.hps["shuffle_stroke"] or self.hps["use_absolute_strokes"]:
                 raise NotImplementedError("shuffle_stroke / use_absolute_strokes are not implemented")
             if not self.hps["use_continuous_data"]:
@@ -181,10 +232,12 @@ class DistributedStroke3DataLoader(BaseDataLoader):
         return conv
 
     def _augment_sketch(self, sketch):
+        """dataloaders/distributed_stroke3.py:155-160: random_scale (:127-137) then utils.sketch.augment_strokes; the
+        random stream is consumed exactly like there: two draws for the scale factors, then one per point."""
         if self.hps["augment_stroke_prob"] > 0 and self.hps["use_continuous_data"]:
             e = self.hps["random_scale_factor"]
             res = np.copy(sketch)
-            res[:, 0] *= (np.random.random() - 0.5) * 2 * e + 1.0
-            res[:, 1] *= (np.random.random() - 0.5) * 2 * e + 1.0
-            return res          # point-dropping augmentation (utils/sketch.py:127-149) is not ported
+            res[:, 0] *= np.float32((np.random.random() - 0.5) * 2 * e + 1.0)
+            res[:, 1] *= np.float32((np.random.random() - 0.5) * 2 * e + 1.0)
+            return augment_strokes(res, self.hps["augment_stroke_prob"], np.random.random(size=len(res)))
         return sketch

@@ -35,9 +35,14 @@ class GridTokenizer(object):
         self.VOCAB_SIZE = self.resolution ** 2 + 4
 
     def encode(self, stroke3, seq_len=0):
-        s = np.asarray(stroke3, dtype=np.float64)
-        xy = np.cumsum(s[:, :2], axis=0)                      # absolute positions (strokes_to_lines, scale 1)
-        cell = np.int64((xy + 1) * self.r)
+        # utils/skt_tools.py:80-88 accumulates the offsets one by one in the dtype of the input (float32 from the loader,
+        # dataloaders/distributed_stroke3.py:96) and utils/tokenizer.py:139-142 bins in that dtype too: np.cumsum is the
+        # same sequential sum, and staying in the input precision keeps points on cell borders in the reference's cell
+        s = np.asarray(stroke3)
+        if s.dtype not in (np.float32, np.float64):
+            s = s.astype(np.float64)
+        xy = np.cumsum(s[:, :2], axis=0, dtype=s.dtype)       # absolute positions (strokes_to_lines, scale 1)
+        cell = np.int64((xy + s.dtype.type(1)) * s.dtype.type(self.r))
         cell[cell == self.resolution] = self.resolution - 1   # upper bound lands in the last cell
         ids = (cell[:, 0] + cell[:, 1] * self.resolution + 1).tolist()
         out = [self.SOS]
@@ -95,11 +100,16 @@ class Tokenizer(object):
     def nearest_center(self, x, y):
         """Index of the closest dictionary centre for every offset (x[i], y[i]) (what KMeans.predict computes);
         squared distances (x-cx)^2 + (y-cy)^2 in float64, first minimum wins; chunked to bound the temporaries."""
-        x, y = np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)
+        x, y = np.asarray(x), np.asarray(y)
         if hasattr(self.dict, "predict") and x.shape[0]:
             # the pickled dictionary is the reference's sklearn KMeans: one predict call for all points of a block
-            # (utils/tokenizer.py:43 calls it per sketch); 40x faster than the numpy fallback below, same labels
-            return np.asarray(self.dict.predict(np.stack([x, y], axis=1).astype(self.centers.dtype)), dtype=np.int64)
+            # (utils/tokenizer.py:43 calls it per sketch); 40x faster than the numpy fallback below.  sklearn computes in
+            # the dtype of the fitted centres - float32 for a dictionary made by prep_data/sketch_token/
+            # create_token_dict.py:52 from float32 offsets, the dtype the loader's offsets have too (current sklearn
+            # refuses a float32 / float64 mix, older versions upcast both) - so the points are cast to that dtype
+            pts = np.stack([x, y], axis=1).astype(np.asarray(self.dict.cluster_centers_).dtype)
+            return np.asarray(self.dict.predict(pts), dtype=np.int64)
+        x, y = x.astype(np.float64), y.astype(np.float64)
         out = np.empty(x.shape[0], dtype=np.int64)
         cx, cy = self.centers[None, :, 0], self.centers[None, :, 1]
         for i in range(0, x.shape[0], 2048):
@@ -108,7 +118,7 @@ class Tokenizer(object):
         return out
 
     def encode(self, stroke3, seq_len=0):
-        s = np.asarray(stroke3, dtype=np.float64)
+        s = np.asarray(stroke3)
         ids = (self.nearest_center(s[:, 0], s[:, 1]) + 1).tolist()
         out = [self.SOS]
         for tok, pen in zip(ids, s[:, 2]):

@@ -9,7 +9,12 @@ they are stubbed in sys.modules; only numpy code paths of the reference are exec
                                                   dataloaders/distributed_stroke3.py:14-26)
   * utils.tokenizer.GridTokenizer encode/decode  (utils/tokenizer.py:104-198)
   * DistributedStroke3DataLoader.preprocess / _cap_pad_and_convert_sketch on seeded synthetic sketches
-                                                 (dataloaders/distributed_stroke3.py:90-153)
+                                                 (dataloaders/distributed_stroke3.py:90-153), grid / dictionary tokens
+                                                 and stroke-5, with and without augmentation (:155-160)
+  * utils.tokenizer.Tokenizer (k-means dictionary) special ids, encode / decode against a synthetic
+    MiniBatchKMeans(n_clusters=1000, random_state=0) pickle    (utils/tokenizer.py:16-101)
+  * utils.sketch.augment_strokes                 (utils/sketch.py:127-149)
+  * the --help-hps listing of README.md:56-97 (parsed from the README text: data, not code)
 
 Only data (inputs and expected outputs) is written - no reference source text.
 Run:  python tests/golden/make_goldens.py
@@ -156,6 +161,96 @@ def main():
     out["loader_preprocess"] = {"raw": [r.tolist() for r in raw], "max_seq_len": 32,
                                 "grid_tokens": np.asarray(grid).tolist(), "grid_dtype": str(np.asarray(grid).dtype),
                                 "continuous": np.asarray(cont).tolist(), "continuous_dtype": str(np.asarray(cont).dtype)}
+
+    # ---- dictionary Tokenizer (utils/tokenizer.py:16-101) against a synthetic k-means dictionary.  The dictionary is fit
+    # on float32 offsets like prep_data/sketch_token/create_token_dict.py:52 makes them; the fixture stores its centres
+    # so that the test does not depend on re-running the fit.
+    import pickle
+    import tempfile
+    from sklearn.cluster import MiniBatchKMeans
+    drng = np.random.RandomState(0)
+    pts = np.concatenate([drng.normal(0, 0.05, size=(60000, 2)), drng.uniform(-0.5, 0.5, size=(20000, 2))]).astype(np.float32)
+    km = MiniBatchKMeans(n_clusters=1000, random_state=0, n_init=1, batch_size=4096, max_iter=5).fit(pts)
+    assert km.cluster_centers_.dtype == np.float32
+    tmpd = tempfile.mkdtemp()
+    dict_path = os.path.join(tmpd, "token_dict.pkl")
+    with open(dict_path, "wb") as f:
+        pickle.dump(km, f)
+    dtok = utils.Tokenizer(dict_path)
+    out["dict_tokenizer_ids"] = {"PAD": dtok.PAD, "SEP": dtok.SEP, "SOS": dtok.SOS, "EOS": dtok.EOS, "VOCAB_SIZE": dtok.VOCAB_SIZE}
+    out["dict_tokenizer_centers"] = {"dtype": str(km.cluster_centers_.dtype), "hex": km.cluster_centers_.tobytes().hex(),
+                                     "sha256": hashlib.sha256(km.cluster_centers_.tobytes()).hexdigest()}
+    denc = []
+    for n in (1, 4, 9, 33, 120):
+        s3 = np.zeros((n, 3), dtype=np.float32)
+        s3[:, :2] = drng.normal(0, 0.06, size=(n, 2))
+        s3[:, 2] = drng.rand(n) < 0.2
+        s3[-1, 2] = 1
+        e = dtok.encode(s3.copy())
+        e_pad = dtok.encode(s3.copy(), seq_len=n + 12)
+        dec = dtok.decode(e)
+        denc.append({"stroke3": s3.tolist(), "tokens": [int(v) for v in e], "tokens_seq_len": [int(v) for v in e_pad],
+                     "decoded": np.asarray(dec, dtype=np.float64).tolist()})
+    tok_cap = utils.Tokenizer(dict_path, max_seq_len=16)          # the max_seq_len branch: pad / truncate with SEP, EOS
+    for item, n in zip(denc, (1, 4, 9, 33, 120)):
+        item["tokens_max16"] = [int(v) for v in tok_cap.encode(np.array(item["stroke3"], dtype=np.float32))]
+    out["dict_tokenizer"] = denc
+    out["dict_tokenizer_decode_list"] = [np.asarray(a, dtype=np.float64).tolist() for a in
+                                         dtok.decode([np.array(denc[1]["tokens"]), np.array(denc[2]["tokens"])])]
+    out["dict_tokenizer_decode_empty"] = np.asarray(dtok.decode([dtok.SOS, dtok.EOS])).tolist()
+
+    # ---- loader preprocessing with the dictionary tokenizer, and with augmentation (continuous mode only, :155-160)
+    raw2 = []
+    for n in (3, 25, 70, 150, 260):
+        s3 = np.zeros((n, 3), dtype=np.float32)
+        s3[:, :2] = rng.randint(-40, 40, size=(n, 2))
+        s3[:, 2] = (rng.rand(n) < 0.12)
+        s3[-1, 2] = 1
+        raw2.append(s3)
+    raw2[2][5, 1] = -7000.0
+    ldd = make_loader(token_type="dictionary")
+    ldd.tokenizer = dtok
+    dict_tokens = ldd.preprocess([r.copy() for r in raw2], augment=False)
+    ldg = make_loader()
+    grid2 = ldg.preprocess([r.copy() for r in raw2], augment=False)
+    lda = make_loader(use_continuous_data=True)
+    cont2 = lda.preprocess([r.copy() for r in raw2], augment=False)
+    np.random.seed(1234)
+    cont_aug = lda.preprocess([r.copy() for r in raw2], augment=True)
+    np.random.seed(99)
+    grid_aug = ldg.preprocess([r.copy() for r in raw2], augment=True)       # token mode: augment is a no-op, no draws
+    after = float(np.random.random())
+    np.random.seed(99)
+    assert after == float(np.random.random())
+    out["loader_preprocess2"] = {"raw": [r.tolist() for r in raw2], "max_seq_len": 32,
+                                 "dict_tokens": np.asarray(dict_tokens).tolist(), "grid_tokens": np.asarray(grid2).tolist(),
+                                 "continuous_hex": np.asarray(cont2, dtype=np.float64).tobytes().hex(),
+                                 "continuous_aug_seed": 1234,
+                                 "continuous_aug_hex": np.asarray(cont_aug, dtype=np.float64).tobytes().hex(),
+                                 "grid_aug_equals_plain": bool(np.array_equal(grid_aug, grid2))}
+
+    # ---- utils.sketch.augment_strokes on its own
+    import utils.sketch as ref_sketch
+    aug_cases = []
+    for n, prob, seed in ((40, 0.1, 0), (200, 0.5, 1), (90, 0.9, 2), (5, 0.9, 3)):
+        s3 = np.zeros((n, 3), dtype=np.float32)
+        s3[:, :2] = rng.normal(0, 3, size=(n, 2))
+        s3[:, 2] = (rng.rand(n) < 0.08)
+        np.random.seed(seed)
+        res = ref_sketch.augment_strokes(s3.copy(), prob)
+        aug_cases.append({"stroke3_hex": s3.tobytes().hex(), "n": n, "prob": prob, "seed": seed,
+                          "dtype": str(np.asarray(res).dtype), "shape": list(np.asarray(res).shape),
+                          "result_hex": np.ascontiguousarray(res).tobytes().hex()})
+    out["augment_strokes"] = aug_cases
+
+    # ---- README.md:56-97: the three default-parameter listings printed by --help-hps
+    import ast
+    import re
+    readme = open(os.path.join(REF, "README.md")).read()
+    blocks = re.findall(r"default parameters:\s*\n(\{.*?\})", readme, flags=re.S)
+    assert len(blocks) == 3, len(blocks)
+    out["readme_help_hps"] = {"base": ast.literal_eval(blocks[0]), "model": ast.literal_eval(blocks[1]),
+                              "loader": ast.literal_eval(blocks[2])}
 
     def default(o):
         if isinstance(o, (np.integer,)):

@@ -98,7 +98,104 @@ def test_loader_preprocess_matches_reference():
     grid = mk().preprocess([r.copy() for r in raw], augment=False)
     assert grid.shape == np.array(want["grid_tokens"]).shape and np.array_equal(grid, np.array(want["grid_tokens"]))
     cont = mk(use_continuous_data=True).preprocess([r.copy() for r in raw], augment=False)
-    np.testing.assert_allclose(cont, np.array(want["continuous"]), atol=1e-6)
+    assert np.array_equal(cont, np.array(want["continuous"]))       # bit for bit (float32 division like the reference)
+
+
+def _golden_dictionary(tmp_path):
+    """The synthetic k-means dictionary of the goldens as a pickle: a sklearn KMeans carrying the stored float32 centres
+    (re-running the fit is not needed and would tie the test to sklearn's RNG details)."""
+    import pickle
+    from sklearn.cluster import KMeans
+    c = np.frombuffer(bytes.fromhex(G["dict_tokenizer_centers"]["hex"]), dtype=np.float32).reshape(-1, 2)
+    assert hashlib.sha256(c.tobytes()).hexdigest() == G["dict_tokenizer_centers"]["sha256"]
+    km = KMeans(n_clusters=len(c))
+    km.cluster_centers_, km._n_threads, km.n_features_in_ = c.copy(), 1, 2
+    path = str(tmp_path / "token_dict.pkl")
+    with open(path, "wb") as f:
+        pickle.dump(km, f)
+    return path
+
+
+def test_dictionary_tokenizer_matches_reference(tmp_path):
+    """SURVEY 8(c) golden item 3: utils/tokenizer.py:16-101 - special ids, encode (SEP insertion, seq_len padding, the
+    max_seq_len pad / truncate branch), decode (single, list, empty) against the reference run on the same dictionary."""
+    from sketchformer_amd.utils import Tokenizer
+    path = _golden_dictionary(tmp_path)
+    tok = Tokenizer(path)
+    assert {k: getattr(tok, k) for k in ("PAD", "SEP", "SOS", "EOS", "VOCAB_SIZE")} == G["dict_tokenizer_ids"]
+    assert tok.VOCAB_SIZE == 1004                      # the vocabulary of BASELINE cfg 1 / 2
+    cap = Tokenizer(path, max_seq_len=16)
+    for case in G["dict_tokenizer"]:
+        s = np.array(case["stroke3"], dtype=np.float32)
+        assert tok.encode(s.copy()).tolist() == case["tokens"]
+        assert tok.encode(s.copy(), seq_len=len(s) + 12).tolist() == case["tokens_seq_len"]
+        assert cap.encode(s.copy()).tolist() == case["tokens_max16"]
+        dec = tok.decode(case["tokens"])
+        assert np.array_equal(np.asarray(dec, dtype=np.float64), np.array(case["decoded"]))
+    lst = tok.decode([np.array(G["dict_tokenizer"][1]["tokens"]), np.array(G["dict_tokenizer"][2]["tokens"])])
+    assert len(lst) == 2 and all(np.array_equal(np.asarray(a, np.float64), np.array(b))
+                                 for a, b in zip(lst, G["dict_tokenizer_decode_list"]))
+    assert np.array_equal(np.asarray(tok.decode([tok.SOS, tok.EOS])), np.array(G["dict_tokenizer_decode_empty"]))
+
+
+def test_loader_preprocess_dictionary_and_augmentation_match_reference(tmp_path):
+    """dataloaders/distributed_stroke3.py:90-160 run by the reference on the same sketches: dictionary / grid tokens and
+    stroke-5 rows bit for bit, incl. the training augmentation (random_scale + utils.sketch.augment_strokes) under the
+    same numpy seed; in token mode augmentation is a no-op that draws nothing."""
+    from sketchformer_amd import dataloaders
+    from sketchformer_amd.utils import GridTokenizer, Tokenizer
+    L = dataloaders.get_dataloader_by_name("stroke3-distributed")
+    want = G["loader_preprocess2"]
+    raw = [np.array(r, dtype=np.float32) for r in want["raw"]]
+
+    def mk(tokenizer, **over):
+        hps = L.default_hparams()
+        hps.parse("token_type=grid,max_seq_len=%d" % want["max_seq_len"])
+        for k, v in over.items():
+            hps.set_hparam(k, v)
+        obj = L.__new__(L)
+        obj.hps, obj.limit, obj.tokenizer = dict(hps.values()), 1000, tokenizer
+        return obj
+    f64 = lambda h: np.frombuffer(bytes.fromhex(h), dtype=np.float64).reshape(len(raw), want["max_seq_len"], 5)
+    ldd = mk(Tokenizer(_golden_dictionary(tmp_path)), token_type="dictionary")
+    ldg = mk(GridTokenizer(resolution=100))
+    ldc = mk(None, use_continuous_data=True)
+    for fn in ("preprocess", "preprocess_per_sketch"):            # the block path and the per-sketch definition
+        assert np.array_equal(getattr(ldd, fn)([r.copy() for r in raw], augment=False), np.array(want["dict_tokens"])), fn
+        assert np.array_equal(getattr(ldg, fn)([r.copy() for r in raw], augment=False), np.array(want["grid_tokens"])), fn
+        got = getattr(ldc, fn)([r.copy() for r in raw], augment=False)
+        assert got.dtype == np.float64 and np.array_equal(got, f64(want["continuous_hex"])), fn
+        np.random.seed(want["continuous_aug_seed"])
+        got = getattr(ldc, fn)([r.copy() for r in raw], augment=True)
+        assert np.array_equal(got, f64(want["continuous_aug_hex"])), fn
+        np.random.seed(99)
+        assert np.array_equal(getattr(ldg, fn)([r.copy() for r in raw], augment=True), np.array(want["grid_tokens"]))
+        after = np.random.random()
+        np.random.seed(99)
+        assert after == np.random.random() and want["grid_aug_equals_plain"]
+
+
+def test_augment_strokes_matches_reference():
+    """utils/sketch.py:127-149 under the reference's own random stream (one draw per point)."""
+    from sketchformer_amd.dataloaders.distributed_stroke3 import augment_strokes
+    for case in G["augment_strokes"]:
+        s = np.frombuffer(bytes.fromhex(case["stroke3_hex"]), dtype=np.float32).reshape(case["n"], 3)
+        np.random.seed(case["seed"])
+        got = augment_strokes(s.copy(), case["prob"], np.random.random(size=case["n"]))
+        want = np.frombuffer(bytes.fromhex(case["result_hex"]), dtype=np.dtype(case["dtype"])).reshape(case["shape"])
+        assert list(got.shape) == case["shape"] and np.array_equal(got.astype(want.dtype), want), case["n"]
+        assert got.shape[0] < case["n"] or case["prob"] < 0.5 or case["n"] < 8
+
+
+def test_default_hparams_equal_readme_listing():
+    """SURVEY 8(c) golden item 6: the --help-hps listing of the reference's README.md:56-97."""
+    from sketchformer_amd import models, dataloaders
+    M = models.get_model_by_name("sketch-transformer-tf2")
+    L = dataloaders.get_dataloader_by_name("stroke3-distributed")
+    R = G["readme_help_hps"]
+    assert M.base_default_hparams().values() == R["base"]
+    assert M.specific_default_hparams().values() == R["model"]
+    assert L.default_hparams().values() == R["loader"]
 
 
 def test_chunk_loader_end_to_end(tmp_path):
