@@ -237,6 +237,65 @@ int skf_decode_select_continuous(const float* pred, int ld, int B, int n_valid, 
                                  unsigned char* selfmask, int mask_ld, int* done_step, int* step_dev,
                                  const long long* dyn, skf_stream_t stream);
 
+/* ------------------------------------------------------------------ bf16 path (BASELINE cfg 5)
+ * bf16 storage + v_mfma_f32_32x32x16_bf16 with fp32 accumulation, fp32 master weights / optimizer state (SkfConfig.act_dtype
+ * = SKF_ACT_BF16).  `void*` tensors below are bf16 (2 bytes per element, pitches in elements); parameters, statistics,
+ * losses and parameter gradients stay fp32.  Same reference lines as the fp32 entries they mirror.
+ *
+ * Dense (builders/layers/transformer.py:154-158,196-197): C[M][N] (+)= A[M][K] . B_nk[N][K]^T (+bias) (act: 0 none, 1 relu,
+ * 2 tanh) (relu mask); both operands contraction-contiguous: the forward passes the [out][in] image of the weight, the input
+ * gradient the [in][out] image (skf_cast_weight_bf16 makes both from the fp32 master).  lda / ldb multiples of 8 and
+ * >= K rounded up to 8 (pad columns must hold zeros: they take part in the contraction); ldc, N multiples of 4.
+ * C_f32: optional fp32 copy of the result. */
+int skf_gemm_bf16(int M, int N, int K, const void* A, int lda, const void* B_nk, int ldb, void* C, int ldc, const float* bias,
+                  int act, const void* relu_src, int ld_relu, int accumulate, float* C_f32, int ldc_f32, skf_stream_t stream);
+/* weight gradient dW[P][Q] = sum_r X[r][P] dY[r][Q] (+ column sums of dY = bias gradient): fp32 partial tiles
+ * [splits][P][Q] (+ [splits][Q]) into `slab`, reduced by skf_splitk_reduce_batch like the fp32 path's. */
+int skf_gemm_bf16_wgrad_splits(int P, int Q, int R);
+size_t skf_gemm_bf16_wgrad_workspace_bytes(int P, int Q, int R, int splits);
+int skf_gemm_bf16_wgrad_partial(int P, int Q, int R, const void* X, int ldx, const void* dY, int lddy, int splits,
+                                int with_bias_grad, float* slab, size_t slab_bytes, int* splits_used_host, skf_stream_t stream);
+/* scaled_dot_product_attention (builders/utils.py:71-105), streaming / online softmax, head size 64, any Lq / Lk;
+ * mask semantics and `stats` as skf_attention_fwd.  The backward is two passes (dQ, then dK / dV) and needs
+ * skf_attention_bf16_bwd_workspace_bytes of scratch (rowsum(dO o O)). */
+int skf_attention_bf16_fwd(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const unsigned char* key_mask,
+                           int key_mask_ld, int causal, int B, int H, int Lq, int Lk, int dh, void* O, int ldo, float* stats,
+                           skf_stream_t stream);
+size_t skf_attention_bf16_bwd_workspace_bytes(int B, int H, int Lq);
+int skf_attention_bf16_bwd(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const void* O, int ldo,
+                           const void* dO, int lddo, const float* stats, const unsigned char* key_mask, int key_mask_ld,
+                           int causal, int B, int H, int Lq, int Lk, int dh, void* dQ, int lddq, void* dK, int lddk, void* dV,
+                           int lddv, void* workspace, size_t workspace_bytes, skf_stream_t stream);
+/* row kernels: the fp32 entries of the same name with bf16 activations (d in {128, 256, 512, 1024}) */
+int skf_embed_fwd_bf16(const long long* tokens, int tok_ld, int B, int L, const float* table, int vocab, int d, const float* pos,
+                       void* out, float rate, unsigned site, const void* step_state, skf_stream_t stream);
+int skf_embed_bwd_sorted_bf16(const void* ws, int B, int L, const void* dx, int vocab, int d, float* dtable, float rate,
+                              unsigned site, const void* step_state, skf_stream_t stream);
+int skf_layernorm_residual_fwd_bf16(const void* x, void* y_inout_z, const float* gamma, const float* beta, void* out,
+                                    float* stats, int rows, int d, float rate, unsigned site, const void* step_state,
+                                    skf_stream_t stream);
+size_t skf_layernorm_bwd_bf16_workspace_bytes(int rows, int d);
+int skf_layernorm_residual_bwd_bf16(const void* dout, const void* z, const float* stats, const float* gamma, void* dz, void* dy,
+                                    float* dgamma, float* dbeta, int rows, int d, float rate, unsigned site,
+                                    const void* step_state, void* workspace, size_t workspace_bytes, skf_stream_t stream);
+/* logits (rows, ld) bf16, even ncls <= ld <= 2048; the gradient is written in place, columns [ncls, ld) as zeros */
+int skf_softmax_ce_bf16(void* logits, int ld, int rows, int ncls, const long long* target, int tgt_ld, int tgt_cols, int tgt_off,
+                        int mask_pad, float scale, float* row_loss, float* row_hit, int write_grad, skf_stream_t stream);
+int skf_pool_fwd_bf16(const void* u, const float* Vw, const void* x, int B, int L, int U, int d, float* a_out, float* emb,
+                      skf_stream_t stream);
+int skf_pool_bwd_bf16(void* u_inout_dpre, const float* Vw, const void* x, const float* a, const float* demb, int B, int L, int U,
+                      int d, void* dx, float* dV, void* workspace, size_t workspace_bytes, skf_stream_t stream);
+int skf_expander_fwd_bf16(const float* emb, const float* w, const float* bias, int B, int L, int d, void* pre, skf_stream_t stream);
+int skf_expander_bwd_bf16(const void* dpre, const float* emb, const float* w, int B, int L, int d, float* demb,
+                          int demb_accumulate, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
+                          skf_stream_t stream);
+/* fp32 master weight [R][C] (row stride ld_src) -> bf16 images dst [R][ld_dst] and / or dst_t [C][ld_t] (NULL = skip);
+ * pad columns are written as zeros.  Plain casts for activations at the fp32 <-> bf16 seams. */
+int skf_cast_weight_bf16(const float* src, int R, int C, int ld_src, void* dst, int ld_dst, void* dst_t, int ld_t,
+                         skf_stream_t stream);
+int skf_cast_f32_to_bf16(const float* src, void* dst, size_t n, skf_stream_t stream);
+int skf_cast_bf16_to_f32(const void* src, float* dst, size_t n, skf_stream_t stream);
+
 /* ------------------------------------------------------------------ the train step
  * Transformer.build_model / call / model_trainer, models/sketchformer.py:63-147, 313-349. */
 typedef struct SkfConfig {
@@ -257,7 +316,13 @@ typedef struct SkfConfig {
    * layer / expander need do_reconstruction; lowerdim == 0 = no bottleneck, the decoder attends to the encoder output */
   int32_t do_classification, do_reconstruction;
   int32_t gemm_precision; /* SKF_PREC_*: arithmetic of every Dense / attention matmul of the step (0 = fp32 MFMA) */
+  /* SKF_ACT_F32 (0): fp32 tensors everywhere (the reference's arithmetic, cfg 1-4).  SKF_ACT_BF16 (1): bf16 activations
+   * and weight images, bf16 MFMA with fp32 accumulation, fp32 master weights / Adam (BASELINE cfg 5); token mode with the
+   * default structure (attn_version 1, bottleneck + classifier + decoder, no class buffers), head size 64 */
+  int32_t act_dtype;
 } SkfConfig;
+#define SKF_ACT_F32 0
+#define SKF_ACT_BF16 1
 
 typedef struct SkfParamEntry {
   char name[96];

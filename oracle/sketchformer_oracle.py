@@ -35,6 +35,7 @@ __all__ = [
     "TrainState", "train_step", "dropout_sites", "MetricState",
     "encode_from_seq", "make_dummy_input", "decode", "predict_from_embedding", "predict",
     "classify_from_embedding_fwd", "classify_from_embedding_bwd", "sgd_momentum_update",
+    "RELU_MASKS", "RELU_PRE",
 ]
 
 
@@ -328,18 +329,35 @@ def mha_bwd(dout, cache, G):
     return dv, dk, dq
 
 
+# ReLU branch bookkeeping for parity tests.  relu(z) is not differentiable at z = 0: a pre-activation within rounding
+# distance of 0 takes one branch in float64 and possibly the other in the device's fp32, and that single unit then
+# changes a whole column of dW1 (observed at the BASELINE sizes: ~1 unit in 10^6).  Like the dropout keep-masks, the
+# branch can therefore be SUPPLIED: RELU_MASKS[prefix] = bool array (True = unit active) overrides `pre > 0`, and
+# RELU_PRE records every pre-activation so that a test can check that overridden units really sit on the kink.
+RELU_MASKS: Dict[str, np.ndarray] = {}
+RELU_PRE: Dict[str, np.ndarray] = {}
+
+
 def ffn_fwd(P, prefix, x):
     """builders/layers/transformer.py:194-198."""
-    h, c1 = dense_fwd(x, P[prefix + "/dense1/kernel"], P[prefix + "/dense1/bias"], "relu")
+    W1, b1 = P[prefix + "/dense1/kernel"], P[prefix + "/dense1/bias"]
+    pre = x @ W1 + b1
+    mask = RELU_MASKS.get(prefix)
+    if mask is None:
+        mask = pre > 0
+    RELU_PRE[prefix] = pre
+    h = pre * mask                                          # == np.maximum(pre, 0) when mask == (pre > 0)
     y, c2 = dense_fwd(h, P[prefix + "/dense2/kernel"], P[prefix + "/dense2/bias"])
-    return y, (c1, c2, prefix)
+    return y, ((x, W1, mask), c2, prefix)
 
 
 def ffn_bwd(dy, cache, G):
-    c1, c2, prefix = cache
+    (x, W1, mask), c2, prefix = cache
     dh, G[prefix + "/dense2/kernel"], G[prefix + "/dense2/bias"] = dense_bwd(dy, c2)
-    dx, G[prefix + "/dense1/kernel"], G[prefix + "/dense1/bias"] = dense_bwd(dh, c1)
-    return dx
+    dh = dh * mask
+    G[prefix + "/dense1/kernel"] = x.reshape(-1, x.shape[-1]).T @ dh.reshape(-1, dh.shape[-1])
+    G[prefix + "/dense1/bias"] = dh.reshape(-1, dh.shape[-1]).sum(0)
+    return dh @ W1.T
 
 
 def _ln_fwd(P, prefix, x):

@@ -1,0 +1,386 @@
+// Dense layers of the bf16 path (BASELINE cfg 5: bf16 storage + bf16 MFMA, fp32 accumulate, fp32 master weights).
+//
+// tf.keras.layers.Dense forward / tape dgrad / wgrad (builders/layers/transformer.py:154-158,196-197;
+// models/sketchformer.py:85-104) on v_mfma_f32_32x32x16_bf16.  Two kernels:
+//
+//   gemm_bf16_nt : C[M][N] = A[M][K] . B[N][K]^T   - both operands contraction-contiguous.  Forward uses the [out][in]
+//                  image of the weight (kept beside the [in][out] image by the optimizer), dgrad uses the [in][out]
+//                  image as it is: dX[m][k] = sum_n dY[m][n] W[k][n].
+//   gemm_bf16_tn : C[P][Q] = sum_r A[r][P] . B[r][Q] - both operands contraction-STRIDED (weight gradient
+//                  dW = X^T dY over the B*L rows).  The tiles go to LDS as they lie in memory and the MFMA operands are
+//                  read with ds_read_b64_tr_b16 (gfx950's transposing LDS read: a 16-lane group fetches a [4][16] block
+//                  and every lane receives one column of it), so nothing is ever transposed in HBM or in registers.
+//                  Split over r into fp32 partial tiles (+ column sums of B = the bias gradient); the existing split-K
+//                  reduction sums them into the fp32 gradient buffer.
+//
+// Tiles: 128 x 128 outputs per 256-thread workgroup (2 x 2 waves, 2 x 2 MFMA tiles of 32 x 32 per wave), 64-deep
+// contraction steps, register-staged double-buffered LDS (one barrier per step), XCD-contiguous tile order with the
+// tiles that share an A panel adjacent.  nt computes C^T tiles (mfma(B, A)) so that a lane owns 4 consecutive columns of
+// one output row: bias / relu-mask / accumulate operands and the bf16 result move as 8-byte pieces.
+#include <stdlib.h>
+#include "skf_common.h"
+#include "skf_bf16.h"
+
+namespace {
+
+struct NtParams {
+  const skf_bf16* A; const skf_bf16* B; skf_bf16* C;
+  int M, N, K, lda, ldb, ldc;
+  const float* bias;            // [N] fp32 or null
+  int act;                      // 0 none, 1 relu, 2 tanh
+  const skf_bf16* relu_src;     // [M][ld_relu]: C = 0 where relu_src <= 0 (dgrad through a relu), or null
+  int ld_relu;
+  int accumulate;               // C += result (read-modify-write in bf16)
+  float* C32; int ldc32;        // optional fp32 copy of the result (used for the small fp32 heads), or null
+  int tiles_m, tiles_n;
+};
+
+// ---- LDS images.  nt: a tile row = 64 bf16 = 128 B; two rows share a 256-byte super-row and the 16-byte chunk slot is
+// XOR-ed with the super-row index, so the 16 lanes of a ds_read_b128 group (16 consecutive rows, one logical chunk) hit
+// 16 different bank groups.
+__device__ __forceinline__ int nt_lds_off(int row, int chunk) {       // byte offset of 16-byte chunk `chunk` (0..7) of tile row `row`
+  const int s = row >> 1, h = row & 1;
+  return s * 256 + ((((h << 3) | chunk) ^ (s & 15)) << 4);
+}
+
+template <bool EXTRA>   // EXTRA: relu_src / accumulate / fp32 copy (separate instantiation keeps the plain epilogue lean)
+__global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(NtParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // buffer b of the A / B tile images: A at b * 32 KB, B 16 KB behind it
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  // XCD-contiguous logical ids, n fastest: the tiles_n workgroups that share an A panel run back to back on one XCD
+  const int lid = skf_xcd_remap(blockIdx.x, gridDim.x);
+  const int tm = lid / p.tiles_n, tn = lid % p.tiles_n;
+  const int m0 = tm * 128, n0 = tn * 128;
+  const int kchunks = (p.K + 7) >> 3;                 // 16-byte chunks along K (row pitches are padded to 8 elements)
+  const int nk = (p.K + 63) >> 6;
+
+  // staging: chunk id = tid + 256 j -> row = id / 8, chunk = id % 8 (8 consecutive threads = one 128-byte row segment)
+  const int srow = tid >> 3, sch = tid & 7;
+  const skf_bf16* ag[4]; const skf_bf16* bg[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = srow + 32 * j;
+    const int ar = min(m0 + r, p.M - 1), br = min(n0 + r, p.N - 1);     // rows past the edge re-read the last row (never stored)
+    ag[j] = p.A + (size_t)ar * p.lda + sch * 8;
+    bg[j] = p.B + (size_t)br * p.ldb + sch * 8;
+  }
+  uint4 ra[4], rb[4];
+  auto gload = [&](int kt) {
+    const bool ok = kt * 8 + sch < kchunks;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ra[j] = ok ? *reinterpret_cast<const uint4*>(ag[j] + kt * 64) : make_uint4(0, 0, 0, 0);
+      rb[j] = ok ? *reinterpret_cast<const uint4*>(bg[j] + kt * 64) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int off = nt_lds_off(srow + 32 * j, sch);
+      *reinterpret_cast<uint4*>((smem + buf * 32768) + off) = ra[j];
+      *reinterpret_cast<uint4*>((smem + buf * 32768 + 16384) + off) = rb[j];
+    }
+  };
+
+  f32x16 acc[2][2];      // [n tile][m tile] of C^T
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  const int lrow = lane & 31, lhi = lane >> 5;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      skf_bf16x8 af[2], bf[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        af[t] = *reinterpret_cast<const skf_bf16x8*>((smem + cur * 32768) + nt_lds_off(wm * 64 + t * 32 + lrow, ks * 2 + lhi));
+        bf[t] = *reinterpret_cast<const skf_bf16x8*>((smem + cur * 32768 + 16384) + nt_lds_off(wn * 64 + t * 32 + lrow, ks * 2 + lhi));
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[a], af[b], acc[a][b], 0, 0, 0);
+    }
+    if (kt + 1 < nk) lstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue.  acc[a][b][r]: n = n0 + wn*64 + a*32 + (r&3) + 8*(r>>2) + 4*lhi, m = m0 + wm*64 + b*32 + lrow
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int m = m0 + wm * 64 + b * 32 + lrow;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + wn * 64 + a * 32 + 8 * q + 4 * lhi;
+        if (n >= p.N) continue;                        // N and the pitches are multiples of 4: a piece is all in or all out
+        float v[4] = {acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+        if (p.bias) {
+          const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+          v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+        }
+        if (p.act == 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (p.act == 2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+        }
+        if constexpr (EXTRA) {
+          if (p.relu_src) {
+            const uint2 hv = *reinterpret_cast<const uint2*>(p.relu_src + (size_t)m * p.ld_relu + n);
+            float h[4]; skf_unpack4(hv, h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = h[e] > 0.f ? v[e] : 0.f;
+          }
+          if (p.accumulate) {
+            const uint2 ov = *reinterpret_cast<const uint2*>(p.C + (size_t)m * p.ldc + n);
+            float o[4]; skf_unpack4(ov, o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += o[e];
+          }
+          if (p.C32) *reinterpret_cast<float4*>(p.C32 + (size_t)m * p.ldc32 + n) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        *reinterpret_cast<uint2*>(p.C + (size_t)m * p.ldc + n) = skf_pack4(v);
+      }
+  }
+}
+
+// ------------------------------------------------------------------ tn (weight gradient)
+struct TnParams {
+  const skf_bf16* A; const skf_bf16* B;   // A [R][P] (lda), B [R][Q] (ldb)
+  int R, P, Q, lda, ldb;
+  int r_chunk;                             // contraction rows per split (multiple of 64)
+  float* slab;                             // [splits][P][Q] fp32 partial tiles
+  float* colsum_slab;                      // [splits][Q] partial column sums of B, or null
+  int tiles_p, tiles_q, splits;
+};
+
+// tile row = 128 bf16 = 256 B = four 64-byte segments; segment slot XOR (row & 3): the four rows a transposing read
+// touches land in four different bank groups
+__device__ __forceinline__ int tn_lds_off(int row, int col) {          // byte offset of element (row, col), col multiple of 4
+  const int seg = col >> 5;
+  return row * 256 + (((seg ^ row) & 3) << 6) + ((col & 31) << 1);
+}
+
+__device__ __forceinline__ skf_bf16x8 tn_read_frag(const char* tile, int r0, int c0, int lane) {
+  // operand fragment of v_mfma_f32_32x32x16_bf16 from a [r][c] image, transposed: lane l gets the 8 contraction values
+  // r0 + 8*(l>>5) .. +7 of column c0 + (l & 31).  16-lane group g: columns c0 + 16*(g&1).., rows r0 + 8*(g>>1)..; inside a
+  // group lane j addresses row (j >> 2) and the four columns 4*(j & 3).. of its block and receives column j of it.
+  const int g = lane >> 4, j = lane & 15;
+  const int row = r0 + 8 * (g >> 1) + (j >> 2), col = c0 + 16 * (g & 1) + 4 * (j & 3);
+  typedef short s4 __attribute__((ext_vector_type(4)));
+  const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4 __attribute__((address_space(3)))*)(tile + tn_lds_off(row, col)));
+  const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4 __attribute__((address_space(3)))*)(tile + tn_lds_off(row + 4, col)));
+  typedef short s8 __attribute__((ext_vector_type(8)));
+  const s8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(skf_bf16x8, v);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(TnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // buffer b of the A / B tile images: A at b * 32 KB, B 16 KB behind it
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wp = wave >> 1, wq = wave & 1;
+  // logical id = (split z, p tile, q tile), q fastest: the q tiles of one (z, p) share the A panel; XCD-contiguous ranges
+  const int lid = skf_xcd_remap(blockIdx.x, gridDim.x);
+  const int tq = lid % p.tiles_q, tp = (lid / p.tiles_q) % p.tiles_p, z = lid / (p.tiles_q * p.tiles_p);
+  const int p0 = tp * 128, q0 = tq * 128;
+  const int rbeg = z * p.r_chunk, rend = min(p.R, rbeg + p.r_chunk);
+  const int nk = (rend - rbeg + 63) >> 6;
+
+  // staging: chunk id = tid + 256 j -> row = id / 16, chunk16 = id % 16 (16 threads = one 256-byte row segment)
+  const int srow = tid >> 4, sch = tid & 15;
+  const bool a_ok = p0 + sch * 8 < p.P, b_ok = q0 + sch * 8 < p.Q;      // P, Q multiples of 8: a chunk is all in or all out
+  const skf_bf16* ag = p.A + (size_t)rbeg * p.lda + p0 + sch * 8;
+  const skf_bf16* bg = p.B + (size_t)rbeg * p.ldb + q0 + sch * 8;
+  uint4 ra[4], rb[4];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = kt * 64 + srow + 16 * j;
+      const bool ok = rbeg + r < rend;
+      ra[j] = (ok && a_ok) ? *reinterpret_cast<const uint4*>(ag + (size_t)r * p.lda) : make_uint4(0, 0, 0, 0);
+      rb[j] = (ok && b_ok) ? *reinterpret_cast<const uint4*>(bg + (size_t)r * p.ldb) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int off = tn_lds_off(srow + 16 * j, sch * 8);
+      *reinterpret_cast<uint4*>((smem + buf * 32768) + off) = ra[j];
+      *reinterpret_cast<uint4*>((smem + buf * 32768 + 16384) + off) = rb[j];
+    }
+  };
+  // bias gradient: the p == 0 tiles also sum the columns of their B tiles (thread: columns q0 + 8*sch .. +7)
+  const bool do_colsum = p.colsum_slab && tp == 0;
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto colsum_acc = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float f[8];
+      skf_unpack8(rb[j], f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cs[e] += f[e];
+    }
+  };
+
+  f32x16 acc[2][2];      // [p tile][q tile]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  if (nk > 0) {
+    gload(0);
+    if (do_colsum) colsum_acc();
+    lstore(0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) { gload(kt + 1); if (do_colsum) colsum_acc(); }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      skf_bf16x8 af[2], bf[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        af[t] = tn_read_frag(smem + cur * 32768, ks * 16, wp * 64 + t * 32, lane);
+        bf[t] = tn_read_frag(smem + cur * 32768 + 16384, ks * 16, wq * 64 + t * 32, lane);
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+    }
+    if (kt + 1 < nk) lstore(cur ^ 1);
+    __syncthreads();
+  }
+  // acc[a][b][r]: row p = p0 + wp*64 + a*32 + (r&3) + 8*(r>>2) + 4*(lane>>5), col q = q0 + wq*64 + b*32 + (lane&31)
+  float* out = p.slab + (size_t)z * p.P * p.Q;
+  const int lcol = lane & 31, lhi = lane >> 5;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int q = q0 + wq * 64 + b * 32 + lcol;
+      if (q >= p.Q) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int pr = p0 + wp * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (pr < p.P) out[(size_t)pr * p.Q + q] = acc[a][b][r];
+      }
+    }
+  if (do_colsum) {
+    float* red = reinterpret_cast<float*>(smem);          // [16 row groups][128 columns]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[srow * 128 + sch * 8 + e] = cs[e];
+    __syncthreads();
+    if (tid < 128 && q0 + tid < p.Q) {
+      float s = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) s += red[g * 128 + tid];
+      p.colsum_slab[(size_t)z * p.Q + q0 + tid] = s;
+    }
+  }
+}
+
+template <typename K>
+int set_smem(K kfn, size_t bytes) {
+  SKF_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return SKF_OK;
+}
+
+}  // namespace
+
+extern "C" int skf_gemm_bf16(int M, int N, int K, const void* A, int lda, const void* B_nk, int ldb, void* C, int ldc,
+                             const float* bias, int act, const void* relu_src, int ld_relu, int accumulate, float* C_f32,
+                             int ldc_f32, skf_stream_t stream) {
+  SKF_CHECK_ARG(M > 0 && N > 0 && K > 0 && A && B_nk && C, "bad problem");
+  SKF_CHECK_ARG(act >= 0 && act <= 2, "bad activation");
+  SKF_CHECK_ARG((lda & 7) == 0 && (ldb & 7) == 0 && (ldc & 3) == 0 && (N & 3) == 0, "pitches must be multiples of 8 (A, B) / 4 (C, N) elements");
+  SKF_CHECK_ARG(lda >= ((K + 7) & ~7) && ldb >= ((K + 7) & ~7), "operand rows must be padded to a multiple of 8 elements along K");
+  SKF_CHECK_ARG((((uintptr_t)A | (uintptr_t)B_nk) & 15) == 0 && ((uintptr_t)C & 7) == 0, "operands must be 16-byte aligned");
+  SKF_CHECK_ARG(!relu_src || ((ld_relu & 3) == 0 && ((uintptr_t)relu_src & 7) == 0), "relu source must be 8-byte aligned");
+  SKF_CHECK_ARG(!C_f32 || ((ldc_f32 & 3) == 0 && ((uintptr_t)C_f32 & 15) == 0), "fp32 copy must be 16-byte aligned");
+  SKF_CHECK_ARG(!bias || ((uintptr_t)bias & 15) == 0, "bias must be 16-byte aligned");
+  NtParams p{};
+  p.A = (const skf_bf16*)A; p.B = (const skf_bf16*)B_nk; p.C = (skf_bf16*)C;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.bias = bias; p.act = act; p.relu_src = (const skf_bf16*)relu_src; p.ld_relu = ld_relu; p.accumulate = accumulate;
+  p.C32 = C_f32; p.ldc32 = ldc_f32;
+  p.tiles_m = skf_cdiv(M, 128); p.tiles_n = skf_cdiv(N, 128);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t smem = 65536;
+  const bool extra = relu_src || accumulate || C_f32;
+  SkfProfScope ps(st, "gemm_bf16_nt", 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * N * (accumulate ? 2 : 1)));
+  int rc;
+  if (extra) {
+    if ((rc = set_smem(gemm_bf16_nt_kernel<true>, smem))) return rc;
+    hipLaunchKernelGGL(gemm_bf16_nt_kernel<true>, dim3(p.tiles_m * p.tiles_n), dim3(256), smem, st, p);
+  } else {
+    if ((rc = set_smem(gemm_bf16_nt_kernel<false>, smem))) return rc;
+    hipLaunchKernelGGL(gemm_bf16_nt_kernel<false>, dim3(p.tiles_m * p.tiles_n), dim3(256), smem, st, p);
+  }
+  SKF_LAUNCH_CHECK();
+  return SKF_OK;
+}
+
+extern "C" int skf_gemm_bf16_wgrad_splits(int P, int Q, int R) {
+  const int tiles = skf_cdiv(P, 128) * skf_cdiv(Q, 128);
+  int splits = (512 + tiles - 1) / tiles;             // ~2 workgroups per CU
+  const int max_splits = skf_cdiv(R, 512);            // at least 8 contraction steps per split
+  if (splits > max_splits) splits = max_splits;
+  return splits < 1 ? 1 : splits;
+}
+
+extern "C" size_t skf_gemm_bf16_wgrad_workspace_bytes(int P, int Q, int R, int splits) {
+  (void)R;
+  if (splits < 1) splits = 1;
+  return ((size_t)P * Q + Q) * (size_t)splits * sizeof(float);
+}
+
+// dW[P][Q] = sum_r X[r][P] dY[r][Q] (+ bias_grad[Q] = sum_r dY[r][Q]): partial tiles into `slab`
+// ([splits][P][Q] then [splits][Q]); the caller reduces them (skf_splitk_reduce_batch / skf_gemm_bf16_wgrad).
+extern "C" int skf_gemm_bf16_wgrad_partial(int P, int Q, int R, const void* X, int ldx, const void* dY, int lddy, int splits,
+                                           int with_bias_grad, float* slab, size_t slab_bytes, int* splits_used_host,
+                                           skf_stream_t stream) {
+  SKF_CHECK_ARG(P > 0 && Q > 0 && R > 0 && X && dY && slab && splits_used_host, "bad argument");
+  SKF_CHECK_ARG((P & 7) == 0 && (Q & 7) == 0 && (ldx & 7) == 0 && (lddy & 7) == 0, "P, Q and the pitches must be multiples of 8 elements");
+  SKF_CHECK_ARG((((uintptr_t)X | (uintptr_t)dY) & 15) == 0 && ((uintptr_t)slab & 15) == 0, "operands must be 16-byte aligned");
+  if (splits < 1) splits = 1;
+  int chunk = skf_cdiv(R, splits);
+  chunk = skf_cdiv(chunk, 64) * 64;
+  splits = skf_cdiv(R, chunk);
+  SKF_CHECK_ARG(slab_bytes >= skf_gemm_bf16_wgrad_workspace_bytes(P, Q, R, splits), "slab too small");
+  TnParams p{};
+  p.A = (const skf_bf16*)X; p.B = (const skf_bf16*)dY; p.R = R; p.P = P; p.Q = Q; p.lda = ldx; p.ldb = lddy;
+  p.r_chunk = chunk; p.slab = slab; p.colsum_slab = with_bias_grad ? slab + (size_t)splits * P * Q : nullptr;
+  p.tiles_p = skf_cdiv(P, 128); p.tiles_q = skf_cdiv(Q, 128); p.splits = splits;
+  *splits_used_host = splits;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t smem = 65536;
+  int rc;
+  if ((rc = set_smem(gemm_bf16_tn_kernel, smem))) return rc;
+  SkfProfScope ps(st, "gemm_bf16_tn(wgrad)", 2.0 * P * Q * R, 2.0 * (double)R * (P + Q) + 4.0 * (double)splits * P * Q);
+  hipLaunchKernelGGL(gemm_bf16_tn_kernel, dim3(p.tiles_p * p.tiles_q * splits), dim3(256), smem, st, p);
+  SKF_LAUNCH_CHECK();
+  return SKF_OK;
+}

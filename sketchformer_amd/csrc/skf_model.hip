@@ -1215,6 +1215,16 @@ extern "C" int skf_model_create(const SkfConfig* cfg, SkfModel** out) {
   reg("dec_output", P.dec[N - 1].out3, B * Ld, d);
   reg("pre_decoder", has_bott(*cfg) ? P.pre : P.enc[N - 1].x2, B * L, M->lay.E);
   reg("bottleneck_attn", P.pool_a, B, L);
+  // the FFN hidden activations relu(x W1 + b1): parity tests read the ReLU branch taken on the device from them
+  static char hnames[2][64][24];
+  for (int i = 0; i < N && i < 64; ++i) {
+    snprintf(hnames[0][i], sizeof(hnames[0][i]), "encoder/layer%d/ffn_h", i);
+    reg(hnames[0][i], P.enc[i].h, B * L, cfg->dff);
+    if (do_recon(*cfg)) {
+      snprintf(hnames[1][i], sizeof(hnames[1][i]), "decoder/layer%d/ffn_h", i);
+      reg(hnames[1][i], P.dec[i].h, B * Ld, cfg->dff);
+    }
+  }
   reg("enc_embed_out", P.enc[0].x_in, B * L, d);
   reg("dec_embed_out", P.dec[0].x_in, B * Ld, d);
   // measured on MI355X: eager launches + a wgrad side stream beat hipGraph replay (graph nodes of different

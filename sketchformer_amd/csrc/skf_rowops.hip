@@ -4,8 +4,17 @@
 // One 64-lane wave owns one (B*L) row; rows are read/written once, fully coalesced
 // (a 128-float row = one 512-byte wave access).
 #include "skf_common.h"
+#include "skf_bf16.h"
 
 namespace {
+
+// two consecutive activation values as fp32 (the bf16 path reuses the sorted embedding gradient kernel)
+__device__ __forceinline__ float2 skf_ld2(const float* p, size_t i) { return *reinterpret_cast<const float2*>(p + i); }
+__device__ __forceinline__ float2 skf_ld2(const skf_bf16* p, size_t i) {
+  float2 r;
+  skf_unpack2(*reinterpret_cast<const uint32_t*>(p + i), r.x, r.y);
+  return r;
+}
 
 #ifndef SKF_LN_FWD_GRID
 #define SKF_LN_FWD_GRID 2048
@@ -184,8 +193,9 @@ __global__ __launch_bounds__(1024) void embed_sort_kernel(const long long* __res
   }
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void embed_bwd_sorted_kernel(const int* __restrict__ hdr, const EmbChunk* __restrict__ chunks,
-                                                               const int* __restrict__ order, const float* __restrict__ dx, int d,
+                                                               const int* __restrict__ order, const T* __restrict__ dx, int d,
                                                                float* __restrict__ dtable, float rate, uint32_t site,
                                                                const SkfStepState* st) {
   extern __shared__ float emb_red[];       // [3 waves][d] partial rows of waves 1..3
@@ -225,7 +235,7 @@ __global__ __launch_bounds__(256) void embed_bwd_sorted_kernel(const int* __rest
       for (int u = 0; u < 8; ++u) {
         const int src = j + u < wcount ? j + u : 0;
         r[u] = __shfl(mine, src, 64);
-        v[u] = *reinterpret_cast<const float2*>(dx + (size_t)r[u] * d + cc);
+        v[u] = skf_ld2(dx, (size_t)r[u] * d + cc);
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -928,8 +938,8 @@ extern "C" int skf_embed_sort(const long long* tokens, int tok_ld, int B, int L,
   SKF_LAUNCH_CHECK();
   return SKF_OK;
 }
-extern "C" int skf_embed_bwd_sorted(const void* ws, int B, int L, const float* dx, int vocab, int d, float* dtable, float rate,
-                                    unsigned site, const void* step_state, skf_stream_t stream) {
+static int embed_bwd_sorted_launch(const void* ws, int B, int L, const void* dx, int dx_bf16, int vocab, int d, float* dtable,
+                                   float rate, unsigned site, const void* step_state, skf_stream_t stream) {
   SKF_CHECK_ARG(ws && dx && dtable, "null operand");
   SKF_CHECK_ARG((d & 1) == 0, "d_model must be even");
   SKF_CHECK_ARG(rate == 0.f || step_state, "dropout needs the step state");
@@ -938,11 +948,24 @@ extern "C" int skf_embed_bwd_sorted(const void* ws, int B, int L, const float* d
   const int* hdr = (const int*)ws;
   const EmbChunk* chunks = (const EmbChunk*)((const char*)ws + 16);
   const int* order = (const int*)((const char*)ws + 16 + maxc * sizeof(EmbChunk));
-  SkfProfScope ps((hipStream_t)stream, "embed_bwd_sorted", 0.0, 4.0 * rows * d + 4.0 * (double)vocab * d);
-  hipLaunchKernelGGL(embed_bwd_sorted_kernel, dim3((unsigned)maxc), dim3(256), (size_t)3 * d * sizeof(float), (hipStream_t)stream, hdr, chunks, order, dx,
-                     d, dtable, rate, site, (const SkfStepState*)step_state);
+  SkfProfScope ps((hipStream_t)stream, dx_bf16 ? "embed_bwd_sorted_bf16" : "embed_bwd_sorted", 0.0,
+                  (dx_bf16 ? 2.0 : 4.0) * rows * d + 4.0 * (double)vocab * d);
+  if (dx_bf16)
+    hipLaunchKernelGGL(embed_bwd_sorted_kernel<skf_bf16>, dim3((unsigned)maxc), dim3(256), (size_t)3 * d * sizeof(float), (hipStream_t)stream,
+                       hdr, chunks, order, (const skf_bf16*)dx, d, dtable, rate, site, (const SkfStepState*)step_state);
+  else
+    hipLaunchKernelGGL(embed_bwd_sorted_kernel<float>, dim3((unsigned)maxc), dim3(256), (size_t)3 * d * sizeof(float), (hipStream_t)stream,
+                       hdr, chunks, order, (const float*)dx, d, dtable, rate, site, (const SkfStepState*)step_state);
   SKF_LAUNCH_CHECK();
   return SKF_OK;
+}
+extern "C" int skf_embed_bwd_sorted(const void* ws, int B, int L, const float* dx, int vocab, int d, float* dtable, float rate,
+                                    unsigned site, const void* step_state, skf_stream_t stream) {
+  return embed_bwd_sorted_launch(ws, B, L, dx, 0, vocab, d, dtable, rate, site, step_state, stream);
+}
+extern "C" int skf_embed_bwd_sorted_bf16(const void* ws, int B, int L, const void* dx, int vocab, int d, float* dtable, float rate,
+                                         unsigned site, const void* step_state, skf_stream_t stream) {
+  return embed_bwd_sorted_launch(ws, B, L, dx, 1, vocab, d, dtable, rate, site, step_state, stream);
 }
 
 extern "C" int skf_layernorm_residual_fwd(const float* x, float* y_inout_z, const float* gamma, const float* beta,

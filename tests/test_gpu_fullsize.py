@@ -10,12 +10,16 @@ with a small batch so that the float64 oracle costs seconds, in both Dense arith
   forward logits rel <= 1e-3 (north star; achieved value printed), token argmax identical wherever the oracle's
   top-2 margin > 1e-4 (count below margin printed), losses <= 1e-5, every gradient <= 1e-3 (per-tensor max-norm),
   and a 3-step Adam trajectory from iterations = 3000 (lr ~ 1e-3) incl. the running Keras metrics.
+ReLU units whose pre-activation is numerically 0 follow the branch the device took (tests/relu_branches.py; the count
+is printed): at 800 rows x 512..1024 units x 8..12 layers one or two such units exist per batch, and each moves one
+column of a dense1 weight gradient by more than the bar.
 """
 import numpy as np
 import pytest
 import torch
 
 import oracle
+from relu_branches import device_relu_branches
 from sketchformer_amd import synthetic
 
 pytestmark = pytest.mark.gpu
@@ -99,13 +103,21 @@ def test_full_dims_losses_and_all_gradients(name, mode):
     P = {k: v.astype(np.float64) for k, v in eng.state_dict_numpy().items()}
     eng.forward_backward(x, None, y)
     torch.cuda.synchronize()
-    losses, out, G = oracle.loss_and_grads(P, ocfg, xo, xo, y)
+    with device_relu_branches(eng, ocfg, B) as chk:      # ReLU units on the kink follow the device (tests/relu_branches.py)
+        losses, out, G = oracle.loss_and_grads(P, ocfg, xo, xo, y)
+    print("\n[%s mode %d] ReLU units on the kink that took the other branch on the device: %d" % (name, mode, chk.flips))
     m = eng.step_metrics()
     for k in ("recon_loss", "class_loss", "total_loss"):
         assert abs(m[k] - losses[k]) < 1e-5 * max(1.0, abs(losses[k])), (k, m[k], losses[k])
     got = eng.state_dict_numpy("grads")
     floor = 1e-3 * np.median([np.abs(G[k]).max() for k in G])
-    rel = {k: np.abs(got[k].astype(np.float64) - G[k]).max() / max(np.abs(G[k]).max(), floor) for k in G}
+    # d loss / d(wk bias) is analytically 0 (a softmax ignores a per-query shift of all its scores): the oracle gives
+    # ~1e-17, fp32 ~1e-8 - those tensors are bounded against the model's gradient scale instead of their own
+    for k in G:
+        if k.endswith("wk/bias"):
+            assert np.abs(got[k]).max() < 10 * floor, (k, np.abs(got[k]).max(), floor)
+    rel = {k: np.abs(got[k].astype(np.float64) - G[k]).max() / max(np.abs(G[k]).max(), floor) for k in G
+           if not k.endswith("wk/bias")}
     worst = max((v, k) for k, v in rel.items())
     print("\n[%s mode %d] worst gradient rel %.3e (%s), median %.3e over %d tensors" %
           (name, mode, worst[0], worst[1], np.median(list(rel.values())), len(rel)))
@@ -124,9 +136,10 @@ def test_full_dims_adam_trajectory(name, mode):
     eng.state[0] = 3000
     for step in range(3):
         x, y, xo = _batch(name, B, ocfg, seed=20 + step)
-        res, losses, _, _ = oracle.train_step(st, ocfg, xo, xo, y)
         eng.train_step(x, y)
         torch.cuda.synchronize()
+        with device_relu_branches(eng, ocfg, B):
+            res, losses, _, _ = oracle.train_step(st, ocfg, xo, xo, y)
         m = eng.step_metrics()
         assert abs(m["total_loss"] - losses["total_loss"]) < 1e-3 * abs(losses["total_loss"]), (step, m, losses)
     assert eng.iterations == 3003

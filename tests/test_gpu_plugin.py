@@ -12,12 +12,12 @@ SMALL = "num_layers=2,d_model=64,dff=128,num_heads=4,lowerdim=32,dropout_rate=0.
 DATA = "max_seq_len=24,vocab_size=52,n_classes=7,n_samples=64"
 
 
-def _build(tmp_path, exp_id="t0", base="batch_size=8,num_epochs=1,log_every=4"):
+def _build(tmp_path, exp_id="t0", base="batch_size=8,num_epochs=1,log_every=4", specific=SMALL):
     from sketchformer_amd import models, dataloaders
     Model = models.get_model_by_name("sketch-transformer-tf2")
     Loader = dataloaders.get_dataloader_by_name("stroke3-synthetic")
     dataset = Loader(Loader.parse_hparams(DATA), None)
-    model = Model(Model.parse_hparams(base=base, specific=SMALL), dataset, str(tmp_path), exp_id)
+    model = Model(Model.parse_hparams(base=base, specific=specific), dataset, str(tmp_path), exp_id)
     return model, dataset
 
 
@@ -61,8 +61,9 @@ def test_train_on_batch_matches_oracle_running_metrics(tmp_path):
 
 
 def test_checkpoint_resume_continues_bit_exactly(tmp_path):
-    a, dataset = _build(tmp_path, "ra", base="batch_size=8,num_epochs=1,log_every=100")
-    a.engine.cfg.dropout_rate = 0.0
+    # (dropout off: its key derives from the experiment id, and the two models below are two experiments)
+    nodrop = SMALL.replace("dropout_rate=0.1", "dropout_rate=0.0")
+    a, dataset = _build(tmp_path, "ra", base="batch_size=8,num_epochs=1,log_every=100", specific=nodrop)
     batches = [next(dataset.batch_iterator("train", 8, False)) for _ in range(1)] * 4
     for b in batches[:2]:
         a.train_on_batch(b)
@@ -70,7 +71,7 @@ def test_checkpoint_resume_continues_bit_exactly(tmp_path):
     a._save(str(tmp_path / "mid.pt"))
     for b in batches[2:]:
         a.train_on_batch(b)
-    b_model, _ = _build(tmp_path, "rb", base="batch_size=8,num_epochs=1,log_every=100")
+    b_model, _ = _build(tmp_path, "rb", base="batch_size=8,num_epochs=1,log_every=100", specific=nodrop)
     b_model.restore_checkpoint_if_exists(str(tmp_path / "mid.pt"))
     assert b_model.current_step == 2 and b_model.engine.iterations == 2
     for b in batches[2:]:
