@@ -45,7 +45,7 @@ class SkfConfig(C.Structure):
         ("optimizer", C.c_int32), ("momentum", C.c_float),
         ("class_buffer_layers", C.c_int32), ("class_dropout", C.c_float),
         ("do_classification", C.c_int32), ("do_reconstruction", C.c_int32),
-        ("gemm_precision", C.c_int32),
+        ("gemm_precision", C.c_int32), ("act_dtype", C.c_int32),
     ]
 
 
@@ -110,6 +110,27 @@ SIGNATURES = {
     "skf_decode_embed": (_I, [_P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P]),
     "skf_decode_select_tokens": (_I, [_P, _I, _I, _I, _I, _I, C.c_longlong, _P, _I, _P, _I, _P, _P, _P, _P, _P]),
     "skf_decode_select_continuous": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P]),
+    "skf_gemm_bf16": (_I, [_I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I, _P]),
+    "skf_gemm_bf16_wgrad_splits": (_I, [_I, _I, _I]),
+    "skf_gemm_bf16_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I]),
+    "skf_gemm_bf16_wgrad_partial": (_I, [_I, _I, _I, _P, _I, _P, _I, _I, _I, _P, _Z, _P, _P]),
+    "skf_attention_bf16_fwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P]),
+    "skf_attention_bf16_bwd_workspace_bytes": (_Z, [_I, _I, _I]),
+    "skf_attention_bf16_bwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I,
+                                    _P, _I, _P, _I, _P, _I, _P, _Z, _P]),
+    "skf_embed_fwd_bf16": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _P, _F, _U, _P, _P]),
+    "skf_embed_bwd_sorted_bf16": (_I, [_P, _I, _I, _P, _I, _I, _P, _F, _U, _P, _P]),
+    "skf_layernorm_residual_fwd_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _U, _P, _P]),
+    "skf_layernorm_bwd_bf16_workspace_bytes": (_Z, [_I, _I]),
+    "skf_layernorm_residual_bwd_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U, _P, _P, _Z, _P]),
+    "skf_softmax_ce_bf16": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _I, _F, _P, _P, _I, _P]),
+    "skf_pool_fwd_bf16": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "skf_pool_bwd_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _Z, _P]),
+    "skf_expander_fwd_bf16": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
+    "skf_expander_bwd_bf16": (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _Z, _P]),
+    "skf_cast_weight_bf16": (_I, [_P, _I, _I, _I, _P, _I, _P, _I, _P]),
+    "skf_cast_f32_to_bf16": (_I, [_P, _P, _Z, _P]),
+    "skf_cast_bf16_to_f32": (_I, [_P, _P, _Z, _P]),
     "skf_config_validate": (_I, [C.POINTER(SkfConfig)]),
     "skf_model_param_floats": (_Z, [C.POINTER(SkfConfig)]),
     "skf_model_param_entries": (_I, [C.POINTER(SkfConfig), C.POINTER(SkfParamEntry), _I]),
