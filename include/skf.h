@@ -85,6 +85,9 @@ typedef struct SkfReduceDesc {
 int skf_gemm_wgrad_partial(int M, int N, int K, const float* A, int lda, const float* B, int ldb, int splits,
                            int with_bias_grad, float* slab, size_t slab_bytes, int* splits_used_host, int precision,
                            skf_stream_t stream);
+/* one slab ([splits][M][N] then [splits][N] when bias_grad != NULL) -> C (+)= sum, bias_grad (+)= column sums */
+int skf_splitk_reduce(const float* slab, int splits, int M, int N, float* C, int ldc, int accumulate, float* bias_grad,
+                      int bias_grad_accumulate, skf_stream_t stream);
 int skf_splitk_reduce_blocks(int M, int N);
 int skf_splitk_reduce_batch(const SkfReduceDesc* descs_dev, int ndesc, int total_blocks, skf_stream_t stream);
 
@@ -255,15 +258,22 @@ int skf_gemm_bf16_wgrad_splits(int P, int Q, int R);
 size_t skf_gemm_bf16_wgrad_workspace_bytes(int P, int Q, int R, int splits);
 int skf_gemm_bf16_wgrad_partial(int P, int Q, int R, const void* X, int ldx, const void* dY, int lddy, int splits,
                                 int with_bias_grad, float* slab, size_t slab_bytes, int* splits_used_host, skf_stream_t stream);
+/* the same + its reduction into the fp32 gradient dW[P][Q] (row stride ldw) and bias_grad[Q] (may be NULL); workspace >=
+ * skf_gemm_bf16_wgrad_workspace_bytes(P, Q, R, skf_gemm_bf16_wgrad_splits(P, Q, R)) (fewer splits are used if it is smaller) */
+int skf_gemm_bf16_wgrad(int P, int Q, int R, const void* X, int ldx, const void* dY, int lddy, float* dW, int ldw,
+                        float* bias_grad, void* workspace, size_t workspace_bytes, skf_stream_t stream);
 /* scaled_dot_product_attention (builders/utils.py:71-105), streaming / online softmax, head size 64, any Lq / Lk;
  * mask semantics and `stats` as skf_attention_fwd.  The backward is two passes (dQ, then dK / dV) and needs
- * skf_attention_bf16_bwd_workspace_bytes of scratch (rowsum(dO o O)). */
+ * skf_attention_bf16_bwd_workspace_bytes of scratch (rowsum(dO o O)).  O_lo (optional, shape and pitch of O): the forward
+ * stores the bf16 rounding residual of O there and the backward adds it back when it forms rowsum(dO o O) - that sum is
+ * subtracted from dO.V^T, which it nearly cancels where the softmax gradient is small, and 8 significand bits of O leave an
+ * error larger than the result in such rows. */
 int skf_attention_bf16_fwd(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const unsigned char* key_mask,
-                           int key_mask_ld, int causal, int B, int H, int Lq, int Lk, int dh, void* O, int ldo, float* stats,
-                           skf_stream_t stream);
+                           int key_mask_ld, int causal, int B, int H, int Lq, int Lk, int dh, void* O, int ldo, void* O_lo,
+                           float* stats, skf_stream_t stream);
 size_t skf_attention_bf16_bwd_workspace_bytes(int B, int H, int Lq);
 int skf_attention_bf16_bwd(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const void* O, int ldo,
-                           const void* dO, int lddo, const float* stats, const unsigned char* key_mask, int key_mask_ld,
+                           const void* O_lo, const void* dO, int lddo, const float* stats, const unsigned char* key_mask, int key_mask_ld,
                            int causal, int B, int H, int Lq, int Lk, int dh, void* dQ, int lddq, void* dK, int lddk, void* dV,
                            int lddv, void* workspace, size_t workspace_bytes, skf_stream_t stream);
 /* row kernels: the fp32 entries of the same name with bf16 activations (d in {128, 256, 512, 1024}) */
@@ -379,7 +389,10 @@ int skf_model_encode(SkfModel* m, const void* inp, skf_stream_t stream);
 int skf_model_greedy_decode(SkfModel* m, const float* embedding, const int* expected_len_host, int n_valid,
                             long long sos, long long eos, int max_steps, void* out, int* out_len_host,
                             skf_stream_t stream);
-/* look up an internal activation by name ("logits", "class_probs", "embedding", "enc_output", ...) */
+/* look up an internal activation by name ("logits", "class_probs", "embedding", "enc_output", ...); skf_model_buffer serves
+ * fp32 buffers, skf_model_buffer_info any buffer with its row pitch (elements) and element type (bf16 models keep their
+ * activations in bf16) */
+int skf_model_buffer_info(SkfModel* m, const char* name, void** ptr, int* rows, int* cols, int* ld, int* is_bf16);
 int skf_model_buffer(SkfModel* m, const char* name, float** ptr, int* rows, int* cols);
 
 #ifdef __cplusplus

@@ -70,6 +70,7 @@ SIGNATURES = {
     "skf_gemm_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "skf_gemm_default_splits": (_I, [_I, _I, _I]),
     "skf_gemm_wgrad_partial": (_I, [_I, _I, _I, _P, _I, _P, _I, _I, _I, _P, _Z, _P, _I, _P]),
+    "skf_splitk_reduce": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _I, _P]),
     "skf_splitk_reduce_blocks": (_I, [_I, _I]),
     "skf_splitk_reduce_batch": (_I, [_P, _I, _I, _P]),
     "skf_gemm_f32": (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _I, _P, _Z, _I, _P]),
@@ -114,9 +115,10 @@ SIGNATURES = {
     "skf_gemm_bf16_wgrad_splits": (_I, [_I, _I, _I]),
     "skf_gemm_bf16_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "skf_gemm_bf16_wgrad_partial": (_I, [_I, _I, _I, _P, _I, _P, _I, _I, _I, _P, _Z, _P, _P]),
-    "skf_attention_bf16_fwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P]),
+    "skf_gemm_bf16_wgrad": (_I, [_I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _Z, _P]),
+    "skf_attention_bf16_fwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P]),
     "skf_attention_bf16_bwd_workspace_bytes": (_Z, [_I, _I, _I]),
-    "skf_attention_bf16_bwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I,
+    "skf_attention_bf16_bwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I,
                                     _P, _I, _P, _I, _P, _I, _P, _Z, _P]),
     "skf_embed_fwd_bf16": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _P, _F, _U, _P, _P]),
     "skf_embed_bwd_sorted_bf16": (_I, [_P, _I, _I, _P, _I, _I, _P, _F, _U, _P, _P]),
@@ -147,6 +149,7 @@ SIGNATURES = {
     "skf_model_greedy_decode": (_I, [_P, _P, C.POINTER(_I), _I, C.c_longlong, C.c_longlong, _I, _P, C.POINTER(_I), _P]),
     "skf_model_apply_gradients": (_I, [_P, _F, _P]),
     "skf_model_buffer": (_I, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(_I), C.POINTER(_I)]),
+    "skf_model_buffer_info": (_I, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
 }
 
 _lib = None

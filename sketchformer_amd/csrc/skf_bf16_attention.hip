@@ -42,6 +42,11 @@ struct AP {
   const skf_bf16* dO; int lddo;
   skf_bf16* dQ; skf_bf16* dK; skf_bf16* dV; int lddq, lddk, lddv;
   float* delta;                 // (B, H, Lq) rowsum(dO o O): written by the dQ pass, read by the dK/dV pass
+  skf_bf16* Olo;                // optional (same shape / pitch as O): O_fp32 - bf16(O), the rounding residual of the output.
+                                // delta = rowsum(dO o O) is subtracted from dP = dO.V^T, which it nearly cancels wherever the
+                                // softmax gradient is small: with O at 8 significand bits the error of delta (2^-9 |delta|)
+                                // exceeded the whole dS of such rows (last encoder layers of cfg 5: 200 % error in dWq / dWk);
+                                // O + Olo carries 16 bits at the price of one more bf16 tensor per attention call
 };
 
 typedef short s4v __attribute__((ext_vector_type(4)));
@@ -144,6 +149,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_q_kernel(AP p) {
   if constexpr (MODE == 1) {
     const skf_bf16* dp = p.dO + (size_t)(b * p.Lq + qc) * p.lddo + h * DH + hi * 8;
     const skf_bf16* op = p.O + (size_t)(b * p.Lq + qc) * p.ldo + h * DH + hi * 8;
+    const skf_bf16* lp = p.Olo ? p.Olo + (size_t)(b * p.Lq + qc) * p.ldo + h * DH + hi * 8 : nullptr;
     float dl = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -151,6 +157,12 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_q_kernel(AP p) {
       dof[ks] = __builtin_bit_cast(skf_bf16x8, dv);
       float df[8], of[8];
       skf_unpack8(dv, df); skf_unpack8(ov, of);
+      if (lp) {
+        float lf[8];
+        skf_unpack8(*reinterpret_cast<const uint4*>(lp + ks * 16), lf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) of[e] += lf[e];
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) dl += df[e] * of[e];
     }
@@ -295,7 +307,14 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_q_kernel(AP p) {
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
         const float v[4] = {acc[dt][4 * r4] * scale, acc[dt][4 * r4 + 1] * scale, acc[dt][4 * r4 + 2] * scale, acc[dt][4 * r4 + 3] * scale};
-        *reinterpret_cast<uint2*>(dst + dt * 32 + 8 * r4 + 4 * hi) = skf_pack4(v);
+        const uint2 pk = skf_pack4(v);
+        *reinterpret_cast<uint2*>(dst + dt * 32 + 8 * r4 + 4 * hi) = pk;
+        if (MODE == 0 && p.Olo) {
+          float hi4[4];
+          skf_unpack4(pk, hi4);
+          const float lo[4] = {v[0] - hi4[0], v[1] - hi4[1], v[2] - hi4[2], v[3] - hi4[3]};
+          *reinterpret_cast<uint2*>(p.Olo + (size_t)(b * p.Lq + q) * p.ldo + h * DH + dt * 32 + 8 * r4 + 4 * hi) = skf_pack4(lo);
+        }
       }
   }
 }
@@ -461,8 +480,9 @@ int set_smem(K kfn, size_t bytes) {
 
 extern "C" int skf_attention_bf16_fwd(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
                                       const unsigned char* key_mask, int key_mask_ld, int causal, int B, int H, int Lq, int Lk,
-                                      int dh, void* O, int ldo, float* stats, skf_stream_t stream) {
+                                      int dh, void* O, int ldo, void* O_lo, float* stats, skf_stream_t stream) {
   AP p{};
+  p.Olo = (skf_bf16*)O_lo;
   p.Q = (const skf_bf16*)Q; p.K = (const skf_bf16*)K; p.V = (const skf_bf16*)V; p.O = (skf_bf16*)O;
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.key_mask = key_mask; p.key_mask_ld = key_mask_ld; p.causal = causal;
   p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.stats = stats;
@@ -481,7 +501,7 @@ extern "C" int skf_attention_bf16_fwd(const void* Q, int ldq, const void* K, int
 extern "C" size_t skf_attention_bf16_bwd_workspace_bytes(int B, int H, int Lq) { return (size_t)B * H * Lq * sizeof(float); }
 
 extern "C" int skf_attention_bf16_bwd(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const void* O,
-                                      int ldo, const void* dO, int lddo, const float* stats, const unsigned char* key_mask,
+                                      int ldo, const void* O_lo, const void* dO, int lddo, const float* stats, const unsigned char* key_mask,
                                       int key_mask_ld, int causal, int B, int H, int Lq, int Lk, int dh, void* dQ, int lddq,
                                       void* dK, int lddk, void* dV, int lddv, void* workspace, size_t workspace_bytes,
                                       skf_stream_t stream) {
@@ -491,6 +511,8 @@ extern "C" int skf_attention_bf16_bwd(const void* Q, int ldq, const void* K, int
   p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.stats = const_cast<float*>(stats);
   p.dO = (const skf_bf16*)dO; p.lddo = lddo; p.dQ = (skf_bf16*)dQ; p.dK = (skf_bf16*)dK; p.dV = (skf_bf16*)dV;
   p.lddq = lddq; p.lddk = lddk; p.lddv = lddv; p.delta = (float*)workspace;
+  p.Olo = (skf_bf16*)const_cast<void*>(O_lo);
+  SKF_CHECK_ARG(!O_lo || ((uintptr_t)O_lo & 15) == 0, "O_lo must be 16-byte aligned");
   int rc = check(p, dh);
   if (rc) return rc;
   SKF_CHECK_ARG(Q && K && V && O && dO && stats && dQ && dK && dV, "null operand");

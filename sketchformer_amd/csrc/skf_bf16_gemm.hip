@@ -21,6 +21,9 @@
 #include "skf_common.h"
 #include "skf_bf16.h"
 
+extern "C" int skf_splitk_reduce(const float* slab, int splits, int M, int N, float* C, int ldc, int accumulate, float* bias_grad,
+                                 int bias_grad_accumulate, skf_stream_t stream);
+
 namespace {
 
 struct NtParams {
@@ -363,7 +366,9 @@ extern "C" int skf_gemm_bf16_wgrad_partial(int P, int Q, int R, const void* X, i
                                            int with_bias_grad, float* slab, size_t slab_bytes, int* splits_used_host,
                                            skf_stream_t stream) {
   SKF_CHECK_ARG(P > 0 && Q > 0 && R > 0 && X && dY && slab && splits_used_host, "bad argument");
-  SKF_CHECK_ARG((P & 7) == 0 && (Q & 7) == 0 && (ldx & 7) == 0 && (lddy & 7) == 0, "P, Q and the pitches must be multiples of 8 elements");
+  // Q may stop inside an 8-element chunk (vocabulary 1004): the rows of dY are padded to the pitch, pad columns are never stored
+  SKF_CHECK_ARG((P & 7) == 0 && (Q & 3) == 0 && (ldx & 7) == 0 && (lddy & 7) == 0 && lddy >= ((Q + 7) & ~7),
+                "P and the pitches must be multiples of 8 elements, Q a multiple of 4 with rows padded to 8");
   SKF_CHECK_ARG((((uintptr_t)X | (uintptr_t)dY) & 15) == 0 && ((uintptr_t)slab & 15) == 0, "operands must be 16-byte aligned");
   if (splits < 1) splits = 1;
   int chunk = skf_cdiv(R, splits);
@@ -383,4 +388,16 @@ extern "C" int skf_gemm_bf16_wgrad_partial(int P, int Q, int R, const void* X, i
   hipLaunchKernelGGL(gemm_bf16_tn_kernel, dim3(p.tiles_p * p.tiles_q * splits), dim3(256), smem, st, p);
   SKF_LAUNCH_CHECK();
   return SKF_OK;
+}
+
+// partial tiles + their reduction into the fp32 gradient: dW[P][Q] (row stride ldw) and bias_grad[Q] (may be NULL)
+extern "C" int skf_gemm_bf16_wgrad(int P, int Q, int R, const void* X, int ldx, const void* dY, int lddy, float* dW, int ldw,
+                                   float* bias_grad, void* workspace, size_t workspace_bytes, skf_stream_t stream) {
+  SKF_CHECK_ARG(dW && workspace, "null operand");
+  int splits = skf_gemm_bf16_wgrad_splits(P, Q, R), used = 0;
+  while (splits > 1 && skf_gemm_bf16_wgrad_workspace_bytes(P, Q, R, splits) > workspace_bytes) --splits;
+  int rc = skf_gemm_bf16_wgrad_partial(P, Q, R, X, ldx, dY, lddy, splits, bias_grad != nullptr, (float*)workspace, workspace_bytes,
+                                       &used, stream);
+  if (rc) return rc;
+  return skf_splitk_reduce((const float*)workspace, used, P, Q, dW, ldw, 0, bias_grad, 0, stream);
 }

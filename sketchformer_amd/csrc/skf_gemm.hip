@@ -379,6 +379,22 @@ __global__ __launch_bounds__(256) void splitk_reduce_batch_kernel(const SkfReduc
 }
 }  // namespace
 
+// one slab -> C (+ bias gradient): the reduction a split-K skf_gemm_f32 call ends with, for callers that produced the slab
+// themselves (the bf16 weight gradient)
+extern "C" int skf_splitk_reduce(const float* slab, int splits, int M, int N, float* C, int ldc, int accumulate,
+                                 float* bias_grad, int bias_grad_accumulate, skf_stream_t stream) {
+  SKF_CHECK_ARG(slab && C && splits > 0 && M > 0 && N > 0, "bad argument");
+  SKF_CHECK_ARG((((size_t)M * N) & 3) == 0 && ((uintptr_t)slab & 15) == 0, "slab must be 16-byte aligned with M*N a multiple of 4");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t total = (size_t)M * N + N;
+  const int blocks = (int)(((total + 3) / 4 + 63) / 64);
+  SkfProfScope ps(st, "splitk_reduce", 0.0, 4.0 * ((double)splits + 1) * total);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, const_cast<float*>(slab), splits, M, N, C, ldc, accumulate,
+                     bias_grad ? const_cast<float*>(slab) + (size_t)splits * M * N : nullptr, bias_grad, bias_grad_accumulate);
+  SKF_LAUNCH_CHECK();
+  return SKF_OK;
+}
+
 extern "C" int skf_splitk_reduce_blocks(int M, int N) { return (int)((((size_t)M * N + N + 3) / 4 + 63) / 64); }
 
 extern "C" int skf_splitk_reduce_batch(const SkfReduceDesc* descs_dev, int ndesc, int total_blocks, skf_stream_t stream) {

@@ -359,10 +359,16 @@ Plan build_plan(const SkfConfig& c) {
 
 }  // namespace
 
+#define SKF_BF16_PART 1
+#include "skf_model_bf16.inc"
+#undef SKF_BF16_PART
+
 struct SkfModel {
   SkfConfig cfg;
   Layout lay;
   Plan plan;
+  Plan16 p16;                        // bf16 path (cfg.act_dtype == SKF_ACT_BF16): its own workspace plan
+  bool bf16 = false;
   float *params = nullptr, *grads = nullptr, *m = nullptr, *v = nullptr, *metrics = nullptr;
   const float* pos = nullptr;
   char* ws = nullptr;
@@ -1142,6 +1148,10 @@ int capture_or_run(SkfModel* M, hipGraphExec_t* exec, hipStream_t s, F body) {
 
 }  // namespace
 
+#define SKF_BF16_PART 2
+#include "skf_model_bf16.inc"
+#undef SKF_BF16_PART
+
 // =========================================================================== C ABI
 extern "C" int skf_config_validate(const SkfConfig* c) {
   SKF_CHECK_ARG(c, "null config");
@@ -1173,6 +1183,19 @@ extern "C" int skf_config_validate(const SkfConfig* c) {
   SKF_CHECK_ARG(c->max_pos >= c->seq_len, "max_pos < seq_len");
   SKF_CHECK_ARG(c->dropout_rate >= 0.f && c->dropout_rate < 1.f, "dropout_rate out of range");
   SKF_CHECK_ARG(c->seq_len <= 512, "seq_len > 512 not supported");
+  SKF_CHECK_ARG(c->act_dtype == SKF_ACT_F32 || c->act_dtype == SKF_ACT_BF16, "act_dtype must be 0 (fp32) or 1 (bf16)");
+  if (c->act_dtype == SKF_ACT_BF16) {
+    // the bf16 path is built for the default structure of the model (what BASELINE cfg 5 trains)
+    if (c->continuous || c->attn_version != 1 || c->lowerdim <= 0 || !c->do_classification || !c->do_reconstruction ||
+        c->class_buffer_layers != 0) {
+      skf_set_error("act_dtype=bf16 supports token mode with attn_version=1, bottleneck + classifier + decoder, no class buffers");
+      return SKF_EUNSUPPORTED;
+    }
+    if (dh != 64) { skf_set_error("act_dtype=bf16: head size %d, the streaming attention kernels are built for 64", dh); return SKF_EUNSUPPORTED; }
+    if (!(c->d_model == 128 || c->d_model == 256 || c->d_model == 512)) { skf_set_error("act_dtype=bf16: d_model %d not in {128,256,512}", c->d_model); return SKF_EUNSUPPORTED; }
+    SKF_CHECK_ARG(c->dff % 8 == 0 && c->lowerdim % 8 == 0, "act_dtype=bf16: dff and lowerdim must be multiples of 8");
+    SKF_CHECK_ARG(c->vocab_size <= 2040, "act_dtype=bf16: vocab_size > 2040 (the cross-entropy kernel keeps a row in registers)");
+  }
   return SKF_OK;
 }
 
@@ -1192,6 +1215,7 @@ extern "C" int skf_model_param_entries(const SkfConfig* cfg, SkfParamEntry* out_
 
 extern "C" size_t skf_model_workspace_bytes(const SkfConfig* cfg) {
   if (skf_config_validate(cfg) != SKF_OK) return 0;
+  if (cfg->act_dtype == SKF_ACT_BF16) return build_plan16(*cfg, build_layout(*cfg)).bytes;
   return build_plan(*cfg).bytes;
 }
 
@@ -1202,6 +1226,17 @@ extern "C" int skf_model_create(const SkfConfig* cfg, SkfModel** out) {
   SkfModel* M = new SkfModel();
   M->cfg = *cfg;
   M->lay = build_layout(*cfg);
+  if (cfg->act_dtype == SKF_ACT_BF16) {
+    M->bf16 = true;
+    M->p16 = build_plan16(*cfg, M->lay);
+    // one stream; gradient buckets like the fp32 path (events cannot be recorded for outside waiters in a captured graph)
+    if (!cfg->use_graph) {
+      M->n_buckets = 2;
+      for (int i = 0; i < 2; ++i) SKF_HIP(hipEventCreateWithFlags(&M->bucket_ready[i], hipEventDisableTiming));
+    }
+    *out = M;
+    return SKF_OK;
+  }
   M->plan = build_plan(*cfg);
   const Plan& P = M->plan;
   const int B = cfg->batch, L = cfg->seq_len, Ld = L - 1, d = cfg->d_model, N = cfg->num_layers;
@@ -1253,7 +1288,7 @@ extern "C" void skf_model_destroy(SkfModel* m) {
 extern "C" int skf_model_bind(SkfModel* m, float* params, float* grads, float* adam_m, float* adam_v, const float* pos,
                               void* workspace, size_t workspace_bytes, float* metrics, void* step_state) {
   SKF_CHECK_ARG(m && params && grads && adam_m && adam_v && pos && workspace && metrics && step_state, "null buffer");
-  SKF_CHECK_ARG(workspace_bytes >= m->plan.bytes, "workspace too small");
+  SKF_CHECK_ARG(workspace_bytes >= (m->bf16 ? m->p16.bytes : m->plan.bytes), "workspace too small");
   SKF_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
   SKF_CHECK_ARG((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)adam_m | (uintptr_t)adam_v) & 15) == 0, "flat buffers must be 16-byte aligned");
   m->params = params; m->grads = grads; m->m = adam_m; m->v = adam_v; m->pos = pos;
@@ -1269,6 +1304,11 @@ extern "C" int skf_model_forward(SkfModel* m, const void* inp, const void* tar, 
                                  skf_stream_t stream) {
   SKF_CHECK_ARG(m && m->ws, "model not bound");
   hipStream_t s = (hipStream_t)stream;
+  if (m->bf16) {
+    SKF_TRY(stage_inputs16(m, inp, tar, tar_ld, nullptr, s));
+    if (training) SKF_TRY(prologue(m, s));
+    return run_forward16(m, training != 0, false, s);
+  }
   SKF_TRY(stage_inputs(m, inp, tar, tar_ld, nullptr, s));
   if (training) SKF_TRY(prologue(m, s));
   return run_forward(m, training != 0, false, s);
@@ -1277,6 +1317,10 @@ extern "C" int skf_model_forward(SkfModel* m, const void* inp, const void* tar, 
 extern "C" int skf_model_encode(SkfModel* m, const void* inp, skf_stream_t stream) {
   SKF_CHECK_ARG(m && m->ws, "model not bound");
   hipStream_t s = (hipStream_t)stream;
+  if (m->bf16) {
+    SKF_TRY(stage_inputs16(m, inp, inp, m->cfg.seq_len, nullptr, s));
+    return run_forward16(m, false, false, s, true);
+  }
   SKF_TRY(stage_inputs(m, inp, inp, m->cfg.seq_len, nullptr, s));
   return run_forward(m, false, false, s, true);
 }
@@ -1289,6 +1333,7 @@ extern "C" int skf_model_greedy_decode(SkfModel* m, const float* embedding, cons
   SKF_CHECK_ARG(n_valid > 0 && n_valid <= m->cfg.batch, "n_valid must be in [1, batch]");
   SKF_CHECK_ARG(max_steps > 0 && max_steps <= m->cfg.seq_len, "max_steps must be in [1, seq_len]");
   SKF_CHECK_ARG(m->cfg.do_reconstruction, "the model was built without a decoder (do_reconstruction = 0)");
+  if (m->bf16) { skf_set_error("greedy decode is not built for act_dtype=bf16 (train the bf16 model, decode with an fp32 one)"); return SKF_EUNSUPPORTED; }
   return run_greedy_decode(m, embedding, expected_len_host, n_valid, sos, eos, max_steps, out, out_len_host,
                            (hipStream_t)stream);
 }
@@ -1323,6 +1368,15 @@ extern "C" int skf_model_forward_backward(SkfModel* m, const void* inp, const vo
   SKF_CHECK_ARG(m && m->ws, "model not bound");
   SKF_CHECK_ARG(labels, "null labels");
   hipStream_t s = (hipStream_t)stream;
+  if (m->bf16) {
+    SKF_TRY(stage_inputs16(m, inp, tar, tar_ld, labels, s));
+    return capture_or_run(m, &m->g_fb, s, [&]() -> int {
+      SKF_TRY(prologue(m, s));
+      SKF_TRY(issue_embed_sorts16(m, s));
+      SKF_TRY(run_forward16(m, true, true, s));
+      return run_backward16(m, s);
+    });
+  }
   SKF_TRY(stage_inputs(m, inp, tar, tar_ld, labels, s));
   return capture_or_run(m, &m->g_fb, s, [&]() -> int {
     SKF_TRY(prologue(m, s));
@@ -1381,8 +1435,34 @@ extern "C" int skf_model_apply_gradients_range(SkfModel* m, size_t offset, size_
   return last ? skf_step_epilogue(m->state, s) : SKF_OK;
 }
 
+extern "C" int skf_model_buffer_info(SkfModel* m, const char* name, void** ptr, int* rows, int* cols, int* ld, int* is_bf16) {
+  SKF_CHECK_ARG(m && m->ws && name && ptr && rows && cols && ld && is_bf16, "bad argument");
+  if (m->bf16) {
+    auto it = m->p16.named.find(name);
+    if (it == m->p16.named.end()) { skf_set_error("skf_model_buffer_info: unknown buffer '%s'", name); return SKF_EINVAL; }
+    *ptr = m->ws + it->second.off; *rows = it->second.rows; *cols = it->second.cols; *ld = it->second.ld; *is_bf16 = it->second.bf16;
+    return SKF_OK;
+  }
+  float* p = nullptr;
+  int rc = skf_model_buffer(m, name, &p, rows, cols);
+  if (rc) return rc;
+  *ptr = p; *ld = *cols; *is_bf16 = 0;
+  return SKF_OK;
+}
+
 extern "C" int skf_model_buffer(SkfModel* m, const char* name, float** ptr, int* rows, int* cols) {
   SKF_CHECK_ARG(m && m->ws && name && ptr, "bad argument");
+  if (m->bf16) {
+    auto it16 = m->p16.named.find(name);
+    if (it16 == m->p16.named.end() || it16->second.bf16) {
+      skf_set_error("skf_model_buffer: '%s' is not an fp32 buffer of this bf16 model (use skf_model_buffer_info)", name);
+      return SKF_EINVAL;
+    }
+    *ptr = reinterpret_cast<float*>(m->ws + it16->second.off);
+    if (rows) *rows = it16->second.rows;
+    if (cols) *cols = it16->second.cols;
+    return SKF_OK;
+  }
   auto it = m->named.find(name);
   if (it == m->named.end()) { skf_set_error("skf_model_buffer: unknown buffer '%s'", name); return SKF_EINVAL; }
   *ptr = m->at<float>(it->second.first);

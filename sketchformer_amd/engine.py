@@ -36,10 +36,13 @@ def make_config(batch, seq_len=200, d_model=128, num_heads=8, dff=512, num_layer
                 lowerdim=256, attn_version=1, continuous=False, blind_decoder_mask=True, dropout_rate=0.1,
                 recon_weight=1.0, class_weight=1.0, lr_scheduler="WarmupDecay", lr=0.01, seed=0, use_graph=True,
                 max_pos=1000, optimizer="Adam", class_buffer_layers=0, class_dropout=0.1, do_classification=True,
-                do_reconstruction=True, gemm_precision=None):
+                do_reconstruction=True, gemm_precision=None, act_dtype="f32"):
     """gemm_precision: SKF_PREC_* arithmetic of the Dense / attention matmuls (0 fp32 MFMA, 6 bf16x6, 3 bf16x3);
-    None = _lib.default_precision() (bf16x6 unless SKF_GEMM_PRECISION says otherwise)."""
+    None = _lib.default_precision() (bf16x6 unless SKF_GEMM_PRECISION says otherwise).
+    act_dtype: "f32" (the reference's arithmetic, cfg 1-4) or "bf16" (BASELINE cfg 5: bf16 activations / weight images /
+    MFMA with fp32 accumulation, fp32 master weights and Adam)."""
     cfg = SkfConfig()
+    cfg.act_dtype = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}[str(act_dtype).lower()]
     cfg.gemm_precision = _lib.default_precision() if gemm_precision is None else int(gemm_precision)
     cfg.batch, cfg.seq_len, cfg.d_model, cfg.num_heads, cfg.dff, cfg.num_layers = batch, seq_len, d_model, num_heads, dff, num_layers
     cfg.vocab_size, cfg.n_classes, cfg.lowerdim, cfg.attn_version = vocab_size or 0, n_classes, lowerdim, attn_version
@@ -350,13 +353,16 @@ class TrainEngine:
         self.apply_gradients()
 
     def buffer(self, name):
-        ptr, rows, cols = C.c_void_p(), C.c_int(), C.c_int()
-        _lib.call("skf_model_buffer", self.handle, name.encode(), C.byref(ptr), C.byref(rows), C.byref(cols))
-        base = self._ws_ptr
-        off = (ptr.value - base) // 4
+        """(rows, cols) view of an internal activation.  fp32 models: a float32 view of the workspace; bf16 models keep
+        most activations in bf16 (row pitch padded to 8 elements): a bfloat16 view - call .float() for arithmetic."""
+        ptr, rows, cols, ld, is16 = C.c_void_p(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        _lib.call("skf_model_buffer_info", self.handle, name.encode(), C.byref(ptr), C.byref(rows), C.byref(cols), C.byref(ld),
+                  C.byref(is16))
+        esz = 2 if is16.value else 4
         lo = self._ws_ptr - self.workspace.data_ptr()
-        ws_f = self.workspace[lo:lo + self._ws_bytes].view(torch.float32)
-        return ws_f[off:off + rows.value * cols.value].view(rows.value, cols.value)
+        ws = self.workspace[lo:lo + self._ws_bytes].view(torch.bfloat16 if is16.value else torch.float32)
+        off = (ptr.value - self._ws_ptr) // esz
+        return ws[off:off + rows.value * ld.value].view(rows.value, ld.value)[:, :cols.value]
 
     def step_metrics(self):
         """This step's five scalars (host sync)."""

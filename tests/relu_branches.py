@@ -14,8 +14,9 @@ import oracle
 class device_relu_branches:
     """with device_relu_branches(eng, ocfg, B) as chk: <run the oracle>; chk.flips = units overridden on the kink."""
 
-    def __init__(self, eng, ocfg, B, kink=2e-5):
-        self.eng, self.ocfg, self.B, self.kink = eng, ocfg, B, kink
+    def __init__(self, eng, ocfg, B, kink=2e-5, max_flips=64):
+        # (a bf16 model evaluates the pre-activations to ~2^-8 relative: pass kink ~ 5e-2 and a max_flips fraction there)
+        self.eng, self.ocfg, self.B, self.kink, self.max_flips = eng, ocfg, B, kink, max_flips
         self.flips = 0
 
     def __enter__(self):
@@ -26,7 +27,7 @@ class device_relu_branches:
             if side == "decoder" and not c.do_reconstruction:
                 continue
             for i in range(c.num_layers):
-                h = self.eng.buffer("%s/layer%d/ffn_h" % (side, i)).cpu().numpy()
+                h = self.eng.buffer("%s/layer%d/ffn_h" % (side, i)).float().cpu().numpy()
                 oracle.RELU_MASKS["%s/layer%d/ffn" % (side, i)] = (h > 0).reshape(self.B, L, c.dff)
         return self
 
@@ -40,7 +41,7 @@ class device_relu_branches:
                     # a unit may only differ where the oracle's own pre-activation is numerically zero
                     assert np.all(np.abs(pre[diff]) < self.kink * max(1.0, np.abs(pre).max())), \
                         (k, int(diff.sum()), float(np.abs(pre[diff]).max()))
-                assert self.flips <= 64, self.flips
+                assert self.flips <= self.max_flips, self.flips
         finally:
             oracle.RELU_MASKS.clear()
             oracle.RELU_PRE.clear()

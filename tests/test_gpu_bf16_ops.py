@@ -135,15 +135,17 @@ def test_attention_bf16_fwd_bwd(lib, B, H, Lq, Lk, causal, with_mask):
     want_o, _, cache = oracle.sdpa_fwd(_split(q, H), _split(k, H), _split(v, H), mask)
     kmd = torch.as_tensor(km).to(torch.uint8).cuda() if km is not None else None
     O = torch.empty(B, Lq, d, dtype=BF, device="cuda")
+    Olo = torch.empty(B, Lq, d, dtype=BF, device="cuda")
     stats = torch.empty(B, H, Lq, 2, dtype=torch.float32, device="cuda")
     lib.call("skf_attention_bf16_fwd", _p(Q), d, _p(K), d, _p(V), d, _p(kmd), Lk if kmd is not None else 0, int(causal), B, H, Lq,
-             Lk, dh, _p(O), d, _p(stats), _s())
+             Lk, dh, _p(O), d, _p(Olo), _p(stats), _s())
     _close(O, _merge(want_o), 1.2e-2, "fwd")                     # P rounded to bf16 as MFMA operand + bf16 output
+    assert float(Olo.float().abs().max()) <= 2.0 ** -8 * float(O.float().abs().max())      # the rounding residual of O
     # backward with the device's own (rounded) O, like the train step
     dq, dk, dv = oracle.sdpa_bwd(_split(do, H), cache)
     ws = torch.empty(B * H * Lq, dtype=torch.float32, device="cuda")
     dQ, dK, dV = (torch.full((B, L, d), 3.0, dtype=BF, device="cuda") for L in (Lq, Lk, Lk))
-    lib.call("skf_attention_bf16_bwd", _p(Q), d, _p(K), d, _p(V), d, _p(O), d, _p(dO), d, _p(stats), _p(kmd),
+    lib.call("skf_attention_bf16_bwd", _p(Q), d, _p(K), d, _p(V), d, _p(O), d, _p(Olo), _p(dO), d, _p(stats), _p(kmd),
              Lk if kmd is not None else 0, int(causal), B, H, Lq, Lk, dh, _p(dQ), d, _p(dK), d, _p(dV), d, _p(ws), ws.numel() * 4, _s())
     # (floor: with a single key dQ and dK are exactly 0 and the device returns the rounding noise of delta, ~1e-7)
     _close(dQ, _merge(dq), 2e-2, "dQ", 1e-4); _close(dK, _merge(dk), 2e-2, "dK", 1e-4); _close(dV, _merge(dv), 2e-2, "dV")
@@ -163,7 +165,7 @@ def test_attention_bf16_fully_padded_sample_is_uniform(lib):
     O = torch.empty(B, L, d, dtype=BF, device="cuda")
     stats = torch.empty(B, H, L, 2, dtype=torch.float32, device="cuda")
     kmd = torch.as_tensor(km).to(torch.uint8).cuda()
-    lib.call("skf_attention_bf16_fwd", _p(Q), d, _p(K), d, _p(V), d, _p(kmd), L, 1, B, H, L, L, dh, _p(O), d, _p(stats), _s())
+    lib.call("skf_attention_bf16_fwd", _p(Q), d, _p(K), d, _p(V), d, _p(kmd), L, 1, B, H, L, L, dh, _p(O), d, None, _p(stats), _s())
     want = np.broadcast_to(v[1].mean(0, keepdims=True), (L, d))   # every key (look-ahead ones too) weighs 1/L
     _close(O[1], want, 1.2e-2, "all-pad sample")
 
