@@ -9,12 +9,24 @@ Workload (BASELINE.json configs[1] / cfg 2): 4 layers, 8 heads, d_model 128, dff
 L=200, per-GPU B=128, V=1004, 345 classes, dropout 0.1, fp32.  Weak scaling: every rank
 runs B=128 (global batch 128*N); one RCCL all-reduce of the flat fp32 gradient buffer
 per step.  Inputs are resident in HBM before the timed region.  Prints ONE JSON line.
+
+The line carries, beside the contract keys: `roofline` (dominant kernel by time, HIP events on the launch stream, HBM
+traffic from two rocprofv3 PMC passes of this same script), `cpu_baseline`, and - single GPU only, none of them part of
+`value` - `full_length` (no padding), `fp32_mfma_mode`, `plugin_path` (the step through train_on_batch), `kernels`
+(serialised per-kernel timing) next to `kernels_concurrent` (rocprofv3 kernel trace of the real two-stream step), `cfg3` and
+`cfg5` sub-records (BASELINE configs[2] and configs[4] per GPU).  `--workload cfg3|cfg5` makes one of those the main line.
 """
 import argparse
+import csv
 import ctypes as C
+import glob
 import json
 import os
+import re
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -27,35 +39,59 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 1
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_f32_16x16x32_bf16 / 32x32x16)
 PEAK_HBM_GBS = 8000.0
 
+WORKLOADS = {
+    # name: (L, d, dff, N, V, continuous, act dtype, description)
+    "cfg2": dict(L=200, d=128, dff=512, N=4, V=1004, cont=False, act="f32",
+                 text="cfg2: sketch-transformer-tf2 4L/8H/d128/dff512 L=200 V=1004 C=345 dropout=0.1, fwd+bwd+Adam(WarmupDecay)"),
+    "cfg3": dict(L=200, d=256, dff=1024, N=6, V=5, cont=True, act="f32",
+                 text="cfg3: sketch-transformer-tf2 6L/8H/d256/dff1024 L=200 continuous stroke-5 C=345 dropout=0.1, fwd+bwd+Adam(WarmupDecay)"),
+    "cfg5": dict(L=512, d=512, dff=2048, N=8, V=1004, cont=False, act="bf16",
+                 text="cfg5: sketch-transformer-tf2 8L/8H/d512/dff2048 L=512 V=1004 C=345 dropout=0.1, bf16 storage/MFMA, fp32 master "
+                      "weights + Adam(WarmupDecay), per-GPU B=128 (BASELINE does not state B)"),
+}
+U, CN = 256, 345
 
-def step_flops(B, L, d, dff, N, V, U, Cn):
+
+def step_flops(B, L, d, dff, N, V, U, Cn, cont=False):
     """Algorithmic FLOPs of one train step, SURVEY.md section 8(d): F_step = 3 * F_fwd."""
     Le, Ld, Lk = L, L - 1, L
     f_enc = N * (8 * B * Le * d * d + 4 * B * Le * Le * d + 4 * B * Le * d * dff)
     f_dec = N * (8 * B * Ld * d * d + 4 * B * Ld * Ld * d + 4 * B * Ld * d * d + 4 * B * Lk * d * d
                  + 4 * B * Ld * Lk * d + 4 * B * Ld * d * dff)
     f_out = 2 * B * Ld * d * V
+    f_emb = 2 * B * (Le + Ld) * 5 * d if cont else 0
     f_bott = 2 * B * Le * d * U + 2 * B * Le * U + 2 * B * Le * d
     f_cls = 2 * B * d * Cn + 2 * B * d * L
-    return 3 * (f_enc + f_dec + f_out + f_bott + f_cls)
+    return 3 * (f_enc + f_dec + f_out + f_emb + f_bott + f_cls)
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """The CPU restatement of the TF2 reference (oracle/, numpy float32, 'port'), timed on this host on a
-    bounded sample: cfg 1 (C=1) at B=16 rows instead of 128 (same L, model and step; tokens/s is per-row linear)."""
+def step_bytes(B, L, d, dff, N, V, P, act_bytes):
+    """Algorithmic HBM bytes of one train step, SURVEY.md section 8(d): every saved activation written once forward and read
+    once backward (flash-style attention: no L x L tensors), weights read twice, optimizer 28 B / parameter."""
+    Le, Ld, Lk = L, L - 1, L
+    A = B * Le * N * (7 * d + dff) + B * Ld * N * (11 * d + dff) + B * Lk * N * 2 * d + B * Ld * V
+    return 2 * A * act_bytes + 2 * P * act_bytes + 28 * P
+
+
+def cpu_baseline(seconds_budget=30.0):
+    """The CPU restatement of the TF2 reference (oracle/, numpy float32, 'port'; TensorFlow itself cannot run here), timed on
+    this host at SURVEY 8(d)'s definition: cfg 1 (4L/8H/d128/dff512, L=200, V=1004, C=1), the full B=128 batch, every core the
+    BLAS behind numpy uses; bounded to ~30 s: one warm-up step, then full train steps until the budget is spent (>= 2)."""
     import oracle
     from sketchformer_amd import synthetic
-    B, L = 16, 200
+    B, L = 128, 200
     cfg = oracle.Config(n_classes=1)
     x, y = synthetic.token_batch(B, L, cfg.vocab_size, 1, seed=0)
     state = oracle.TrainState.create(oracle.init_params(cfg, 0, np.float32))
     rng = np.random.RandomState(0)
     drops = {n: rng.rand(B, L if t == "enc" else L - 1, cfg.d_model) >= cfg.dropout_rate
              for n, t in oracle.dropout_sites(cfg)}
+    t0 = time.perf_counter()
     oracle.train_step(state, cfg, x, x, y, drops)          # warm-up
+    warm = time.perf_counter() - t0
     times = []
     t_start = time.perf_counter()
-    while len(times) < 5 and time.perf_counter() - t_start < seconds_budget:
+    while len(times) < 2 or (len(times) < 5 and time.perf_counter() - t_start + warm < seconds_budget):
         t0 = time.perf_counter()
         oracle.train_step(state, cfg, x, x, y, drops)
         times.append(time.perf_counter() - t0)
@@ -66,33 +102,96 @@ def cpu_baseline(seconds_budget=25.0):
     except Exception:
         cores = os.cpu_count() or 1
     return {"value": B * L / med, "unit": "stroke-tokens/sec", "cores": int(cores), "kind": "port",
-            "sample": "numpy float32 oracle, cfg1 (4L/8H/d128/dff512, L=200, V=1004, C=1), B=16 of 128 rows, "
-                      "median of %d full train steps (%.2f s each), host has %d logical cores"
-                      % (len(times), med, os.cpu_count() or 1)}
+            "sample": "numpy float32 oracle (CPU restatement of the TF2 reference), cfg1 (4L/8H/d128/dff512, L=200, V=1004, C=1), "
+                      "B=128, median of %d full train steps after 1 warm-up (%.2f s each), BLAS threads %d of %d logical cores"
+                      % (len(times), med, int(cores), os.cpu_count() or 1)}
 
 
-def _gemm_precision():
-    from sketchformer_amd import _lib
-    return int(_lib.default_precision())
-
-
-def pmc_traffic(tag):
-    """HBM bytes per launch of the kernel behind a profiler tag, from the committed rocprofv3 PMC passes
-    (profiles/*pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate runs, gfx950 corrections applied)."""
-    import glob
-    import re
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
-    if not files:
-        return None
-    table = json.load(open(files[-1]))
+def _kernel_prefix(tag):
+    """profiler tag -> prefix of the demangled kernel name in rocprofv3 output"""
     m = re.match(r"gemm_ws(x?)<K(\d+),CW(\d+)", tag)
     if m:   # kernel template is <K, columns per lane = CW/16, ...>
-        prefix = "gemm_ws%s_kernel<%s, %d," % (m.group(1), m.group(2), int(m.group(3)) // 16)
-    else:
-        prefix = {"wgrad<64x64>": "wgrad_kernel", "attn_bwd<dh16>": "attn_bwd_kernel<16", "attn_fwd<dh16>": "attn_fwd_kernel<16",
-                  "ln_fwd": "ln_fwd_kernel", "ln_bwd": "ln_bwd_kernel"}.get(tag)
-    if not prefix:
+        return "gemm_ws%s_kernel<%s, %d," % (m.group(1), m.group(2), int(m.group(3)) // 16)
+    table = {"wgrad<64x64>": "wgrad_kernel", "wgrad<64x64,bf16x6>": "wgrad_x_kernel<3", "wgrad<64x64,bf16x3>": "wgrad_x_kernel<2",
+             "attn_bwd<dh16>": "attn_bwd_kernel<16", "attn_fwd<dh16>": "attn_fwd_kernel<16", "attn_bwd<dh32>": "attn_bwd_kernel<32",
+             "attn_fwd<dh32>": "attn_fwd_kernel<32", "ln_fwd": "ln_fwd", "ln_bwd": "ln_bwd", "gemm_bf16_nt": "gemm_bf16_nt_kernel",
+             "gemm_bf16_tn(wgrad)": "gemm_bf16_tn_kernel", "attn_bf16_fwd<dh64>": "attn_bf16_q_kernel<0",
+             "attn_bf16_bwd_dq<dh64>": "attn_bf16_q_kernel<1", "attn_bf16_bwd_dkv<dh64>": "attn_bf16_kv_kernel"}
+    return table.get(tag)
+
+
+def _clean(name):
+    return name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+
+
+def _run_self_under_rocprof(extra_rocprof, bench_args, outdir, timeout=240):
+    """rocprofv3 <extra> -- python bench.py <bench_args> with the profiler's files under outdir; returns the CSV paths."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
         return None
+    env = dict(os.environ, TMPDIR="/tmp")
+    cmd = [exe] + extra_rocprof + ["--output-format", "csv", "-d", outdir, "--", sys.executable, os.path.join(ROOT, "bench.py")] + bench_args
+    try:
+        subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout, check=False)
+    except Exception:
+        return None
+    return glob.glob(os.path.join(outdir, "**", "*.csv"), recursive=True)
+
+
+def rocprof_views(workload, steps=15):
+    """Two facts only a hardware profiler of the REAL (two-stream, un-instrumented) step can give, collected by running this
+    script as a child of rocprofv3 (separate runs: a kernel trace, then one PMC pass per counter, as MI355X_MICROARCH.md
+    prescribes): per-kernel average durations under concurrency, and HBM bytes per launch (FETCH_SIZE doubled for the gfx950
+    wide-load under-count, x1024)."""
+    out = {"kernels_concurrent": None, "traffic": None, "wall_per_step_us": None}
+    base = ["--workload", workload, "--no-profile", "--no-cpu-baseline", "--no-extras"]
+    tmp = tempfile.mkdtemp(prefix="skf_rocprof_")
+    try:
+        files = _run_self_under_rocprof(["--kernel-trace"], base + ["--steps", str(steps), "--warmup", "5"], os.path.join(tmp, "kt"))
+        trace = [f for f in (files or []) if f.endswith("kernel_trace.csv")]
+        if trace:
+            rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), _clean(r["Kernel_Name"])) for r in csv.DictReader(open(trace[0]))]
+            rows.sort()
+            ends = [i for i, r in enumerate(rows) if "adam" in r[2] or "sgd" in r[2]][-(steps + 1):]
+            if len(ends) >= 2:
+                seg = rows[ends[0] + 1: ends[-1] + 1]
+                n = len(ends) - 1
+                agg = {}
+                for s, e, k in seg:
+                    a = agg.setdefault(k, [0, 0.0])
+                    a[0] += 1; a[1] += (e - s) / 1e3
+                out["kernels_concurrent"] = sorted(({"kernel": k[:90], "launches_per_step": round(v[0] / n, 2), "avg_us": round(v[1] / v[0], 2),
+                                                     "per_step_ms": round(v[1] / n / 1e3, 4)} for k, v in agg.items()),
+                                                   key=lambda r: -r["per_step_ms"])[:16]
+                out["wall_per_step_us"] = (seg[-1][1] - seg[0][0]) / 1e3 / n
+                out["kernels_per_step"] = len(seg) / n
+        traffic = {}
+        for counter, scale in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+            files = _run_self_under_rocprof(["--pmc", counter], base + ["--steps", "3", "--warmup", "1"], os.path.join(tmp, counter))
+            cc = [f for f in (files or []) if f.endswith("counter_collection.csv")]
+            if not cc:
+                traffic = None
+                break
+            for r in csv.DictReader(open(cc[0])):
+                if r["Counter_Name"] == counter:
+                    t = traffic.setdefault(_clean(r["Kernel_Name"]), {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0]})
+                    t[counter][0] += float(r["Counter_Value"]) * scale * 1024.0
+                    t[counter][1] += 1
+        if traffic:
+            out["traffic"] = {k: (v["FETCH_SIZE"][0] / max(v["FETCH_SIZE"][1], 1)) + (v["WRITE_SIZE"][0] / max(v["WRITE_SIZE"][1], 1))
+                              for k, v in traffic.items()}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
+def committed_traffic(tag):
+    """fallback when rocprofv3 cannot run here: the latest committed PMC summary under profiles/"""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    prefix = _kernel_prefix(tag)
+    if not files or not prefix:
+        return None
+    table = json.load(open(files[-1]))
     rows = [v for k, v in table.items() if k.startswith(prefix)]
     n = sum(r["launches"] for r in rows)
     return sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows) / n if n else None
@@ -117,9 +216,127 @@ def kernel_profile(engine_mod, cfg_kwargs, x, y, steps=3):
     for r in rows:
         r["avg_us"] = 1e3 * r["ms"] / r["count"]
         r["per_step_ms"] = r["ms"] / steps
+        r["launches_per_step"] = r["count"] / steps
+    n_floats = eng.n_floats
     del eng
     torch.cuda.empty_cache()
-    return rows
+    return rows, n_floats
+
+
+def make_batch(synthetic, w, B, seed, full):
+    if w["cont"]:
+        xs, ys = synthetic.continuous_batch(B, w["L"], CN, seed=seed, full=full)
+    else:
+        xs, ys = synthetic.token_batch(B, w["L"], w["V"], CN, seed=seed, full=full)
+    return xs, ys
+
+
+def timed(eng, x, y, steps, warmup):
+    for _ in range(warmup):
+        eng.train_step(x, y)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.train_step(x, y)
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+def roofline_of(rows, act, steps_profiled=3):
+    """`roofline` object for the dominant kernel of a per-kernel profile (rows sorted by time)."""
+    top = rows[0]
+    is_mfma = top["flops"] > 0
+    bf16_pipe = act == "bf16"
+    if is_mfma:
+        ach = top["flops"] / (top["ms"] * 1e-3) / 1e12
+        peak = PEAK_BF16_MFMA_TFLOPS if bf16_pipe else PEAK_F32_MFMA_TFLOPS
+        roof = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None}
+        if "bf16x" in top["tag"]:
+            # split-operand kernel: fp32-equivalent FLOPs priced against the fp32 MFMA peak (the dtype of the path); the bf16
+            # matrix cores execute n_prod times as many - frac_of_executing_pipe prices THAT against the pipe that runs it
+            n_prod = int(top["tag"].split("bf16x")[1].rstrip(">"))
+            roof["issued_bf16_tflops"] = ach * n_prod
+            roof["frac_of_executing_pipe"] = ach * n_prod / PEAK_BF16_MFMA_TFLOPS
+            roof["executing_pipe"] = "bf16 MFMA, %d products per fp32 product, peak %.0f TFLOP/s" % (n_prod, PEAK_BF16_MFMA_TFLOPS)
+        else:
+            roof["frac_of_executing_pipe"] = roof["frac"]
+            roof["executing_pipe"] = "bf16 MFMA" if bf16_pipe else "fp32 MFMA"
+    else:
+        ach = top["bytes"] / (top["ms"] * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": None}
+    roof["algorithmic_per_launch"] = (top["flops"] if is_mfma else top["bytes"]) / top["count"]
+    roof.update({"kernel": top["tag"], "launches_per_step": top["launches_per_step"], "avg_launch_us": top["avg_us"],
+                 "per_step_ms": top["per_step_ms"]})
+    return roof
+
+
+def kernel_table(rows):
+    return [{"tag": r["tag"], "launches_per_step": round(r["launches_per_step"], 2), "avg_us": round(r["avg_us"], 2),
+             "per_step_ms": round(r["per_step_ms"], 4),
+             "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 2) if r["flops"] else None,
+             "gbs": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1) if r["bytes"] else None} for r in rows]
+
+
+def sub_record(engine, synthetic, name, B, steps, warmup, seed=0):
+    """ms/step, tokens/s, dominant kernel + roofline fraction of another BASELINE config on this GPU (not part of `value`)."""
+    w = WORKLOADS[name]
+    kw = dict(batch=B, seq_len=w["L"], d_model=w["d"], num_heads=8, dff=w["dff"], num_layers=w["N"], vocab_size=None if w["cont"] else w["V"],
+              n_classes=CN, lowerdim=U, dropout_rate=0.1, seed=1234, continuous=w["cont"], act_dtype=w["act"])
+    rec = {"workload": w["text"], "per_gpu_batch": B, "dtype": w["act"]}
+    eng = engine.TrainEngine(engine.make_config(use_graph=False, **kw), init_seed=0)
+    for full in (False, True):
+        xs, ys = make_batch(synthetic, w, B, seed, full)
+        x, y = torch.from_numpy(xs).cuda(), torch.from_numpy(ys).cuda()
+        e = timed(eng, x, y, steps, warmup)
+        key = "full_length" if full else "padded"
+        rec[key] = {"ms_per_step": 1e3 * e / steps, "value": B * w["L"] * steps / e,
+                    "pad_fraction": float((xs[..., 4] == 1).mean() if w["cont"] else (xs == 0).mean())}
+    assert np.isfinite(eng.step_metrics()["total_loss"])
+    P = eng.n_floats
+    del eng
+    torch.cuda.empty_cache()
+    xs, ys = make_batch(synthetic, w, B, seed, False)
+    x, y = torch.from_numpy(xs).cuda(), torch.from_numpy(ys).cuda()
+    rows, _ = kernel_profile(engine, kw, x, y)
+    rows.sort(key=lambda r: -r["ms"])
+    f_step = step_flops(B, w["L"], w["d"], w["dff"], w["N"], w["V"], U, CN, w["cont"])
+    peak = PEAK_BF16_MFMA_TFLOPS if w["act"] == "bf16" else PEAK_F32_MFMA_TFLOPS
+    t = rec["padded"]["ms_per_step"] * 1e-3
+    rec.update({"ms_per_step": rec["padded"]["ms_per_step"], "value": rec["padded"]["value"], "unit": "stroke-tokens/sec",
+                "step_tflops": f_step / t / 1e12, "step_mfma_frac": f_step / t / (peak * 1e12), "step_mfma_peak_tflops": peak,
+                "achieved_hbm": step_bytes(B, w["L"], w["d"], w["dff"], w["N"], w["V"], P, 2 if w["act"] == "bf16" else 4) / t / (PEAK_HBM_GBS * 1e9),
+                "roofline": roofline_of(rows, w["act"]), "kernels": kernel_table(rows)[:10]})
+    return rec
+
+
+def plugin_path_record(steps, warmup, B):
+    """The same cfg-2 step driven through the reference's plugin surface (Model.train_on_batch, models/sketchformer.py:351-359):
+    the metrics come back as a lazily read mapping, so the loop is not host-synchronised per step."""
+    from sketchformer_amd import models, dataloaders
+    Model = models.get_model_by_name("sketch-transformer-tf2")
+    Loader = dataloaders.get_dataloader_by_name("stroke3-synthetic")
+    dataset = Loader(Loader.parse_hparams("max_seq_len=200,vocab_size=1004,n_classes=345,n_samples=%d" % (B * 64)), None)
+    tmp = tempfile.mkdtemp(prefix="skf_bench_")
+    try:
+        model = Model(Model.parse_hparams(base="batch_size=%d,log_every=1000000" % B, specific=None), dataset, tmp, "bench")
+        it = dataset.batch_iterator("train", B, False)
+        xs, ys = next(it)
+        batch = (torch.from_numpy(xs).cuda(), torch.from_numpy(ys).cuda())
+        pend = []
+        for _ in range(warmup):
+            pend.append(model.train_on_batch(batch))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            pend.append(model.train_on_batch(batch))
+        torch.cuda.synchronize()
+        e = time.perf_counter() - t0
+        last = dict(pend[-1])
+        assert np.isfinite(last["total_loss"])
+        return {"ms_per_step": 1e3 * e / steps, "value": B * 200 * steps / e,
+                "what": "Model.train_on_batch on a device-resident batch, metrics deferred (one read-back at the end)"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def main():
@@ -129,11 +346,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel profile (and with it `roofline`)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the sub-records, the rocprofv3 child runs and the plugin-path leg")
     ap.add_argument("--graph", action="store_true", help="replay the step from hipGraphs instead of eager launches + wgrad side stream")
     ap.add_argument("--full-length", action="store_true", help="all rows have n = L (worst case, no padding)")
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3"],
-                    help="cfg2 = the headline config (default); cfg3 = 6L/d256/dff1024 continuous stroke-5 (parity-test config)")
+    ap.add_argument("--allreduce", default="bucketed", choices=["bucketed", "single"],
+                    help="data parallel: gradient buckets overlapped with backward / optimizer (default) or ONE all-reduce of the whole buffer")
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS),
+                    help="cfg2 = the headline config (default); cfg3 = 6L/d256/dff1024 continuous; cfg5 = 8L/d512/dff2048 L=512 bf16")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -153,23 +373,20 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         pg = dist.group.WORLD
 
-    from sketchformer_amd import build, engine, synthetic
+    from sketchformer_amd import build, engine, synthetic, _lib
     if rank == 0:
         build.build_library(verbose=False)
     if world > 1:
         dist.barrier()
 
-    B, L, d, dff, N, V, U, Cn = args.batch, 200, 128, 512, 4, 1004, 256, 345
-    cont = args.workload == "cfg3"
-    if cont:
-        d, dff, N, V = 256, 1024, 6, 5
+    w = WORKLOADS[args.workload]
+    B, L, d, dff, N, V = args.batch, w["L"], w["d"], w["dff"], w["N"], w["V"]
+    cont = w["cont"]
     cfg_kwargs = dict(batch=B, seq_len=L, d_model=d, num_heads=8, dff=dff, num_layers=N, vocab_size=None if cont else V,
-                      n_classes=Cn, lowerdim=U, dropout_rate=0.1, seed=1234 + rank, continuous=cont)
+                      n_classes=CN, lowerdim=U, dropout_rate=0.1, seed=1234 + rank, continuous=cont, act_dtype=w["act"])
     eng = engine.TrainEngine(engine.make_config(use_graph=args.graph, **cfg_kwargs), init_seed=0, process_group=pg)
-    if cont:
-        xs, ys = synthetic.continuous_batch(B, L, Cn, seed=rank, full=args.full_length)
-    else:
-        xs, ys = synthetic.token_batch(B, L, V, Cn, seed=rank, full=args.full_length)
+    eng.dp_mode = args.allreduce
+    xs, ys = make_batch(synthetic, w, B, rank, args.full_length)
     x = torch.from_numpy(xs).cuda()
     y = torch.from_numpy(ys).cuda()
 
@@ -196,68 +413,89 @@ def main():
 
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * B * L * args.steps / elapsed
-    f_step = step_flops(B, L, d, dff, N, V, U, Cn)
+    f_step = step_flops(B, L, d, dff, N, V, U, CN, cont)
+    prec = _lib.default_precision()
+    peak = PEAK_BF16_MFMA_TFLOPS if w["act"] == "bf16" else PEAK_F32_MFMA_TFLOPS
+    bytes_step = step_bytes(B, L, d, dff, N, V, eng.n_floats, 2 if w["act"] == "bf16" else 4)
+    arithmetic = ("bf16 operands on the bf16 matrix cores, fp32 accumulate; fp32 master weights / Adam" if w["act"] == "bf16" else
+                  {0: "fp32 MFMA", 6: "fp32 operands split exactly into 3 bf16 pieces, 6 products on the bf16 matrix cores, fp32 "
+                                     "accumulate (error below the fp32-MFMA kernel's)", 3: "bf16x3 (opt-in fast mode)"}[prec])
     out = {
         "metric": "stroke-tokens/sec training step, d_model=128 L=200 B=128, 1/2/4/8 GPU",
         "value": value, "unit": "stroke-tokens/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": ("cfg3: sketch-transformer-tf2 6L/8H/d256/dff1024 L=200 continuous stroke-5 C=345 dropout=0.1, "
-                                "fwd+bwd+Adam(WarmupDecay)") if cont else
-                               ("cfg2: sketch-transformer-tf2 4L/8H/d128/dff512 L=200 V=1004 C=345 dropout=0.1, "
-                                "fwd+bwd+Adam(WarmupDecay)"), "global_batch": B * world, "per_gpu_batch": B,
-                   "seq_len": L, "parallelism": "dp%d" % world, "hip_graph": args.graph,
-                   "dense_gemm_arithmetic": {0: "fp32 MFMA", 6: "fp32 operands split exactly into 3 bf16 pieces, 6 products on the bf16 "
-                                                "matrix cores, fp32 accumulate (error below the fp32-MFMA kernel's)",
-                                             3: "bf16x3 (opt-in fast mode)"}[_gemm_precision()],
+        "dtype": w["act"], "data": "synthetic",
+        "config": {"workload": w["text"], "global_batch": B * world, "per_gpu_batch": B, "seq_len": L, "parallelism": "dp%d" % world,
+                   "hip_graph": args.graph, "dense_gemm_arithmetic": arithmetic, "gradient_allreduce": args.allreduce if world > 1 else None,
                    "pad_fraction": float((xs[..., 4] == 1).mean() if cont else (xs == 0).mean())},
-        "step_mfma_frac": f_step / (elapsed / args.steps) / (PEAK_F32_MFMA_TFLOPS * 1e12),
+        "step_mfma_frac": f_step / (elapsed / args.steps) / (peak * 1e12), "step_mfma_peak_tflops": peak,
         "step_tflops": f_step / (elapsed / args.steps) / 1e12,
+        "achieved_hbm": bytes_step / (elapsed / args.steps) / (PEAK_HBM_GBS * 1e9), "algorithmic_bytes_per_step": bytes_step,
         "final_total_loss": metrics["total_loss"],
     }
-    if rank == 0 and world == 1 and _gemm_precision() != 0 and not args.no_profile:
-        # the same step with the Dense matmuls on v_mfma_f32_16x16x4_f32 (SKF_GEMM_PRECISION=f32), timed the same way on the
-        # same engine after the headline region: reported beside it, never part of `value`
+    single = rank == 0 and world == 1
+    extras = single and not args.no_extras
+    if extras and not args.full_length:
+        xf, yf = make_batch(synthetic, w, B, rank, True)
+        e1 = timed(eng, torch.from_numpy(xf).cuda(), torch.from_numpy(yf).cuda(), args.steps, 5)
+        out["full_length"] = {"ms_per_step": 1e3 * e1 / args.steps, "value": B * L * args.steps / e1, "pad_fraction": 0.0,
+                              "what": "the same step with every row at n = L (SURVEY 8(d) worst case)"}
+    if extras and w["act"] == "f32" and prec != 0:
+        # the same step with the Dense matmuls on v_mfma_f32_16x16x4_f32, timed the same way: reported beside the headline
         eng0 = engine.TrainEngine(engine.make_config(use_graph=args.graph, gemm_precision=0, **cfg_kwargs), init_seed=0)
-        for _ in range(max(2, min(args.warmup, 5))):
-            eng0.train_step(x, y)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            eng0.train_step(x, y)
-        torch.cuda.synchronize()
-        e1 = time.perf_counter() - t1
+        e1 = timed(eng0, x, y, args.steps, 5)
         del eng0
         out["fp32_mfma_mode"] = {"ms_per_step": 1e3 * e1 / args.steps, "value": B * L * args.steps / e1,
                                  "step_mfma_frac": f_step / (e1 / args.steps) / (PEAK_F32_MFMA_TFLOPS * 1e12)}
+    del eng
+    torch.cuda.empty_cache()
     if rank == 0 and not args.no_profile:
-        rows = kernel_profile(engine, cfg_kwargs, x, y)
+        rows, _ = kernel_profile(engine, cfg_kwargs, x, y)
         rows.sort(key=lambda r: -r["ms"])
-        top = rows[0]
-        is_mfma = top["flops"] > 0
-        if is_mfma:
-            ach = top["flops"] / (top["ms"] * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None}
-        else:
-            ach = top["bytes"] / (top["ms"] * 1e-3) / 1e9
-            roof = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
-                    "traffic": None}
-        if "bf16x" in top["tag"]:   # split-operand kernel: fp32-equivalent FLOPs priced against the fp32 MFMA peak (the dtype of
-            n_prod = int(top["tag"].split("bf16x")[1].rstrip(">"))   # the path); the bf16 matrix cores execute n_prod x as many
-            roof["issued_bf16_tflops"] = ach * n_prod
-            roof["issued_frac_of_bf16_peak"] = ach * n_prod / PEAK_BF16_MFMA_TFLOPS
-        roof["traffic"] = pmc_traffic(top["tag"])
-        roof["algorithmic_per_launch"] = (top["flops"] if is_mfma else top["bytes"]) / top["count"]
-        roof.update({"kernel": top["tag"], "launches_per_step": top["count"] // 3, "avg_launch_us": top["avg_us"],
-                     "per_step_ms": top["per_step_ms"]})
+        roof = roofline_of(rows, w["act"])
+        out["kernels"] = kernel_table(rows)
+        out["kernels_note"] = ("`kernels`: in-library launch profiler (HIP events around every launch on its stream; the events serialise "
+                               "the two streams of the step); `kernels_concurrent`: rocprofv3 kernel trace of the un-instrumented step")
+        # attention FLOPs are counted dense in `tflops`; padded key tiles are skipped (exactly): second figure over the work done
+        if not cont and not args.full_length:
+            lens = (xs != 0).sum(1)
+            dense = float(B * L * L)
+            done = float(sum(L * (int(n + 15) // 16 * 16) for n in lens))
+            out["attention_work_fraction"] = {"self_attention_key_tiles_visited": done / dense,
+                                              "what": "share of (query, key) pairs in non-skipped 16-key tiles, encoder self-attention; "
+                                                      "multiply the attn_* tflops by it for FLOPs over work actually done"}
+        if extras:
+            views = rocprof_views(args.workload)
+            prefix = _kernel_prefix(roof["kernel"])
+            if views["traffic"] and prefix:
+                vals = [v for k, v in views["traffic"].items() if k.startswith(prefix)]
+                if vals:
+                    roof["traffic"] = float(np.mean(vals))
+                    roof["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two child runs of this script (FETCH doubled, x1024)"
+            if views["kernels_concurrent"]:
+                out["kernels_concurrent"] = views["kernels_concurrent"]
+                out["kernels_per_step"] = views.get("kernels_per_step")
+                out["rocprof_wall_per_step_us"] = views["wall_per_step_us"]
+                if prefix:
+                    conc = [r for r in views["kernels_concurrent"] if r["kernel"].startswith(prefix)]
+                    if conc:
+                        n = sum(r["launches_per_step"] for r in conc)
+                        avg = sum(r["avg_us"] * r["launches_per_step"] for r in conc) / n
+                        roof["avg_launch_us_concurrent"] = avg
+                        roof["frac_concurrent"] = roof["frac"] * roof["avg_launch_us"] / avg
+        if roof["traffic"] is None:
+            roof["traffic"] = committed_traffic(roof["kernel"])
+            if roof["traffic"] is not None:
+                roof["traffic_source"] = "committed profiles/*pmc_traffic.json (rocprofv3 not runnable in this invocation)"
         out["roofline"] = roof
-        out["kernels"] = [{"tag": r["tag"], "launches_per_step": r["count"] // 3, "avg_us": round(r["avg_us"], 2),
-                           "per_step_ms": round(r["per_step_ms"], 4),
-                           "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 2) if r["flops"] else None,
-                           "gbs": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1) if r["bytes"] else None}
-                          for r in rows]
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if extras and args.workload == "cfg2" and not args.graph:
+        out["plugin_path"] = plugin_path_record(args.steps, args.warmup, B)
+        for name, st, wu in (("cfg3", 20, 5), ("cfg5", 8, 3)):
+            try:
+                out[name] = sub_record(engine, synthetic, name, 128, st, wu)
+            except Exception as e:      # a sub-record must never cost the headline line
+                out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if single and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(out), flush=True)
