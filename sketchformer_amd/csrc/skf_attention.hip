@@ -24,25 +24,10 @@
 // accumulated across waves with LDS float atomics and written once.
 #include <stdlib.h>
 #include "skf_common.h"
+#include "skf_attention_params.h"
 
 namespace {
 
-struct AttnParams {
-  const float* Q; const float* K; const float* V; float* O;
-  int ldq, ldk, ldv, ldo;
-  const unsigned char* key_mask;  // (B, key_mask_ld) 1 = masked key, or null
-  int key_mask_ld;
-  int causal;
-  int B, H, Lq, Lk;
-  float* stats;                   // (B, H, Lq, 2): row max, 1/sum
-  // backward only
-  int xcd_remap;                  // XCD-contiguous (sample, head) ids (default on; env SKF_ATTN_XCD=0 turns it off)
-  int ablate;                     // diagnostics (env SKF_ATTN_ABLATE): 1 = no dQ atomics
-  long long* dbg;                 // diagnostics: s_memtime stamps of a few workgroups (env SKF_ATTN_DBG)
-  const float* dO; int lddo;
-  float* dQ; float* dK; float* dV;
-  int lddq, lddk, lddv;
-};
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -625,7 +610,7 @@ extern "C" int skf_attention_bwd(const float* Q, int ldq, const float* K, int ld
                                  const float* O, int ldo, const float* dO, int lddo, const float* stats,
                                  const unsigned char* key_mask, int key_mask_ld, int causal, int B, int H, int Lq, int Lk,
                                  int dh, float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv, int precision, skf_stream_t stream) {
-  (void)precision;
+
   AttnParams p{};
   p.Q = Q; p.K = K; p.V = V; p.O = const_cast<float*>(O); p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
   p.key_mask = key_mask; p.key_mask_ld = key_mask_ld; p.causal = causal; p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk;
@@ -638,6 +623,10 @@ extern "C" int skf_attention_bwd(const float* Q, int ldq, const float* K, int ld
   if (rc) return rc;
   SKF_CHECK_ARG(Q && K && V && O && dO && stats && dQ && dK && dV, "null operand");
   SKF_CHECK_ARG((lddo & 3) == 0 && (lddq & 3) == 0 && (lddk & 3) == 0 && (lddv & 3) == 0, "row strides must be multiples of 4");
+  // head size 16 in the split arithmetic modes: the two-pass kernel on the bf16 matrix cores (skf_attention_bwd2.hip);
+  // SKF_PREC_F32 keeps the fp32-MFMA kernel below (SKF_ATTN_BWD2=0 forces it)
+  static const bool bwd2_off = getenv("SKF_ATTN_BWD2") && getenv("SKF_ATTN_BWD2")[0] == '0';
+  if (dh == 16 && precision != SKF_PREC_F32 && !bwd2_off && Lk <= 512 && Lq <= 512) return skf_attention_bwd2_launch(p, (hipStream_t)stream);
   const size_t smem = bwd_smem(dh, Lq);
   SKF_CHECK_ARG(smem <= 160 * 1024, "Q/dO/dQ of one head do not fit in LDS");
   hipStream_t st = (hipStream_t)stream;

@@ -1,0 +1,23 @@
+// Launch parameters shared by the fp32-path attention kernels (skf_attention.hip, skf_attention_bwd2.hip).
+#pragma once
+#include "skf_common.h"
+
+struct AttnParams {
+  const float* Q; const float* K; const float* V; float* O;
+  int ldq, ldk, ldv, ldo;
+  const unsigned char* key_mask;  // (B, key_mask_ld) 1 = masked key, or null
+  int key_mask_ld;
+  int causal;
+  int B, H, Lq, Lk;
+  float* stats;                   // (B, H, Lq, 2): row max, 1/sum
+  // backward only
+  int xcd_remap;                  // XCD-contiguous (sample, head) ids (default on; env SKF_ATTN_XCD=0 turns it off)
+  int ablate;                     // diagnostics (env SKF_ATTN_ABLATE): 1 = no dQ atomics
+  long long* dbg;                 // diagnostics: s_memtime stamps of a few workgroups (env SKF_ATTN_DBG)
+  const float* dO; int lddo;
+  float* dQ; float* dK; float* dV;
+  int lddq, lddk, lddv;
+};
+
+// two-pass backward on the bf16 matrix cores with exactly split fp32 operands (head size 16); returns SKF_OK after launching
+int skf_attention_bwd2_launch(const AttnParams& p, hipStream_t st);

@@ -16,12 +16,12 @@ def _dev(a, dtype=torch.float32):
     return torch.as_tensor(np.ascontiguousarray(a)).to(dtype).cuda()
 
 
-def _close(got, want, rtol=RTOL, name=""):
+def _close(got, want, rtol=RTOL, name="", floor=1e-30):
     got = got.detach().cpu().numpy().astype(np.float64) if torch.is_tensor(got) else np.asarray(got, np.float64)
     want = np.asarray(want, np.float64)
     assert got.shape == want.shape, (name, got.shape, want.shape)
     assert np.isfinite(got).all(), name + ": non-finite output"
-    scale = max(np.abs(want).max(), 1e-30)
+    scale = max(np.abs(want).max(), floor)
     err = np.abs(got - want).max() / scale
     assert err <= rtol, "%s: max err %.3e of scale %.3e (rel %.3e > %.1e)" % (name, np.abs(got - want).max(), scale, err, rtol)
 
@@ -266,8 +266,9 @@ def test_attention_fwd_bwd(ops, B, H, Lq, Lk, dh, causal, with_mask):
     _close(o, _merge(want_o), name="attn fwd")
     dq, dk, dv = oracle.sdpa_bwd(_split(do, H), cache)
     gq, gk, gv = ops.attention_bwd(_dev(q), _dev(k), _dev(v), o, _dev(do), stats, H, key_mask=kmd, causal=causal)
-    _close(gq, _merge(dq), rtol=5e-5, name="attn dQ")
-    _close(gk, _merge(dk), rtol=5e-5, name="attn dK")
+    # (floor: with a single key dQ = dK = 0 exactly; dP - delta is then the rounding noise of two fp32 evaluations, ~1e-6)
+    _close(gq, _merge(dq), rtol=5e-5, name="attn dQ", floor=0.1)
+    _close(gk, _merge(dk), rtol=5e-5, name="attn dK", floor=0.1)
     _close(gv, _merge(dv), rtol=5e-5, name="attn dV")
 
 
