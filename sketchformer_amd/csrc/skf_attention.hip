@@ -623,10 +623,11 @@ extern "C" int skf_attention_bwd(const float* Q, int ldq, const float* K, int ld
   if (rc) return rc;
   SKF_CHECK_ARG(Q && K && V && O && dO && stats && dQ && dK && dV, "null operand");
   SKF_CHECK_ARG((lddo & 3) == 0 && (lddq & 3) == 0 && (lddk & 3) == 0 && (lddv & 3) == 0, "row strides must be multiples of 4");
-  // head size 16 in the split arithmetic modes: the two-pass kernel on the bf16 matrix cores (skf_attention_bwd2.hip);
+  // head size 16 / 32 in the split arithmetic modes: the two-pass kernel on the bf16 matrix cores (skf_attention_bwd2.hip);
   // SKF_PREC_F32 keeps the fp32-MFMA kernel below (SKF_ATTN_BWD2=0 forces it)
   static const bool bwd2_off = getenv("SKF_ATTN_BWD2") && getenv("SKF_ATTN_BWD2")[0] == '0';
-  if (dh == 16 && precision != SKF_PREC_F32 && !bwd2_off && Lk <= 512 && Lq <= 512) return skf_attention_bwd2_launch(p, (hipStream_t)stream);
+  if ((dh == 16 || (dh == 32 && Lk <= 256 && Lq <= 256)) && precision != SKF_PREC_F32 && !bwd2_off && Lk <= 512 && Lq <= 512)
+    return skf_attention_bwd2_launch(p, dh, (hipStream_t)stream);
   const size_t smem = bwd_smem(dh, Lq);
   SKF_CHECK_ARG(smem <= 160 * 1024, "Q/dO/dQ of one head do not fit in LDS");
   hipStream_t st = (hipStream_t)stream;

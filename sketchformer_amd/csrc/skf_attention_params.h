@@ -19,5 +19,5 @@ struct AttnParams {
   int lddq, lddk, lddv;
 };
 
-// two-pass backward on the bf16 matrix cores with exactly split fp32 operands (head size 16); returns SKF_OK after launching
-int skf_attention_bwd2_launch(const AttnParams& p, hipStream_t st);
+// two-pass backward on the bf16 matrix cores with exactly split fp32 operands (head size 16 or 32); returns SKF_OK after launching
+int skf_attention_bwd2_launch(const AttnParams& p, int dh, hipStream_t st);

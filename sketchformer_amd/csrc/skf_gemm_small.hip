@@ -97,6 +97,10 @@ int skf_gemm_small_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, f
   const char* off = getenv("SKF_GEMM_NO_SMALL");
   if (off && off[0] == '1') return SKF_OK;
   if ((double)p.M * p.N * p.K > 33554432.0) return SKF_OK;
+  // a long contraction over few outputs (weight gradient of a narrow layer over the B*L rows, e.g. Dense(d -> 5) of the
+  // continuous mode: 256 x 5 x 25472) would run on a handful of workgroups here (measured 150 us at cfg 3): leave it to
+  // the split-K path
+  if (p.K > 4096 && (double)p.M * p.N <= 65536.0) return SKF_OK;
   *handled = 1;
   SmallParams q{};
   q.A = p.A; q.B = p.B; q.C = p.C; q.M = p.M; q.N = p.N; q.K = p.K; q.ldc = p.ldc;

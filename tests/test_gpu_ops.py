@@ -254,6 +254,8 @@ def _merge(x):
     (3, 8, 199, 200, 16, False, False),    # blind cross-attention
     (2, 4, 37, 53, 16, False, True),       # ragged tiles
     (2, 8, 200, 200, 32, False, True),     # cfg 3 head dim
+    (2, 4, 199, 199, 32, True, True),      # cfg 3 decoder self-attention
+    (2, 4, 199, 200, 32, False, False),    # cfg 3 cross-attention
     (2, 4, 64, 64, 64, True, False),       # head dim 64
     (2, 2, 16, 16, 16, True, True),
     (1, 1, 1, 1, 16, False, False),        # degenerate
