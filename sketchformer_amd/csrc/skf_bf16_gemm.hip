@@ -36,28 +36,51 @@ struct NtParams {
   int accumulate;               // C += result (read-modify-write in bf16)
   float* C32; int ldc32;        // optional fp32 copy of the result (used for the small fp32 heads), or null
   int tiles_m, tiles_n;
+  int wide_c;                   // C (and relu_src) rows are 16-byte aligned: the epilogue moves 16-byte pieces
 };
 
 // ---- LDS images.  nt: a tile row = 64 bf16 = 128 B; two rows share a 256-byte super-row and the 16-byte chunk slot is
 // XOR-ed with the super-row index, so the 16 lanes of a ds_read_b128 group (16 consecutive rows, one logical chunk) hit
 // 16 different bank groups.
-__device__ __forceinline__ int nt_lds_off(int row, int chunk) {       // byte offset of 16-byte chunk `chunk` (0..7) of tile row `row`
-  const int s = row >> 1, h = row & 1;
-  return s * 256 + ((((h << 3) | chunk) ^ (s & 15)) << 4);
+template <int BK>
+__device__ __forceinline__ int nt_lds_off(int row, int chunk) {       // byte offset of 16-byte chunk `chunk` of tile row `row`
+  constexpr int CPR = BK / 8, RPS = 16 / CPR;
+  const int s = row / RPS, h = row % RPS;
+  return s * 256 + (((h * CPR + chunk) ^ (s & 15)) << 4);
 }
 
-template <bool EXTRA>   // EXTRA: relu_src / accumulate / fp32 copy (separate instantiation keeps the plain epilogue lean)
-__global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(NtParams p) {
+// DMA: the tiles travel global -> LDS directly (global_load_lds_dwordx4: the LDS address of a wave instruction is a uniform
+// base + 16 B per lane, i.e. a linear 1-KB piece = 4 super-rows, so the chunk swizzle is applied on the SOURCE side: lane l of
+// piece P fetches the logical chunk whose swizzled slot is l).  No staging registers, no ds_write pass; needs K % 64 == 0
+// (a DMA cannot zero-fill a partial step) - other K take the register-staged variant.
+// The loop's barrier also waits for the loads of the NEXT step (vmcnt(0) before s_barrier).  Measured (M = 65536, cfg-5
+// shapes): a step costs ~1.9 us whatever the tile, i.e. the K loop runs at the ~14 B/cycle/CU the fabric delivers to a CU when
+// all 256 fetch at once - more resident workgroups of a smaller step (BK = 32, four per CU) bought nothing; fewer bytes per
+// flop do:
+// BIG: 256 x 256 outputs per 512-thread workgroup (2 x 4 waves, 4 x 2 MFMA tiles per wave), 128 KB of LDS, one workgroup per
+// CU.  What a step can overlap with its own memory round trip is the MFMA work of the resident workgroups, and per LDS
+// byte that is proportional to BM BN / (BM + BN): the large tile doubles it (and halves the L2 -> LDS traffic per flop).
+// EXTRA: relu_src / accumulate / fp32 copy, TANH: act == 2 - separate instantiations keep the plain epilogue lean (unrolled
+// over the 32 pieces of a lane, a runtime tanh branch made it 50 KB of code that every piece jumps across)
+template <bool EXTRA, bool DMA, int BK, bool BIG, bool TANH>
+__global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_bf16_nt_kernel(NtParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // buffer b of the A / B tile images: A at b * 32 KB, B 16 KB behind it
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  constexpr int WN = BIG ? 4 : 2, MT = BIG ? 4 : 2, NT = 2, NW = 2 * WN;    // waves along n, MFMA tiles per wave, waves
+  constexpr int BM = 2 * MT * 32, BN = WN * NT * 32;
+  constexpr int CPR = BK / 8;                 // 16-byte chunks per tile row
+  constexpr int TBA = BM * BK * 2, TBB = BN * BK * 2, TB2 = TBA + TBB;      // bytes of the tile images / of one buffer
+  constexpr int NJ = TBA / 1024 / NW;         // DMA pieces per wave and tile
+  static_assert(BM == BN, "the staging below assumes equally tall A and B tiles");
+  static_assert(DMA || (BK == 64 && !BIG), "the register-staged variant is written for 128 x 128 tiles and 64-deep steps");
+  // buffer b of the A / B tile images: A at b * TB2, B TBA behind it
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
   // XCD-contiguous logical ids, n fastest: the tiles_n workgroups that share an A panel run back to back on one XCD
   const int lid = skf_xcd_remap(blockIdx.x, gridDim.x);
   const int tm = lid / p.tiles_n, tn = lid % p.tiles_n;
-  const int m0 = tm * 128, n0 = tn * 128;
+  const int m0 = tm * BM, n0 = tn * BN;
   const int kchunks = (p.K + 7) >> 3;                 // 16-byte chunks along K (row pitches are padded to 8 elements)
-  const int nk = (p.K + 63) >> 6;
+  const int nk = (p.K + BK - 1) / BK;
 
   // staging: chunk id = tid + 256 j -> row = id / 8, chunk = id % 8 (8 consecutive threads = one 128-byte row segment)
   const int srow = tid >> 3, sch = tid & 7;
@@ -81,85 +104,220 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(NtParams p) {
   auto lstore = [&](int buf) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int off = nt_lds_off(srow + 32 * j, sch);
-      *reinterpret_cast<uint4*>((smem + buf * 32768) + off) = ra[j];
-      *reinterpret_cast<uint4*>((smem + buf * 32768 + 16384) + off) = rb[j];
+      const int off = nt_lds_off<BK>(srow + 32 * j, sch);
+      *reinterpret_cast<uint4*>((smem + buf * TB2) + off) = ra[j];
+      *reinterpret_cast<uint4*>((smem + buf * TB2 + TBA) + off) = rb[j];
     }
   };
 
-  f32x16 acc[2][2];      // [n tile][m tile] of C^T
+  f32x16 acc[NT][MT];      // [n tile][m tile] of C^T
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < NT; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < MT; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  gload(0);
-  lstore(0);
+  // DMA addressing: wave w moves pieces 4w .. 4w+3 of each tile; lane l -> slot l of the piece = super-row S = 4*piece + l/16,
+  // slot q = l % 16 -> logical (h, chunk) = q ^ (S & 15), row = 2 S + h
+  const skf_bf16* da[NJ]; const skf_bf16* db[NJ];
+  if constexpr (DMA) {
+#pragma unroll
+    for (int j2 = 0; j2 < NJ; ++j2) {
+      const int S = 4 * (NJ * wave + j2) + (lane >> 4), hc = (lane & 15) ^ (S & 15), r = (16 / CPR) * S + hc / CPR, c = hc % CPR;
+      da[j2] = p.A + (size_t)min(m0 + r, p.M - 1) * p.lda + c * 8;
+      db[j2] = p.B + (size_t)min(n0 + r, p.N - 1) * p.ldb + c * 8;
+    }
+  }
+  auto dma = [&](int kt, int buf) {
+#pragma unroll
+    for (int j2 = 0; j2 < NJ; ++j2) {
+      char* la = smem + buf * TB2 + (NJ * wave + j2) * 1024;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(da[j2] + kt * BK),
+                                       (__attribute__((address_space(3))) void*)la, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(db[j2] + kt * BK),
+                                       (__attribute__((address_space(3))) void*)(la + TBA), 16, 0, 0);
+    }
+  };
+  if constexpr (DMA) {
+    dma(0, 0);
+  } else {
+    gload(0);
+    lstore(0);
+  }
   __syncthreads();
   const int lrow = lane & 31, lhi = lane >> 5;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);
+    if constexpr (DMA) { if (kt + 1 < nk) dma(kt + 1, cur ^ 1); }
+    else { if (kt + 1 < nk) gload(kt + 1); }
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      skf_bf16x8 af[2], bf[2];
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      skf_bf16x8 af[MT], bf[NT];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        af[t] = *reinterpret_cast<const skf_bf16x8*>((smem + cur * 32768) + nt_lds_off(wm * 64 + t * 32 + lrow, ks * 2 + lhi));
-        bf[t] = *reinterpret_cast<const skf_bf16x8*>((smem + cur * 32768 + 16384) + nt_lds_off(wn * 64 + t * 32 + lrow, ks * 2 + lhi));
-      }
+      for (int t = 0; t < NT; ++t)
+        bf[t] = *reinterpret_cast<const skf_bf16x8*>((smem + cur * TB2 + TBA) + nt_lds_off<BK>(wn * (NT * 32) + t * 32 + lrow, ks * 2 + lhi));
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int t = 0; t < MT; ++t)
+        af[t] = *reinterpret_cast<const skf_bf16x8*>((smem + cur * TB2) + nt_lds_off<BK>(wm * (MT * 32) + t * 32 + lrow, ks * 2 + lhi));
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[a], af[b], acc[a][b], 0, 0, 0);
     }
-    if (kt + 1 < nk) lstore(cur ^ 1);
+    if constexpr (!DMA) { if (kt + 1 < nk) lstore(cur ^ 1); }
     __syncthreads();
   }
 
-  // ---- epilogue.  acc[a][b][r]: n = n0 + wn*64 + a*32 + (r&3) + 8*(r>>2) + 4*lhi, m = m0 + wm*64 + b*32 + lrow
+  // ---- epilogue.  acc[a][b][r]: n = n0 + wn*64 + a*32 + (r&3) + 8*(r>>2) + 4*lhi, m = m0 + wm*(MT*32) + b*32 + lrow.
+  // A lane owns 4 consecutive columns of 32 different rows: stored from there, a wave instruction touches 32 cache lines
+  // with 16 bytes each and the store tail is issue-bound (measured: ~8 us of a 30-us workgroup at K = 512).  So the
+  // [MT*32][64] block of a wave goes through a wave-private LDS image (the staging buffers are dead after the loop's last
+  // barrier; 144-byte pitch: the 8-byte writes of 32 rows and the 16-byte reads of 8 rows both spread over all banks) and
+  // leaves as full 128-byte row segments, 8 rows per instruction.  bias / activation are applied on the way in (fp32),
+  // the relu mask and the accumulate operand on the way out (16-byte coalesced reads; the sum is formed in fp32 from the
+  // bf16-rounded product).  The fp32 copy needs the unrounded values: that (small-head) case keeps the direct stores.
+  constexpr int EP = 144;
+  const bool direct = EXTRA && p.C32;
+  // the lane's 8 bias pieces in ONE batch of loads (fetched piece by piece inside the branches below, each was a full,
+  // serialised L2 round trip: 32 of them = 6 us per workgroup)
+  const float act_floor = p.act == 1 ? 0.f : -__builtin_inff();
+  float4 bias_r[NT][4];
 #pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    const int m = m0 + wm * 64 + b * 32 + lrow;
-    if (m >= p.M) continue;
+  for (int a = 0; a < NT; ++a)
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int q = 0; q < 4; ++q) {
+      const int n = n0 + wn * (NT * 32) + a * 32 + 8 * q + 4 * lhi;
+      bias_r[a][q] = (p.bias && n < p.N) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  char* ew = smem + wave * (MT * 32 * EP);
+#pragma unroll
+  for (int b = 0; b < MT; ++b) {
+    const int m = m0 + wm * (MT * 32) + b * 32 + lrow;
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int n = n0 + wn * 64 + a * 32 + 8 * q + 4 * lhi;
-        if (n >= p.N) continue;                        // N and the pitches are multiples of 4: a piece is all in or all out
+        const int nl = a * 32 + 8 * q + 4 * lhi, n = n0 + wn * (NT * 32) + nl;
+        const bool in = m < p.M && n < p.N;              // N and the pitches are multiples of 4: a piece is all in or all out
         float v[4] = {acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
-        if (p.bias) {
-          const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
-          v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-        }
-        if (p.act == 1) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        } else if (p.act == 2) {
+        v[0] += bias_r[a][q].x; v[1] += bias_r[a][q].y; v[2] += bias_r[a][q].z; v[3] += bias_r[a][q].w;
+        if constexpr (TANH) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], act_floor);      // relu, or a no-op floor
         }
         if constexpr (EXTRA) {
-          if (p.relu_src) {
-            const uint2 hv = *reinterpret_cast<const uint2*>(p.relu_src + (size_t)m * p.ld_relu + n);
-            float h[4]; skf_unpack4(hv, h);
+          if (direct) {
+            if (!in) continue;
+            if (p.relu_src) {
+              const uint2 hv = *reinterpret_cast<const uint2*>(p.relu_src + (size_t)m * p.ld_relu + n);
+              float h[4]; skf_unpack4(hv, h);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = h[e] > 0.f ? v[e] : 0.f;
-          }
-          if (p.accumulate) {
-            const uint2 ov = *reinterpret_cast<const uint2*>(p.C + (size_t)m * p.ldc + n);
-            float o[4]; skf_unpack4(ov, o);
+              for (int e = 0; e < 4; ++e) v[e] = h[e] > 0.f ? v[e] : 0.f;
+            }
+            if (p.accumulate) {
+              const uint2 ov = *reinterpret_cast<const uint2*>(p.C + (size_t)m * p.ldc + n);
+              float o[4]; skf_unpack4(ov, o);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += o[e];
+              for (int e = 0; e < 4; ++e) v[e] += o[e];
+            }
+            *reinterpret_cast<float4*>(p.C32 + (size_t)m * p.ldc32 + n) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<uint2*>(p.C + (size_t)m * p.ldc + n) = skf_pack4(v);
+            continue;
           }
-          if (p.C32) *reinterpret_cast<float4*>(p.C32 + (size_t)m * p.ldc32 + n) = make_float4(v[0], v[1], v[2], v[3]);
         }
-        *reinterpret_cast<uint2*>(p.C + (size_t)m * p.ldc + n) = skf_pack4(v);
+        *reinterpret_cast<uint2*>(ew + (b * 32 + lrow) * EP + nl * 2) = skf_pack4(v);
       }
+  }
+  if (direct) return;
+  // way out: lane -> row it*8 + lane/8, 16-byte chunk lane%8 (wave-private image: no workgroup barrier, the compiler's
+  // lgkmcnt wait orders the ds_write / ds_read pair of one wave)
+  const int orow = lane >> 3, och = lane & 7;
+  const int n = n0 + wn * (NT * 32) + och * 8;
+  const bool wide = p.wide_c;
+  if (wide && m0 + wm * (MT * 32) + MT * 32 <= p.M && n + 8 <= p.N) {
+    // interior block (every tile of the cfg-5 shapes): no per-row conditions, and the mask / accumulate operands of all
+    // MT*4 rows of the lane are requested in one batch before the first is used (one memory round trip, not MT*4)
+    skf_bf16* cp = p.C + (size_t)(m0 + wm * (MT * 32) + orow) * p.ldc + n;
+    if constexpr (EXTRA) {
+      uint4 hv[MT * 4], ov[MT * 4];
+      if (p.relu_src) {
+        const skf_bf16* hp = p.relu_src + (size_t)(m0 + wm * (MT * 32) + orow) * p.ld_relu + n;
+#pragma unroll
+        for (int it = 0; it < MT * 4; ++it) hv[it] = *reinterpret_cast<const uint4*>(hp + (size_t)it * 8 * p.ld_relu);
+      }
+      if (p.accumulate) {
+#pragma unroll
+        for (int it = 0; it < MT * 4; ++it) ov[it] = *reinterpret_cast<const uint4*>(cp + (size_t)it * 8 * p.ldc);
+      }
+#pragma unroll
+      for (int it = 0; it < MT * 4; ++it) {
+        uint4 w = *reinterpret_cast<const uint4*>(ew + (it * 8 + orow) * EP + och * 16);
+        float v[8];
+        skf_unpack8(w, v);
+        if (p.relu_src) {
+          float h[8]; skf_unpack8(hv[it], h);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = h[e] > 0.f ? v[e] : 0.f;
+        }
+        if (p.accumulate) {
+          float o[8]; skf_unpack8(ov[it], o);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += o[e];
+        }
+        *reinterpret_cast<uint4*>(cp + (size_t)it * 8 * p.ldc) = skf_pack8(v);
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < MT * 4; ++it)
+        *reinterpret_cast<uint4*>(cp + (size_t)it * 8 * p.ldc) = *reinterpret_cast<const uint4*>(ew + (it * 8 + orow) * EP + och * 16);
+    }
+    return;
+  }
+#pragma unroll 1
+  for (int it = 0; it < MT * 4; ++it) {
+    const int rl = it * 8 + orow, m = m0 + wm * (MT * 32) + rl;
+    if (m >= p.M || n >= p.N) continue;
+    uint4 w = *reinterpret_cast<const uint4*>(ew + rl * EP + och * 16);
+    const bool full = n + 8 <= p.N;                      // else the chunk's first 4 columns only
+    skf_bf16* cp = p.C + (size_t)m * p.ldc + n;
+    if constexpr (EXTRA) {
+      float v[8];
+      skf_unpack8(w, v);
+      if (p.relu_src) {
+        const skf_bf16* hp = p.relu_src + (size_t)m * p.ld_relu + n;
+        uint4 hv;
+        if (wide && full) hv = *reinterpret_cast<const uint4*>(hp);
+        else {
+          const uint2 h0 = *reinterpret_cast<const uint2*>(hp), h1 = full ? *reinterpret_cast<const uint2*>(hp + 4) : make_uint2(0, 0);
+          hv = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        }
+        float h[8]; skf_unpack8(hv, h);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = h[e] > 0.f ? v[e] : 0.f;
+      }
+      if (p.accumulate) {
+        uint4 ov;
+        if (wide && full) ov = *reinterpret_cast<const uint4*>(cp);
+        else {
+          const uint2 o0 = *reinterpret_cast<const uint2*>(cp), o1 = full ? *reinterpret_cast<const uint2*>(cp + 4) : make_uint2(0, 0);
+          ov = make_uint4(o0.x, o0.y, o1.x, o1.y);
+        }
+        float o[8]; skf_unpack8(ov, o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += o[e];
+      }
+      w = skf_pack8(v);
+    }
+    if (wide && full) *reinterpret_cast<uint4*>(cp) = w;
+    else {
+      *reinterpret_cast<uint2*>(cp) = make_uint2(w.x, w.y);
+      if (full) *reinterpret_cast<uint2*>(cp + 4) = make_uint2(w.z, w.w);
+    }
   }
 }
 
@@ -329,19 +487,31 @@ extern "C" int skf_gemm_bf16(int M, int N, int K, const void* A, int lda, const 
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.bias = bias; p.act = act; p.relu_src = (const skf_bf16*)relu_src; p.ld_relu = ld_relu; p.accumulate = accumulate;
   p.C32 = C_f32; p.ldc32 = ldc_f32;
-  p.tiles_m = skf_cdiv(M, 128); p.tiles_n = skf_cdiv(N, 128);
   hipStream_t st = (hipStream_t)stream;
-  const size_t smem = 65536;
   const bool extra = relu_src || accumulate || C_f32;
+  // SKF_BF16_GEMM_DMA=0: register-staged tiles everywhere; SKF_BF16_GEMM_TILE=128: no 256 x 256 tiles (measurement knobs)
+  static const bool dma_off = getenv("SKF_BF16_GEMM_DMA") && getenv("SKF_BF16_GEMM_DMA")[0] == '0';
+  static const int tile_env = getenv("SKF_BF16_GEMM_TILE") ? atoi(getenv("SKF_BF16_GEMM_TILE")) : 0;
+  const bool dma = (K & 63) == 0 && !dma_off;
+  // the 256 x 256 tile: one workgroup per CU, so only where there are enough tiles to fill the chip
+  const bool big = dma && tile_env != 128 && act != 2 && N >= 256 && ((long)skf_cdiv(M, 256) * skf_cdiv(N, 256) >= 256 || tile_env == 256);
+  const int tile = big ? 256 : 128;
+  p.tiles_m = skf_cdiv(M, tile); p.tiles_n = skf_cdiv(N, tile);
+  p.wide_c = (ldc & 7) == 0 && ((uintptr_t)C & 15) == 0 && (!relu_src || ((ld_relu & 7) == 0 && ((uintptr_t)relu_src & 15) == 0));
+  const size_t smem = big ? 8 * 128 * 144 : 65536;      // the epilogue's wave-private images (144-byte rows) exceed the 128 KB of tile buffers
   SkfProfScope ps(st, "gemm_bf16_nt", 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * N * (accumulate ? 2 : 1)));
   int rc;
-  if (extra) {
-    if ((rc = set_smem(gemm_bf16_nt_kernel<true>, smem))) return rc;
-    hipLaunchKernelGGL(gemm_bf16_nt_kernel<true>, dim3(p.tiles_m * p.tiles_n), dim3(256), smem, st, p);
-  } else {
-    if ((rc = set_smem(gemm_bf16_nt_kernel<false>, smem))) return rc;
-    hipLaunchKernelGGL(gemm_bf16_nt_kernel<false>, dim3(p.tiles_m * p.tiles_n), dim3(256), smem, st, p);
+#define SKF_NT_GO(EX, DM, BG, TH)                                                                                            \
+  {                                                                                                                          \
+    if ((rc = set_smem(gemm_bf16_nt_kernel<EX, DM, 64, BG, TH>, smem))) return rc;                                           \
+    hipLaunchKernelGGL((gemm_bf16_nt_kernel<EX, DM, 64, BG, TH>), dim3(p.tiles_m * p.tiles_n), dim3(BG ? 512 : 256), smem, st, p); \
   }
+#define SKF_NT_GO2(EX, TH)                                                                                         \
+  { if (big) SKF_NT_GO(EX, true, true, false) else if (dma) SKF_NT_GO(EX, true, false, TH) else SKF_NT_GO(EX, false, false, TH) }
+  if (act == 2) { if (extra) SKF_NT_GO2(true, true) else SKF_NT_GO2(false, true) }
+  else { if (extra) SKF_NT_GO2(true, false) else SKF_NT_GO2(false, false) }
+#undef SKF_NT_GO2
+#undef SKF_NT_GO
   SKF_LAUNCH_CHECK();
   return SKF_OK;
 }

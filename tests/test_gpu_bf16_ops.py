@@ -53,7 +53,8 @@ def lib():
 
 
 # ------------------------------------------------------------------ Dense
-@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (300, 260, 200), (1000, 1004, 512), (796, 512, 1004), (65, 36, 24), (4096, 2048, 512)])
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (300, 260, 200), (1000, 1004, 512), (796, 512, 1004), (65, 36, 24), (4096, 2048, 512),
+                                   (32808, 516, 512), (16384, 1024, 128)])      # the last two take the 256 x 256 tile variant
 def test_gemm_bf16_nt_epilogues(lib, M, N, K):
     rng = np.random.RandomState(M + N + K)
     Kp, Np = (K + 7) // 8 * 8, (N + 7) // 8 * 8
