@@ -463,6 +463,122 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(TnParams p) {
   }
 }
 
+// ---- 256 x 256 tiles, direct-to-LDS (the shapes of cfg 5).  Same reasoning as the nt kernel: what bounds the loop is the
+// rate at which a CU's LDS can be filled (~15 B/cycle/CU measured), so the tile that needs half the bytes per flop runs
+// nearly twice as fast (128 x 128: 576-604 TFLOP/s measured = that rate).  512 threads = 2 x 4 waves, 4 x 2 MFMA tiles per
+// wave; a tile row is 256 bf16 = 512 B = eight 64-byte segments, slot = segment XOR (row & 3) in its low two bits.  The DMA
+// moves linear 1-KB pieces (two tile rows): lane l lands at slot l % 32 of row 2 piece + l / 32, so it FETCHES the logical
+// chunk that belongs there.  Needs whole 64-row steps (R % 64 == 0 - a DMA cannot zero-fill; garbage in the columns past
+// P / Q is harmless, those outputs are never stored).
+// Bias gradient: the column sums of the dY tile are one more MFMA per step with an all-ones A operand on the B fragments that
+// are in registers anyway (p tile 0, waves wp == 0) - exact products, fp32 accumulation, no extra LDS or HBM traffic.
+__device__ __forceinline__ int tnb_lds_off(int row, int col) {         // byte offset of element (row, col), col multiple of 4
+  const int seg = col >> 5;
+  return row * 512 + ((seg ^ (row & 3)) << 6) + ((col & 31) << 1);
+}
+
+__device__ __forceinline__ skf_bf16x8 tnb_read_frag(const char* tile, int r0, int c0, int lane) {
+  const int g = lane >> 4, j = lane & 15;
+  const int row = r0 + 8 * (g >> 1) + (j >> 2), col = c0 + 16 * (g & 1) + 4 * (j & 3);
+  typedef short s4 __attribute__((ext_vector_type(4)));
+  const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4 __attribute__((address_space(3)))*)(tile + tnb_lds_off(row, col)));
+  const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4 __attribute__((address_space(3)))*)(tile + tnb_lds_off(row + 4, col)));
+  typedef short s8 __attribute__((ext_vector_type(8)));
+  const s8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(skf_bf16x8, v);
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_bf16_tn_big_kernel(TnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // buffer b of the A / B tile images: A at b * 64 KB, B 32 KB behind it
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wp = wave >> 2, wq = wave & 3;
+  const int lid = skf_xcd_remap(blockIdx.x, gridDim.x);
+  const int tq = lid % p.tiles_q, tp = (lid / p.tiles_q) % p.tiles_p, z = lid / (p.tiles_q * p.tiles_p);
+  const int p0 = tp * 256, q0 = tq * 256;
+  const int rbeg = z * p.r_chunk, rend = min(p.R, rbeg + p.r_chunk);
+  const int nk = (rend - rbeg) >> 6;
+
+  const skf_bf16* da[4]; const skf_bf16* db[4];
+  const int qpad = (p.Q + 7) & ~7;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = 2 * (4 * wave + j) + (lane >> 5), s = lane & 31;
+    const int col = ((((s >> 2) ^ (row & 3)) << 2) | (s & 3)) * 8;
+    da[j] = p.A + (size_t)(rbeg + row) * p.lda + min(p0 + col, p.P - 8);
+    db[j] = p.B + (size_t)(rbeg + row) * p.ldb + min(q0 + col, qpad - 8);
+  }
+  auto dma = [&](int kt, int buf) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      char* la = smem + buf * 65536 + (4 * wave + j) * 1024;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(da[j] + (size_t)kt * 64 * p.lda),
+                                       (__attribute__((address_space(3))) void*)la, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(db[j] + (size_t)kt * 64 * p.ldb),
+                                       (__attribute__((address_space(3))) void*)(la + 32768), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[4][2];      // [p tile][q tile]
+  f32x16 cs[2];          // column sums of the B tiles (every row of the MFMA result holds the same sums)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { acc[a][0][r] = 0.f; acc[a][1][r] = 0.f; }
+    cs[0][r] = 0.f; cs[1][r] = 0.f;
+  }
+  const bool do_colsum = p.colsum_slab && tp == 0 && wp == 0;       // wave-uniform
+  const skf_bf16x8 ones = __builtin_bit_cast(skf_bf16x8, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
+
+  if (nk > 0) dma(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) dma(kt + 1, cur ^ 1);
+    const char* At = smem + cur * 65536;
+    const char* Bt = At + 32768;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      skf_bf16x8 af[4], bf[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) bf[t] = tnb_read_frag(Bt, ks * 16, wq * 64 + t * 32, lane);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) af[t] = tnb_read_frag(At, ks * 16, wp * 128 + t * 32, lane);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+      if (do_colsum) {
+        cs[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bf[0], cs[0], 0, 0, 0);
+        cs[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bf[1], cs[1], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // acc[a][b][r]: row p = p0 + wp*128 + a*32 + (r&3) + 8*(r>>2) + 4*(lane>>5), col q = q0 + wq*64 + b*32 + (lane&31)
+  float* out = p.slab + (size_t)z * p.P * p.Q;
+  const int lcol = lane & 31, lhi = lane >> 5;
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int q = q0 + wq * 64 + b * 32 + lcol;
+    if (q >= p.Q) continue;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int pr = p0 + wp * 128 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (pr < p.P) out[(size_t)pr * p.Q + q] = acc[a][b][r];
+      }
+    if (do_colsum && lhi == 0) p.colsum_slab[(size_t)z * p.Q + q] = cs[b][0];
+  }
+}
+
+__host__ inline bool tn_use_big(int P, int Q, int R) {
+  static const int tile_env = getenv("SKF_BF16_GEMM_TILE") ? atoi(getenv("SKF_BF16_GEMM_TILE")) : 0;
+  return tile_env != 128 && (R & 63) == 0 && P >= 256 && Q >= 256 && R >= 16384;
+}
+
 template <typename K>
 int set_smem(K kfn, size_t bytes) {
   SKF_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
@@ -517,8 +633,10 @@ extern "C" int skf_gemm_bf16(int M, int N, int K, const void* A, int lda, const 
 }
 
 extern "C" int skf_gemm_bf16_wgrad_splits(int P, int Q, int R) {
-  const int tiles = skf_cdiv(P, 128) * skf_cdiv(Q, 128);
-  int splits = (512 + tiles - 1) / tiles;             // ~2 workgroups per CU
+  const bool big = tn_use_big(P, Q, R);
+  const int tiles = big ? skf_cdiv(P, 256) * skf_cdiv(Q, 256) : skf_cdiv(P, 128) * skf_cdiv(Q, 128);
+  // two 128 x 128 workgroups per CU, or ONE 256 x 256 - there a 257th workgroup would be a second round: round down
+  int splits = big ? 256 / tiles : (512 + tiles - 1) / tiles;
   const int max_splits = skf_cdiv(R, 512);            // at least 8 contraction steps per split
   if (splits > max_splits) splits = max_splits;
   return splits < 1 ? 1 : splits;
@@ -548,14 +666,21 @@ extern "C" int skf_gemm_bf16_wgrad_partial(int P, int Q, int R, const void* X, i
   TnParams p{};
   p.A = (const skf_bf16*)X; p.B = (const skf_bf16*)dY; p.R = R; p.P = P; p.Q = Q; p.lda = ldx; p.ldb = lddy;
   p.r_chunk = chunk; p.slab = slab; p.colsum_slab = with_bias_grad ? slab + (size_t)splits * P * Q : nullptr;
-  p.tiles_p = skf_cdiv(P, 128); p.tiles_q = skf_cdiv(Q, 128); p.splits = splits;
+  const bool big = tn_use_big(P, Q, R);
+  const int tile = big ? 256 : 128;
+  p.tiles_p = skf_cdiv(P, tile); p.tiles_q = skf_cdiv(Q, tile); p.splits = splits;
   *splits_used_host = splits;
   hipStream_t st = (hipStream_t)stream;
-  const size_t smem = 65536;
+  const size_t smem = big ? 131072 : 65536;
   int rc;
-  if ((rc = set_smem(gemm_bf16_tn_kernel, smem))) return rc;
   SkfProfScope ps(st, "gemm_bf16_tn(wgrad)", 2.0 * P * Q * R, 2.0 * (double)R * (P + Q) + 4.0 * (double)splits * P * Q);
-  hipLaunchKernelGGL(gemm_bf16_tn_kernel, dim3(p.tiles_p * p.tiles_q * splits), dim3(256), smem, st, p);
+  if (big) {
+    if ((rc = set_smem(gemm_bf16_tn_big_kernel, smem))) return rc;
+    hipLaunchKernelGGL(gemm_bf16_tn_big_kernel, dim3(p.tiles_p * p.tiles_q * splits), dim3(512), smem, st, p);
+  } else {
+    if ((rc = set_smem(gemm_bf16_tn_kernel, smem))) return rc;
+    hipLaunchKernelGGL(gemm_bf16_tn_kernel, dim3(p.tiles_p * p.tiles_q * splits), dim3(256), smem, st, p);
+  }
   SKF_LAUNCH_CHECK();
   return SKF_OK;
 }

@@ -79,7 +79,8 @@ def test_gemm_bf16_nt_epilogues(lib, M, N, K):
     _close(C32[:, :N], w2, 1e-4, "fp32 copy")                      # before the bf16 rounding: fp32 accumulation error only
 
 
-@pytest.mark.parametrize("R,P,Q", [(4096, 128, 128), (3000, 512, 1008), (796, 512, 2048), (65408, 512, 512), (100, 24, 40)])
+@pytest.mark.parametrize("R,P,Q", [(4096, 128, 128), (3000, 512, 1008), (796, 512, 2048), (65408, 512, 512), (100, 24, 40),
+                                   (16448, 264, 1008), (32768, 2048, 512)])     # R % 64 == 0, P, Q >= 256: the 256 x 256 tile variant (as 65408)
 def test_gemm_bf16_wgrad(lib, R, P, Q):
     rng = np.random.RandomState(R + P + Q)
     X, x64 = _bf(rng.randn(R, P))
