@@ -389,7 +389,10 @@ int launch_wsx(const GemmParams& p, int b_kc, hipStream_t st) {
   GemmParams q = p;
   // K >= 384 (N = 128): the two column groups of a worker read the same A tiles - XCD-contiguous ids keep the second read
   // in the L2 (PMC: 132 -> ~80 MB per launch); with one or two groups of short tiles (K <= 256) the remap only costs
-  if (!getenv("SKF_WS_XCD")) q.xcd_remap = K >= 384 && groups > 1;
+  // K = 128 with three or more column groups (N = 384 / 512 / 1004): round-robin ids put the group-mates of a worker on
+  // different XCDs, i.e. every A tile is fetched into `groups` L2s (PMC, round 1: 1.55x the algorithmic bytes)
+  static const char* xcd_env = getenv("SKF_WS_XCD");     // "0" / "1" force it (measurement)
+  q.xcd_remap = xcd_env ? xcd_env[0] == '1' : (groups > 1 && (K >= 384 || groups >= 3));
 #define SKF_WSX_LAUNCH(BKC, EX)                                                                                    \
   do {                                                                                                             \
     static bool attr_done = false;                                                                                 \
