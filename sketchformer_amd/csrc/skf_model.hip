@@ -10,6 +10,7 @@
 #include <vector>
 #include <map>
 #include "skf_common.h"
+#include "skf_decode_fused.h"
 
 // ------------------------------------------------------------------ error plumbing
 static thread_local char g_err[512] = "";
@@ -1071,7 +1072,54 @@ int run_greedy_decode(SkfModel* M, const float* embedding, const int* expected_l
     return skf_decode_select_tokens(logits, Vout, B, Vout, 0, 0, 0, tokens, Ti, selfmask, Le + 1, eos_seen, done_step,
                                     step_dev, dyn, s);
   };
+  // One launch per position (skf_decode_fused.hip) unless SKF_DECODE_FUSED=0 asks for the layer-by-layer path above
+  const char* fused_env = getenv("SKF_DECODE_FUSED");       // read per call: the tests compare the two paths in one process
+  const bool fused_off = fused_env && fused_env[0] == '0';
+  const bool fused = !fused_off && skf_decode_fused_supported(d, H, F, Le, N, Vout);
+  SkfDecodeFused fp{};
+  if (fused) {
+    auto dn = [&](const DenseP& w) {
+      SkfDecDense r{M->P(w.w), M->P(w.b), w.in, w.out, w.ld, 0};
+      r.vec4 = (w.ld & 3) == 0 && (w.out & 3) == 0 && ((uintptr_t)r.w & 15) == 0;
+      return r;
+    };
+    fp.B = B; fp.Le = Le; fp.d = d; fp.H = H; fp.F = F; fp.N = N; fp.Vout = Vout; fp.vocab = c.vocab_size;
+    fp.blind = c.blind_decoder_mask ? 1 : 0; fp.hs_len = F > Vout ? F : Vout;
+    for (int l = 0; l < N; ++l) {
+      const DecLayerP& w = L.dec[l];
+      SkfDecLayer& o = fp.layer[l];
+      o.qkv = dn(w.mha1.qkv); o.o = dn(w.mha1.o); o.q2 = dn(w.mha2.q); o.o2 = dn(w.mha2.o); o.f1 = dn(w.f1); o.f2 = dn(w.f2);
+      o.ln1_g = M->P(w.ln1.g); o.ln1_b = M->P(w.ln1.b); o.ln2_g = M->P(w.ln2.g); o.ln2_b = M->P(w.ln2.b);
+      o.ln3_g = M->P(w.ln3.g); o.ln3_b = M->P(w.ln3.b);
+      o.cache = M->at<float>(P.dc_cache[l]); o.kv2 = M->at<float>(P.dec[l].kv2);
+    }
+    fp.out = dn(L.out);
+    fp.emb_table = c.continuous ? nullptr : M->P(L.dec_emb);
+    fp.embd_w = c.continuous ? M->P(L.dec_embd.w) : nullptr; fp.embd_b = c.continuous ? M->P(L.dec_embd.b) : nullptr;
+    fp.pos = M->pos; fp.tokens = tokens; fp.cont = cont; fp.Ti = Ti; fp.selfmask = selfmask; fp.mask_ld = Le + 1;
+    fp.eos_seen = eos_seen; fp.done_step = done_step; fp.step_dev = step_dev; fp.ticket = done_step + 1;
+    fp.dyn = dyn; fp.limit = limit;
+    SKF_HIP(hipMemsetAsync(fp.ticket, 0, sizeof(int), s));
+  }
   static const bool use_graph = !(getenv("SKF_DECODE_GRAPH") && getenv("SKF_DECODE_GRAPH")[0] == '0');
+  if (fused) {
+    for (int i = 0; i < max_steps; ++i) {
+      SKF_TRY(skf_decode_fused_launch(fp, s));
+      if ((i & 7) == 7 || i + 1 == max_steps) {
+        int done = -1;
+        SKF_HIP(hipMemcpyAsync(&done, done_step, sizeof(int), hipMemcpyDeviceToHost, s));
+        SKF_HIP(hipStreamSynchronize(s));
+        if (done >= 0 || i + 1 == max_steps) {
+          const int ncols = (done >= 0 ? done + 1 : i + 1) + 1;
+          if (out_len_host) *out_len_host = ncols;
+          const size_t esz = c.continuous ? 5 * sizeof(float) : sizeof(long long);
+          SKF_HIP(hipMemcpy2DAsync(out, (size_t)T * esz, c.continuous ? (const void*)cont : (const void*)tokens, (size_t)Ti * esz,
+                                   (size_t)ncols * esz, B, hipMemcpyDeviceToDevice, s));
+          return SKF_OK;
+        }
+      }
+    }
+  }
   if (use_graph && !M->g_dec) {
     hipGraph_t graph = nullptr;
     SKF_HIP(hipStreamSynchronize(s));        // nothing of the setup above may end up inside the captured step
