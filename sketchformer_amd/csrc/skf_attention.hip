@@ -20,8 +20,11 @@
 // Backward: each wave owns a 16-key tile (K/V fragments live in registers, dK/dV
 // accumulate in registers) and walks the query tiles; S / dP are computed untransposed
 // (row = query) so they feed dV^T += dO^T.P and dK^T += Q^T.dS directly; dS is
-// transposed through a wave-private LDS scratch for dQ^T += K^T.dS^T, which is
-// accumulated across waves with LDS float atomics and written once.
+// transposed through a wave-private LDS scratch for dQ^T += K^T.dS^T; each wave writes its
+// 16 x DH partial of dQ to its own LDS slot and the workgroup sums the four slots into global
+// dQ (no atomics: fixed summation order).  Head sizes 16 and 32 (L <= 256) with the split
+// arithmetic take the two-pass kernel of skf_attention_bwd2.hip instead; this one serves the
+// fp32-MFMA mode, head size 64 and long sequences.
 #include <stdlib.h>
 #include "skf_common.h"
 #include "skf_attention_params.h"
