@@ -85,6 +85,26 @@ typedef struct SkfReduceDesc {
 int skf_gemm_wgrad_partial(int M, int N, int K, const float* A, int lda, const float* B, int ldb, int splits,
                            int with_bias_grad, float* slab, size_t slab_bytes, int* splits_used_host, int precision,
                            skf_stream_t stream);
+/* ---- rows that are known to be zero (decoder-side backward of a padded batch, token mode) ----
+ * The masked cross-entropy (builders/losses.py; models/sketchformer.py:313-349) gives padded target positions a zero
+ * gradient and the decoder is causal, so every decoder-side gradient row at or behind a sample's last unmasked position
+ * is exactly zero.  skf_target_live_len: live_len[b] = 1 + last t < Ld with tar[b][t + 1] != 0 (tar = the (B, tar_ld)
+ * int64 target tokens, decoder row t is trained on tar[b][t + 1]).  skf_row_blocks_build: the blocks of `granule`
+ * consecutive rows of the flattened (B * rows_per_sample) rows, as {n_live, n_blocks, live ids ascending, dead ids
+ * ascending} (skf_row_blocks_bytes ints).  skf_gemm_f32_rows (dgrad form, A [M][K], granule 16: rows of A in dead blocks
+ * are zero -> their C rows are stored as zeros without being computed, or left alone when accumulating) and
+ * skf_gemm_wgrad_partial_rows (granule 32: contraction rows in dead blocks are zero in B = dY and are not visited) are
+ * EXACT: what is skipped is x * 0.  Kernels other than the split-arithmetic weight-stationary ones ignore the list. */
+int skf_target_live_len(const long long* tar, int tar_ld, int B, int Ld, int* live_len, skf_stream_t stream);
+size_t skf_row_blocks_bytes(int rows, int granule);
+int skf_row_blocks_build(const int* live_len, int B, int rows_per_sample, int granule, int* blocks, skf_stream_t stream);
+int skf_gemm_f32_rows(int a_kcontig, int b_kcontig, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                      float* C, int ldc, const float* bias, int act, const float* relu_src, int ld_relu, int accumulate,
+                      int splits, float* bias_grad, int bias_grad_accumulate, void* workspace, size_t workspace_bytes,
+                      int precision, const int* row_blocks, int row_block_rows, skf_stream_t stream);
+int skf_gemm_wgrad_partial_rows(int M, int N, int K, const float* A, int lda, const float* B, int ldb, int splits,
+                                int with_bias_grad, float* slab, size_t slab_bytes, int* splits_used_host, int precision,
+                                const int* row_blocks, int row_block_rows, skf_stream_t stream);
 /* one slab ([splits][M][N] then [splits][N] when bias_grad != NULL) -> C (+)= sum, bias_grad (+)= column sums */
 int skf_splitk_reduce(const float* slab, int splits, int M, int N, float* C, int ldc, int accumulate, float* bias_grad,
                       int bias_grad_accumulate, skf_stream_t stream);

@@ -407,9 +407,9 @@ extern "C" int skf_splitk_reduce_batch(const SkfReduceDesc* descs_dev, int ndesc
 
 // wgrad main kernel only: dW partials (+ column sums of B when with_bias_grad) into `slab`
 // ([splits][M][N] then [splits][N]); *splits_used receives the effective split count.  Needs M, N, lda, ldb % 4 == 0.
-extern "C" int skf_gemm_wgrad_partial(int M, int N, int K, const float* A, int lda, const float* B, int ldb, int splits,
-                                      int with_bias_grad, float* slab, size_t slab_bytes, int* splits_used,
-                                      int precision, skf_stream_t stream) {
+extern "C" int skf_gemm_wgrad_partial_rows(int M, int N, int K, const float* A, int lda, const float* B, int ldb, int splits,
+                                           int with_bias_grad, float* slab, size_t slab_bytes, int* splits_used,
+                                           int precision, const int* row_blocks, int row_block_rows, skf_stream_t stream) {
   SKF_CHECK_ARG(M > 0 && N > 0 && K > 0 && A && B && slab && splits_used, "bad argument");
   SKF_CHECK_ARG(precision == SKF_PREC_F32 || precision == SKF_PREC_BF16X3 || precision == SKF_PREC_BF16X6, "precision must be 0 (fp32 MFMA), 6 (bf16x6) or 3 (bf16x3)");
   if (splits < 1) splits = 1;
@@ -422,6 +422,7 @@ extern "C" int skf_gemm_wgrad_partial(int M, int N, int K, const float* A, int l
   p.a_vec = ((lda & 3) == 0) && (((uintptr_t)A & 15) == 0);
   p.b_vec = ((ldb & 3) == 0) && (((uintptr_t)B & 15) == 0);
   p.k_chunk = chunk; p.slab = slab; p.precision = precision;
+  p.row_blocks = row_blocks; p.row_block_rows = row_blocks ? row_block_rows : 0;
   p.colsum_slab = with_bias_grad ? slab + (size_t)splits * M * N : nullptr;
   p.tiles_m = skf_cdiv(M, 64); p.tiles_n = skf_cdiv(N, 64);
   *splits_used = splits;
@@ -431,11 +432,28 @@ extern "C" int skf_gemm_wgrad_partial(int M, int N, int K, const float* A, int l
   return launch_variant<64, 64, 2, true>(p, 0, 0, splits, (hipStream_t)stream);
 }
 
+extern "C" int skf_gemm_wgrad_partial(int M, int N, int K, const float* A, int lda, const float* B, int ldb, int splits,
+                                      int with_bias_grad, float* slab, size_t slab_bytes, int* splits_used,
+                                      int precision, skf_stream_t stream) {
+  return skf_gemm_wgrad_partial_rows(M, N, K, A, lda, B, ldb, splits, with_bias_grad, slab, slab_bytes, splits_used, precision,
+                                     nullptr, 0, stream);
+}
+
 extern "C" int skf_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K,
                             const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                             const float* bias, int act, const float* relu_src, int ld_relu, int accumulate,
                             int splits, float* bias_grad, int bias_grad_accumulate,
                             void* workspace, size_t workspace_bytes, int precision, skf_stream_t stream) {
+  return skf_gemm_f32_rows(a_kcontig, b_kcontig, M, N, K, A, lda, B, ldb, C, ldc, bias, act, relu_src, ld_relu, accumulate, splits,
+                           bias_grad, bias_grad_accumulate, workspace, workspace_bytes, precision, nullptr, 0, stream);
+}
+
+extern "C" int skf_gemm_f32_rows(int a_kcontig, int b_kcontig, int M, int N, int K,
+                                 const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                                 const float* bias, int act, const float* relu_src, int ld_relu, int accumulate,
+                                 int splits, float* bias_grad, int bias_grad_accumulate,
+                                 void* workspace, size_t workspace_bytes, int precision, const int* row_blocks,
+                                 int row_block_rows, skf_stream_t stream) {
   SKF_CHECK_ARG(M > 0 && N > 0 && K > 0, "empty problem");
   SKF_CHECK_ARG(precision == SKF_PREC_F32 || precision == SKF_PREC_BF16X3 || precision == SKF_PREC_BF16X6, "precision must be 0 (fp32 MFMA), 6 (bf16x6) or 3 (bf16x3)");
   SKF_CHECK_ARG(A && B && C, "null operand");
@@ -446,6 +464,9 @@ extern "C" int skf_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K,
   p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.bias = bias; p.act = act; p.relu_src = relu_src; p.ld_relu = ld_relu; p.accumulate = accumulate;
   p.precision = precision;
+  SKF_CHECK_ARG(!row_blocks || (a_kcontig && row_block_rows > 0 && !bias && splits <= 1 && !bias_grad),
+                "a row-block list goes with the dgrad form: A [M][K], no bias, no split");
+  p.row_blocks = row_blocks; p.row_block_rows = row_blocks ? row_block_rows : 0;
   p.a_vec = ((lda & 3) == 0) && (((uintptr_t)A & 15) == 0);
   p.b_vec = ((ldb & 3) == 0) && (((uintptr_t)B & 15) == 0);
   p.tiles_m = skf_cdiv(M, 128); p.tiles_n = skf_cdiv(N, 128);

@@ -166,12 +166,12 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_x_kernel(GemmParams p) {   /
   const bool aok = a0 + 4 * i < p.M, bok = b0 + 4 * i < p.N;
   const bool do_colsum = p.colsum_slab != nullptr && tile_m == 0;
   constexpr unsigned OOB = 0x7ffffff0u;
-  // per-lane byte offsets of the eight rows of a step (row 32*wave + 8g + j of a 128-row iteration)
+  // per-lane byte offsets of the eight rows of a step (row 8g + j of the wave's 32-row block)
   unsigned xo[8], yo[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    xo[j] = aok ? (unsigned)((32 * wave + 8 * g + j) * p.lda + a0 + 4 * i) * 4u : OOB;
-    yo[j] = bok ? (unsigned)((32 * wave + 8 * g + j) * p.ldb + b0 + 4 * i) * 4u : OOB;
+    xo[j] = aok ? (unsigned)((8 * g + j) * p.lda + a0 + 4 * i) * 4u : OOB;
+    yo[j] = bok ? (unsigned)((8 * g + j) * p.ldb + b0 + 4 * i) * 4u : OOB;
   }
   f32x4 acc[4][4];
 #pragma unroll
@@ -181,12 +181,27 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_x_kernel(GemmParams p) {   /
   f32x4 csum = {0.f, 0.f, 0.f, 0.f};
 
   constexpr int RI = 32 * NW;                       // rows per iteration of the workgroup
-  const int niter = (ke - kb + RI - 1) / RI;
+  // With a row-block list (32-row blocks) the contraction runs over the LIVE blocks only: split z takes the list entries
+  // [z * per, (z + 1) * per), wave w every NW-th of them - the rows of a dead block are zero in dY, so leaving them out is exact.
+  const int* blk = p.row_blocks;
+  int eb = 0, ee = 0;
+  if (blk) {
+    const int nlive = blk[0], per = (nlive + (int)gridDim.x / ntile - 1) / ((int)gridDim.x / ntile);
+    eb = split * per; ee = min(nlive, eb + per);
+  }
+  const int niter = blk ? (max(ee - eb, 0) + NW - 1) / NW : (ke - kb + RI - 1) / RI;
   // two register sets of operand rows, used alternately (no copies: the split works in place on the rows)
   f32x4 xa0[8], yb0[8], xa1[8], yb1[8];
   auto load_step = [&](int it, f32x4 (&xa)[8], f32x4 (&yb)[8]) {
-    const __amdgpu_buffer_rsrc_t rx = wg_rows_rsrc(p.A, p.lda, kb + RI * it, ke);
-    const __amdgpu_buffer_rsrc_t ry = wg_rows_rsrc(p.B, p.ldb, kb + RI * it, ke);
+    int r0, r1;                                     // the wave's rows of this iteration: [r0, r1)
+    if (blk) {
+      const int e = eb + NW * it + wave;
+      r0 = e < ee ? blk[2 + e] * 32 : p.K; r1 = min(p.K, r0 + 32);
+    } else {
+      r0 = kb + RI * it + 32 * wave; r1 = ke;
+    }
+    const __amdgpu_buffer_rsrc_t rx = wg_rows_rsrc(p.A, p.lda, r0, r1);
+    const __amdgpu_buffer_rsrc_t ry = wg_rows_rsrc(p.B, p.ldb, r0, r1);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       xa[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xo[j], 0, 0));
@@ -280,6 +295,7 @@ int skf_gemm_wgrad_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, i
   if (((uintptr_t)p.slab & 15) || (p.k_chunk & 63)) return SKF_OK;
   *handled = 1;
   GemmParams q = p;
+  if (q.row_block_rows != 32) q.row_blocks = nullptr;       // wgrad_x walks 32-row blocks; the fp32 kernel ignores the list
   q.tiles_m = skf_cdiv(p.M, 64); q.tiles_n = skf_cdiv(p.N, 64);
   const size_t smem = (size_t)(4 * 4096 + 4 * 64) * sizeof(float);
   static bool attr_done = false;

@@ -129,6 +129,12 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
   const bool nok = n_lane < p.N;
   const int n_ld = nok ? n_lane : p.N - NB;
   const int ntiles = (p.M + TR - 1) / TR;
+  // Row-block list (16-row blocks = tiles): the loop below walks list POSITIONS [0, nlive); phys() maps a position to its
+  // tile (positions past the live ones map past the matrix: empty descriptors, nothing loaded or stored).  The dead
+  // tiles' output rows are zero-filled at the end.
+  const int* blk = p.row_blocks;
+  const int nlive = blk ? blk[0] : ntiles;
+  auto phys = [&](int pos) -> int { return pos < nlive ? (blk ? blk[2 + pos] : pos) : ntiles; };
 
   long long* dbg = (p.dbg && lane == 0 && wave == 0 && (blockIdx.x % 64) == 0 && blockIdx.x / 64 < 8) ? p.dbg + (blockIdx.x / 64) * 32 : nullptr;   // same XCD: comparable clocks
   int dbi = 0;
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
   f32x4 ra[R][NV];
   int tile = worker;
 #pragma unroll
-  for (int j = 0; j < R; ++j) wsx_load_tile<K>(p.A, p.lda, p.M, tile + j * workers, a_voff, ra[j]);
+  for (int j = 0; j < R; ++j) wsx_load_tile<K>(p.A, p.lda, p.M, phys(tile + j * workers), a_voff, ra[j]);
 
   // ---- weight slice -> split bf16 operands (once): bq[nb][s][q] = pieces q of B[k = 32s + 8g + e][n_lane + nb], e < 8
   u32x4 bq[NB][NKS][P];
@@ -197,7 +203,7 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
   SKF_STAMP();   // weight slice loaded + split
   wsx_store_tile<K, P, PITCH>(As, ra[0], sel);
   __syncthreads();
-  wsx_load_tile<K>(p.A, p.lda, p.M, tile + R * workers, a_voff, ra[0]);
+  wsx_load_tile<K>(p.A, p.lda, p.M, phys(tile + R * workers), a_voff, ra[0]);
   SKF_STAMP();   // first A tile in LDS
 
   vecn cprev[4], hsrc[4], oacc[4];
@@ -292,12 +298,13 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
       if (s == NKS / 2 - 1) {
         SKF_WSX_SCHED_BARRIER();
         wsx_store_tile<K, P, PITCH>(As + (cur ^ 1) * TILE_B, rn, sel);
-        wsx_load_tile<K>(p.A, p.lda, p.M, tile + (R + 1) * workers, a_voff, rn);
+        wsx_load_tile<K>(p.A, p.lda, p.M, phys(tile + (R + 1) * workers), a_voff, rn);
         if (EXTRA) {
-          const __amdgpu_buffer_rsrc_t rh = wsx_rows_rsrc(has_relu ? p.relu_src : p.C, p.ld_relu, has_relu ? p.M : 0, tile * TR);
+          const int ptile = phys(tile);
+          const __amdgpu_buffer_rsrc_t rh = wsx_rows_rsrc(has_relu ? p.relu_src : p.C, p.ld_relu, has_relu ? p.M : 0, ptile * TR);
 #pragma unroll
           for (int r = 0; r < 4; ++r) hsrc[r] = wsx_buf_load<NB>(rh, h_voff[r]);
-          const __amdgpu_buffer_rsrc_t ro = wsx_rows_rsrc(p.C, p.ldc, p.accumulate ? p.M : 0, tile * TR);
+          const __amdgpu_buffer_rsrc_t ro = wsx_rows_rsrc(p.C, p.ldc, p.accumulate ? p.M : 0, ptile * TR);
 #pragma unroll
           for (int r = 0; r < 4; ++r) oacc[r] = wsx_buf_load<NB>(ro, c_voff[r]);
         }
@@ -344,7 +351,7 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) reinterpret_cast<float*>(&cprev[r])[nb] = tanhf(reinterpret_cast<float*>(&cprev[r])[nb]);
     }
-    prev_tile = tile;
+    prev_tile = phys(tile);
     if (!EARLY) __syncthreads();
     SKF_STAMP();   // tile done
   };
@@ -355,15 +362,25 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
     if ((u) & 1) do_tile(1, ra[((u) + 1) % R], afB, afA);            \
     else do_tile(0, ra[((u) + 1) % R], afA, afB);                    \
     tile += workers;                                                 \
-    if (tile >= ntiles) break;                                       \
+    if (tile >= nlive) break;                                        \
   }
-  while (tile < ntiles) {
+  while (tile < nlive) {
     SKF_WSX_STEP(0) SKF_WSX_STEP(1)
     if constexpr (U > 2) { SKF_WSX_STEP(2) SKF_WSX_STEP(3) }
     if constexpr (U > 4) { SKF_WSX_STEP(4) SKF_WSX_STEP(5) }
   }
 #undef SKF_WSX_STEP
   store_prev();
+  if (blk && !p.accumulate) {                        // rows of dead tiles: zeros (an accumulating call leaves them as they are)
+    vecn zero;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) reinterpret_cast<float*>(&zero)[nb] = 0.f;
+    for (int pos = nlive + worker; pos < ntiles; pos += workers) {
+      const __amdgpu_buffer_rsrc_t rz = wsx_rows_rsrc(p.C, p.ldc, p.M, blk[2 + pos] * TR);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) wsx_buf_store<NB>(zero, rz, c_voff[r]);
+    }
+  }
   SKF_STAMP();
 #if SKF_WS_STAMPS
   if (dbg) { dbg[30] = wall_clock64() - wall0; dbg[31] = clock64() - cyc0; }
@@ -387,6 +404,7 @@ int launch_wsx(const GemmParams& p, int b_kc, hipStream_t st) {
                   4.0 * ((double)p.M * p.K + (double)p.K * p.N + (double)p.M * p.N * (p.accumulate ? 2 : 1)));
   const bool extra = p.relu_src || p.accumulate;
   GemmParams q = p;
+  if (q.row_block_rows != TR) q.row_blocks = nullptr;       // the list's blocks must be this kernel's tiles
   // K >= 384 (N = 128): the two column groups of a worker read the same A tiles - XCD-contiguous ids keep the second read
   // in the L2 (PMC: 132 -> ~80 MB per launch); with one or two groups of short tiles (K <= 256) the remap only costs
   // K = 128 with three or more column groups (N = 384 / 512 / 1004): round-robin ids put the group-mates of a worker on

@@ -265,7 +265,8 @@ struct Plan {
   // KV-cached greedy decode (inference): per-layer self-attention K|V cache (B, L, 2d) + one-row-per-sample step buffers
   std::vector<size_t> dc_cache;
   size_t dc_x[2], dc_q, dc_o, dc_z, dc_out1, dc_out2, dc_h, dc_logits, dc_stats, dc_mask, dc_flags, dc_limit;
-  size_t dc_tok, dc_cont, dc_kvnew, dc_dyn;   // internal (B, L+1) output image, newest K|V rows, per-call scalars + step index
+  size_t dc_tok, dc_cont, dc_kvnew, dc_dyn;
+  size_t live_len = 0, live16 = 0, live32 = 0;   // decoder-side live rows of the step (token mode): per-sample count, block lists   // internal (B, L+1) output image, newest K|V rows, per-call scalars + step index
 };
 
 size_t wgrad_ws(int in, int out, int rows) {
@@ -354,6 +355,8 @@ Plan build_plan(const SkfConfig& c) {
   P.dc_flags = b.take((B + 16) * sizeof(int)); P.dc_limit = b.take(B * sizeof(int));
   P.dc_tok = b.take(B * (L + 1) * 8); P.dc_cont = b.take(B * (L + 1) * 5 * f); P.dc_kvnew = b.take(B * 2 * d * f);
   P.dc_dyn = b.take(64);
+  P.live_len = b.take(B * sizeof(int));
+  P.live16 = b.take(skf_row_blocks_bytes(B * (L - 1), 16)); P.live32 = b.take(skf_row_blocks_bytes(B * (L - 1), 32));
   P.bytes = b.off;
   return P;
 }
@@ -383,7 +386,10 @@ struct SkfModel {
   size_t next_event = 0;
   std::map<const void*, hipEvent_t> pending_readers;   // buffer -> completion event of its last side-stream reader
   // kind 0: dW = X^T dY (+ bias grad); kind 1: an input gradient nobody on the main stream needs soon (dx (+)= dY W^T)
-  struct QueuedWgrad { DenseP w; const float* x; int ldx; const float* dy; int lddy; int rows; int kind = 0; float* dx = nullptr; int lddx = 0; int accumulate = 0; };
+  struct QueuedWgrad { DenseP w; const float* x; int ldx; const float* dy; int lddy; int rows; int kind = 0; float* dx = nullptr; int lddx = 0; int accumulate = 0; const int* blocks32 = nullptr; };
+  // Live row blocks of the decoder-side backward (skf_row_blocks.hip): set while the decoder layers' gradients are issued,
+  // consulted by dense_dgrad / dense_wgrad for problems with exactly `live_rows` rows; null = every row is visited
+  const int* live16 = nullptr; const int* live32 = nullptr; int live_rows = 0;
   std::map<const void*, hipEvent_t> pending_writers;   // buffers a side-stream dgrad still writes
   std::vector<QueuedWgrad> wq;                         // wgrads of the current layer, not yet issued
   bool side_used = false;
@@ -450,7 +456,9 @@ int before_write(SkfModel* M, const void* buf, hipStream_t s) {
 // dW = X^T dY (+ bias grad).  Eager path: queued, and issued per layer on the side stream by issue_wgrads().
 int dense_wgrad(SkfModel* M, const DenseP& w, const float* x, int ldx, const float* dy, int lddy, int rows, hipStream_t s) {
   if (!M->side) return dense_wgrad_on(M, w, x, ldx, dy, lddy, rows, s);
-  M->wq.push_back({w, x, ldx, dy, lddy, rows});
+  SkfModel::QueuedWgrad q{w, x, ldx, dy, lddy, rows};
+  if (M->live32 && rows == M->live_rows) q.blocks32 = M->live32;
+  M->wq.push_back(q);
   return SKF_OK;
 }
 // Main-stream kernels that read `buf` first wait for the side-stream dgrad that writes it.
@@ -497,7 +505,8 @@ int issue_wgrads(SkfModel* M, hipStream_t s) {
     SKF_CHECK_ARG(M->slab_cursor + bytes <= M->plan.slab_arena_bytes && M->desc_cursor < M->plan.n_wgrads, "slab arena exhausted");
     float* slab = M->at<float>(M->plan.slab_arena + M->slab_cursor);
     int used = 0;
-    SKF_TRY(skf_gemm_wgrad_partial(w.in, w.out, q.rows, q.x, q.ldx, q.dy, q.lddy, splits, 1, slab, bytes, &used, M->cfg.gemm_precision, M->side));
+    SKF_TRY(skf_gemm_wgrad_partial_rows(w.in, w.out, q.rows, q.x, q.ldx, q.dy, q.lddy, splits, 1, slab, bytes, &used, M->cfg.gemm_precision,
+                                        q.blocks32, 32, M->side));
     SkfReduceDesc d;
     d.slab = slab; d.C = M->G(w.w); d.bias_grad = M->G(w.b); d.splits = used; d.M = w.in; d.N = w.out; d.ldc = w.ld;
     d.block_begin = M->reduce_blocks; d.pad = 0;
@@ -560,8 +569,9 @@ int flush_wgrads(SkfModel* M, hipStream_t s, int bucket, bool final) {
 int dense_dgrad(SkfModel* M, const DenseP& w, const float* dy, int lddy, int rows, float* dx, int lddx, int accumulate,
                 const float* relu_src, int ld_relu, hipStream_t s) {
   SKF_TRY(before_write(M, dx, s));
-  return skf_gemm_f32(1, 1, rows, w.in, w.out, dy, lddy, M->P(w.w), w.ld, dx, lddx, nullptr, 0, relu_src, ld_relu,
-                      accumulate, 1, nullptr, 0, nullptr, 0, M->cfg.gemm_precision, s);
+  const int* blocks = (M->live16 && rows == M->live_rows) ? M->live16 : nullptr;
+  return skf_gemm_f32_rows(1, 1, rows, w.in, w.out, dy, lddy, M->P(w.w), w.ld, dx, lddx, nullptr, 0, relu_src, ld_relu,
+                           accumulate, 1, nullptr, 0, nullptr, 0, M->cfg.gemm_precision, blocks, 16, s);
 }
 
 // dx (+)= dY W^T for a dx that the main stream reads much later (the encoder-output gradient sent back by the decoder's
@@ -818,6 +828,16 @@ int run_backward(SkfModel* M, hipStream_t s) {
   float* enc_out = M->at<float>(P.enc[N - 1].x2);
   const float* pre = bott ? M->at<float>(P.pre) : enc_out;      // pre_decoder (see run_forward)
   if (recon) {
+  // From the output layer to the decoder embedding every (B * Ld)-row gradient is exactly zero behind a sample's last trained position
+  // (skf_row_blocks.hip): the split-arithmetic GEMMs walk the live row blocks only.  Not in continuous mode (its pen-state
+  // loss has a gradient at every position), not for the fp32-MFMA kernels (they ignore the lists).
+  static const bool rows_off = getenv("SKF_NO_ROW_BLOCKS") && getenv("SKF_NO_ROW_BLOCKS")[0] == '1';
+  if (!c.continuous && !rows_off && M->cfg.gemm_precision != SKF_PREC_F32) {
+    SKF_TRY(skf_target_live_len(tar, Le, B, Ld, M->at<int>(P.live_len), s));
+    SKF_TRY(skf_row_blocks_build(M->at<int>(P.live_len), B, Ld, 16, M->at<int>(P.live16), s));
+    SKF_TRY(skf_row_blocks_build(M->at<int>(P.live_len), B, Ld, 32, M->at<int>(P.live32), s));
+    M->live16 = M->at<int>(P.live16); M->live32 = M->at<int>(P.live32); M->live_rows = Md;
+  }
   // output layer: logits buffer now holds dlogits
   const float* dlog = M->at<float>(P.logits);
   SKF_TRY(dense_wgrad(M, L.out, M->at<float>(P.dec[N - 1].out3), d, dlog, L.out.out, Md, s));
@@ -866,6 +886,7 @@ int run_backward(SkfModel* M, hipStream_t s) {
     float* t = G; G = G2; G2 = t;
     SKF_TRY(issue_wgrads(M, s));          // the 8 weight gradients of this layer: one event pair
   }
+  M->live16 = M->live32 = nullptr; M->live_rows = 0;
   // decoder embedding
   if (c.continuous) {
     SKF_TRY(skf_embed_continuous_bwd(M->at<float>(P.tar), Le, B, Ld, G, d, M->G(L.dec_embd.w), M->G(L.dec_embd.b), rate,

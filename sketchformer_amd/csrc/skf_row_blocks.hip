@@ -1,0 +1,82 @@
+// Which rows of the decoder-side backward can be non-zero, as lists the GEMM kernels walk.
+//
+// Token mode (builders/losses.py masked cross-entropy; models/sketchformer.py:313-349): the reconstruction loss is masked
+// where the target token is PAD, so d(logits) of such a position is exactly zero; the decoder is causal (look-ahead mask), so
+// the gradient of EVERY decoder tensor at position t is exactly zero once all positions >= t are masked: its own row
+// receives nothing from the loss, and as a self-attention key it is only seen by queries >= t, whose dO is zero.  QuickDraw-
+// shaped batches are 58 % padding (83 % at seq_len 512).  live_len[b] = 1 + the last unmasked position of sample b; rows
+// [b * Ld + live_len[b], (b + 1) * Ld) of every decoder-side gradient are zero, the dgrad GEMMs need not compute them and
+// the weight gradients need not contract over them - exact, not an approximation (the products left out are x * 0).
+// (Continuous mode has no such rows: the pen-state cross-entropy is a global mean over all positions, losses.py:43-66.)
+#include "skf_common.h"
+#include "../../include/skf.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void target_live_len_kernel(const long long* __restrict__ tar, int tar_ld, int B, int Ld,
+                                                              int* __restrict__ live_len) {
+  // one wave per sample: position t (decoder row) is unmasked iff tar[b][t + 1] != 0
+  const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  int last = -1;
+  for (int t = lane; t < Ld; t += 64)
+    if (tar[(size_t)b * tar_ld + t + 1] != 0) last = t;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o, 64));
+  if (lane == 0) live_len[b] = last + 1;
+}
+
+// One workgroup.  Block k covers rows [k * g, (k + 1) * g) of the flattened (B * rps) rows; it is live when any of its
+// rows r = b * rps + t has t < live_len[b].  Stable compaction: live ids ascending, then dead ids ascending.
+__global__ __launch_bounds__(1024) void row_blocks_kernel(const int* __restrict__ live_len, int B, int rps, int g,
+                                                          int* __restrict__ blocks) {
+  __shared__ int part[1024];
+  const int tid = threadIdx.x;
+  const int rows = B * rps, nb = (rows + g - 1) / g;
+  const int per = (nb + 1023) / 1024;
+  auto is_live = [&](int k) -> bool {
+    const int r0 = k * g, r1 = min(rows, r0 + g);
+    for (int b = r0 / rps; b * rps < r1; ++b) {                 // the samples the block touches
+      const int lo = max(r0, b * rps), hi = b * rps + live_len[b];
+      if (lo < hi) return true;
+    }
+    return false;
+  };
+  int cnt = 0;
+  for (int k = tid * per; k < min(nb, (tid + 1) * per); ++k) cnt += is_live(k) ? 1 : 0;
+  part[tid] = cnt;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int a = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += a;
+    __syncthreads();
+  }
+  const int nlive = part[1023];
+  int lpos = part[tid] - cnt;                                   // live blocks before this thread's range
+  for (int k = tid * per; k < min(nb, (tid + 1) * per); ++k) {
+    if (is_live(k)) blocks[2 + lpos++] = k;
+    else blocks[2 + nlive + (k - lpos)] = k;                    // dead blocks before k = k - (live blocks before k)
+  }
+  if (tid == 0) { blocks[0] = nlive; blocks[1] = nb; }
+}
+
+}  // namespace
+
+extern "C" int skf_target_live_len(const long long* tar, int tar_ld, int B, int Ld, int* live_len, skf_stream_t stream) {
+  SKF_CHECK_ARG(tar && live_len && B > 0 && Ld > 0 && tar_ld > Ld, "bad argument");
+  hipLaunchKernelGGL(target_live_len_kernel, dim3(skf_cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, tar, tar_ld, B, Ld, live_len);
+  SKF_LAUNCH_CHECK();
+  return SKF_OK;
+}
+
+extern "C" size_t skf_row_blocks_bytes(int rows, int granule) {
+  return granule > 0 ? (size_t)(2 + skf_cdiv(rows, granule)) * sizeof(int) : 0;
+}
+
+extern "C" int skf_row_blocks_build(const int* live_len, int B, int rows_per_sample, int granule, int* blocks, skf_stream_t stream) {
+  SKF_CHECK_ARG(live_len && blocks && B > 0 && rows_per_sample > 0 && granule > 0, "bad argument");
+  hipLaunchKernelGGL(row_blocks_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, live_len, B, rows_per_sample, granule, blocks);
+  SKF_LAUNCH_CHECK();
+  return SKF_OK;
+}

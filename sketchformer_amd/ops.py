@@ -63,10 +63,29 @@ def read_step_state(state):
     return {"iterations": it, "lr": lr, "alpha": alpha, "drop_key": key}
 
 
+def target_live_len(tar, Ld):
+    """(B, >= Ld + 1) int64 target tokens -> int32 (B,): 1 + last decoder row t < Ld trained on a non-PAD token tar[b, t+1]."""
+    assert tar.dtype == torch.int64 and tar.dim() == 2 and tar.shape[1] > Ld
+    out = torch.empty(tar.shape[0], dtype=torch.int32, device=tar.device)
+    _lib.call("skf_target_live_len", _p(tar), tar.stride(0), tar.shape[0], Ld, _p(out), _stream())
+    return out
+
+
+def row_blocks(live_len, rows_per_sample, granule):
+    """{n_live, n_blocks, live block ids, dead block ids} (int32) over `granule`-row blocks of the (B * rows_per_sample) rows."""
+    B = live_len.shape[0]
+    n = _lib.load().skf_row_blocks_bytes(B * rows_per_sample, granule) // 4
+    out = torch.empty(n, dtype=torch.int32, device=live_len.device)
+    _lib.call("skf_row_blocks_build", _p(live_len), B, rows_per_sample, granule, _p(out), _stream())
+    return out
+
+
 def gemm(a, b, a_kcontig=True, b_kcontig=False, bias=None, act=0, relu_src=None, out=None, accumulate=False,
-         splits=1, bias_grad=None, precision=None):
+         splits=1, bias_grad=None, precision=None, row_blocks=None, row_block_rows=0):
     """C[M,N] (+)= opA(a) . opB(b).  a: [M,K] (a_kcontig) or [K,M]; b: [K,N] or [N,K] (b_kcontig).
-    precision: SKF_PREC_* (0 fp32 MFMA, 6 bf16x6, 3 bf16x3); None = _lib.default_precision()."""
+    precision: SKF_PREC_* (0 fp32 MFMA, 6 bf16x6, 3 bf16x3); None = _lib.default_precision().
+    row_blocks: list from ``row_blocks()`` - dgrad form with 16-row blocks (dead rows of a are zero), or the weight
+    gradient (splits > 1 / bias_grad) with 32-row blocks over the contraction rows."""
     _f32(a, "a"); _f32(b, "b")
     M, K = (a.shape[0], a.shape[1]) if a_kcontig else (a.shape[1], a.shape[0])
     N = b.shape[0] if b_kcontig else b.shape[1]
@@ -78,6 +97,19 @@ def gemm(a, b, a_kcontig=True, b_kcontig=False, bias=None, act=0, relu_src=None,
     if splits > 1 or bias_grad is not None:
         wsb = _lib.load().skf_gemm_workspace_bytes(M, N, K, splits, 1)
         ws = _ws(wsb, a.device)
+    if row_blocks is not None and (splits > 1 or bias_grad is not None):
+        # the weight gradient in its two phases: partial tiles over the live contraction blocks, then the slab reduction
+        assert not a_kcontig and not b_kcontig
+        used = C.c_int(0)
+        _lib.call("skf_gemm_wgrad_partial_rows", M, N, K, _p(a), a.stride(0), _p(b), b.stride(0), splits,
+                  int(bias_grad is not None), _p(ws), wsb, C.byref(used), _prec(precision), _p(row_blocks), row_block_rows, _stream())
+        _lib.call("skf_splitk_reduce", _p(ws), used.value, M, N, _p(out), out.stride(0), int(accumulate), _p(bias_grad), 0, _stream())
+        return out
+    if row_blocks is not None:
+        _lib.call("skf_gemm_f32_rows", int(a_kcontig), int(b_kcontig), M, N, K, _p(a), a.stride(0), _p(b), b.stride(0),
+                  _p(out), out.stride(0), _p(bias), act, _p(relu_src), relu_src.stride(0) if relu_src is not None else 0,
+                  int(accumulate), splits, _p(bias_grad), 0, _p(ws), wsb, _prec(precision), _p(row_blocks), row_block_rows, _stream())
+        return out
     _lib.call("skf_gemm_f32", int(a_kcontig), int(b_kcontig), M, N, K, _p(a), a.stride(0), _p(b), b.stride(0),
               _p(out), out.stride(0), _p(bias), act, _p(relu_src), relu_src.stride(0) if relu_src is not None else 0,
               int(accumulate), splits, _p(bias_grad), 0, _p(ws), wsb, _prec(precision), _stream())

@@ -205,6 +205,79 @@ def test_gemm_modes_extreme_operands(ops, kind):
     assert (np.abs(y6.astype(np.float64) - want)[~nf] / scale[~nf]).max() < 2e-6
 
 
+def _padded_case(rng, B, Ld, width):
+    """targets with PAD tails (one empty, one full sample) -> live_len, and a (B*Ld, width) gradient that is zero on dead rows"""
+    lens = rng.randint(1, Ld + 1, size=B); lens[0] = 0; lens[1] = Ld
+    tar = np.zeros((B, Ld + 1), np.int64)
+    for b in range(B):
+        tar[b, :lens[b] + 1] = rng.randint(1, 1000, size=lens[b] + 1)
+        if lens[b] > 3:
+            tar[b, 2] = 0                                  # a PAD inside the live range does not end it
+    tar[0, 0] = 5                                           # SOS only: no trained position
+    g = rng.randn(B * Ld, width)
+    for b in range(B):
+        g[b * Ld + lens[b]:(b + 1) * Ld] = 0.0
+    return tar, lens, g
+
+
+def test_row_blocks_lists(ops):
+    rng = np.random.RandomState(3)
+    B, Ld = 37, 199
+    tar, lens, _ = _padded_case(rng, B, Ld, 4)
+    ll = ops.target_live_len(_dev(tar, torch.int64), Ld)
+    assert np.array_equal(ll.cpu().numpy(), lens)
+    for g in (16, 32, 64, 256):
+        got = ops.row_blocks(ll, Ld, g).cpu().numpy()
+        nb = -(-B * Ld // g)
+        live_row = np.concatenate([np.arange(Ld) < n for n in lens])
+        live = np.array([live_row[k * g:(k + 1) * g].any() for k in range(nb)])
+        assert got[0] == live.sum() and got[1] == nb
+        assert np.array_equal(got[2:2 + got[0]], np.nonzero(live)[0]) and np.array_equal(got[2 + got[0]:], np.nonzero(~live)[0])
+
+
+@pytest.mark.parametrize("N,K,relu,acc", [(128, 128, False, False), (128, 384, False, True), (512, 128, True, False), (128, 512, False, False),
+                                          (128, 256, False, False), (1004, 128, False, False)])
+def test_gemm_dgrad_over_live_row_blocks_is_exact(ops, N, K, relu, acc):
+    """dX = dY W^T visiting only the 16-row tiles that hold live rows: bit-identical to the dense call (dead rows of dY are
+    zero, so the dense kernel computes exact zeros there), for every weight-stationary shape family of the step."""
+    rng = np.random.RandomState(N + K)
+    B, Ld = 40, 199
+    tar, lens, dy = _padded_case(rng, B, Ld, K)
+    w = rng.randn(N, K) / np.sqrt(K)
+    h = rng.randn(B * Ld, N) if relu else None
+    c0 = rng.randn(B * Ld, N)
+    for b in range(B):
+        c0[b * Ld + lens[b]:(b + 1) * Ld] = 0.0
+    blocks = ops.row_blocks(ops.target_live_len(_dev(tar, torch.int64), Ld), Ld, 16)
+    kw = dict(a_kcontig=True, b_kcontig=True, relu_src=_dev(h) if relu else None, accumulate=acc)
+    dense = ops.gemm(_dev(dy), _dev(w), out=_dev(c0), **kw)
+    rows = ops.gemm(_dev(dy), _dev(w), out=_dev(c0) if acc else torch.full((B * Ld, N), 7.0, device="cuda"), row_blocks=blocks,
+                    row_block_rows=16, **kw)
+    assert torch.equal(dense, rows)
+    want = dy @ w.T
+    if relu:
+        want = want * (h > 0)
+    _close(rows, want + (c0 if acc else 0.0), name="dgrad over live blocks")
+
+
+@pytest.mark.parametrize("inf,outf", [(128, 384), (128, 128), (512, 128), (128, 1004)])
+def test_gemm_wgrad_over_live_row_blocks(ops, inf, outf):
+    """dW = X^T dY contracting over the live 32-row blocks only; X is dense (forward activations exist at padded positions)."""
+    from sketchformer_amd import _lib
+    rng = np.random.RandomState(inf + outf)
+    B, Ld = 64, 199
+    tar, lens, dy = _padded_case(rng, B, Ld, outf)
+    x = rng.randn(B * Ld, inf)
+    blocks = ops.row_blocks(ops.target_live_len(_dev(tar, torch.int64), Ld), Ld, 32)
+    splits = _lib.load().skf_gemm_default_splits(inf, outf, B * Ld)
+    bg = torch.zeros(outf, device="cuda"); bg2 = torch.zeros(outf, device="cuda")
+    dense = ops.gemm(_dev(x), _dev(dy), a_kcontig=False, b_kcontig=False, splits=splits, bias_grad=bg)
+    rows = ops.gemm(_dev(x), _dev(dy), a_kcontig=False, b_kcontig=False, splits=splits, bias_grad=bg2, row_blocks=blocks, row_block_rows=32)
+    _close(rows, x.T @ dy, rtol=5e-5, name="wgrad over live blocks")
+    _close(bg2, dy.sum(0), rtol=5e-5, name="bias grad over live blocks")
+    _close(rows, dense.cpu().numpy(), rtol=2e-6, name="vs dense")
+
+
 def test_gemm_strided_views(ops):
     """fused QKV layout: W stored [d][3d]; outputs written into a (rows, 3d) buffer at a column offset."""
     rng = np.random.RandomState(5)
