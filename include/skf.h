@@ -91,7 +91,7 @@ int skf_gemm_wgrad_partial(int M, int N, int K, const float* A, int lda, const f
  * is exactly zero.  skf_target_live_len: live_len[b] = 1 + last t < Ld with tar[b][t + 1] != 0 (tar = the (B, tar_ld)
  * int64 target tokens, decoder row t is trained on tar[b][t + 1]).  skf_row_blocks_build: the blocks of `granule`
  * consecutive rows of the flattened (B * rows_per_sample) rows, as {n_live, n_blocks, live ids ascending, dead ids
- * ascending} (skf_row_blocks_bytes ints).  skf_gemm_f32_rows (dgrad form, A [M][K], granule 16: rows of A in dead blocks
+ * ascending, one 0/1 live flag per block in block order} (skf_row_blocks_bytes bytes).  skf_gemm_f32_rows (dgrad form, A [M][K], granule 16: rows of A in dead blocks
  * are zero -> their C rows are stored as zeros without being computed, or left alone when accumulating) and
  * skf_gemm_wgrad_partial_rows (granule 32: contraction rows in dead blocks are zero in B = dY and are not visited) are
  * EXACT: what is skipped is x * 0.  Kernels other than the split-arithmetic weight-stationary ones ignore the list. */
@@ -282,6 +282,20 @@ int skf_gemm_bf16_wgrad_partial(int P, int Q, int R, const void* X, int ldx, con
  * skf_gemm_bf16_wgrad_workspace_bytes(P, Q, R, skf_gemm_bf16_wgrad_splits(P, Q, R)) (fewer splits are used if it is smaller) */
 int skf_gemm_bf16_wgrad(int P, int Q, int R, const void* X, int ldx, const void* dY, int lddy, float* dW, int ldw,
                         float* bias_grad, void* workspace, size_t workspace_bytes, skf_stream_t stream);
+/* the same over live rows (see skf_row_blocks_build): the dgrad form takes a live-ROW list (granule 1) and runs its m
+ * tiles over the compacted live rows - rows of A / C / relu_src are gathered through the list, which costs nothing with
+ * per-lane load addresses (zero_dead: the dead rows of C are stored as zeros; never when accumulating); the weight
+ * gradient contracts over the live 64-row blocks (256 x 256 kernel only; the 128 x 128 kernel visits every row). */
+int skf_gemm_bf16_tile_rows(int M, int N, int K, int act);   /* 256 or 128: the m-tile height skf_gemm_bf16 uses for this problem */
+int skf_gemm_bf16_rows(int M, int N, int K, const void* A, int lda, const void* B_nk, int ldb, void* C, int ldc,
+                       const float* bias, int act, const void* relu_src, int ld_relu, int accumulate, float* C_f32,
+                       int ldc_f32, const int* row_list, int zero_dead, skf_stream_t stream);
+int skf_gemm_bf16_wgrad_partial_rows(int P, int Q, int R, const void* X, int ldx, const void* dY, int lddy, int splits,
+                                     int with_bias_grad, float* slab, size_t slab_bytes, int* splits_used_host,
+                                     const int* row_blocks_64, skf_stream_t stream);
+int skf_gemm_bf16_wgrad_rows(int P, int Q, int R, const void* X, int ldx, const void* dY, int lddy, float* dW, int ldw,
+                             float* bias_grad, void* workspace, size_t workspace_bytes, const int* row_blocks_64,
+                             skf_stream_t stream);
 /* scaled_dot_product_attention (builders/utils.py:71-105), streaming / online softmax, head size 64, any Lq / Lk;
  * mask semantics and `stats` as skf_attention_fwd.  The backward is two passes (dQ, then dK / dV) and needs
  * skf_attention_bf16_bwd_workspace_bytes of scratch (rowsum(dO o O)).  O_lo (optional, shape and pitch of O): the forward

@@ -37,6 +37,8 @@ struct NtParams {
   float* C32; int ldc32;        // optional fp32 copy of the result (used for the small fp32 heads), or null
   int tiles_m, tiles_n;
   int wide_c;                   // C (and relu_src) rows are 16-byte aligned: the epilogue moves 16-byte pieces
+  const int* row_blocks;        // live-ROW list (skf_row_blocks_build with granule 1: {n_live, M, live rows, dead rows, flags}) or null:
+  int zero_dead;                //   the m tiles run over the compacted live rows; dead rows of C are zero-filled if zero_dead
 };
 
 // ---- LDS images.  nt: a tile row = 64 bf16 = 128 B; two rows share a 256-byte super-row and the 16-byte chunk slot is
@@ -76,9 +78,41 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_bf16_nt_kernel(NtPara
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   // XCD-contiguous logical ids, n fastest: the tiles_n workgroups that share an A panel run back to back on one XCD
-  const int lid = skf_xcd_remap(blockIdx.x, gridDim.x);
+  // (with a live-row list the computing tiles are the first few logical ids: XCD-contiguous ids would put them all on one
+  //  or two XCDs - measured 129 us instead of ~80 with 82 live workgroups - so there the ids stay round-robin)
+  const int lid = p.row_blocks ? (int)blockIdx.x : skf_xcd_remap(blockIdx.x, gridDim.x);
   const int tm = lid / p.tiles_n, tn = lid % p.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
+  // Live-row list: tile rows are positions of the list (live rows first, then the dead ones), prow() maps a position to its
+  // row of A / C / relu_src.  A tile that starts behind the live rows has nothing to compute: its rows of C become zeros.
+  const int* rl = p.row_blocks;
+  const int nlive = rl ? rl[0] : p.M;
+  auto prow = [&](int m) -> int { return rl ? rl[2 + m] : m; };
+  if (m0 >= nlive) {
+    if (p.zero_dead && !p.accumulate) {
+      constexpr int CPRow = BN / 8, NTH = BIG ? 512 : 256, RPI = NTH / CPRow, NIT = BM / RPI;
+      const int c8 = (threadIdx.x % CPRow) * 8, r0 = threadIdx.x / CPRow, n = n0 + c8;
+      int pm[NIT];                                       // the row ids first, in one batch (not one load round trip per row)
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) { const int m = m0 + r0 + it * RPI; pm[it] = m < p.M ? prow(m) : -1; }
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        if (pm[it] < 0 || n >= p.N) continue;
+        skf_bf16* cp = p.C + (size_t)pm[it] * p.ldc + n;
+        if (p.wide_c && n + 8 <= p.N) *reinterpret_cast<uint4*>(cp) = make_uint4(0, 0, 0, 0);
+        else {
+          *reinterpret_cast<uint2*>(cp) = make_uint2(0, 0);
+          if (n + 8 <= p.N) *reinterpret_cast<uint2*>(cp + 4) = make_uint2(0, 0);
+        }
+        if (EXTRA && p.C32) {
+          float* c32 = p.C32 + (size_t)pm[it] * p.ldc32 + n;
+          *reinterpret_cast<float4*>(c32) = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (n + 8 <= p.N) *reinterpret_cast<float4*>(c32 + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+    }
+    return;
+  }
   const int kchunks = (p.K + 7) >> 3;                 // 16-byte chunks along K (row pitches are padded to 8 elements)
   const int nk = (p.K + BK - 1) / BK;
 
@@ -88,7 +122,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_bf16_nt_kernel(NtPara
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int r = srow + 32 * j;
-    const int ar = min(m0 + r, p.M - 1), br = min(n0 + r, p.N - 1);     // rows past the edge re-read the last row (never stored)
+    const int ar = prow(min(m0 + r, p.M - 1)), br = min(n0 + r, p.N - 1);     // rows past the edge re-read the last row (never stored)
     ag[j] = p.A + (size_t)ar * p.lda + sch * 8;
     bg[j] = p.B + (size_t)br * p.ldb + sch * 8;
   }
@@ -125,7 +159,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_bf16_nt_kernel(NtPara
 #pragma unroll
     for (int j2 = 0; j2 < NJ; ++j2) {
       const int S = 4 * (NJ * wave + j2) + (lane >> 4), hc = (lane & 15) ^ (S & 15), r = (16 / CPR) * S + hc / CPR, c = hc % CPR;
-      da[j2] = p.A + (size_t)min(m0 + r, p.M - 1) * p.lda + c * 8;
+      da[j2] = p.A + (size_t)prow(min(m0 + r, p.M - 1)) * p.lda + c * 8;
       db[j2] = p.B + (size_t)min(n0 + r, p.N - 1) * p.ldb + c * 8;
     }
   }
@@ -213,20 +247,21 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_bf16_nt_kernel(NtPara
         if constexpr (EXTRA) {
           if (direct) {
             if (!in) continue;
+            const int pm = prow(m);
             if (p.relu_src) {
-              const uint2 hv = *reinterpret_cast<const uint2*>(p.relu_src + (size_t)m * p.ld_relu + n);
+              const uint2 hv = *reinterpret_cast<const uint2*>(p.relu_src + (size_t)pm * p.ld_relu + n);
               float h[4]; skf_unpack4(hv, h);
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = h[e] > 0.f ? v[e] : 0.f;
             }
             if (p.accumulate) {
-              const uint2 ov = *reinterpret_cast<const uint2*>(p.C + (size_t)m * p.ldc + n);
+              const uint2 ov = *reinterpret_cast<const uint2*>(p.C + (size_t)pm * p.ldc + n);
               float o[4]; skf_unpack4(ov, o);
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] += o[e];
             }
-            *reinterpret_cast<float4*>(p.C32 + (size_t)m * p.ldc32 + n) = make_float4(v[0], v[1], v[2], v[3]);
-            *reinterpret_cast<uint2*>(p.C + (size_t)m * p.ldc + n) = skf_pack4(v);
+            *reinterpret_cast<float4*>(p.C32 + (size_t)pm * p.ldc32 + n) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<uint2*>(p.C + (size_t)pm * p.ldc + n) = skf_pack4(v);
             continue;
           }
         }
@@ -242,17 +277,18 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_bf16_nt_kernel(NtPara
   if (wide && m0 + wm * (MT * 32) + MT * 32 <= p.M && n + 8 <= p.N) {
     // interior block (every tile of the cfg-5 shapes): no per-row conditions, and the mask / accumulate operands of all
     // MT*4 rows of the lane are requested in one batch before the first is used (one memory round trip, not MT*4)
-    skf_bf16* cp = p.C + (size_t)(m0 + wm * (MT * 32) + orow) * p.ldc + n;
+    int pr[MT * 4];                                      // rows of C (and of the mask) behind the lane's MT*4 tile rows
+#pragma unroll
+    for (int it = 0; it < MT * 4; ++it) pr[it] = prow(m0 + wm * (MT * 32) + it * 8 + orow);
     if constexpr (EXTRA) {
       uint4 hv[MT * 4], ov[MT * 4];
       if (p.relu_src) {
-        const skf_bf16* hp = p.relu_src + (size_t)(m0 + wm * (MT * 32) + orow) * p.ld_relu + n;
 #pragma unroll
-        for (int it = 0; it < MT * 4; ++it) hv[it] = *reinterpret_cast<const uint4*>(hp + (size_t)it * 8 * p.ld_relu);
+        for (int it = 0; it < MT * 4; ++it) hv[it] = *reinterpret_cast<const uint4*>(p.relu_src + (size_t)pr[it] * p.ld_relu + n);
       }
       if (p.accumulate) {
 #pragma unroll
-        for (int it = 0; it < MT * 4; ++it) ov[it] = *reinterpret_cast<const uint4*>(cp + (size_t)it * 8 * p.ldc);
+        for (int it = 0; it < MT * 4; ++it) ov[it] = *reinterpret_cast<const uint4*>(p.C + (size_t)pr[it] * p.ldc + n);
       }
 #pragma unroll
       for (int it = 0; it < MT * 4; ++it) {
@@ -269,27 +305,28 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_bf16_nt_kernel(NtPara
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += o[e];
         }
-        *reinterpret_cast<uint4*>(cp + (size_t)it * 8 * p.ldc) = skf_pack8(v);
+        *reinterpret_cast<uint4*>(p.C + (size_t)pr[it] * p.ldc + n) = skf_pack8(v);
       }
     } else {
 #pragma unroll
       for (int it = 0; it < MT * 4; ++it)
-        *reinterpret_cast<uint4*>(cp + (size_t)it * 8 * p.ldc) = *reinterpret_cast<const uint4*>(ew + (it * 8 + orow) * EP + och * 16);
+        *reinterpret_cast<uint4*>(p.C + (size_t)pr[it] * p.ldc + n) = *reinterpret_cast<const uint4*>(ew + (it * 8 + orow) * EP + och * 16);
     }
     return;
   }
 #pragma unroll 1
   for (int it = 0; it < MT * 4; ++it) {
-    const int rl = it * 8 + orow, m = m0 + wm * (MT * 32) + rl;
+    const int rloc = it * 8 + orow, m = m0 + wm * (MT * 32) + rloc;
     if (m >= p.M || n >= p.N) continue;
-    uint4 w = *reinterpret_cast<const uint4*>(ew + rl * EP + och * 16);
+    const int pm = prow(m);
+    uint4 w = *reinterpret_cast<const uint4*>(ew + rloc * EP + och * 16);
     const bool full = n + 8 <= p.N;                      // else the chunk's first 4 columns only
-    skf_bf16* cp = p.C + (size_t)m * p.ldc + n;
+    skf_bf16* cp = p.C + (size_t)pm * p.ldc + n;
     if constexpr (EXTRA) {
       float v[8];
       skf_unpack8(w, v);
       if (p.relu_src) {
-        const skf_bf16* hp = p.relu_src + (size_t)m * p.ld_relu + n;
+        const skf_bf16* hp = p.relu_src + (size_t)pm * p.ld_relu + n;
         uint4 hv;
         if (wide && full) hv = *reinterpret_cast<const uint4*>(hp);
         else {
@@ -329,6 +366,7 @@ struct TnParams {
   float* slab;                             // [splits][P][Q] fp32 partial tiles
   float* colsum_slab;                      // [splits][Q] partial column sums of B, or null
   int tiles_p, tiles_q, splits;
+  const int* row_blocks;                   // 256 x 256 kernel: live 64-row blocks of the contraction (dead ones are zero in B) or null
 };
 
 // tile row = 128 bf16 = 256 B = four 64-byte segments; segment slot XOR (row & 3): the four rows a transposing read
@@ -496,8 +534,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_big_kernel(TnParams p) {
   const int lid = skf_xcd_remap(blockIdx.x, gridDim.x);
   const int tq = lid % p.tiles_q, tp = (lid / p.tiles_q) % p.tiles_p, z = lid / (p.tiles_q * p.tiles_p);
   const int p0 = tp * 256, q0 = tq * 256;
-  const int rbeg = z * p.r_chunk, rend = min(p.R, rbeg + p.r_chunk);
-  const int nk = (rend - rbeg) >> 6;
+  // contraction steps of this split: 64-row steps of [rbeg, rend), or (with a live-block list) the entries [eb, ee) of the
+  // list - the dead 64-row blocks hold zeros in B (= dY), leaving them out is exact
+  const int* blk = p.row_blocks;
+  int rbeg = z * p.r_chunk, nk = (min(p.R, rbeg + p.r_chunk) - rbeg) >> 6, eb = 0;
+  if (blk) {
+    const int nlive = blk[0], per = (nlive + p.splits - 1) / p.splits;
+    eb = z * per; nk = max(min(nlive, eb + per) - eb, 0); rbeg = 0;
+  }
 
   const skf_bf16* da[4]; const skf_bf16* db[4];
   const int qpad = (p.Q + 7) & ~7;
@@ -509,12 +553,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_big_kernel(TnParams p) {
     db[j] = p.B + (size_t)(rbeg + row) * p.ldb + min(q0 + col, qpad - 8);
   }
   auto dma = [&](int kt, int buf) {
+    const size_t r64 = blk ? (size_t)blk[2 + eb + kt] : (size_t)kt;      // 64-row block of this step (relative to rbeg)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       char* la = smem + buf * 65536 + (4 * wave + j) * 1024;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(da[j] + (size_t)kt * 64 * p.lda),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(da[j] + r64 * 64 * p.lda),
                                        (__attribute__((address_space(3))) void*)la, 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(db[j] + (size_t)kt * 64 * p.ldb),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(db[j] + r64 * 64 * p.ldb),
                                        (__attribute__((address_space(3))) void*)(la + 32768), 16, 0, 0);
     }
   };
@@ -587,9 +632,26 @@ int set_smem(K kfn, size_t bytes) {
 
 }  // namespace
 
+// rows per output tile the launcher will use for this problem (a live-row block list must be built for that height)
+extern "C" int skf_gemm_bf16_tile_rows(int M, int N, int K, int act) {
+  static const bool dma_off = getenv("SKF_BF16_GEMM_DMA") && getenv("SKF_BF16_GEMM_DMA")[0] == '0';
+  static const int tile_env = getenv("SKF_BF16_GEMM_TILE") ? atoi(getenv("SKF_BF16_GEMM_TILE")) : 0;
+  const bool dma = (K & 63) == 0 && !dma_off;
+  // the 256 x 256 tile: one workgroup per CU, so only where there are enough tiles to fill the chip
+  const bool big = dma && tile_env != 128 && act != 2 && N >= 256 && ((long)skf_cdiv(M, 256) * skf_cdiv(N, 256) >= 256 || tile_env == 256);
+  return big ? 256 : 128;
+}
+
 extern "C" int skf_gemm_bf16(int M, int N, int K, const void* A, int lda, const void* B_nk, int ldb, void* C, int ldc,
                              const float* bias, int act, const void* relu_src, int ld_relu, int accumulate, float* C_f32,
                              int ldc_f32, skf_stream_t stream) {
+  return skf_gemm_bf16_rows(M, N, K, A, lda, B_nk, ldb, C, ldc, bias, act, relu_src, ld_relu, accumulate, C_f32, ldc_f32, nullptr, 0, stream);
+}
+
+extern "C" int skf_gemm_bf16_rows(int M, int N, int K, const void* A, int lda, const void* B_nk, int ldb, void* C, int ldc,
+                                  const float* bias, int act, const void* relu_src, int ld_relu, int accumulate, float* C_f32,
+                                  int ldc_f32, const int* row_list, int zero_dead, skf_stream_t stream) {
+  SKF_CHECK_ARG(!row_list || !bias, "a live-row list goes with the dgrad form (no bias: dead rows must come out as zeros)");
   SKF_CHECK_ARG(M > 0 && N > 0 && K > 0 && A && B_nk && C, "bad problem");
   SKF_CHECK_ARG(act >= 0 && act <= 2, "bad activation");
   SKF_CHECK_ARG((lda & 7) == 0 && (ldb & 7) == 0 && (ldc & 3) == 0 && (N & 3) == 0, "pitches must be multiples of 8 (A, B) / 4 (C, N) elements");
@@ -607,12 +669,11 @@ extern "C" int skf_gemm_bf16(int M, int N, int K, const void* A, int lda, const 
   const bool extra = relu_src || accumulate || C_f32;
   // SKF_BF16_GEMM_DMA=0: register-staged tiles everywhere; SKF_BF16_GEMM_TILE=128: no 256 x 256 tiles (measurement knobs)
   static const bool dma_off = getenv("SKF_BF16_GEMM_DMA") && getenv("SKF_BF16_GEMM_DMA")[0] == '0';
-  static const int tile_env = getenv("SKF_BF16_GEMM_TILE") ? atoi(getenv("SKF_BF16_GEMM_TILE")) : 0;
   const bool dma = (K & 63) == 0 && !dma_off;
-  // the 256 x 256 tile: one workgroup per CU, so only where there are enough tiles to fill the chip
-  const bool big = dma && tile_env != 128 && act != 2 && N >= 256 && ((long)skf_cdiv(M, 256) * skf_cdiv(N, 256) >= 256 || tile_env == 256);
+  const bool big = skf_gemm_bf16_tile_rows(M, N, K, act) == 256;
   const int tile = big ? 256 : 128;
   p.tiles_m = skf_cdiv(M, tile); p.tiles_n = skf_cdiv(N, tile);
+  p.row_blocks = row_list; p.zero_dead = zero_dead;
   p.wide_c = (ldc & 7) == 0 && ((uintptr_t)C & 15) == 0 && (!relu_src || ((ld_relu & 7) == 0 && ((uintptr_t)relu_src & 15) == 0));
   const size_t smem = big ? 8 * 128 * 144 : 65536;      // the epilogue's wave-private images (144-byte rows) exceed the 128 KB of tile buffers
   SkfProfScope ps(st, "gemm_bf16_nt", 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * N * (accumulate ? 2 : 1)));
@@ -653,6 +714,12 @@ extern "C" size_t skf_gemm_bf16_wgrad_workspace_bytes(int P, int Q, int R, int s
 extern "C" int skf_gemm_bf16_wgrad_partial(int P, int Q, int R, const void* X, int ldx, const void* dY, int lddy, int splits,
                                            int with_bias_grad, float* slab, size_t slab_bytes, int* splits_used_host,
                                            skf_stream_t stream) {
+  return skf_gemm_bf16_wgrad_partial_rows(P, Q, R, X, ldx, dY, lddy, splits, with_bias_grad, slab, slab_bytes, splits_used_host, nullptr, stream);
+}
+
+extern "C" int skf_gemm_bf16_wgrad_partial_rows(int P, int Q, int R, const void* X, int ldx, const void* dY, int lddy, int splits,
+                                                int with_bias_grad, float* slab, size_t slab_bytes, int* splits_used_host,
+                                                const int* row_blocks_64, skf_stream_t stream) {
   SKF_CHECK_ARG(P > 0 && Q > 0 && R > 0 && X && dY && slab && splits_used_host, "bad argument");
   // Q may stop inside an 8-element chunk (vocabulary 1004): the rows of dY are padded to the pitch, pad columns are never stored
   SKF_CHECK_ARG((P & 7) == 0 && (Q & 3) == 0 && (ldx & 7) == 0 && (lddy & 7) == 0 && lddy >= ((Q + 7) & ~7),
@@ -674,6 +741,7 @@ extern "C" int skf_gemm_bf16_wgrad_partial(int P, int Q, int R, const void* X, i
   const size_t smem = big ? 131072 : 65536;
   int rc;
   SkfProfScope ps(st, "gemm_bf16_tn(wgrad)", 2.0 * P * Q * R, 2.0 * (double)R * (P + Q) + 4.0 * (double)splits * P * Q);
+  p.row_blocks = big ? row_blocks_64 : nullptr;      // the 128 x 128 kernel contracts over every row
   if (big) {
     if ((rc = set_smem(gemm_bf16_tn_big_kernel, smem))) return rc;
     hipLaunchKernelGGL(gemm_bf16_tn_big_kernel, dim3(p.tiles_p * p.tiles_q * splits), dim3(512), smem, st, p);
@@ -688,11 +756,17 @@ extern "C" int skf_gemm_bf16_wgrad_partial(int P, int Q, int R, const void* X, i
 // partial tiles + their reduction into the fp32 gradient: dW[P][Q] (row stride ldw) and bias_grad[Q] (may be NULL)
 extern "C" int skf_gemm_bf16_wgrad(int P, int Q, int R, const void* X, int ldx, const void* dY, int lddy, float* dW, int ldw,
                                    float* bias_grad, void* workspace, size_t workspace_bytes, skf_stream_t stream) {
+  return skf_gemm_bf16_wgrad_rows(P, Q, R, X, ldx, dY, lddy, dW, ldw, bias_grad, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int skf_gemm_bf16_wgrad_rows(int P, int Q, int R, const void* X, int ldx, const void* dY, int lddy, float* dW, int ldw,
+                                        float* bias_grad, void* workspace, size_t workspace_bytes, const int* row_blocks_64,
+                                        skf_stream_t stream) {
   SKF_CHECK_ARG(dW && workspace, "null operand");
   int splits = skf_gemm_bf16_wgrad_splits(P, Q, R), used = 0;
   while (splits > 1 && skf_gemm_bf16_wgrad_workspace_bytes(P, Q, R, splits) > workspace_bytes) --splits;
-  int rc = skf_gemm_bf16_wgrad_partial(P, Q, R, X, ldx, dY, lddy, splits, bias_grad != nullptr, (float*)workspace, workspace_bytes,
-                                       &used, stream);
+  int rc = skf_gemm_bf16_wgrad_partial_rows(P, Q, R, X, ldx, dY, lddy, splits, bias_grad != nullptr, (float*)workspace, workspace_bytes,
+                                            &used, row_blocks_64, stream);
   if (rc) return rc;
   return skf_splitk_reduce((const float*)workspace, used, P, Q, dW, ldw, 0, bias_grad, 0, stream);
 }

@@ -27,7 +27,8 @@ __global__ __launch_bounds__(256) void target_live_len_kernel(const long long* _
 }
 
 // One workgroup.  Block k covers rows [k * g, (k + 1) * g) of the flattened (B * rps) rows; it is live when any of its
-// rows r = b * rps + t has t < live_len[b].  Stable compaction: live ids ascending, then dead ids ascending.
+// rows r = b * rps + t has t < live_len[b].  Stable compaction: live ids ascending, then dead ids ascending; behind the ids
+// one flag per block in block order (1 = live) for kernels that are launched per block rather than walking the list.
 __global__ __launch_bounds__(1024) void row_blocks_kernel(const int* __restrict__ live_len, int B, int rps, int g,
                                                           int* __restrict__ blocks) {
   __shared__ int part[1024];
@@ -55,7 +56,9 @@ __global__ __launch_bounds__(1024) void row_blocks_kernel(const int* __restrict_
   const int nlive = part[1023];
   int lpos = part[tid] - cnt;                                   // live blocks before this thread's range
   for (int k = tid * per; k < min(nb, (tid + 1) * per); ++k) {
-    if (is_live(k)) blocks[2 + lpos++] = k;
+    const bool lv = is_live(k);
+    blocks[2 + nb + k] = lv ? 1 : 0;
+    if (lv) blocks[2 + lpos++] = k;
     else blocks[2 + nlive + (k - lpos)] = k;                    // dead blocks before k = k - (live blocks before k)
   }
   if (tid == 0) { blocks[0] = nlive; blocks[1] = nb; }
@@ -71,7 +74,7 @@ extern "C" int skf_target_live_len(const long long* tar, int tar_ld, int B, int 
 }
 
 extern "C" size_t skf_row_blocks_bytes(int rows, int granule) {
-  return granule > 0 ? (size_t)(2 + skf_cdiv(rows, granule)) * sizeof(int) : 0;
+  return granule > 0 ? (size_t)(2 + 2 * skf_cdiv(rows, granule)) * sizeof(int) : 0;
 }
 
 extern "C" int skf_row_blocks_build(const int* live_len, int B, int rows_per_sample, int granule, int* blocks, skf_stream_t stream) {

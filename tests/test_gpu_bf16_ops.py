@@ -309,3 +309,73 @@ def test_cast_weight_images_and_sorted_embedding_gradient(lib):
         lib.call(fn, _p(ws), B, L, _p(x), V, d, _p(out), 0.0, 0, None, _s())
     want = np.zeros((V, d)); np.add.at(want, tok.reshape(-1), dx64.reshape(-1, d) * np.sqrt(d))
     _close(g16, want, 1e-5, "embedding gradient"); _close(g32, want, 1e-5, "embedding gradient (fp32 kernel)")
+
+
+# ------------------------------------------------------------------ live row blocks (decoder-side backward of padded batches)
+def _padded_rows(rng, B, Ld):
+    lens = rng.randint(1, 140, size=B); lens[0] = 0; lens[1] = Ld
+    tar = np.zeros((B, Ld + 1), np.int64)
+    for b in range(B):
+        tar[b, :lens[b] + 1] = rng.randint(1, 1000, size=lens[b] + 1)
+    tar[0, 0] = 7
+    live = np.concatenate([np.arange(Ld) < n for n in lens])
+    return torch.as_tensor(tar).cuda(), lens, live
+
+
+@pytest.mark.parametrize("N,K,relu,acc", [(512, 512, False, False), (2048, 512, True, False), (512, 1536, False, True)])
+def test_gemm_bf16_dgrad_over_live_row_blocks_is_exact(lib, N, K, relu, acc):
+    """cfg-5 decoder rows (128 x 511): the tiles run over the compacted live rows only; every row equals the dense call."""
+    from sketchformer_amd import ops
+    rng = np.random.RandomState(N + K)
+    B, Ld = 128, 511
+    tar, lens, live = _padded_rows(rng, B, Ld)
+    M = B * Ld
+    ll = ops.target_live_len(tar, Ld)
+    rows1 = ops.row_blocks(ll, Ld, 1)
+    assert int(rows1[0]) == int(live.sum()) and int(rows1[1]) == M
+    lv = torch.as_tensor(live[:, None].astype(np.float32)).cuda()
+    dy = (torch.randn(M, K, device="cuda") * lv).to(BF)
+    w = (torch.randn(N, K, device="cuda") / K ** 0.5).to(BF)
+    h = torch.randn(M, N, device="cuda").to(BF) if relu else None
+    c0 = (torch.randn(M, N, device="cuda") * lv).to(BF)
+    outs = []
+    for rows in (False, True):
+        c = c0.clone() if acc else torch.full((M, N), 7.0, dtype=BF, device="cuda")
+        args = [M, N, K, _p(dy), K, _p(w), K, _p(c), N, None, 0, _p(h), N if relu else 0, int(acc), None, 0]
+        if rows:
+            lib.call("skf_gemm_bf16_rows", *args, _p(rows1), 1, _s())
+        else:
+            lib.call("skf_gemm_bf16", *args, _s())
+        outs.append(c)
+    assert torch.equal(outs[0], outs[1])
+    assert float(outs[1][~torch.as_tensor(live).cuda()].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("P,Q", [(512, 512), (512, 2048), (2048, 512)])
+def test_gemm_bf16_wgrad_over_live_row_blocks(lib, P, Q):
+    from sketchformer_amd import ops
+    rng = np.random.RandomState(P + Q)
+    B, Ld = 128, 511
+    tar, lens, live = _padded_rows(rng, B, Ld)
+    R = B * Ld
+    b64 = ops.row_blocks(ops.target_live_len(tar, Ld), Ld, 64)
+    lv = torch.as_tensor(live[:, None].astype(np.float32)).cuda()
+    x = torch.randn(R, P, device="cuda").to(BF)
+    dy = (torch.randn(R, Q, device="cuda") * lv).to(BF)
+    l = lib.load()
+    nb = l.skf_gemm_bf16_wgrad_workspace_bytes(P, Q, R, l.skf_gemm_bf16_wgrad_splits(P, Q, R))
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    res = []
+    for rows in (False, True):
+        dw = torch.empty(P, Q, device="cuda"); db = torch.empty(Q, device="cuda")
+        if rows:
+            lib.call("skf_gemm_bf16_wgrad_rows", P, Q, R, _p(x), P, _p(dy), Q, _p(dw), Q, _p(db), _p(ws), nb, _p(b64), _s())
+        else:
+            lib.call("skf_gemm_bf16_wgrad", P, Q, R, _p(x), P, _p(dy), Q, _p(dw), Q, _p(db), _p(ws), nb, _s())
+        res.append((dw, db))
+    want = x.double().T @ dy.double()
+    scale = (x.double().abs().T @ dy.double().abs()).cpu().numpy()
+    for dw, db in res:
+        err = np.abs(_np(dw) - want.cpu().numpy()) / scale
+        assert err.max() < 2e-6, err.max()                       # fp32 accumulation of exact bf16 products
+        _close(db, dy.double().sum(0).cpu().numpy(), 1e-5, "bias grad")

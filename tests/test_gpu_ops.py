@@ -232,7 +232,8 @@ def test_row_blocks_lists(ops):
         live_row = np.concatenate([np.arange(Ld) < n for n in lens])
         live = np.array([live_row[k * g:(k + 1) * g].any() for k in range(nb)])
         assert got[0] == live.sum() and got[1] == nb
-        assert np.array_equal(got[2:2 + got[0]], np.nonzero(live)[0]) and np.array_equal(got[2 + got[0]:], np.nonzero(~live)[0])
+        assert np.array_equal(got[2:2 + got[0]], np.nonzero(live)[0]) and np.array_equal(got[2 + got[0]:2 + nb], np.nonzero(~live)[0])
+        assert np.array_equal(got[2 + nb:], live.astype(np.int32))
 
 
 @pytest.mark.parametrize("N,K,relu,acc", [(128, 128, False, False), (128, 384, False, True), (512, 128, True, False), (128, 512, False, False),
