@@ -310,6 +310,13 @@ int skf_attention_bf16_bwd(const void* Q, int ldq, const void* K, int ldk, const
                            const void* O_lo, const void* dO, int lddo, const float* stats, const unsigned char* key_mask, int key_mask_ld,
                            int causal, int B, int H, int Lq, int Lk, int dh, void* dQ, int lddq, void* dK, int lddk, void* dV,
                            int lddv, void* workspace, size_t workspace_bytes, skf_stream_t stream);
+/* the same with per-sample live query counts (skf_target_live_len): query rows >= q_live_len[b] have dO == 0 exactly, so the
+ * dQ pass stores zeros for their blocks and the dK / dV pass stops at the last live block */
+int skf_attention_bf16_bwd_rows(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const void* O, int ldo,
+                                const void* O_lo, const void* dO, int lddo, const float* stats, const unsigned char* key_mask,
+                                int key_mask_ld, int causal, int B, int H, int Lq, int Lk, int dh, void* dQ, int lddq, void* dK,
+                                int lddk, void* dV, int lddv, void* workspace, size_t workspace_bytes, const int* q_live_len,
+                                skf_stream_t stream);
 /* row kernels: the fp32 entries of the same name with bf16 activations (d in {128, 256, 512, 1024}) */
 int skf_embed_fwd_bf16(const long long* tokens, int tok_ld, int B, int L, const float* table, int vocab, int d, const float* pos,
                        void* out, float rate, unsigned site, const void* step_state, skf_stream_t stream);

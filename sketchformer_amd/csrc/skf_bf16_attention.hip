@@ -42,6 +42,7 @@ struct AP {
   const skf_bf16* dO; int lddo;
   skf_bf16* dQ; skf_bf16* dK; skf_bf16* dV; int lddq, lddk, lddv;
   float* delta;                 // (B, H, Lq) rowsum(dO o O): written by the dQ pass, read by the dK/dV pass
+  const int* q_live;            // optional (B): query rows >= q_live[b] have dO == 0 exactly (skf_target_live_len) - backward only
   skf_bf16* Olo;                // optional (same shape / pitch as O): O_fp32 - bf16(O), the rounding residual of the output.
                                 // delta = rowsum(dO o O) is subtracted from dP = dO.V^T, which it nearly cancels wherever the
                                 // softmax gradient is small: with O at 8 significand bits the error of delta (2^-9 |delta|)
@@ -134,6 +135,18 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_q_kernel(AP p) {
   const int qb = lid % nqb, bh = lid / nqb, b = bh / p.H, h = bh % p.H;
   const int q0 = qb * 128 + wave * 32, q = q0 + lq;
   const bool qok = q < p.Lq;
+  if constexpr (MODE == 1) {
+    // a query block behind the sample's last live row: dO is zero there, so is dQ (and delta, which the dK/dV pass never
+    // reads for these rows) - stored, not computed
+    if (p.q_live && qb * 128 >= p.q_live[b]) {
+      if (qok) {
+        skf_bf16* dst = p.dQ + (size_t)(b * p.Lq + q) * p.lddq + h * DH + hi * 32;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) *reinterpret_cast<uint2*>(dst + 4 * c) = make_uint2(0, 0);      // lddq is a multiple of 4 elements
+      }
+      return;
+    }
+  }
   const int qc = qok ? q : p.Lq - 1;
   const unsigned char* km = p.key_mask ? p.key_mask + (size_t)b * p.key_mask_ld : nullptr;
   const float c2 = LOG2E / sqrtf((float)DH);
@@ -356,7 +369,8 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kv_kernel(AP p) {
   (void)has_pad;
   const bool can_skip = p.causal && !(km && km[0]);
   const bool pad_skip = lastk >= 0 && (!p.causal || can_skip);       // same rule as the forward: padded keys have P == 0 exactly
-  const int nqb = (p.Lq + 63) >> 6;
+  // query blocks behind the sample's last live row have dO == 0: they contribute nothing to dK / dV
+  const int nqb = ((p.q_live ? min(p.Lq, p.q_live[b]) : p.Lq) + 63) >> 6;
   // a workgroup whose keys are all padding (or past Lk) writes zeros; causal: queries before the first key see none of them
   const bool dead = pad_skip && kbk * 128 > lastk;
   const int qb_first = can_skip ? (kbk * 128) >> 6 : 0;
@@ -505,7 +519,17 @@ extern "C" int skf_attention_bf16_bwd(const void* Q, int ldq, const void* K, int
                                       int key_mask_ld, int causal, int B, int H, int Lq, int Lk, int dh, void* dQ, int lddq,
                                       void* dK, int lddk, void* dV, int lddv, void* workspace, size_t workspace_bytes,
                                       skf_stream_t stream) {
+  return skf_attention_bf16_bwd_rows(Q, ldq, K, ldk, V, ldv, O, ldo, O_lo, dO, lddo, stats, key_mask, key_mask_ld, causal, B, H, Lq, Lk, dh,
+                                     dQ, lddq, dK, lddk, dV, lddv, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int skf_attention_bf16_bwd_rows(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const void* O,
+                                           int ldo, const void* O_lo, const void* dO, int lddo, const float* stats,
+                                           const unsigned char* key_mask, int key_mask_ld, int causal, int B, int H, int Lq, int Lk,
+                                           int dh, void* dQ, int lddq, void* dK, int lddk, void* dV, int lddv, void* workspace,
+                                           size_t workspace_bytes, const int* q_live_len, skf_stream_t stream) {
   AP p{};
+  p.q_live = q_live_len;
   p.Q = (const skf_bf16*)Q; p.K = (const skf_bf16*)K; p.V = (const skf_bf16*)V; p.O = (skf_bf16*)const_cast<void*>(O);
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.key_mask = key_mask; p.key_mask_ld = key_mask_ld; p.causal = causal;
   p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.stats = const_cast<float*>(stats);

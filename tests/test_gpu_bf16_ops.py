@@ -158,6 +158,33 @@ def test_attention_bf16_fwd_bwd(lib, B, H, Lq, Lk, causal, with_mask):
             assert float(dK[b, first:].float().abs().max()) == 0.0 and float(dV[b, first:].float().abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("causal,Lk", [(True, 511), (False, 512)])
+def test_attention_bf16_bwd_live_query_counts_is_exact(lib, causal, Lk):
+    """dO is zero behind each sample's live length (decoder rows of a padded batch): with the counts the dQ pass stores zeros
+    for the dead query blocks and the dK / dV pass stops early - every output equals the call without them."""
+    B, H, Lq, dh = 6, 2, 511, 64
+    d = H * dh
+    rng = np.random.RandomState(9 + Lk)
+    Q, _ = _bf(rng.randn(B, Lq, d)); K, _ = _bf(rng.randn(B, Lk, d)); V, _ = _bf(rng.randn(B, Lk, d))
+    lens = np.array([0, 511, 1, 63, 130, 257], np.int32)
+    do = rng.randn(B, Lq, d) * (np.arange(Lq)[None, :, None] < lens[:, None, None])
+    dO, _ = _bf(do)
+    O = torch.empty(B, Lq, d, dtype=BF, device="cuda"); Olo = torch.empty_like(O)
+    stats = torch.empty(B, H, Lq, 2, dtype=torch.float32, device="cuda")
+    lib.call("skf_attention_bf16_fwd", _p(Q), d, _p(K), d, _p(V), d, None, 0, int(causal), B, H, Lq, Lk, dh, _p(O), d, _p(Olo), _p(stats), _s())
+    ws = torch.empty(B * H * Lq, dtype=torch.float32, device="cuda")
+    ll = torch.as_tensor(lens).cuda()
+    res = []
+    for counts in (None, ll):
+        dQ, dK, dV = (torch.full((B, L, d), 3.0, dtype=BF, device="cuda") for L in (Lq, Lk, Lk))
+        lib.call("skf_attention_bf16_bwd_rows", _p(Q), d, _p(K), d, _p(V), d, _p(O), d, _p(Olo), _p(dO), d, _p(stats), None, 0, int(causal),
+                 B, H, Lq, Lk, dh, _p(dQ), d, _p(dK), d, _p(dV), d, _p(ws), ws.numel() * 4, _p(counts), _s())
+        res.append((dQ, dK, dV))
+    for a, b_ in zip(res[0], res[1]):
+        assert torch.equal(a, b_)
+    assert float(res[1][0][0].float().abs().max()) == 0.0          # sample 0 has no live row at all
+
+
 def test_attention_bf16_fully_padded_sample_is_uniform(lib):
     B, H, L, dh = 2, 2, 130, 64
     d = H * dh
