@@ -329,6 +329,11 @@ size_t skf_layernorm_bwd_bf16_workspace_bytes(int rows, int d);
 int skf_layernorm_residual_bwd_bf16(const void* dout, const void* z, const float* stats, const float* gamma, void* dz, void* dy,
                                     float* dgamma, float* dbeta, int rows, int d, float rate, unsigned site,
                                     const void* step_state, void* workspace, size_t workspace_bytes, skf_stream_t stream);
+/* rows = B * rows_per_sample; row t of sample b with t >= live_len[b] has dout == 0 exactly: zeros are stored for it */
+int skf_layernorm_residual_bwd_bf16_rows(const void* dout, const void* z, const float* stats, const float* gamma, void* dz,
+                                         void* dy, float* dgamma, float* dbeta, int rows, int d, float rate, unsigned site,
+                                         const void* step_state, void* workspace, size_t workspace_bytes, const int* live_len,
+                                         int rows_per_sample, skf_stream_t stream);
 /* logits (rows, ld) bf16, even ncls <= ld <= 2048; the gradient is written in place, columns [ncls, ld) as zeros */
 int skf_softmax_ce_bf16(void* logits, int ld, int rows, int ncls, const long long* target, int tgt_ld, int tgt_cols, int tgt_off,
                         int mask_pad, float scale, float* row_loss, float* row_hit, int write_grad, skf_stream_t stream);

@@ -135,6 +135,7 @@ SIGNATURES = {
     "skf_layernorm_residual_fwd_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _U, _P, _P]),
     "skf_layernorm_bwd_bf16_workspace_bytes": (_Z, [_I, _I]),
     "skf_layernorm_residual_bwd_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U, _P, _P, _Z, _P]),
+    "skf_layernorm_residual_bwd_bf16_rows": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U, _P, _P, _Z, _P, _I, _P]),
     "skf_softmax_ce_bf16": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _I, _F, _P, _P, _I, _P]),
     "skf_pool_fwd_bf16": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "skf_pool_bwd_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _Z, _P]),

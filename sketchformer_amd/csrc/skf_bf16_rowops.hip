@@ -120,7 +120,8 @@ template <int VPL>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const skf_bf16* __restrict__ dout, const skf_bf16* __restrict__ z,
                                                      const float* __restrict__ stats, const float* __restrict__ gamma,
                                                      skf_bf16* __restrict__ dz, skf_bf16* __restrict__ dy, float* __restrict__ part,
-                                                     int rows, float rate, uint32_t site, const SkfStepState* st) {
+                                                     int rows, float rate, uint32_t site, const SkfStepState* st,
+                                                     const int* __restrict__ live_len, int rps) {
   constexpr int D = VPL * 64;
   __shared__ float red[3][2][D];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -133,6 +134,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const skf_bf16* __restrict_
   for (int c = 0; c < VPL; ++c) { dg[c] = 0.f; db[c] = 0.f; }
   for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
     const size_t off = (size_t)row * D + lane * VPL;
+    if (live_len) {
+      // row t of sample b with t >= live_len[b]: dout is exactly zero (skf_target_live_len), so are dz, dy and the row's
+      // share of dgamma / dbeta - stored, not computed
+      const int b = row / rps;
+      if (row - b * rps >= live_len[b]) {
+        float o[VPL];
+#pragma unroll
+        for (int c = 0; c < VPL; ++c) o[c] = 0.f;
+        strow<VPL>(dz + off, o);
+        if (rate > 0.f || dy != dz) strow<VPL>(dy + off, o);
+        continue;
+      }
+    }
     float dv[VPL], zv[VPL];
     ldrow<VPL>(dout + off, dv);
     ldrow<VPL>(z + off, zv);
@@ -475,6 +489,15 @@ extern "C" int skf_layernorm_residual_bwd_bf16(const void* dout, const void* z, 
                                                void* dy, float* dgamma, float* dbeta, int rows, int d, float rate, unsigned site,
                                                const void* step_state, void* workspace, size_t workspace_bytes,
                                                skf_stream_t stream) {
+  return skf_layernorm_residual_bwd_bf16_rows(dout, z, stats, gamma, dz, dy, dgamma, dbeta, rows, d, rate, site, step_state, workspace,
+                                              workspace_bytes, nullptr, 0, stream);
+}
+
+extern "C" int skf_layernorm_residual_bwd_bf16_rows(const void* dout, const void* z, const float* stats, const float* gamma, void* dz,
+                                                    void* dy, float* dgamma, float* dbeta, int rows, int d, float rate, unsigned site,
+                                                    const void* step_state, void* workspace, size_t workspace_bytes,
+                                                    const int* live_len, int rows_per_sample, skf_stream_t stream) {
+  SKF_CHECK_ARG(!live_len || (rows_per_sample > 0 && rows % rows_per_sample == 0), "live_len needs rows = B * rows_per_sample");
   SKF_CHECK_ARG(dout && z && stats && gamma && dz && dy && dgamma && dbeta && rows > 0, "bad argument");
   SKF_CHECK_ARG(rate >= 0.f && rate < 1.f && (rate == 0.f || step_state), "bad dropout arguments");
   SKF_CHECK_ARG(workspace && workspace_bytes >= skf_layernorm_bwd_bf16_workspace_bytes(rows, d), "workspace too small");
@@ -484,7 +507,8 @@ extern "C" int skf_layernorm_residual_bwd_bf16(const void* dout, const void* z, 
     SkfProfScope ps(st, "ln_bwd_bf16", 0.0, (double)rows * d * 2.0 * (rate > 0.f ? 4.0 : 3.0));
     int rc = dispatch_d(d, [&](auto vpl) {
       hipLaunchKernelGGL((ln_bwd_kernel<decltype(vpl)::value>), dim3(g), dim3(256), 0, st, (const skf_bf16*)dout, (const skf_bf16*)z,
-                         stats, gamma, (skf_bf16*)dz, (skf_bf16*)dy, (float*)workspace, rows, rate, site, (const SkfStepState*)step_state);
+                         stats, gamma, (skf_bf16*)dz, (skf_bf16*)dy, (float*)workspace, rows, rate, site, (const SkfStepState*)step_state,
+                         live_len, rows_per_sample);
       return SKF_OK;
     });
     if (rc) return rc;
