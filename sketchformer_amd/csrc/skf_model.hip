@@ -390,6 +390,7 @@ struct SkfModel {
   // Live row blocks of the decoder-side backward (skf_row_blocks.hip): set while the decoder layers' gradients are issued,
   // consulted by dense_dgrad / dense_wgrad for problems with exactly `live_rows` rows; null = every row is visited
   const int* live16 = nullptr; const int* live32 = nullptr; int live_rows = 0;
+  bool lists_built = false;             // this step's lists are in P.live16 / P.live32 (issued, not necessarily complete)
   std::map<const void*, hipEvent_t> pending_writers;   // buffers a side-stream dgrad still writes
   std::vector<QueuedWgrad> wq;                         // wgrads of the current layer, not yet issued
   bool side_used = false;
@@ -801,6 +802,21 @@ int ln_bwd(SkfModel* M, const LnP& ln, const float* dout, const float* z, const 
   return SKF_OK;
 }
 
+// Row-block lists of the decoder-side backward (token mode, split arithmetic only: the fp32-MFMA kernels ignore them)
+int build_row_lists(SkfModel* M, hipStream_t s) {
+  const SkfConfig& c = M->cfg;
+  const Plan& P = M->plan;
+  static const bool rows_off = getenv("SKF_NO_ROW_BLOCKS") && getenv("SKF_NO_ROW_BLOCKS")[0] == '1';
+  M->lists_built = false;
+  if (c.continuous || rows_off || !do_recon(c) || c.gemm_precision == SKF_PREC_F32) return SKF_OK;
+  const int B = c.batch, Le = c.seq_len, Ld = c.seq_len - 1;
+  SKF_TRY(skf_target_live_len(M->at<long long>(P.tar), Le, B, Ld, M->at<int>(P.live_len), s));
+  SKF_TRY(skf_row_blocks_build(M->at<int>(P.live_len), B, Ld, 16, M->at<int>(P.live16), s));
+  SKF_TRY(skf_row_blocks_build(M->at<int>(P.live_len), B, Ld, 32, M->at<int>(P.live32), s));
+  M->lists_built = true;
+  return SKF_OK;
+}
+
 int run_backward(SkfModel* M, hipStream_t s) {
   M->next_event = 0;
   M->pending_readers.clear();
@@ -831,13 +847,10 @@ int run_backward(SkfModel* M, hipStream_t s) {
   // From the output layer to the decoder embedding every (B * Ld)-row gradient is exactly zero behind a sample's last trained position
   // (skf_row_blocks.hip): the split-arithmetic GEMMs walk the live row blocks only.  Not in continuous mode (its pen-state
   // loss has a gradient at every position), not for the fp32-MFMA kernels (they ignore the lists).
-  static const bool rows_off = getenv("SKF_NO_ROW_BLOCKS") && getenv("SKF_NO_ROW_BLOCKS")[0] == '1';
-  if (!c.continuous && !rows_off && M->cfg.gemm_precision != SKF_PREC_F32) {
-    SKF_TRY(skf_target_live_len(tar, Le, B, Ld, M->at<int>(P.live_len), s));
-    SKF_TRY(skf_row_blocks_build(M->at<int>(P.live_len), B, Ld, 16, M->at<int>(P.live16), s));
-    SKF_TRY(skf_row_blocks_build(M->at<int>(P.live_len), B, Ld, 32, M->at<int>(P.live32), s));
-    M->live16 = M->at<int>(P.live16); M->live32 = M->at<int>(P.live32); M->live_rows = Md;
-  }
+  // (the lists only depend on the staged targets: issue_embed_sorts builds them on the side stream under the forward)
+  if (!M->lists_built) SKF_TRY(build_row_lists(M, s));
+  if (M->lists_built) { M->live16 = M->at<int>(P.live16); M->live32 = M->at<int>(P.live32); M->live_rows = Md; }
+  M->lists_built = false;
   // output layer: logits buffer now holds dlogits
   const float* dlog = M->at<float>(P.logits);
   SKF_TRY(dense_wgrad(M, L.out, M->at<float>(P.dec[N - 1].out3), d, dlog, L.out.out, Md, s));
@@ -1429,7 +1442,7 @@ int issue_embed_sorts(SkfModel* M, hipStream_t s) {
   if (do_recon(c))
     SKF_TRY(skf_embed_sort(M->at<long long>(P.tar), Le, B, Ld, c.vocab_size, M->G(L.dec_emb), d, M->at<char>(P.emb_sort[1]),
                            P.emb_sort_bytes, ss));
-  return SKF_OK;
+  return build_row_lists(M, ss);
 }
 
 extern "C" int skf_model_forward_backward(SkfModel* m, const void* inp, const void* tar, int tar_ld,
