@@ -120,31 +120,69 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* __restr
   }
 }
 
-// Atomic-light embedding gradient in two launches.
+// Atomic-free, run-to-run deterministic embedding gradient in two launches.
 //  (1) embed_sort_kernel (ONE workgroup; depends on the tokens only, so the train step runs it on the side stream under the
-//      forward): counting sort of the B*L token positions by id -> order[], and a chunk list {id, first, count, single}:
-//      every id gets ceil(count / 256) chunks, at least one (count 0 = "store zeros"), so the gradient kernel never needs a
-//      pre-zeroed table except for the few ids with more than one chunk (PAD, frequent tokens) - those rows are zeroed here.
-//  (2) embed_bwd_sorted_kernel: one workgroup per chunk (a wave per 64 positions, summed through LDS) sums the dx rows of its positions (512-byte coalesced rows, dropout mask
-//      and sqrt(d) as in embed_bwd_kernel) and STORES the table row (single chunk) or adds it atomically (split ids).
-// Global float atomics run at ~25 G/s on this part: the ballot-grouping kernel above spends 46 us on ~1.4 M of them.
+//      forward): STABLE counting sort of the B*L token positions by id -> order[] (the positions of an id ascend), and a chunk
+//      list {id, first, count, n, j}: every id gets n = ceil(count / 256) chunks, at least one (count 0 = "store zeros").
+//      Stability without a histogram per thread: wave w owns a contiguous range of rows and its own histogram [vocab] in
+//      LDS; an exclusive scan over the 16 waves gives each wave its base inside every id's segment, and inside a 64-row
+//      step the rank of a lane among the lanes with the same id comes from ballots (one per distinct id of the step).
+//      (vocab > kEmbOrderedVocab does not fit 16 histograms in LDS: the scatter falls back to an LDS-atomic cursor, whose
+//      order - and with it the summation order of ids with more than 64 positions - changes between runs.)
+//  (2) embed_bwd_sorted_kernel: one workgroup per chunk (a wave per 64 positions, summed through LDS in wave order) sums the
+//      dx rows of its positions (512-byte coalesced rows, dropout mask and sqrt(d) as in embed_bwd_kernel).  Single-chunk ids
+//      STORE the table row; the chunks of a split id (PAD, frequent tokens) leave partial rows in the workspace and whichever
+//      finishes last (a ticket per id) adds them up IN CHUNK ORDER and stores the row - no float atomics anywhere, so the
+//      result does not depend on which workgroup runs when.
 constexpr int kEmbChunk = 256;   // positions per chunk = per workgroup of the gradient kernel (4 waves x 64)
-struct EmbChunk { int id, first, count, single; };
+constexpr int kEmbOrderedVocab = 2032;   // 19 tables of vocab ints + the 8 KB of scan scratch must fit 160 KB of LDS
+constexpr int kEmbMaxD = 512;    // widest row the partial slab of the workspace is sized for
+struct EmbChunk { int id, first, count, n, j, pad; };   // n chunks of this id, this one is the j-th
 
+template <bool ORDERED>
 __global__ __launch_bounds__(1024) void embed_sort_kernel(const long long* __restrict__ tok, int tok_ld, int Lrows, int rows,
                                                           int vocab, int* __restrict__ hdr, EmbChunk* __restrict__ chunks,
-                                                          int* __restrict__ order, float* __restrict__ zero_table, int d) {
+                                                          int* __restrict__ order, int* __restrict__ done) {
   extern __shared__ int smem_i[];
   int* cnt = smem_i;                     // [vocab]      positions per id -> later the write cursor of the id
   int* pst = smem_i + vocab;             // [vocab]      first position of the id in order[]
   int* cst = smem_i + 2 * vocab;         // [vocab + 1]  first chunk of the id (exclusive scan; [vocab] = number of chunks)
+  int* hist = cst + vocab + 1;           // ORDERED: [16][vocab] positions per (wave, id) -> the wave's cursor inside the id's segment
   __shared__ int part_tok[1024], part_chk[1024];
-  const int tid = threadIdx.x;
-  for (int v = tid; v < vocab; v += 1024) cnt[v] = 0;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int RW = ((rows + 15) / 16 + 63) & ~63;      // rows per wave (ORDERED), a multiple of the 64-row step
+  for (int v = tid; v < vocab; v += 1024) { cnt[v] = 0; done[v] = 0; }
+  if (ORDERED) for (int e = tid; e < 16 * vocab; e += 1024) hist[e] = 0;
   __syncthreads();
-  for (int r = tid; r < rows; r += 1024) {
-    const long long tk = tok[(size_t)(r / Lrows) * tok_ld + (r % Lrows)];
-    if (tk >= 0 && tk < vocab) atomicAdd(&cnt[(int)tk], 1);
+  // token of row r, or -1 (row past the end / id out of range).  The passes below request TB steps of tokens before using
+  // the first: one at a time, every 64-row step was a memory round trip of its own (2 x 25 of them at the cfg-2 size)
+  constexpr int TB = 8;
+  auto token_of = [&](int r) -> int {
+    if (r >= rows) return -1;
+    const long long t = tok[(size_t)(r / Lrows) * tok_ld + (r % Lrows)];
+    return (t >= 0 && t < vocab) ? (int)t : -1;
+  };
+  const int rend = min(rows, (wave + 1) * RW);
+  if (ORDERED) {
+    for (int r0 = wave * RW; r0 < rend; r0 += 64 * TB) {
+      int tk[TB];
+#pragma unroll
+      for (int u = 0; u < TB; ++u) { const int r = r0 + 64 * u + lane; tk[u] = r < rend ? token_of(r) : -1; }
+#pragma unroll
+      for (int u = 0; u < TB; ++u)
+        if (tk[u] >= 0) atomicAdd(&hist[wave * vocab + tk[u]], 1);
+    }
+    __syncthreads();
+    for (int v = tid; v < vocab; v += 1024) {          // counts per id; hist -> exclusive prefix over the waves
+      int run = 0;
+      for (int w = 0; w < 16; ++w) { const int c = hist[w * vocab + v]; hist[w * vocab + v] = run; run += c; }
+      cnt[v] = run;
+    }
+  } else {
+    for (int r = tid; r < rows; r += 1024) {
+      const long long tk = tok[(size_t)(r / Lrows) * tok_ld + (r % Lrows)];
+      if (tk >= 0 && tk < vocab) atomicAdd(&cnt[(int)tk], 1);
+    }
   }
   __syncthreads();
   // exclusive scans over ids: positions and chunks.  Thread t owns ids [t*per, (t+1)*per)
@@ -179,17 +217,49 @@ __global__ __launch_bounds__(1024) void embed_sort_kernel(const long long* __res
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (cst[mid] <= ci) lo = mid; else hi = mid - 1; }
     const int v = lo, j = ci - cst[v], c = cnt[v];
     const int left = c - j * kEmbChunk;
-    chunks[ci] = EmbChunk{v, pst[v] + j * kEmbChunk, left < kEmbChunk ? (left > 0 ? left : 0) : kEmbChunk, cst[v + 1] - cst[v] == 1};
-    // rows of ids with several chunks are accumulated atomically: zero them now (a handful of rows; the first chunk does it)
-    if (zero_table && j == 0 && cst[v + 1] - cst[v] > 1)
-      for (int cc = 0; cc < d; ++cc) zero_table[(size_t)v * d + cc] = 0.f;
+    chunks[ci] = EmbChunk{v, pst[v] + j * kEmbChunk, left < kEmbChunk ? (left > 0 ? left : 0) : kEmbChunk, cst[v + 1] - cst[v], j, 0};
   }
   __syncthreads();
-  for (int v = tid; v < vocab; v += 1024) cnt[v] = pst[v];      // counts -> write cursors
-  __syncthreads();
-  for (int r = tid; r < rows; r += 1024) {
-    const long long tk = tok[(size_t)(r / Lrows) * tok_ld + (r % Lrows)];
-    if (tk >= 0 && tk < vocab) order[atomicAdd(&cnt[(int)tk], 1)] = r;
+  if (ORDERED) {
+    // stable scatter: wave w walks its rows in order; inside a 64-row step the lanes with equal ids are ranked by lane
+    for (int rb = wave * RW; rb < rend; rb += 64 * TB) {
+     int tkb[TB];
+#pragma unroll
+     for (int u = 0; u < TB; ++u) { const int rr = rb + 64 * u + lane; tkb[u] = rr < rend ? token_of(rr) : -1; }
+#pragma unroll
+     for (int u = 0; u < TB; ++u) {
+      const int r = rb + 64 * u + lane;
+      const int tk = tkb[u];
+      // Size of the lane's group (lanes of the step with the same id) from ONE LDS atomic on the high half of the cursor word
+      // (only the count is used, not the order in which the adds land); ids that occur once - most of them - are done.  The
+      // others (PAD, repeats) get their rank among the equal lanes from ballots, one round per such id.
+      const int slot = wave * vocab + (tk >= 0 ? tk : 0);
+      if (tk >= 0) atomicAdd(&hist[slot], 1 << 16);
+      const int wv = tk >= 0 ? reinterpret_cast<volatile int*>(hist)[slot] : 0;       // LDS operations of a wave execute in order
+      const int cur = wv & 0xffff, grp = wv >> 16;
+      int rank = 0;
+      bool lead = grp == 1;
+      unsigned long long active = __ballot(grp > 1);
+      while (active) {
+        const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)active) - 1);
+        const int id0 = __builtin_amdgcn_readlane(tk, leader);
+        const unsigned long long m = __ballot(tk == id0);
+        if (tk == id0) { rank = __popcll(m & ((1ull << lane) - 1ull)); lead = lane == leader; }
+        active &= ~m;
+      }
+      if (tk >= 0) {
+        order[pst[tk] + cur + rank] = r;
+        if (lead) hist[slot] = cur + grp;                            // cursor advanced, count cleared
+      }
+     }
+    }
+  } else {
+    for (int v = tid; v < vocab; v += 1024) cnt[v] = pst[v];      // counts -> write cursors
+    __syncthreads();
+    for (int r = tid; r < rows; r += 1024) {
+      const long long tk = tok[(size_t)(r / Lrows) * tok_ld + (r % Lrows)];
+      if (tk >= 0 && tk < vocab) order[atomicAdd(&cnt[(int)tk], 1)] = r;
+    }
   }
 }
 
@@ -197,8 +267,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void embed_bwd_sorted_kernel(const int* __restrict__ hdr, const EmbChunk* __restrict__ chunks,
                                                                const int* __restrict__ order, const T* __restrict__ dx, int d,
                                                                float* __restrict__ dtable, float rate, uint32_t site,
-                                                               const SkfStepState* st) {
+                                                               const SkfStepState* st, float* __restrict__ partial,
+                                                               int* __restrict__ done) {
   extern __shared__ float emb_red[];       // [3 waves][d] partial rows of waves 1..3
+  __shared__ int s_last;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ci = blockIdx.x;
   if (ci >= hdr[0]) return;
@@ -256,11 +328,34 @@ __global__ __launch_bounds__(256) void embed_bwd_sorted_kernel(const int* __rest
 #pragma unroll
       for (int w = 0; w < 3; ++w) { const float2 t = *reinterpret_cast<const float2*>(&emb_red[w * d + c]); gx += t.x; gy += t.y; }
       gx *= sq; gy *= sq;
-      float* dst = dtable + (size_t)ch.id * d + c;
-      if (ch.single) *reinterpret_cast<float2*>(dst) = make_float2(gx, gy);
-      else { atomicAdd(dst, gx); atomicAdd(dst + 1, gy); }
+      float* dst = ch.n == 1 ? dtable + (size_t)ch.id * d + c : partial + (size_t)ci * d + c;
+      *reinterpret_cast<float2*>(dst) = make_float2(gx, gy);
     }
     __syncthreads();
+  }
+  if (ch.n > 1) {
+    // split id: the chunk that finishes last adds the partial rows of all chunks in chunk order
+    if (threadIdx.x == 0) {
+      __threadfence();
+      s_last = atomicAdd(&done[ch.id], 1) == ch.n - 1;
+    }
+    __syncthreads();
+    if (s_last) {
+      __threadfence();
+      const float* p0 = partial + (size_t)(ci - ch.j) * d;
+      for (int c = threadIdx.x; c < d; c += 256) {
+        float sum = 0.f;
+        for (int j0 = 0; j0 < ch.n; j0 += 16) {                      // 16 partial rows requested at once, added in chunk order
+          float v[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u)
+            v[u] = j0 + u < ch.n ? __hip_atomic_load(p0 + (size_t)(j0 + u) * d + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+#pragma unroll
+          for (int u = 0; u < 16; ++u) sum += v[u];
+        }
+        dtable[(size_t)ch.id * d + c] = sum;
+      }
+    }
   }
 }
 
@@ -915,47 +1010,67 @@ extern "C" int skf_embed_bwd(const long long* tokens, int tok_ld, int B, int L, 
   return SKF_OK;
 }
 
-extern "C" size_t skf_embed_sort_workspace_bytes(int B, int L, int vocab) {
+struct EmbWs { int* hdr; EmbChunk* chunks; int* order; int* done; float* partial; size_t bytes; };
+static EmbWs emb_ws_layout(void* ws, int B, int L, int vocab) {
   const size_t rows = (size_t)B * L, maxc = (size_t)vocab + rows / kEmbChunk + 1;
-  return 16 + maxc * sizeof(EmbChunk) + rows * sizeof(int);
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  size_t off = 0;
+  EmbWs w;
+  char* base = (char*)ws;
+  w.hdr = (int*)(base + off); off += 256;
+  w.chunks = (EmbChunk*)(base + off); off += up(maxc * sizeof(EmbChunk));
+  w.order = (int*)(base + off); off += up(rows * sizeof(int));
+  w.done = (int*)(base + off); off += up((size_t)vocab * sizeof(int));
+  w.partial = (float*)(base + off); off += up(maxc * kEmbMaxD * sizeof(float));
+  w.bytes = off;
+  return w;
 }
+extern "C" size_t skf_embed_sort_workspace_bytes(int B, int L, int vocab) { return emb_ws_layout(nullptr, B, L, vocab).bytes; }
 extern "C" int skf_embed_sort(const long long* tokens, int tok_ld, int B, int L, int vocab, float* zero_table, int d,
                               void* ws, size_t ws_bytes, skf_stream_t stream) {
+  (void)zero_table; (void)d;              // (the gradient kernel no longer accumulates into the table: nothing to pre-zero)
   SKF_CHECK_ARG(tokens && ws, "null operand");
   SKF_CHECK_ARG(ws_bytes >= skf_embed_sort_workspace_bytes(B, L, vocab) && (((uintptr_t)ws) & 15) == 0, "workspace too small or misaligned");
   SKF_CHECK_ARG(vocab > 0 && vocab <= 12288, "vocabulary does not fit the sort kernel's LDS tables");
   const int rows = B * L;
-  const size_t maxc = (size_t)vocab + (size_t)rows / kEmbChunk + 1;
-  int* hdr = (int*)ws;
-  EmbChunk* chunks = (EmbChunk*)((char*)ws + 16);
-  int* order = (int*)((char*)ws + 16 + maxc * sizeof(EmbChunk));
-  const size_t smem = ((size_t)3 * vocab + 1) * sizeof(int);
+  const EmbWs w = emb_ws_layout(ws, B, L, vocab);
+  const bool ordered = vocab <= kEmbOrderedVocab && rows / 16 + 64 < 65536;      // (a wave's cursor lives in 16 bits)
+  const size_t smem = ((size_t)3 * vocab + 1 + (ordered ? (size_t)16 * vocab : 0)) * sizeof(int);
   static bool attr_done = false;
-  if (!attr_done) { SKF_HIP(hipFuncSetAttribute((const void*)embed_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (3 * 12288 + 1) * 4)); attr_done = true; }
+  if (!attr_done) {
+    SKF_HIP(hipFuncSetAttribute((const void*)embed_sort_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (3 * 12288 + 1) * 4));
+    SKF_HIP(hipFuncSetAttribute((const void*)embed_sort_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (19 * kEmbOrderedVocab + 1) * 4));
+    attr_done = true;
+  }
   SkfProfScope ps((hipStream_t)stream, "embed_sort", 0.0, 12.0 * rows);
-  hipLaunchKernelGGL(embed_sort_kernel, dim3(1), dim3(1024), smem, (hipStream_t)stream, tokens, tok_ld, L, rows, vocab, hdr, chunks,
-                     order, zero_table, d);
+  if (ordered)
+    hipLaunchKernelGGL(embed_sort_kernel<true>, dim3(1), dim3(1024), smem, (hipStream_t)stream, tokens, tok_ld, L, rows, vocab, w.hdr, w.chunks,
+                       w.order, w.done);
+  else
+    hipLaunchKernelGGL(embed_sort_kernel<false>, dim3(1), dim3(1024), smem, (hipStream_t)stream, tokens, tok_ld, L, rows, vocab, w.hdr, w.chunks,
+                       w.order, w.done);
   SKF_LAUNCH_CHECK();
   return SKF_OK;
 }
 static int embed_bwd_sorted_launch(const void* ws, int B, int L, const void* dx, int dx_bf16, int vocab, int d, float* dtable,
                                    float rate, unsigned site, const void* step_state, skf_stream_t stream) {
   SKF_CHECK_ARG(ws && dx && dtable, "null operand");
-  SKF_CHECK_ARG((d & 1) == 0, "d_model must be even");
+  SKF_CHECK_ARG((d & 1) == 0 && d <= kEmbMaxD, "d_model must be even and <= 512");
   SKF_CHECK_ARG(rate == 0.f || step_state, "dropout needs the step state");
   const int rows = B * L;
   const size_t maxc = (size_t)vocab + (size_t)rows / kEmbChunk + 1;
-  const int* hdr = (const int*)ws;
-  const EmbChunk* chunks = (const EmbChunk*)((const char*)ws + 16);
-  const int* order = (const int*)((const char*)ws + 16 + maxc * sizeof(EmbChunk));
+  const EmbWs w = emb_ws_layout(const_cast<void*>(ws), B, L, vocab);
+  const int* hdr = w.hdr;
+  const EmbChunk* chunks = w.chunks;
+  const int* order = w.order;
   SkfProfScope ps((hipStream_t)stream, dx_bf16 ? "embed_bwd_sorted_bf16" : "embed_bwd_sorted", 0.0,
                   (dx_bf16 ? 2.0 : 4.0) * rows * d + 4.0 * (double)vocab * d);
   if (dx_bf16)
     hipLaunchKernelGGL(embed_bwd_sorted_kernel<skf_bf16>, dim3((unsigned)maxc), dim3(256), (size_t)3 * d * sizeof(float), (hipStream_t)stream,
-                       hdr, chunks, order, (const skf_bf16*)dx, d, dtable, rate, site, (const SkfStepState*)step_state);
+                       hdr, chunks, order, (const skf_bf16*)dx, d, dtable, rate, site, (const SkfStepState*)step_state, w.partial, w.done);
   else
     hipLaunchKernelGGL(embed_bwd_sorted_kernel<float>, dim3((unsigned)maxc), dim3(256), (size_t)3 * d * sizeof(float), (hipStream_t)stream,
-                       hdr, chunks, order, (const float*)dx, d, dtable, rate, site, (const SkfStepState*)step_state);
+                       hdr, chunks, order, (const float*)dx, d, dtable, rate, site, (const SkfStepState*)step_state, w.partial, w.done);
   SKF_LAUNCH_CHECK();
   return SKF_OK;
 }
