@@ -120,7 +120,7 @@ __device__ __forceinline__ void stage_key_mask(float* Ms, const unsigned char* k
 // ============================================================================ forward / dQ pass (stream K, V)
 // MODE 0: forward.  MODE 1: dQ pass of the backward.
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void attn_bf16_q_kernel(AP p) {
+__global__ __launch_bounds__(256, 3) void attn_bf16_q_kernel(AP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Kt = smem;                       // [2][TILE]
   char* Vt = smem + 2 * TILE;            // [2][TILE]
