@@ -349,6 +349,14 @@ int skf_expander_bwd_bf16(const void* dpre, const float* emb, const float* w, in
  * pad columns are written as zeros.  Plain casts for activations at the fp32 <-> bf16 seams. */
 int skf_cast_weight_bf16(const float* src, int R, int C, int ld_src, void* dst, int ld_dst, void* dst_t, int ld_t,
                          skf_stream_t stream);
+/* many images in one launch: a DEVICE array of descriptors whose block_begin fields are the running sum of
+ * skf_cast_weight_bf16_blocks(R, C, ld_dst, ld_t, &blocks_x) (dst / dst_t may be NULL individually) */
+typedef struct SkfCastDesc {
+  const float* src; void* dst; void* dst_t;
+  int32_t R, C, ld_src, ld_dst, ld_t, block_begin, blocks_x, pad;
+} SkfCastDesc;
+int skf_cast_weight_bf16_blocks(int R, int C, int ld_dst, int ld_t, int* blocks_x);
+int skf_cast_weight_bf16_batch(const SkfCastDesc* descs_dev, int n, int total_blocks, skf_stream_t stream);
 int skf_cast_f32_to_bf16(const float* src, void* dst, size_t n, skf_stream_t stream);
 int skf_cast_bf16_to_f32(const void* src, float* dst, size_t n, skf_stream_t stream);
 

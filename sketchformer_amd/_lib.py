@@ -142,6 +142,8 @@ SIGNATURES = {
     "skf_expander_fwd_bf16": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
     "skf_expander_bwd_bf16": (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _Z, _P]),
     "skf_cast_weight_bf16": (_I, [_P, _I, _I, _I, _P, _I, _P, _I, _P]),
+    "skf_cast_weight_bf16_blocks": (_I, [_I, _I, _I, _I, _P]),
+    "skf_cast_weight_bf16_batch": (_I, [_P, _I, _I, _P]),
     "skf_cast_f32_to_bf16": (_I, [_P, _P, _Z, _P]),
     "skf_cast_bf16_to_f32": (_I, [_P, _P, _Z, _P]),
     "skf_config_validate": (_I, [C.POINTER(SkfConfig)]),

@@ -420,6 +420,35 @@ __global__ __launch_bounds__(256) void cast_weight_kernel(const float* __restric
     }
   }
 }
+// the same for MANY weights in one launch: descs[i].block_begin is the running sum of the 32 x 32 blocks of the problems before
+// i (the ~90 images of a step were 90 launches of a few microseconds each)
+__global__ __launch_bounds__(256) void cast_weight_batch_kernel(const SkfCastDesc* __restrict__ descs, int n) {
+  __shared__ float tile[32][33];
+  int i = 0;
+  while (i + 1 < n && descs[i + 1].block_begin <= (int)blockIdx.x) ++i;      // wave-uniform scan of a short table
+  const SkfCastDesc d = descs[i];
+  const int local = blockIdx.x - d.block_begin;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int r0 = (local / d.blocks_x) * 32, c0 = (local % d.blocks_x) * 32;
+  const float* src = d.src;
+  uint16_t* dst = reinterpret_cast<uint16_t*>(d.dst);
+  uint16_t* dstT = reinterpret_cast<uint16_t*>(d.dst_t);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = r0 + ty + 8 * j, c = c0 + tx;
+    const float v = (r < d.R && c < d.C) ? src[(size_t)r * d.ld_src + c] : 0.f;
+    tile[ty + 8 * j][tx] = v;
+    if (dst && r < d.R && c < d.ld_dst) dst[(size_t)r * d.ld_dst + c] = (uint16_t)skf_f2bf(v);
+  }
+  __syncthreads();
+  if (dstT) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = c0 + ty + 8 * j, r = r0 + tx;
+      if (c < d.C && r < d.ld_t) dstT[(size_t)c * d.ld_t + r] = (uint16_t)skf_f2bf(tile[tx][ty + 8 * j]);
+    }
+  }
+}
 __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ src, skf_bf16* __restrict__ dst, size_t n) {
   for (size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2; e < n; e += (size_t)gridDim.x * 512) {
     const float a = src[e], b = e + 1 < n ? src[e + 1] : 0.f;
@@ -498,7 +527,7 @@ extern "C" int skf_layernorm_residual_bwd_bf16_rows(const void* dout, const void
                                                     const void* step_state, void* workspace, size_t workspace_bytes,
                                                     const int* live_len, int rows_per_sample, skf_stream_t stream) {
   SKF_CHECK_ARG(!live_len || (rows_per_sample > 0 && rows % rows_per_sample == 0), "live_len needs rows = B * rows_per_sample");
-  SKF_CHECK_ARG(dout && z && stats && gamma && dz && dy && dgamma && dbeta && rows > 0, "bad argument");
+  SKF_CHECK_ARG(dout && z && stats && gamma && dz && dy && rows > 0 && ((dgamma == nullptr) == (dbeta == nullptr)), "bad argument");
   SKF_CHECK_ARG(rate >= 0.f && rate < 1.f && (rate == 0.f || step_state), "bad dropout arguments");
   SKF_CHECK_ARG(workspace && workspace_bytes >= skf_layernorm_bwd_bf16_workspace_bytes(rows, d), "workspace too small");
   hipStream_t st = (hipStream_t)stream;
@@ -514,6 +543,7 @@ extern "C" int skf_layernorm_residual_bwd_bf16_rows(const void* dout, const void
     if (rc) return rc;
     SKF_LAUNCH_CHECK();
   }
+  if (!dgamma) return SKF_OK;             // the caller sums the [g][2d] partial rows of `workspace` itself (batched with others)
   if (dbeta == dgamma + d) return skf_colsum((const float*)workspace, g, 2 * d, 2 * d, dgamma, 0, stream);
   int rc = skf_colsum((const float*)workspace, g, 2 * d, d, dgamma, 0, stream);
   if (rc) return rc;
@@ -597,6 +627,18 @@ extern "C" int skf_cast_weight_bf16(const float* src, int R, int C, int ld_src, 
   const int cols = dst ? (ld_dst > C ? ld_dst : C) : C, rws = dst_t ? (ld_t > R ? ld_t : R) : R;
   hipLaunchKernelGGL(cast_weight_kernel, dim3((cols + 31) / 32, (rws + 31) / 32), dim3(256), 0, (hipStream_t)stream, src, R, C, ld_src,
                      (skf_bf16*)dst, ld_dst, (skf_bf16*)dst_t, ld_t);
+  SKF_LAUNCH_CHECK();
+  return SKF_OK;
+}
+
+extern "C" int skf_cast_weight_bf16_blocks(int R, int C, int ld_dst, int ld_t, int* blocks_x) {
+  const int cols = ld_dst > C ? ld_dst : C, rws = ld_t > R ? ld_t : R;
+  if (blocks_x) *blocks_x = (cols + 31) / 32;
+  return ((cols + 31) / 32) * ((rws + 31) / 32);
+}
+extern "C" int skf_cast_weight_bf16_batch(const SkfCastDesc* descs_dev, int n, int total_blocks, skf_stream_t stream) {
+  SKF_CHECK_ARG(descs_dev && n > 0 && total_blocks > 0, "bad argument");
+  hipLaunchKernelGGL(cast_weight_batch_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, n);
   SKF_LAUNCH_CHECK();
   return SKF_OK;
 }
