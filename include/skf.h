@@ -161,6 +161,12 @@ size_t skf_layernorm_bwd_workspace_bytes(int rows, int d);
 int skf_layernorm_residual_bwd(const float* dout, const float* z, const float* stats, const float* gamma, float* dz,
                                float* dy, float* dgamma, float* dbeta, int rows, int d, float rate, unsigned site,
                                const void* step_state, void* workspace, size_t workspace_bytes, skf_stream_t stream);
+/* rows = B * rows_per_sample; row t of sample b with t >= live_len[b] has dout == 0 exactly (skf_target_live_len): it is not
+ * read, zeros are stored (d <= 256; wider rows take the dense kernel) */
+int skf_layernorm_residual_bwd_rows(const float* dout, const float* z, const float* stats, const float* gamma, float* dz,
+                                    float* dy, float* dgamma, float* dbeta, int rows, int d, float rate, unsigned site,
+                                    const void* step_state, void* workspace, size_t workspace_bytes, const int* live_len,
+                                    int rows_per_sample, skf_stream_t stream);
 int skf_colsum(const float* in, int nrows, int ld, int ncols, float* out, int accumulate, skf_stream_t stream);
 
 /* ------------------------------------------------------------------ loss heads + metrics

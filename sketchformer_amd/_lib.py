@@ -91,6 +91,7 @@ SIGNATURES = {
     "skf_layernorm_residual_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _U, _P, _P]),
     "skf_layernorm_bwd_workspace_bytes": (_Z, [_I, _I]),
     "skf_layernorm_residual_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U, _P, _P, _Z, _P]),
+    "skf_layernorm_residual_bwd_rows": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U, _P, _P, _Z, _P, _I, _P]),
     "skf_colsum": (_I, [_P, _I, _I, _I, _P, _I, _P]),
     "skf_softmax_ce": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _I, _F, _P, _P, _P, _I, _P]),
     "skf_metrics_update": (_I, [_P, _P, _I, _F, _P, _P, _I, _F, _P, _P, _P]),

@@ -123,6 +123,25 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   const int tile_m = logical / p.tiles_n, tile_n = logical % p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
+  if constexpr (!SPLITK && A_KC) {
+    // Row-block list of 16-row blocks (skf_row_blocks_build): a tile none of whose blocks is live has all-zero rows of A -
+    // its C rows are zeros (stored unless the call accumulates), nothing is loaded or multiplied
+    if (p.row_blocks && p.row_block_rows == 16) {
+      const int nb = p.row_blocks[1];
+      const int* flags = p.row_blocks + 2 + nb;
+      int live = 0;
+#pragma unroll
+      for (int j = 0; j < BM / 16; ++j) { const int k = tile_m * (BM / 16) + j; live |= k < nb ? flags[k] : 0; }
+      if (!live) {
+        if (!p.accumulate)
+          for (int e = threadIdx.x; e < BM * BN; e += 256) {
+            const int m = m0 + e / BN, n = n0 + e % BN;
+            if (m < p.M && n < p.N) p.C[(size_t)m * p.ldc + n] = 0.f;
+          }
+        return;
+      }
+    }
+  }
   int kb = 0, ke = p.K;
   if (SPLITK) { kb = blockIdx.z * p.k_chunk; ke = min(p.K, kb + p.k_chunk); }
   const int nk = (ke - kb + BK - 1) / BK;

@@ -25,7 +25,8 @@ struct GemmParams {
   // Row-block list (skf_row_blocks_build): {n_live, n_blocks, live block ids ..., dead block ids ...} over blocks of
   // `row_block_rows` consecutive rows of the M (dgrad: output / A rows) or K (wgrad: contraction rows) dimension whose A
   // (and, for the wgrad, dY) rows are known to be all zero when dead.  The weight-stationary bf16x kernels visit only the
-  // live blocks (dead output rows are stored as zeros, or left alone when accumulating); every other kernel ignores it.
+  // live blocks (dead output rows are stored as zeros, or left alone when accumulating); the generic tiled kernel skips the
+  // tiles without a live 16-row block (dgrad form); every other kernel ignores it.
   const int* row_blocks;
   int row_block_rows;
   int ablate;              // generic kernel, diagnostics only (env SKF_GEMM_ABLATE): 1 no MFMA, 2 no C store, 3 no global reload

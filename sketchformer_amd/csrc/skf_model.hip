@@ -777,16 +777,19 @@ int ln_bwd(SkfModel* M, const LnP& ln, const float* dout, const float* z, const 
   const int d = M->cfg.d_model;
   SKF_TRY(before_write(M, dz, s));
   if (dy != dz) SKF_TRY(before_write(M, dy, s));
+  // decoder side of a padded batch: rows behind a sample's live length have dout == 0 and are not read
+  const int* ll = (M->live16 && rows == M->live_rows) ? M->at<int>(P.live_len) : nullptr;
+  const int rps = M->cfg.seq_len - 1;
   if (!M->side || ln.b != ln.g + (size_t)d)
-    return skf_layernorm_residual_bwd(dout, z, st, M->P(ln.g), dz, dy, M->G(ln.g), M->G(ln.b), rows, d, rate,
-                                      site, M->state, M->at<char>(P.small_ws), P.small_ws_bytes, s);
+    return skf_layernorm_residual_bwd_rows(dout, z, st, M->P(ln.g), dz, dy, M->G(ln.g), M->G(ln.b), rows, d, rate,
+                                           site, M->state, M->at<char>(P.small_ws), P.small_ws_bytes, ll, rps, s);
   // eager path: leave the [g][2d] partials in this LayerNorm's own slice; their column sums ride in the batched
   // split-K reduction of the wgrads (a "slab" of g splits of a 1 x 2d matrix) instead of one tiny launch per LayerNorm
   SKF_CHECK_ARG(M->ln_cursor < 5 * (size_t)M->cfg.num_layers && M->desc_cursor < P.n_wgrads, "LayerNorm partial arena exhausted");
   float* part = M->at<float>(P.ln_part + M->ln_cursor * P.ln_part_stride);
   const size_t bytes = skf_layernorm_bwd_workspace_bytes(rows, d);
-  SKF_TRY(skf_layernorm_residual_bwd(dout, z, st, M->P(ln.g), dz, dy, nullptr, nullptr, rows, d, rate, site, M->state, part,
-                                     bytes, s));
+  SKF_TRY(skf_layernorm_residual_bwd_rows(dout, z, st, M->P(ln.g), dz, dy, nullptr, nullptr, rows, d, rate, site, M->state, part,
+                                          bytes, ll, rps, s));
   SkfReduceDesc r;
   r.slab = part; r.C = M->G(ln.g); r.bias_grad = nullptr; r.splits = (int)(bytes / (8 * (size_t)d)); r.M = 1; r.N = 2 * d;
   r.ldc = 2 * d; r.block_begin = M->reduce_blocks; r.pad = 0;

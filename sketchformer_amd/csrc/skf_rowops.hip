@@ -530,7 +530,7 @@ __global__ __launch_bounds__(256) void ln_bwd_v4_kernel(const float* __restrict_
                                                         const float* __restrict__ stats, const float* __restrict__ gamma,
                                                         float* __restrict__ dz, float* __restrict__ dy,
                                                         float* __restrict__ part, int rows, float rate, uint32_t site,
-                                                        const SkfStepState* st) {
+                                                        const SkfStepState* st, const int* __restrict__ live_len, int rps) {
   constexpr int D = 4 * LPR, RPW = 64 / LPR, UR = SKF_LN_UR;
   __shared__ float red[4][2][D];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -553,8 +553,13 @@ __global__ __launch_bounds__(256) void ln_bwd_v4_kernel(const float* __restrict_
       const int rr = ok[u] ? row : rows - 1;
       off[u] = (size_t)rr * D + 4 * sub;
       mean[u] = stats[2 * (size_t)rr]; rstd[u] = stats[2 * (size_t)rr + 1];
-      dv[u] = *reinterpret_cast<const f32x4*>(dout + off[u]);
-      zv[u] = *reinterpret_cast<const f32x4*>(z + off[u]);
+      // row t of sample b with t >= live_len[b]: dout is exactly zero (skf_target_live_len) - neither it nor z is read, the
+      // arithmetic below then yields the zeros that are stored
+      bool lv = true;
+      if (live_len) { const int b = rr / rps; lv = rr - b * rps < live_len[b]; }
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      dv[u] = lv ? *reinterpret_cast<const f32x4*>(dout + off[u]) : zero;
+      zv[u] = lv ? *reinterpret_cast<const f32x4*>(z + off[u]) : zero;
     }
 #pragma unroll
     for (int u = 0; u < UR; ++u) {
@@ -1122,6 +1127,15 @@ extern "C" int skf_layernorm_residual_bwd(const float* dout, const float* z, con
                                           float* dz, float* dy, float* dgamma, float* dbeta, int rows, int d, float rate,
                                           unsigned site, const void* step_state, void* workspace, size_t workspace_bytes,
                                           skf_stream_t stream) {
+  return skf_layernorm_residual_bwd_rows(dout, z, stats, gamma, dz, dy, dgamma, dbeta, rows, d, rate, site, step_state, workspace,
+                                         workspace_bytes, nullptr, 0, stream);
+}
+
+extern "C" int skf_layernorm_residual_bwd_rows(const float* dout, const float* z, const float* stats, const float* gamma,
+                                               float* dz, float* dy, float* dgamma, float* dbeta, int rows, int d, float rate,
+                                               unsigned site, const void* step_state, void* workspace, size_t workspace_bytes,
+                                               const int* live_len, int rows_per_sample, skf_stream_t stream) {
+  SKF_CHECK_ARG(!live_len || (rows_per_sample > 0 && rows % rows_per_sample == 0), "live_len needs rows = B * rows_per_sample");
   SKF_CHECK_ARG(dout && z && stats && gamma && dz, "null operand");
   SKF_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "dgamma and dbeta must both be given or both be NULL");
   SKF_CHECK_ARG(workspace && workspace_bytes >= skf_layernorm_bwd_workspace_bytes(rows, d), "workspace too small");
@@ -1136,9 +1150,9 @@ extern "C" int skf_layernorm_residual_bwd(const float* dout, const float* z, con
   SkfProfScope ps(s, "ln_bwd", 0.0, (rate > 0.f ? 16.0 : 12.0) * rows * d);
   static const bool v4 = !(getenv("SKF_LN_V4") && getenv("SKF_LN_V4")[0] == '0');
   const bool al = ((((uintptr_t)dout | (uintptr_t)z | (uintptr_t)dz | (uintptr_t)dyp | (uintptr_t)gamma) & 15) == 0);
-  if (v4 && al && d == 64) hipLaunchKernelGGL(ln_bwd_v4_kernel<16>, grid, block, 0, s, dout, z, stats, gamma, dz, dyp, part, rows, rate, site, st);
-  else if (v4 && al && d == 128) hipLaunchKernelGGL(ln_bwd_v4_kernel<32>, grid, block, 0, s, dout, z, stats, gamma, dz, dyp, part, rows, rate, site, st);
-  else if (v4 && al && d == 256) hipLaunchKernelGGL(ln_bwd_v4_kernel<64>, grid, block, 0, s, dout, z, stats, gamma, dz, dyp, part, rows, rate, site, st);
+  if (v4 && al && d == 64) hipLaunchKernelGGL(ln_bwd_v4_kernel<16>, grid, block, 0, s, dout, z, stats, gamma, dz, dyp, part, rows, rate, site, st, live_len, rows_per_sample);
+  else if (v4 && al && d == 128) hipLaunchKernelGGL(ln_bwd_v4_kernel<32>, grid, block, 0, s, dout, z, stats, gamma, dz, dyp, part, rows, rate, site, st, live_len, rows_per_sample);
+  else if (v4 && al && d == 256) hipLaunchKernelGGL(ln_bwd_v4_kernel<64>, grid, block, 0, s, dout, z, stats, gamma, dz, dyp, part, rows, rate, site, st, live_len, rows_per_sample);
   else
   switch (d) {
     case 128: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, 0, s, dout, z, stats, gamma, dz, dyp, part, rows, rate, site, st); break;

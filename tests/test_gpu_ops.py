@@ -237,7 +237,7 @@ def test_row_blocks_lists(ops):
 
 
 @pytest.mark.parametrize("N,K,relu,acc", [(128, 128, False, False), (128, 384, False, True), (512, 128, True, False), (128, 512, False, False),
-                                          (128, 256, False, False), (1004, 128, False, False)])
+                                          (128, 256, False, False), (1004, 128, False, False), (128, 1004, False, False)])   # (the last: generic tiled kernel)
 def test_gemm_dgrad_over_live_row_blocks_is_exact(ops, N, K, relu, acc):
     """dX = dY W^T visiting only the 16-row tiles that hold live rows: bit-identical to the dense call (dead rows of dY are
     zero, so the dense kernel computes exact zeros there), for every weight-stationary shape family of the step."""
