@@ -105,6 +105,13 @@ int skf_gemm_f32_rows(int a_kcontig, int b_kcontig, int M, int N, int K, const f
 int skf_gemm_wgrad_partial_rows(int M, int N, int K, const float* A, int lda, const float* B, int ldb, int splits,
                                 int with_bias_grad, float* slab, size_t slab_bytes, int* splits_used_host, int precision,
                                 const int* row_blocks, int row_block_rows, skf_stream_t stream);
+/* the partial-tile kernels of up to 8 weight gradients in one launch (a transformer layer's, issued together); a HOST array,
+ * splits_used is written per problem; problems the split-arithmetic kernel cannot take fall back to one launch each */
+typedef struct SkfWgradProblem {
+  const float* A; const float* B; float* slab; size_t slab_bytes; const int* row_blocks;   /* row_blocks may be NULL */
+  int32_t M, N, K, lda, ldb, splits, with_bias_grad, row_block_rows, splits_used, pad;
+} SkfWgradProblem;
+int skf_gemm_wgrad_partial_group(SkfWgradProblem* probs, int n, int precision, skf_stream_t stream);
 /* one slab ([splits][M][N] then [splits][N] when bias_grad != NULL) -> C (+)= sum, bias_grad (+)= column sums */
 int skf_splitk_reduce(const float* slab, int splits, int M, int N, float* C, int ldc, int accumulate, float* bias_grad,
                       int bias_grad_accumulate, skf_stream_t stream);

@@ -70,6 +70,7 @@ SIGNATURES = {
     "skf_gemm_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "skf_gemm_default_splits": (_I, [_I, _I, _I]),
     "skf_gemm_wgrad_partial": (_I, [_I, _I, _I, _P, _I, _P, _I, _I, _I, _P, _Z, _P, _I, _P]),
+    "skf_gemm_wgrad_partial_group": (_I, [_P, _I, _I, _P]),
     "skf_gemm_wgrad_partial_rows": (_I, [_I, _I, _I, _P, _I, _P, _I, _I, _I, _P, _Z, _P, _I, _P, _I, _P]),
     "skf_gemm_f32_rows": (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _I, _P, _Z, _I, _P, _I, _P]),
     "skf_target_live_len": (_I, [_P, _I, _I, _I, _P, _P]),

@@ -451,6 +451,54 @@ extern "C" int skf_gemm_wgrad_partial_rows(int M, int N, int K, const float* A, 
   return launch_variant<64, 64, 2, true>(p, 0, 0, splits, (hipStream_t)stream);
 }
 
+// the partial-tile kernels of several weight gradients in ONE launch (falls back to one launch each when a problem is not
+// one for the split-arithmetic fast path); probs[i].splits_used is written
+extern "C" int skf_gemm_wgrad_partial_group(SkfWgradProblem* probs, int n, int precision, skf_stream_t stream) {
+  SKF_CHECK_ARG(probs && n > 0, "bad argument");
+  SKF_CHECK_ARG(precision == SKF_PREC_F32 || precision == SKF_PREC_BF16X3 || precision == SKF_PREC_BF16X6, "precision must be 0 (fp32 MFMA), 6 (bf16x6) or 3 (bf16x3)");
+  if (n <= 8) {
+    GemmParams ps[8];
+    int splits[8];
+    bool ok = true;
+    for (int i = 0; i < n; ++i) {
+      SkfWgradProblem& w = probs[i];
+      SKF_CHECK_ARG(w.M > 0 && w.N > 0 && w.K > 0 && w.A && w.B && w.slab, "bad problem");
+      int sp = w.splits < 1 ? 1 : w.splits;
+      int chunk = skf_cdiv(w.K, sp);
+      chunk = skf_cdiv(chunk, 64) * 64;
+      sp = skf_cdiv(w.K, chunk);
+      SKF_CHECK_ARG(w.slab_bytes >= skf_gemm_workspace_bytes(w.M, w.N, w.K, sp, 1), "slab too small");
+      GemmParams p{};
+      p.A = w.A; p.B = w.B; p.M = w.M; p.N = w.N; p.K = w.K; p.lda = w.lda; p.ldb = w.ldb;
+      p.a_vec = ((w.lda & 3) == 0) && (((uintptr_t)w.A & 15) == 0);
+      p.b_vec = ((w.ldb & 3) == 0) && (((uintptr_t)w.B & 15) == 0);
+      p.k_chunk = chunk; p.slab = w.slab; p.precision = precision;
+      p.row_blocks = w.row_blocks; p.row_block_rows = w.row_blocks ? w.row_block_rows : 0;
+      p.colsum_slab = w.with_bias_grad ? w.slab + (size_t)sp * w.M * w.N : nullptr;
+      ps[i] = p; splits[i] = sp;
+      ok = ok && precision != SKF_PREC_F32;
+    }
+    int handled = 0;
+    if (ok) {
+      int rc = skf_gemm_wgrad_group_dispatch(ps, splits, n, (hipStream_t)stream, &handled);
+      if (rc != SKF_OK) return rc;
+    }
+    if (handled) {
+      for (int i = 0; i < n; ++i) probs[i].splits_used = splits[i];
+      return SKF_OK;
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    SkfWgradProblem& w = probs[i];
+    int used = 0;
+    int rc = skf_gemm_wgrad_partial_rows(w.M, w.N, w.K, w.A, w.lda, w.B, w.ldb, w.splits, w.with_bias_grad, w.slab, w.slab_bytes, &used,
+                                         precision, w.row_blocks, w.row_block_rows, stream);
+    if (rc != SKF_OK) return rc;
+    w.splits_used = used;
+  }
+  return SKF_OK;
+}
+
 extern "C" int skf_gemm_wgrad_partial(int M, int N, int K, const float* A, int lda, const float* B, int ldb, int splits,
                                       int with_bias_grad, float* slab, size_t slab_bytes, int* splits_used,
                                       int precision, skf_stream_t stream) {

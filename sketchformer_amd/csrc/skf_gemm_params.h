@@ -38,6 +38,8 @@ int skf_gemm_ws_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, hipS
 int skf_gemm_wsx_launch(const GemmParams& p, int b_kcontig, int pieces, hipStream_t st);
 // wgrad (X^T.dY) fast path writing the split-K slab; sets *handled when it launched the problem
 int skf_gemm_wgrad_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, int splits, hipStream_t st, int* handled);
+// several wgrad fast-path problems (k_chunk, slab, colsum_slab, row_blocks set as for skf_gemm_wgrad_dispatch) in one launch
+int skf_gemm_wgrad_group_dispatch(const GemmParams* ps, const int* splits, int n, hipStream_t st, int* handled);
 // small-problem path (M*N*K <= 2^25): any layout, all epilogues, optional bias gradient (column sums of B) in the same launch
 int skf_gemm_small_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, float* bias_grad, int bias_grad_accumulate,
                             hipStream_t st, int* handled);

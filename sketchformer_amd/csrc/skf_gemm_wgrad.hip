@@ -150,15 +150,16 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t wg_rows_rsrc(const float* base
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(base) + off), 0, rem, 0x00020000);
 }
 
+// bid / nblocks: the workgroup's index inside its problem and the problem's workgroup count (the kernel's own grid for a
+// single problem; a slice of the grid that starts at a multiple of 8 - so that bid % 8 is still the XCD - in a grouped launch)
 template <int P, int NW>   // NW waves per workgroup = intra-workgroup split of the row range
-__global__ __launch_bounds__(64 * NW, 1) void wgrad_x_kernel(GemmParams p) {   // grids are ~one workgroup per CU: registers before occupancy
-  extern __shared__ __attribute__((aligned(16))) float smem[];   // [NW waves][64][64] + [NW][64] column sums
+__device__ __forceinline__ void wgrad_x_body(const GemmParams& p, const int bid, const int nblocks, float* smem) {
   const SkfSplitSel sel = skf_split_sel();
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, g = lane >> 4;
   const int ntile = p.tiles_m * p.tiles_n;
-  const int logical = skf_xcd_remap(blockIdx.x, gridDim.x);
+  const int logical = skf_xcd_remap(bid, nblocks);
   const int split = logical / ntile, tile = logical % ntile;
   const int tile_m = tile / p.tiles_n, tile_n = tile % p.tiles_n;
   const int a0 = tile_m * 64, b0 = tile_n * 64;
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_x_kernel(GemmParams p) {   /
   const int* blk = p.row_blocks;
   int eb = 0, ee = 0;
   if (blk) {
-    const int nlive = blk[0], per = (nlive + (int)gridDim.x / ntile - 1) / ((int)gridDim.x / ntile);
+    const int nlive = blk[0], per = (nlive + nblocks / ntile - 1) / (nblocks / ntile);
     eb = split * per; ee = min(nlive, eb + per);
   }
   const int niter = blk ? (max(ee - eb, 0) + NW - 1) / NW : (ke - kb + RI - 1) / RI;
@@ -282,6 +283,26 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_x_kernel(GemmParams p) {   /
   }
 }
 
+template <int P, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void wgrad_x_kernel(GemmParams p) {   // grids are ~one workgroup per CU: registers before occupancy
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [NW waves][64][64] + [NW][64] column sums
+  wgrad_x_body<P, NW>(p, blockIdx.x, gridDim.x, smem);
+}
+
+// Several weight gradients in ONE launch (the 4-8 of a transformer layer, issued together on the side stream): problem g owns
+// the workgroups [start[g], start[g + 1]) of the grid, every start a multiple of 8; the padding workgroups exit at once.
+constexpr int kWgradGroupMax = 8;
+struct WgradGroup { int n; int start[kWgradGroupMax + 1]; int nblocks[kWgradGroupMax]; GemmParams p[kWgradGroupMax]; };
+template <int P, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void wgrad_x_group_kernel(WgradGroup grp) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int gi = 0;
+  while (gi + 1 < grp.n && (int)blockIdx.x >= grp.start[gi + 1]) ++gi;       // wave-uniform scan of a short table
+  const int bid = (int)blockIdx.x - grp.start[gi];
+  if (bid >= grp.nblocks[gi]) return;
+  wgrad_x_body<P, NW>(grp.p[gi], bid, grp.nblocks[gi], smem);
+}
+
 }  // namespace
 
 // wgrad fast path: A = X stored [K=rows][M=Kin], B = dY stored [K=rows][N=Nout]; writes the split-K slab
@@ -326,6 +347,48 @@ int skf_gemm_wgrad_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, i
   }
   SkfProfScope ps(st, "wgrad<64x64>", 2.0 * p.M * p.N * p.K, 4.0 * (double)p.K * (p.M + p.N));
   hipLaunchKernelGGL(wgrad_kernel, dim3(q.tiles_m * q.tiles_n * splits), dim3(256), smem, st, q);
+  SKF_LAUNCH_CHECK();
+  return SKF_OK;
+}
+
+// Grouped form of the fast path above: every problem must be one that skf_gemm_wgrad_dispatch would hand to wgrad_x_kernel
+// (split arithmetic, aligned, 32-bit offsets); *handled = 0 when any is not (the caller then issues them one by one).
+int skf_gemm_wgrad_group_dispatch(const GemmParams* ps, const int* splits, int n, hipStream_t st, int* handled) {
+  *handled = 0;
+  const char* off = getenv("SKF_GEMM_NO_WGRAD");
+  static const bool group_off = getenv("SKF_NO_WGRAD_GROUP") && getenv("SKF_NO_WGRAD_GROUP")[0] == '1';
+  if ((off && off[0] == '1') || group_off || n < 2 || n > kWgradGroupMax) return SKF_OK;
+  WgradGroup grp{};
+  grp.n = n;
+  int cursor = 0;
+  const int prec = ps[0].precision;
+  double flops = 0.0, bytes = 0.0;
+  for (int g = 0; g < n; ++g) {
+    const GemmParams& p = ps[g];
+    if ((p.M & 3) || (p.N & 3) || (p.lda & 3) || (p.ldb & 3) || ((uintptr_t)p.A & 15) || ((uintptr_t)p.B & 15)) return SKF_OK;
+    if (((uintptr_t)p.slab & 15) || (p.k_chunk & 63) || !p.precision || p.precision != prec) return SKF_OK;
+    if (!((double)p.K * p.lda * 4 < 2147483648.0 && (double)p.K * p.ldb * 4 < 2147483648.0)) return SKF_OK;
+    GemmParams q = p;
+    if (q.row_block_rows != 32) q.row_blocks = nullptr;
+    q.tiles_m = skf_cdiv(p.M, 64); q.tiles_n = skf_cdiv(p.N, 64);
+    grp.p[g] = q;
+    grp.start[g] = cursor;
+    grp.nblocks[g] = q.tiles_m * q.tiles_n * splits[g];
+    cursor += (grp.nblocks[g] + 7) & ~7;
+    flops += 2.0 * p.M * p.N * p.K; bytes += 4.0 * (double)p.K * (p.M + p.N);
+  }
+  grp.start[n] = cursor;
+  *handled = 1;
+  const size_t smem_x = (size_t)4 * (4096 + 64) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    SKF_HIP(hipFuncSetAttribute((const void*)wgrad_x_group_kernel<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_x));
+    SKF_HIP(hipFuncSetAttribute((const void*)wgrad_x_group_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_x));
+    attr = true;
+  }
+  SkfProfScope ps_(st, prec == 3 ? "wgrad_group<64x64,bf16x3>" : "wgrad_group<64x64,bf16x6>", flops, bytes);
+  if (prec == 3) hipLaunchKernelGGL((wgrad_x_group_kernel<2, 4>), dim3(cursor), dim3(256), smem_x, st, grp);
+  else hipLaunchKernelGGL((wgrad_x_group_kernel<3, 4>), dim3(cursor), dim3(256), smem_x, st, grp);
   SKF_LAUNCH_CHECK();
   return SKF_OK;
 }

@@ -639,3 +639,43 @@ def test_attention_decode_appends_new_row_and_reads_step_from_device(ops):
         cur = ct.cpu().numpy()
         want2, _, _ = oracle.sdpa_fwd(sp(q[:, None, :], 1), sp(cur[:, :, :d], cap), sp(cur[:, :, d:], cap), m)
         _close(o2, want2.transpose(0, 2, 1, 3).reshape(B, d), 3e-5, "limit_from_step %d" % i)
+
+
+def test_gemm_wgrad_partial_group_equals_single_launches(ops):
+    """Four weight gradients of a cfg-2 layer (one with a live-row-block list) as ONE grouped launch of the partial-tile kernel:
+    the slabs are bit-identical to those of four separate launches."""
+    import ctypes as C
+    from sketchformer_amd import _lib
+    lib = _lib.load()
+    rng = np.random.RandomState(17)
+    B, Ld = 64, 199
+    R = B * Ld
+    tar, lens, _ = _padded_case(rng, B, Ld, 4)
+    blocks = ops.row_blocks(ops.target_live_len(_dev(tar, torch.int64), Ld), Ld, 32)
+
+    class Prob(C.Structure):
+        _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("slab", C.c_void_p), ("slab_bytes", C.c_size_t), ("row_blocks", C.c_void_p),
+                    ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("lda", C.c_int32), ("ldb", C.c_int32), ("splits", C.c_int32),
+                    ("with_bias_grad", C.c_int32), ("row_block_rows", C.c_int32), ("splits_used", C.c_int32), ("pad", C.c_int32)]
+
+    shapes = [(128, 384, False), (128, 128, True), (128, 512, False), (512, 128, False)]
+    keep, probs, singles = [], (Prob * len(shapes))(), []
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for i, (inf, outf, rows_list) in enumerate(shapes):
+        x = _dev(rng.randn(R, inf)); dy = _dev(rng.randn(R, outf))
+        sp = lib.skf_gemm_default_splits(inf, outf, R)
+        nb = lib.skf_gemm_workspace_bytes(inf, outf, R, sp, 1)
+        slab_g = torch.full((nb // 4,), 7.0, device="cuda"); slab_s = torch.full((nb // 4,), 9.0, device="cuda")
+        keep += [x, dy, slab_g, slab_s]
+        probs[i] = Prob(x.data_ptr(), dy.data_ptr(), slab_g.data_ptr(), nb, blocks.data_ptr() if rows_list else None, inf, outf, R, inf, outf, sp, 1,
+                        32, 0, 0)
+        used = C.c_int(0)
+        _lib.call("skf_gemm_wgrad_partial_rows", inf, outf, R, C.c_void_p(x.data_ptr()), inf, C.c_void_p(dy.data_ptr()), outf, sp, 1,
+                  C.c_void_p(slab_s.data_ptr()), nb, C.byref(used), 6, C.c_void_p(blocks.data_ptr()) if rows_list else None, 32, stream)
+        singles.append((slab_s, slab_g, used.value, inf, outf))
+    _lib.call("skf_gemm_wgrad_partial_group", C.byref(probs), len(shapes), 6, stream)
+    torch.cuda.synchronize()
+    for i, (slab_s, slab_g, used, inf, outf) in enumerate(singles):
+        assert probs[i].splits_used == used
+        n = used * (inf * outf + outf)
+        assert torch.equal(slab_s[:n], slab_g[:n])
