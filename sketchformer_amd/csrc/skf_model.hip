@@ -514,10 +514,10 @@ int issue_wgrads(SkfModel* M, hipStream_t s) {
     M->slab_cursor += bytes;
     probs.push_back(pr); prob_q.push_back(&q);
   }
-  // (measured: grouping the ~1 GFLOP problems of cfg 2 shortens the step by 0.6 %, grouping the 5-GFLOP ones of cfg 3 lengthens
+  // (measured: grouping the 1-3 GFLOP problems of cfg 2 shortens the step by 0.6 %, grouping the 3-13 GFLOP ones of cfg 3 lengthens
   //  it by 1.3 % - those fill the chip for ~90 us each and gain nothing from sharing a grid)
   bool small = true;
-  for (const auto& pr : probs) small = small && 2.0 * pr.M * pr.N * pr.K < 2.5e9;
+  for (const auto& pr : probs) small = small && 2.0 * pr.M * pr.N * pr.K < 4e9;
   const size_t gmax = small ? 8 : 1;
   for (size_t b0 = 0; b0 < probs.size(); b0 += gmax) {
     const int nb = (int)std::min<size_t>(gmax, probs.size() - b0);
