@@ -261,12 +261,13 @@ def test_softmax_ce_bf16(lib, V, ld):
     assert float(LG[:, V:].float().abs().max()) == 0.0
 
 
-def test_embed_pool_expander_bf16(lib):
+@pytest.mark.parametrize("L,d,U", [(40, 128, 64), (70, 512, 512), (37, 256, 128)])     # (the last two: the 1024-thread pooling / expander backward)
+def test_embed_pool_expander_bf16(lib, L, d, U):
     from sketchformer_amd import engine, ops
-    B, L, V, d, U, rate, site = 4, 40, 52, 128, 64, 0.1, 2
+    B, V, rate, site = 4, 52, 0.1, 2
     rng = np.random.RandomState(1)
     tok = rng.randint(0, V, size=(B, L + 1)); tok[:, 25:] = 0
-    table, pos = rng.uniform(-0.05, 0.05, (V, d)), engine.positional_encoding(64, d)
+    table, pos = rng.uniform(-0.05, 0.05, (V, d)), engine.positional_encoding(L + 24, d)
     st = ops.new_step_state("cuda", iterations=9)
     ops.step_prologue(st, seed=1)
     keep = ops.dropout_keep_mask(ops.read_step_state(st)["drop_key"], site, rate, B * L * d).reshape(B, L, d) / (1 - rate)
