@@ -64,6 +64,39 @@ __global__ __launch_bounds__(1024) void row_blocks_kernel(const int* __restrict_
   if (tid == 0) { blocks[0] = nlive; blocks[1] = nb; }
 }
 
+// granule 1 (row lists of 10^4..10^5 rows): the live rows of a sample are its first live_len[b] rows, so a row's slot follows
+// from the running sum of the live lengths alone - every workgroup scans the B lengths and places its 1024 rows
+__global__ __launch_bounds__(1024) void row_list_kernel(const int* __restrict__ live_len, int B, int rps, int* __restrict__ blocks) {
+  extern __shared__ int pre[];                 // [B + 1] exclusive running sum of min(live_len, rps)
+  __shared__ int part[1024];
+  const int tid = threadIdx.x;
+  const int per = (B + 1023) / 1024;
+  int cnt = 0;
+  for (int b = tid * per; b < min(B, (tid + 1) * per); ++b) cnt += min(max(live_len[b], 0), rps);
+  part[tid] = cnt;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int a = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += a;
+    __syncthreads();
+  }
+  int run = part[tid] - cnt;
+  for (int b = tid * per; b < min(B, (tid + 1) * per); ++b) { pre[b] = run; run += min(max(live_len[b], 0), rps); }
+  if (tid == 1023) pre[B] = part[1023];
+  __syncthreads();
+  const int rows = B * rps, nlive = pre[B];
+  const int r = blockIdx.x * 1024 + tid;
+  if (r < rows) {
+    const int b = r / rps, t = r - b * rps, len = min(max(live_len[b], 0), rps);
+    const bool lv = t < len;
+    const int live_before = pre[b] + min(t, len);
+    blocks[2 + (lv ? live_before : nlive + (r - live_before))] = r;
+    blocks[2 + rows + r] = lv ? 1 : 0;
+  }
+  if (blockIdx.x == 0 && tid == 0) { blocks[0] = nlive; blocks[1] = rows; }
+}
+
 }  // namespace
 
 extern "C" int skf_target_live_len(const long long* tar, int tar_ld, int B, int Ld, int* live_len, skf_stream_t stream) {
@@ -79,6 +112,10 @@ extern "C" size_t skf_row_blocks_bytes(int rows, int granule) {
 
 extern "C" int skf_row_blocks_build(const int* live_len, int B, int rows_per_sample, int granule, int* blocks, skf_stream_t stream) {
   SKF_CHECK_ARG(live_len && blocks && B > 0 && rows_per_sample > 0 && granule > 0, "bad argument");
+  if (granule == 1 && B <= 8192)
+    hipLaunchKernelGGL(row_list_kernel, dim3(skf_cdiv(B * rows_per_sample, 1024)), dim3(1024), (size_t)(B + 1) * sizeof(int), (hipStream_t)stream,
+                       live_len, B, rows_per_sample, blocks);
+  else
   hipLaunchKernelGGL(row_blocks_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, live_len, B, rows_per_sample, granule, blocks);
   SKF_LAUNCH_CHECK();
   return SKF_OK;

@@ -226,7 +226,7 @@ def test_row_blocks_lists(ops):
     tar, lens, _ = _padded_case(rng, B, Ld, 4)
     ll = ops.target_live_len(_dev(tar, torch.int64), Ld)
     assert np.array_equal(ll.cpu().numpy(), lens)
-    for g in (16, 32, 64, 256):
+    for g in (1, 16, 32, 64, 256):
         got = ops.row_blocks(ll, Ld, g).cpu().numpy()
         nb = -(-B * Ld // g)
         live_row = np.concatenate([np.arange(Ld) < n for n in lens])
