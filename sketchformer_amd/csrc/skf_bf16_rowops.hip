@@ -563,11 +563,105 @@ extern "C" int skf_softmax_ce_bf16(void* logits, int ld, int rows, int ncls, con
   return SKF_OK;
 }
 
+constexpr int WNT = 1024;
+__device__ __forceinline__ float group_sum(float v, int lanes) {     // sum over `lanes` adjacent lanes (power of two <= 64)
+  for (int o = 1; o < lanes; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+static bool wide_ok(int w) { return w == 128 || w == 256 || w == 512; }
+
+// pooling forward, 1024 threads per sample (see the backward kernels below for the access pattern)
+__global__ __launch_bounds__(WNT) void pool_fwd_wide_kernel(const skf_bf16* __restrict__ u, const float* __restrict__ Vw,
+                                                           const skf_bf16* __restrict__ x, int L, int U, int d,
+                                                           float* __restrict__ a_out, float* __restrict__ emb) {
+  extern __shared__ float sm[];        // [L] scores -> weights, [32] reduction scratch, [TG][d] column partials
+  float* sc = sm;
+  float* red = sm + L;
+  float* colp = red + 32;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  {
+    const int LPU = U >> 3, TGU = WNT / LPU, c8 = (tid % LPU) * 8, tg = tid / LPU;
+    const skf_bf16* ub = u + (size_t)b * L * U + c8;
+    float vw[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) vw[e] = Vw[c8 + e];
+    for (int t0 = tg; t0 < L; t0 += 4 * TGU) {
+      uint4 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const int t = t0 + k * TGU; v[k] = *reinterpret_cast<const uint4*>(ub + (size_t)(t < L ? t : L - 1) * U); }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int t = t0 + k * TGU;
+        float p[8];
+        skf_unpack8(v[k], p);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += p[e] * vw[e];
+        s = group_sum(s, LPU);
+        if (c8 == 0 && t < L) sc[t] = s;
+      }
+    }
+  }
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int t = tid; t < L; t += WNT) mx = fmaxf(mx, sc[t]);
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = red[0];
+#pragma unroll
+  for (int q = 1; q < WNT / 64; ++q) mx = fmaxf(mx, red[q]);
+  float s = 0.f;
+  for (int t = tid; t < L; t += WNT) { const float e = __expf(sc[t] - mx); sc[t] = e; s += e; }
+  s = wave_sum(s);
+  if (lane == 0) red[16 + wave] = s;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int q = 0; q < WNT / 64; ++q) tot += red[16 + q];
+  const float inv = 1.0f / tot;
+  for (int t = tid; t < L; t += WNT) { const float a = sc[t] * inv; sc[t] = a; a_out[(size_t)b * L + t] = a; }
+  __syncthreads();
+  {
+    const int LPRW = d >> 3, TG = WNT / LPRW, c8 = (tid % LPRW) * 8, tg = tid / LPRW;
+    const skf_bf16* xb = x + (size_t)b * L * d + c8;
+    float g[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] = 0.f;
+    for (int t0 = tg; t0 < L; t0 += 4 * TG) {
+      uint4 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const int t = t0 + k * TG; v[k] = *reinterpret_cast<const uint4*>(xb + (size_t)(t < L ? t : L - 1) * d); }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int t = t0 + k * TG;
+        float p[8];
+        skf_unpack8(v[k], p);
+        const float at = t < L ? sc[t] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] += at * p[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) colp[tg * d + c8 + e] = g[e];
+    __syncthreads();
+    for (int c = tid; c < d; c += WNT) {
+      float t = 0.f;
+      for (int q = 0; q < TG; ++q) t += colp[q * d + c];
+      emb[(size_t)b * d + c] = t;
+    }
+  }
+}
+
 extern "C" int skf_pool_fwd_bf16(const void* u, const float* Vw, const void* x, int B, int L, int U, int d, float* a_out, float* emb,
                                  skf_stream_t stream) {
   SKF_CHECK_ARG(u && Vw && x && a_out && emb && B > 0 && L > 0 && (U & 1) == 0 && (d & 1) == 0, "bad argument");
   hipStream_t st = (hipStream_t)stream;
   SkfProfScope ps(st, "pool_fwd_bf16", 0.0, (double)B * L * (U + d) * 2.0);
+  if (wide_ok(d) && wide_ok(U) && ((((uintptr_t)u | (uintptr_t)x) & 15) == 0))
+    hipLaunchKernelGGL(pool_fwd_wide_kernel, dim3(B), dim3(WNT), (size_t)(L + 32 + 8 * WNT) * sizeof(float), st, (const skf_bf16*)u, Vw,
+                       (const skf_bf16*)x, L, U, d, a_out, emb);
+  else
   hipLaunchKernelGGL(pool_fwd_kernel, dim3(B), dim3(256), (size_t)(L + 8) * sizeof(float), st, (const skf_bf16*)u, Vw, (const skf_bf16*)x,
                      L, U, d, a_out, emb);
   SKF_LAUNCH_CHECK();
@@ -578,11 +672,6 @@ extern "C" int skf_pool_fwd_bf16(const void* u, const float* Vw, const void* x, 
 // 16-byte access per lane of a (d/8)-lane group, four row groups of loads are in flight before the first is used, and the
 // column reductions over the L rows are split over the row groups and folded through LDS in a fixed order.  (The kernels
 // above walk a sample's rows one memory round trip at a time: 450 / 385 us per launch at cfg 5.)
-constexpr int WNT = 1024;
-__device__ __forceinline__ float group_sum(float v, int lanes) {     // sum over `lanes` adjacent lanes (power of two <= 64)
-  for (int o = 1; o < lanes; o <<= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
 
 __global__ __launch_bounds__(WNT) void expander_bwd_wide_kernel(const skf_bf16* __restrict__ dpre, const float* __restrict__ emb,
                                                                const float* __restrict__ w, int L, int d, float* __restrict__ demb,
@@ -708,7 +797,6 @@ __global__ __launch_bounds__(WNT) void pool_bwd_wide_kernel(skf_bf16* __restrict
     }
   }
 }
-static bool wide_ok(int w) { return w == 128 || w == 256 || w == 512; }
 
 // workspace >= B*U floats (per-sample dV partials); dV receives their sum
 extern "C" int skf_pool_bwd_bf16(void* u_inout_dpre, const float* Vw, const void* x, const float* a, const float* demb, int B, int L,
