@@ -1434,7 +1434,7 @@ extern "C" int skf_model_greedy_decode(SkfModel* m, const float* embedding, cons
   SKF_CHECK_ARG(n_valid > 0 && n_valid <= m->cfg.batch, "n_valid must be in [1, batch]");
   SKF_CHECK_ARG(max_steps > 0 && max_steps <= m->cfg.seq_len, "max_steps must be in [1, seq_len]");
   SKF_CHECK_ARG(m->cfg.do_reconstruction, "the model was built without a decoder (do_reconstruction = 0)");
-  if (m->bf16) { skf_set_error("greedy decode is not built for act_dtype=bf16 (train the bf16 model, decode with an fp32 one)"); return SKF_EUNSUPPORTED; }
+  if (m->bf16) return run_greedy_decode16(m, embedding, expected_len_host, n_valid, sos, eos, max_steps, out, out_len_host, (hipStream_t)stream);
   return run_greedy_decode(m, embedding, expected_len_host, n_valid, sos, eos, max_steps, out, out_len_host,
                            (hipStream_t)stream);
 }

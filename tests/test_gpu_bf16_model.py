@@ -144,3 +144,24 @@ def test_bf16_adam_trajectory_and_graph_replay():
     print("\n[bf16 trajectory] 4 Adam steps: |displacement| %.3e, relative L2 distance to the oracle's displacement %.3e, cosine %.5f"
           % (np.linalg.norm(do), rel_l2, cos))
     assert rel_l2 < 0.15 and cos > 0.99, (rel_l2, cos)
+
+
+@pytest.mark.parametrize("blind", [True, False])
+def test_bf16_model_greedy_decode_matches_oracle_from_its_own_embedding(blind):
+    """predict_from_embedding on a bf16-trained model: the decoder runs in fp32 on the master weights (one launch per
+    position), starting from the embedding of the bf16 encoder - token sequences identical to the oracle's decode of that
+    same embedding (blind / expected-length cross mask, an early stop)."""
+    B = 5
+    eng, ocfg = _build(SMALL, B, blind=blind)
+    sos, eos = ocfg.vocab_size - 2, ocfg.vocab_size - 1
+    b = eng.get("output/bias"); b[eos] += 2.5; eng.set("output/bias", b)          # samples stop at different positions
+    x, _ = synthetic.token_batch(B, ocfg.seq_len, ocfg.vocab_size, ocfg.n_classes, seed=4)
+    eng.encode(x)
+    emb = eng.buffer("embedding").float().cpu().numpy()
+    P = {k: v.astype(np.float64) for k, v in eng.state_dict_numpy().items()}
+    tlen = None if blind else np.sum(x > 0, axis=-1)
+    want = oracle.predict_from_embedding(P, ocfg, emb.astype(np.float64), sos, eos, expected_len=tlen)["recon"]
+    got = eng.greedy_decode(None, expected_len=tlen, sos=sos, eos=eos)
+    assert got.shape == want.shape and np.array_equal(got, want)
+    got2 = eng.greedy_decode(emb, expected_len=tlen, n_valid=B, sos=sos, eos=eos)      # explicit embedding: same answer
+    assert np.array_equal(got2, want)
