@@ -52,6 +52,14 @@ def augment_strokes(strokes, prob, urnd):
     return out
 
 
+def convert_to_absolute(sketch):
+    """utils/sketch.py:169-175: offsets -> running positions (row 0 kept, pen states kept); the running sum is taken in the
+    array's own precision, one row after the other, like the reference's loop."""
+    out = np.array(sketch, copy=True)
+    out[:, :2] = np.cumsum(sketch[:, :2], axis=0, dtype=sketch.dtype)
+    return out
+
+
 class DistributedStroke3DataLoader(BaseDataLoader):
     name = "stroke3-distributed"
 
@@ -205,8 +213,12 @@ class DistributedStroke3DataLoader(BaseDataLoader):
             min_x, max_x, min_y, max_y = get_bounds(sketch)
             # a float32 division: the reference's bounds are Python floats, which numpy rounds to the array's precision
             sketch[:, :2] /= np.float32(max([max_x - min_x, max_y - min_y, 1]))
-            if self.hps["shuffle_stroke"] or self.hps["use_absolute_strokes"]:
-                raise NotImplementedError("shuffle_stroke / use_absolute_strokes are not implemented")
+            if self.hps["shuffle_stroke"]:
+                # the reference calls utils.tu_sketch_tools.strokes_to_lines here (:107-110), a module its repository does
+                # not contain: the option raises there as well
+                raise NotImplementedError("shuffle_stroke needs utils.tu_sketch_tools, which the reference does not ship")
+            if self.hps["use_absolute_strokes"]:
+                sketch = convert_to_absolute(sketch)
             if not self.hps["use_continuous_data"]:
                 sketch = self.tokenizer.encode(sketch)
             if len(sketch) > self.hps["max_seq_len"]:

@@ -161,6 +161,10 @@ def main():
     out["loader_preprocess"] = {"raw": [r.tolist() for r in raw], "max_seq_len": 32,
                                 "grid_tokens": np.asarray(grid).tolist(), "grid_dtype": str(np.asarray(grid).dtype),
                                 "continuous": np.asarray(cont).tolist(), "continuous_dtype": str(np.asarray(cont).dtype)}
+    # use_absolute_strokes (dataloaders/distributed_stroke3.py:111-112 -> utils/sketch.py:169-175), both output formats
+    grid_abs = make_loader(use_absolute_strokes=True).preprocess([r.copy() for r in raw], augment=False)
+    cont_abs = make_loader(use_continuous_data=True, use_absolute_strokes=True).preprocess([r.copy() for r in raw], augment=False)
+    out["loader_preprocess_absolute"] = {"grid_tokens": np.asarray(grid_abs).tolist(), "continuous": np.asarray(cont_abs).tolist()}
 
     # ---- dictionary Tokenizer (utils/tokenizer.py:16-101) against a synthetic k-means dictionary.  The dictionary is fit
     # on float32 offsets like prep_data/sketch_token/create_token_dict.py:52 makes them; the fixture stores its centres

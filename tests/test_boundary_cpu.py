@@ -99,6 +99,14 @@ def test_loader_preprocess_matches_reference():
     assert grid.shape == np.array(want["grid_tokens"]).shape and np.array_equal(grid, np.array(want["grid_tokens"]))
     cont = mk(use_continuous_data=True).preprocess([r.copy() for r in raw], augment=False)
     assert np.array_equal(cont, np.array(want["continuous"]))       # bit for bit (float32 division like the reference)
+    # use_absolute_strokes (reference :111-112): running positions instead of offsets, both output formats
+    wa = G["loader_preprocess_absolute"]
+    grid_abs = mk(use_absolute_strokes=True).preprocess([r.copy() for r in raw], augment=False)
+    assert np.array_equal(grid_abs, np.array(wa["grid_tokens"]))
+    cont_abs = mk(use_continuous_data=True, use_absolute_strokes=True).preprocess([r.copy() for r in raw], augment=False)
+    assert np.array_equal(cont_abs, np.array(wa["continuous"]))
+    with pytest.raises(NotImplementedError):        # the reference raises too (missing module)
+        mk(shuffle_stroke=True).preprocess([r.copy() for r in raw], augment=False)
 
 
 def _golden_dictionary(tmp_path):
