@@ -355,6 +355,7 @@ __global__ __launch_bounds__(256) void embed_bwd_sorted_kernel(const int* __rest
         }
         dtable[(size_t)ch.id * d + c] = sum;
       }
+      if (threadIdx.x == 0) done[ch.id] = 0;          // ready for another gradient pass over the same sort
     }
   }
 }

@@ -460,6 +460,18 @@ def test_embed_bwd_sorted_is_run_to_run_deterministic(ops):
     st = ops.new_step_state("cuda", iterations=3)
     ops.step_prologue(st, seed=5)
     first = ops.embed_bwd_sorted(tokd, dx, V, L=L, rate=0.1, site=2, state=st)
+    # one sort serves any number of gradient passes (the split ids' tickets are reset by the chunk that used them up)
+    import ctypes as C
+    from sketchformer_amd import _lib
+    nbytes = _lib.load().skf_embed_sort_workspace_bytes(B, L, V)
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.int32, device="cuda")
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.call("skf_embed_sort", C.c_void_p(tokd.data_ptr()), L, B, L, V, None, d, C.c_void_p(ws.data_ptr()), nbytes, stream)
+    for _ in range(2):
+        t = torch.full((V, d), float("nan"), device="cuda")
+        _lib.call("skf_embed_bwd_sorted", C.c_void_p(ws.data_ptr()), B, L, C.c_void_p(dx.data_ptr()), V, d, C.c_void_p(t.data_ptr()), 0.1, 2,
+                  C.c_void_p(st.data_ptr()), stream)
+        assert torch.equal(t, first)
     for _ in range(8):
         busy = torch.randn(4096, 4096, device="cuda") @ torch.randn(4096, 4096, device="cuda")      # perturb the scheduling
         again = ops.embed_bwd_sorted(tokd, dx, V, L=L, rate=0.1, site=2, state=st)
