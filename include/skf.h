@@ -133,6 +133,13 @@ int skf_attention_bwd(const float* Q, int ldq, const float* K, int ldk, const fl
                       const float* dO, int lddo, const float* stats, const unsigned char* key_mask, int key_mask_ld,
                       int causal, int B, int H, int Lq, int Lk, int dh, float* dQ, int lddq, float* dK, int lddk,
                       float* dV, int lddv, int precision, skf_stream_t stream);
+/* the same with per-sample live query counts (skf_target_live_len): query rows >= q_live_len[b] have dO == 0 exactly; the
+ * one-pass kernel neither stages nor visits their tiles and stores zeros into their dQ rows (the two-pass kernel finds
+ * all-zero dO tiles by itself) */
+int skf_attention_bwd_rows(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* O, int ldo,
+                           const float* dO, int lddo, const float* stats, const unsigned char* key_mask, int key_mask_ld,
+                           int causal, int B, int H, int Lq, int Lk, int dh, float* dQ, int lddq, float* dK, int lddk,
+                           float* dV, int lddv, int precision, const int* q_live_len, skf_stream_t stream);
 
 /* ------------------------------------------------------------------ embedding stage
  * Encoder.call / Decoder.call head, builders/layers/transformer.py:288-296, 325-334:

@@ -273,8 +273,10 @@ __global__ __launch_bounds__(256, SKF_ATTN_BWD_WAVES) void attn_bwd_kernel(AttnP
   // other half belongs to the neighbouring head.  XCD-contiguous ids put all heads of a sample on ONE XCD (one L2),
   // consecutively in time, so the neighbour's half is an L2 hit instead of a second HBM fetch of the same line.
   const int bh = p.xcd_remap ? skf_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x, b = bh / p.H, h = bh % p.H;
-  const int nkt = (p.Lk + 15) >> 4, nqt = (p.Lq + 15) >> 4;
-  const int QR = nqt * 16;
+  const int nkt = (p.Lk + 15) >> 4, nqt_all = (p.Lq + 15) >> 4;
+  // query tiles behind the sample's last live row have dO == 0: they add nothing to dK / dV and their dQ is zero
+  const int nqt = p.q_live ? min(nqt_all, (max(p.q_live[b], 0) + 15) >> 4) : nqt_all;
+  const int QR = nqt_all * 16;
   constexpr int RLD = DH + 1;          // row pitch of the dQ reduction slots
   float* Qs = smem;                   // [QR][LD]
   float* dOs = Qs + QR * LD;          // [QR][LD]
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(256, SKF_ATTN_BWD_WAVES) void attn_bwd_kernel(AttnP
   // 4 float4 x 3 arrays instead of one per element), delta = sum_d dO*O is reduced over the DH/4 lanes of a row.
   {
     constexpr int F4 = DH / 4;
-    const int total = QR * F4;
+    const int total = nqt * 16 * F4;
     for (int e0 = tid; e0 < total; e0 += 1024) {
       f32x4 qv[4], dv[4], ov[4];
 #pragma unroll
@@ -334,11 +336,13 @@ __global__ __launch_bounds__(256, SKF_ATTN_BWD_WAVES) void attn_bwd_kernel(AttnP
     for (int o = 32; o > 0; o >>= 1) lv = max(lv, __shfl_xor(lv, o, 64));
     if (lane == 0) last_valid[wave] = lv;
   }
-  for (int row = tid; row < QR; row += 256) {
+  for (int row = tid; row < nqt * 16; row += 256) {
     float2 st = make_float2(0.f, 0.f);
     if (row < p.Lq) st = reinterpret_cast<const float2*>(p.stats)[(size_t)bh * p.Lq + row];
     Mx[row] = st.x; Ri[row] = st.y;
   }
+  // dQ of the dead query tiles: zeros (their tiles are never visited below)
+  for (int e = nqt * 16 * DH + tid; e < p.Lq * DH; e += 256) p.dQ[(size_t)(b * p.Lq + e / DH) * p.lddq + h * DH + e % DH] = 0.f;
   __syncthreads();
   SKF_STAMP();   // staging done
 
@@ -613,8 +617,17 @@ extern "C" int skf_attention_bwd(const float* Q, int ldq, const float* K, int ld
                                  const float* O, int ldo, const float* dO, int lddo, const float* stats,
                                  const unsigned char* key_mask, int key_mask_ld, int causal, int B, int H, int Lq, int Lk,
                                  int dh, float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv, int precision, skf_stream_t stream) {
+  return skf_attention_bwd_rows(Q, ldq, K, ldk, V, ldv, O, ldo, dO, lddo, stats, key_mask, key_mask_ld, causal, B, H, Lq, Lk, dh, dQ, lddq,
+                                dK, lddk, dV, lddv, precision, nullptr, stream);
+}
 
+extern "C" int skf_attention_bwd_rows(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
+                                      const float* O, int ldo, const float* dO, int lddo, const float* stats,
+                                      const unsigned char* key_mask, int key_mask_ld, int causal, int B, int H, int Lq, int Lk,
+                                      int dh, float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv, int precision,
+                                      const int* q_live_len, skf_stream_t stream) {
   AttnParams p{};
+  p.q_live = q_live_len;
   p.Q = Q; p.K = K; p.V = V; p.O = const_cast<float*>(O); p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
   p.key_mask = key_mask; p.key_mask_ld = key_mask_ld; p.causal = causal; p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk;
   p.stats = const_cast<float*>(stats);
@@ -628,8 +641,13 @@ extern "C" int skf_attention_bwd(const float* Q, int ldq, const float* K, int ld
   SKF_CHECK_ARG((lddo & 3) == 0 && (lddq & 3) == 0 && (lddk & 3) == 0 && (lddv & 3) == 0, "row strides must be multiples of 4");
   // head size 16 / 32 in the split arithmetic modes: the two-pass kernel on the bf16 matrix cores (skf_attention_bwd2.hip);
   // SKF_PREC_F32 keeps the fp32-MFMA kernel below (SKF_ATTN_BWD2=0 forces it)
-  static const bool bwd2_off = getenv("SKF_ATTN_BWD2") && getenv("SKF_ATTN_BWD2")[0] == '0';
-  if ((dh == 16 || (dh == 32 && Lk <= 256 && Lq <= 256)) && precision != SKF_PREC_F32 && !bwd2_off && Lk <= 512 && Lq <= 512)
+  // Head size 16: only the causal (decoder self-attention) calls take it - measured at the cfg-2 shape, the one-pass kernel
+  // below is faster without a look-ahead mask (encoder self 89 vs 95 us; cross 101 vs 124 us with every dO row live, and
+  // with the dead query tiles left out by q_live it also wins on padded batches); SKF_ATTN_BWD2=1 forces the two-pass kernel.
+  static const char* bwd2_env = getenv("SKF_ATTN_BWD2");
+  const bool bwd2_off = bwd2_env && bwd2_env[0] == '0', bwd2_all = bwd2_env && bwd2_env[0] == '1';
+  const bool bwd2_shape = (dh == 16 && (causal || bwd2_all)) || (dh == 32 && Lk <= 256 && Lq <= 256);
+  if (bwd2_shape && precision != SKF_PREC_F32 && !bwd2_off && Lk <= 512 && Lq <= 512)
     return skf_attention_bwd2_launch(p, dh, (hipStream_t)stream);
   const size_t smem = bwd_smem(dh, Lq);
   SKF_CHECK_ARG(smem <= 160 * 1024, "Q/dO/dQ of one head do not fit in LDS");

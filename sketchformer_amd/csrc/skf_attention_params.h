@@ -17,6 +17,8 @@ struct AttnParams {
   const float* dO; int lddo;
   float* dQ; float* dK; float* dV;
   int lddq, lddk, lddv;
+  const int* q_live;              // optional (B): query rows >= q_live[b] have dO == 0 exactly (skf_target_live_len); one-pass
+                                  // backward: their tiles are neither staged nor visited, dQ is stored as zeros
 };
 
 // two-pass backward on the bf16 matrix cores with exactly split fp32 operands (head size 16 or 32); returns SKF_OK after launching

@@ -893,9 +893,10 @@ int run_backward(SkfModel* M, hipStream_t s) {
     const float* kv2 = M->at<float>(a.kv2);
     SKF_TRY(before_write(M, dq2, s));
     SKF_TRY(before_write(M, dkv2, s));
-    SKF_TRY(skf_attention_bwd(M->at<float>(a.q2), d, kv2, 2 * d, kv2 + d, 2 * d, M->at<float>(a.o2), d, dO, d,
-                              M->at<float>(a.astats2), cross_mask, Le, 0, B, H, Ld, Le, dh, dq2, d, dkv2, 2 * d,
-                              dkv2 + d, 2 * d, M->cfg.gemm_precision, s));
+    const int* qlive = M->live16 ? M->at<int>(P.live_len) : nullptr;      // decoder query rows behind it have dO == 0
+    SKF_TRY(skf_attention_bwd_rows(M->at<float>(a.q2), d, kv2, 2 * d, kv2 + d, 2 * d, M->at<float>(a.o2), d, dO, d,
+                                   M->at<float>(a.astats2), cross_mask, Le, 0, B, H, Ld, Le, dh, dq2, d, dkv2, 2 * d,
+                                   dkv2 + d, 2 * d, M->cfg.gemm_precision, qlive, s));
     SKF_TRY(dense_wgrad(M, w.mha2.q, M->at<float>(a.out1), d, dq2, d, Md, s));
     SKF_TRY(dense_dgrad(M, w.mha2.q, dq2, d, Md, G, d, 1, nullptr, 0, s));
     SKF_TRY(dense_wgrad(M, w.mha2.kv, pre, L.E, dkv2, 2 * d, Me, s));
@@ -910,9 +911,9 @@ int run_backward(SkfModel* M, hipStream_t s) {
     SKF_TRY(dense_dgrad(M, w.mha1.o, dy1, d, Md, dO, d, 0, nullptr, 0, s));
     const float* qkv = M->at<float>(a.qkv);
     SKF_TRY(before_write(M, dqkv, s));
-    SKF_TRY(skf_attention_bwd(qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, M->at<float>(a.o1), d, dO, d,
-                              M->at<float>(a.astats1), dmask, Ld, 1, B, H, Ld, Ld, dh, dqkv, 3 * d, dqkv + d, 3 * d,
-                              dqkv + 2 * d, 3 * d, M->cfg.gemm_precision, s));
+    SKF_TRY(skf_attention_bwd_rows(qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, M->at<float>(a.o1), d, dO, d,
+                                   M->at<float>(a.astats1), dmask, Ld, 1, B, H, Ld, Ld, dh, dqkv, 3 * d, dqkv + d, 3 * d,
+                                   dqkv + 2 * d, 3 * d, M->cfg.gemm_precision, qlive, s));
     SKF_TRY(dense_wgrad(M, w.mha1.qkv, M->at<float>(a.x_in), d, dqkv, 3 * d, Md, s));
     SKF_TRY(dense_dgrad(M, w.mha1.qkv, dqkv, 3 * d, Md, G2, d, 1, nullptr, 0, s));
     float* t = G; G = G2; G2 = t;

@@ -143,16 +143,17 @@ def attention_decode(q, k, v, num_heads, n_keys=None, key_mask=None, key_limit=N
     return o
 
 
-def attention_bwd(q, k, v, o, do, stats, num_heads, key_mask=None, causal=False, precision=None):
+def attention_bwd(q, k, v, o, do, stats, num_heads, key_mask=None, causal=False, precision=None, q_live_len=None):
+    """q_live_len: optional int32 (B,) - query rows at or behind it have do == 0 exactly (``target_live_len``)."""
     B, Lq, d = q.shape
     Lk = k.shape[1]
-    dq = torch.empty(B, Lq, d, dtype=torch.float32, device=q.device)
+    dq = torch.full((B, Lq, d), float("nan"), dtype=torch.float32, device=q.device)
     dk = torch.empty(B, Lk, d, dtype=torch.float32, device=q.device)
     dv = torch.empty(B, Lk, d, dtype=torch.float32, device=q.device)
-    _lib.call("skf_attention_bwd", _p(q), q.stride(1), _p(k), k.stride(1), _p(v), v.stride(1), _p(o), o.stride(1),
+    _lib.call("skf_attention_bwd_rows", _p(q), q.stride(1), _p(k), k.stride(1), _p(v), v.stride(1), _p(o), o.stride(1),
               _p(do), do.stride(1), _p(stats), _p(key_mask), key_mask.stride(0) if key_mask is not None else 0,
               int(causal), B, num_heads, Lq, Lk, d // num_heads, _p(dq), dq.stride(1), _p(dk), dk.stride(1),
-              _p(dv), dv.stride(1), _prec(precision), _stream())
+              _p(dv), dv.stride(1), _prec(precision), _p(q_live_len), _stream())
     return dq, dk, dv
 
 

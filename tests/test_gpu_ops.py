@@ -397,6 +397,25 @@ def test_attention_strided_qkv(ops):
 
 
 # ------------------------------------------------------------------ embedding / layernorm / dropout
+@pytest.mark.parametrize("H,causal,mode", [(8, False, None), (8, True, None), (8, False, 0), (4, False, None)])
+def test_attention_bwd_live_query_counts_is_exact(ops, H, causal, mode):
+    """dO is zero behind each sample's live length (decoder rows of a padded batch): with the counts the one-pass kernel leaves
+    the dead query tiles out (not staged, not visited, dQ stored as zeros) - every output equals the call without them
+    (head size 16 non-causal and the fp32-MFMA mode take the one-pass kernel, the causal case the two-pass one)."""
+    B, Lq, Lk, d = 7, 199, 200, 128
+    rng = np.random.RandomState(3 + H)
+    q, k, v = (_dev(rng.randn(B, L, d)) for L in (Lq, Lk if not causal else Lq, Lk if not causal else Lq))
+    lens = np.array([0, 199, 1, 15, 16, 17, 120], np.int32)
+    do = _dev(rng.randn(B, Lq, d) * (np.arange(Lq)[None, :, None] < lens[:, None, None]))
+    o, st = ops.attention_fwd(q, k, v, H, causal=causal, precision=mode)
+    ll = torch.as_tensor(lens).cuda()
+    a = ops.attention_bwd(q, k, v, o, do, st, H, causal=causal, precision=mode)
+    b = ops.attention_bwd(q, k, v, o, do, st, H, causal=causal, precision=mode, q_live_len=ll)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert float(b[0][0].abs().max()) == 0.0
+
+
 def test_embed_fwd_bwd_with_dropout(ops):
     from sketchformer_amd import engine
     B, L, V, d, rate, site = 5, 33, 52, 128, 0.1, 3
