@@ -143,19 +143,42 @@ class BaseModel(object, metaclass=ABCMeta):
                 self.quick_metrics[name].append_to_history(value)
 
     def status_report(self, end_of_epoch=False):
+        """core/models.py:203-225: builds and returns the log string on EVERY call.  The device metrics are only read back
+        (flush_quick_metrics: collective under data parallelism, every rank gets here at the same step) on the steps that
+        print; on the others the string carries the last resolved values.  At notify_every / end of epoch the slow metrics are
+        computed, plotted and appended like the reference does (rank 0; SKF_TRAIN_SLOW_METRICS=0 skips them)."""
         cur_iter = self.current_step % self.batches_per_epoch
-        if not ((cur_iter % self.hps['log_every'] == 0) or (cur_iter % self.hps['notify_every'] == 0) or end_of_epoch):
-            return None                       # nothing is printed: the metrics stay on the device
-        self.flush_quick_metrics()            # (collective under data parallelism: every rank gets here at the same step)
+        printing = (cur_iter % self.hps['log_every'] == 0) or (cur_iter % self.hps['notify_every'] == 0) or end_of_epoch
+        if printing:
+            self.flush_quick_metrics()
         log = "Epoch {} Batch {}/{}".format(self.epoch, cur_iter, self.batches_per_epoch)
         for k, m in self.quick_metrics.items():
             log = "{}|{}={:4.4f}".format(log, k, m.last_value)
-        if self.rank == 0:
+        if ((cur_iter != 0 and cur_iter % self.hps['notify_every'] == 0) or end_of_epoch) and self.rank == 0 \
+                and os.environ.get("SKF_TRAIN_SLOW_METRICS", "1") != "0":
+            log = self.prepare_plot_send_slow_metrics(log)
+        if printing and self.rank == 0:
             print(log)
         return log
 
+    def prepare_plot_send_slow_metrics(self, msg):
+        """core/models.py:227-235 without the Slack notifier: compute every slow metric, one PNG, their values in the log.
+        A failing metric is reported and skipped (the reference's metric workers swallow exceptions, core/metrics.py:127-133)."""
+        try:
+            self.compute_all_metrics()
+            for metric in self.slow_metrics.values():
+                if metric is not None:
+                    metric.wait()
+            self.plot_metrics(self.slow_metrics, "plots_step{}.png".format(self.current_step))
+            for sm, metric in self.slow_metrics.items():
+                if metric is not None:
+                    msg = "{}, {}={}".format(msg, sm, metric.last_value_repr)
+        except Exception as e:      # noqa: BLE001
+            print("[slow metrics] skipped: {}: {}".format(type(e).__name__, e))
+        return msg
+
     # ---- slow metrics (core/models.py:218-296 of the reference): computed on demand (evaluate-metrics.py /
-    # compute_all_metrics); the training loop itself never computes them here; plotting = one PNG per call, no Slack
+    # compute_all_metrics) and by the training loop at notify_every / end of epoch; plotting = one PNG per call, no Slack
     def build_slow_metrics(self, names=None):
         from .. import metrics
         names = list(self.slow_metrics) if names is None else names
@@ -234,6 +257,9 @@ class BaseModel(object, metaclass=ABCMeta):
         self._safety = sorted(glob.glob(os.path.join(self.wgt_out_dir, 'ckpt-*.pt')),
                               key=lambda p: int(os.path.basename(p)[5:-3]))
 
+    def prepare_metrics_for_save(self):
+        """Hook for models whose running metrics live per rank (data parallelism): called on every rank before rank 0 writes."""
+
     @abstractmethod
     def state_dict(self):
         pass
@@ -247,6 +273,10 @@ class BaseModel(object, metaclass=ABCMeta):
     # ahead into the next collective while the file is written, and every rank restores from the same file.
     def _save(self, path):
         import torch
+        # every rank: queued metric snapshots enter the histories, and (data parallel) the per-rank running-metric accumulators
+        # are summed into rank 0's copy so that the file holds the history of ALL ranks (prepare_metrics_for_save)
+        self.flush_quick_metrics()
+        self.prepare_metrics_for_save()
         self._barrier()
         if self.rank == 0:
             state = self.state_dict()

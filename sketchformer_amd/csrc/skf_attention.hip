@@ -601,8 +601,10 @@ extern "C" int skf_attention_fwd(const float* Q, int ldq, const float* K, int ld
     hipLaunchKernelGGL(kfn, grid, block, smem, st, p);          \
   }
   static const char* const tags[3] = {"attn_fwd<dh16>", "attn_fwd<dh32>", "attn_fwd<dh64>"};
+  const double visited = skf_prof_attention_fraction(key_mask, key_mask_ld, causal, B, Lq, Lk, nullptr, 16, 16);
   SkfProfScope ps(st, tags[dh == 16 ? 0 : dh == 32 ? 1 : 2], 4.0 * B * H * (double)Lq * Lk * dh,
                   4.0 * B * H * dh * (2.0 * Lq + 2.0 * Lk));
+  ps.done(4.0 * B * H * (double)Lq * Lk * dh * visited, 4.0 * B * H * dh * (2.0 * Lq + 2.0 * Lk));
   const bool small = Lk <= 208;
   if (dh == 16 && split) { if (small) SKF_ATTN_FWD(16, 13, true) else SKF_ATTN_FWD(16, 32, true) }
   else if (dh == 16) { if (small) SKF_ATTN_FWD(16, 13, false) else SKF_ATTN_FWD(16, 32, false) }
@@ -666,8 +668,10 @@ extern "C" int skf_attention_bwd_rows(const float* Q, int ldq, const float* K, i
     }                                                           \
   }
   static const char* const tags[3] = {"attn_bwd<dh16>", "attn_bwd<dh32>", "attn_bwd<dh64>"};
+  const double visited = skf_prof_attention_fraction(key_mask, key_mask_ld, causal, B, Lq, Lk, q_live_len, 16, 16);
   SkfProfScope ps(st, tags[dh == 16 ? 0 : dh == 32 ? 1 : 2], 8.0 * B * H * (double)Lq * Lk * dh,
                   4.0 * B * H * dh * (4.0 * Lq + 4.0 * Lk));
+  ps.done(8.0 * B * H * (double)Lq * Lk * dh * visited, 4.0 * B * H * dh * (4.0 * Lq + 4.0 * Lk));
   if (dh == 16) SKF_ATTN_BWD(16) else if (dh == 32) SKF_ATTN_BWD(32) else SKF_ATTN_BWD(64)
 #undef SKF_ATTN_BWD
   SKF_LAUNCH_CHECK();

@@ -370,8 +370,12 @@ static int bwd2_launch(const AttnParams& p, hipStream_t st) {
     SKF_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr[p.causal ? 1 : 0] = true;
   }
+  // (query tiles whose dO rows are all zero are skipped as well; with the live lengths of the train step those are the tiles
+  //  behind q_live - without the lengths the figure below only knows the masks)
+  const double visited = skf_prof_attention_fraction(p.key_mask, p.key_mask_ld, p.causal, p.B, p.Lq, p.Lk, p.q_live, 16, 16);
   SkfProfScope ps(st, NC == 1 ? "attn_bwd2<dh16,bf16x6>" : "attn_bwd2<dh32,bf16x6>", 8.0 * p.B * p.H * (double)p.Lq * p.Lk * 16 * NC,
                   4.0 * p.B * p.H * 16 * NC * (4.0 * p.Lq + 4.0 * p.Lk));
+  ps.done(8.0 * p.B * p.H * (double)p.Lq * p.Lk * 16 * NC * visited, 4.0 * p.B * p.H * 16 * NC * (4.0 * p.Lq + 4.0 * p.Lk));
   if (p.causal) hipLaunchKernelGGL((attn_bwd2_kernel<NC, true>), dim3(p.B * p.H), dim3(256), smem, st, p);
   else hipLaunchKernelGGL((attn_bwd2_kernel<NC, false>), dim3(p.B * p.H), dim3(256), smem, st, p);
   SKF_LAUNCH_CHECK();

@@ -506,7 +506,9 @@ extern "C" int skf_attention_bf16_fwd(const void* Q, int ldq, const void* K, int
   SKF_CHECK_ARG((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) == 0 && ((uintptr_t)O & 7) == 0, "operands must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   if ((rc = set_smem(attn_bf16_q_kernel<0>, Q_SMEM))) return rc;
+  const double visited = skf_prof_attention_fraction(key_mask, key_mask_ld, causal, B, Lq, Lk, nullptr, 128, 64);
   SkfProfScope ps(st, "attn_bf16_fwd<dh64>", 4.0 * B * H * (double)Lq * Lk * dh, 2.0 * B * H * dh * (2.0 * Lq + 2.0 * Lk));
+  ps.done(4.0 * B * H * (double)Lq * Lk * dh * visited, 2.0 * B * H * dh * (2.0 * Lq + 2.0 * Lk));
   hipLaunchKernelGGL(attn_bf16_q_kernel<0>, dim3(B * H * ((Lq + 127) / 128)), dim3(256), Q_SMEM, st, p);
   SKF_LAUNCH_CHECK();
   return SKF_OK;
@@ -546,13 +548,17 @@ extern "C" int skf_attention_bf16_bwd_rows(const void* Q, int ldq, const void* K
   hipStream_t st = (hipStream_t)stream;
   if ((rc = set_smem(attn_bf16_q_kernel<1>, Q_SMEM))) return rc;
   if ((rc = set_smem(attn_bf16_kv_kernel, KV_SMEM))) return rc;
+  const double vis_q = skf_prof_attention_fraction(key_mask, key_mask_ld, causal, B, Lq, Lk, q_live_len, 128, 64);
+  const double vis_kv = skf_prof_attention_fraction(key_mask, key_mask_ld, causal, B, Lq, Lk, q_live_len, 64, 128);
   {
     SkfProfScope ps(st, "attn_bf16_bwd_dq<dh64>", 6.0 * B * H * (double)Lq * Lk * dh, 2.0 * B * H * dh * (4.0 * Lq + 2.0 * Lk));
+    ps.done(6.0 * B * H * (double)Lq * Lk * dh * vis_q, 2.0 * B * H * dh * (4.0 * Lq + 2.0 * Lk));
     hipLaunchKernelGGL(attn_bf16_q_kernel<1>, dim3(B * H * ((Lq + 127) / 128)), dim3(256), Q_SMEM, st, p);
     SKF_LAUNCH_CHECK();
   }
   {
     SkfProfScope ps(st, "attn_bf16_bwd_dkv<dh64>", 8.0 * B * H * (double)Lq * Lk * dh, 2.0 * B * H * dh * (2.0 * Lq + 4.0 * Lk));
+    ps.done(8.0 * B * H * (double)Lq * Lk * dh * vis_kv, 2.0 * B * H * dh * (2.0 * Lq + 4.0 * Lk));
     hipLaunchKernelGGL(attn_bf16_kv_kernel, dim3(B * H * ((Lk + 127) / 128)), dim3(256), KV_SMEM, st, p);
     SKF_LAUNCH_CHECK();
   }

@@ -676,7 +676,10 @@ extern "C" int skf_gemm_bf16_rows(int M, int N, int K, const void* A, int lda, c
   p.row_blocks = row_list; p.zero_dead = zero_dead;
   p.wide_c = (ldc & 7) == 0 && ((uintptr_t)C & 15) == 0 && (!relu_src || ((ld_relu & 7) == 0 && ((uintptr_t)relu_src & 15) == 0));
   const size_t smem = big ? 8 * 128 * 144 : 65536;      // the epilogue's wave-private images (144-byte rows) exceed the 128 KB of tile buffers
-  SkfProfScope ps(st, "gemm_bf16_nt", 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * N * (accumulate ? 2 : 1)));
+  const double live = skf_prof_list_fraction(row_list);      // live rows of A that are loaded and multiplied (C is written in full)
+  const double a_c = (double)M * K + (double)M * N * ((accumulate ? 1 : 0) + (relu_src ? 1 : 0));
+  SkfProfScope ps(st, "gemm_bf16_nt", 2.0 * M * N * K, 2.0 * (a_c + (double)N * K + (double)M * N));
+  ps.done(2.0 * M * N * K * live, 2.0 * (a_c * live + (double)N * K + (double)M * N));
   int rc;
 #define SKF_NT_GO(EX, DM, BG, TH)                                                                                            \
   {                                                                                                                          \
@@ -740,8 +743,10 @@ extern "C" int skf_gemm_bf16_wgrad_partial_rows(int P, int Q, int R, const void*
   hipStream_t st = (hipStream_t)stream;
   const size_t smem = big ? 131072 : 65536;
   int rc;
-  SkfProfScope ps(st, "gemm_bf16_tn(wgrad)", 2.0 * P * Q * R, 2.0 * (double)R * (P + Q) + 4.0 * (double)splits * P * Q);
   p.row_blocks = big ? row_blocks_64 : nullptr;      // the 128 x 128 kernel contracts over every row
+  const double live = skf_prof_list_fraction(p.row_blocks);
+  SkfProfScope ps(st, "gemm_bf16_tn(wgrad)", 2.0 * P * Q * R, 2.0 * (double)R * (P + Q) + 4.0 * (double)splits * P * Q);
+  ps.done(2.0 * P * Q * R * live, 2.0 * (double)R * (P + Q) * live + 4.0 * (double)splits * P * Q);
   if (big) {
     if ((rc = set_smem(gemm_bf16_tn_big_kernel, smem))) return rc;
     hipLaunchKernelGGL(gemm_bf16_tn_big_kernel, dim3(p.tiles_p * p.tiles_q * splits), dim3(512), smem, st, p);

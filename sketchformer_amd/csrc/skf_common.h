@@ -43,9 +43,20 @@ void skf_set_error(const char* fmt, ...);
 struct SkfProfScope {
   SkfProfScope(hipStream_t st, const char* tag, double flops, double bytes);
   ~SkfProfScope();
+  // Work the launch actually performs when it walks a live-row / live-tile list or skips masked tiles (flops, bytes are the
+  // dense figures).  Call only when active(): the fractions below synchronise the device and read the lists back.
+  void done(double flops_done, double bytes_done);
+  bool active() const { return idx_ >= 0; }
   hipStream_t st_;
   int idx_;
 };
+// Profiling only (both synchronise the device): live share of a {n_live, n_total, ...} list (skf_row_blocks.hip), and the
+// share of (query tile, key tile) pairs an attention launch visits: per sample the query tiles below q_live[b] (all when
+// null), the key tiles up to the last un-padded key (all when the mask is null) and, with a look-ahead mask that may be
+// skipped (key 0 visible), only key tiles kt <= qt.
+double skf_prof_list_fraction(const int* list);
+double skf_prof_attention_fraction(const unsigned char* key_mask, int mask_ld, int causal, int B, int Lq, int Lk,
+                                   const int* q_live, int qtile, int ktile);
 
 static inline int skf_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

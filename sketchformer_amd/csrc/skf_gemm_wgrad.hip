@@ -338,7 +338,9 @@ int skf_gemm_wgrad_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, i
       SKF_HIP(hipFuncSetAttribute((const void*)wgrad_x_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_x));
       attr_x = true;
     }
+    const double live = skf_prof_list_fraction(q.row_blocks);      // contraction over the live 32-row blocks only
     SkfProfScope ps(st, prec == 3 ? "wgrad<64x64,bf16x3>" : "wgrad<64x64,bf16x6>", 2.0 * p.M * p.N * p.K, 4.0 * (double)p.K * (p.M + p.N));
+    ps.done(2.0 * p.M * p.N * p.K * live, 4.0 * (double)p.K * (p.M + p.N) * live);
     const dim3 grid(nwg), block(256);
     if (prec == 3) hipLaunchKernelGGL((wgrad_x_kernel<2, 4>), grid, block, smem_x, st, q);
     else hipLaunchKernelGGL((wgrad_x_kernel<3, 4>), grid, block, smem_x, st, q);
@@ -362,7 +364,7 @@ int skf_gemm_wgrad_group_dispatch(const GemmParams* ps, const int* splits, int n
   grp.n = n;
   int cursor = 0;
   const int prec = ps[0].precision;
-  double flops = 0.0, bytes = 0.0;
+  double flops = 0.0, bytes = 0.0, flops_done = 0.0, bytes_done = 0.0;
   for (int g = 0; g < n; ++g) {
     const GemmParams& p = ps[g];
     if ((p.M & 3) || (p.N & 3) || (p.lda & 3) || (p.ldb & 3) || ((uintptr_t)p.A & 15) || ((uintptr_t)p.B & 15)) return SKF_OK;
@@ -376,6 +378,8 @@ int skf_gemm_wgrad_group_dispatch(const GemmParams* ps, const int* splits, int n
     grp.nblocks[g] = q.tiles_m * q.tiles_n * splits[g];
     cursor += (grp.nblocks[g] + 7) & ~7;
     flops += 2.0 * p.M * p.N * p.K; bytes += 4.0 * (double)p.K * (p.M + p.N);
+    const double live = skf_prof_list_fraction(q.row_blocks);
+    flops_done += 2.0 * p.M * p.N * p.K * live; bytes_done += 4.0 * (double)p.K * (p.M + p.N) * live;
   }
   grp.start[n] = cursor;
   *handled = 1;
@@ -387,6 +391,7 @@ int skf_gemm_wgrad_group_dispatch(const GemmParams* ps, const int* splits, int n
     attr = true;
   }
   SkfProfScope ps_(st, prec == 3 ? "wgrad_group<64x64,bf16x3>" : "wgrad_group<64x64,bf16x6>", flops, bytes);
+  ps_.done(flops_done, bytes_done);
   if (prec == 3) hipLaunchKernelGGL((wgrad_x_group_kernel<2, 4>), dim3(cursor), dim3(256), smem_x, st, grp);
   else hipLaunchKernelGGL((wgrad_x_group_kernel<3, 4>), dim3(cursor), dim3(256), smem_x, st, grp);
   SKF_LAUNCH_CHECK();

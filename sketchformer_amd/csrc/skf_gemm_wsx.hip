@@ -400,11 +400,14 @@ int launch_wsx(const GemmParams& p, int b_kc, hipStream_t st) {
   const size_t smem = (size_t)2 * P * TR * (2 * K + 32);
   dim3 grid(groups * workers), block(256);
   static const std::string tag = "gemm_wsx<K" + std::to_string(K) + ",CW" + std::to_string(CW) + ",bf16x" + std::to_string(P * (P + 1) / 2) + ">";
-  SkfProfScope ps(st, tag.c_str(), 2.0 * p.M * p.N * p.K,
-                  4.0 * ((double)p.M * p.K + (double)p.K * p.N + (double)p.M * p.N * (p.accumulate ? 2 : 1)));
   const bool extra = p.relu_src || p.accumulate;
   GemmParams q = p;
   if (q.row_block_rows != TR) q.row_blocks = nullptr;       // the list's blocks must be this kernel's tiles
+  // profiling: the dense figures, and the work of the live tiles only (A rows read / multiplied; every C row is still written)
+  const double live = skf_prof_list_fraction(q.row_blocks);
+  const double a_c = (double)p.M * p.K + (double)p.M * p.N * ((p.accumulate ? 1 : 0) + (p.relu_src ? 1 : 0));
+  SkfProfScope ps(st, tag.c_str(), 2.0 * p.M * p.N * p.K, 4.0 * (a_c + (double)p.K * p.N + (double)p.M * p.N));
+  ps.done(2.0 * p.M * p.N * p.K * live, 4.0 * (a_c * live + (double)p.K * p.N + (double)p.M * p.N));
   // K >= 384 (N = 128): the two column groups of a worker read the same A tiles - XCD-contiguous ids keep the second read
   // in the L2 (PMC: 132 -> ~80 MB per launch); with one or two groups of short tiles (K <= 256) the remap only costs
   // K = 128 with three or more column groups (N = 384 / 512 / 1004): round-robin ids put the group-mates of a worker on

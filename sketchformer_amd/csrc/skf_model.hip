@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 #include <map>
+#include <algorithm>
 #include "skf_common.h"
 #include "skf_decode_fused.h"
 
@@ -38,7 +39,7 @@ extern "C" int skf_device_info(char* name_host, size_t name_len, int* n_devices_
 
 // ------------------------------------------------------------------ launch profiler
 namespace {
-struct ProfRec { const char* tag; double flops, bytes; hipEvent_t e0, e1; };
+struct ProfRec { const char* tag; double flops, bytes, flops_done, bytes_done; hipEvent_t e0, e1; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 }  // namespace
@@ -47,7 +48,7 @@ SkfProfScope::SkfProfScope(hipStream_t st, const char* tag, double flops, double
   if (!g_prof_on) return;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return;
-  ProfRec r{tag, flops, bytes, nullptr, nullptr};
+  ProfRec r{tag, flops, bytes, flops, bytes, nullptr, nullptr};
   if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
   (void)hipEventRecord(r.e0, st);
   g_prof.push_back(r);
@@ -55,6 +56,52 @@ SkfProfScope::SkfProfScope(hipStream_t st, const char* tag, double flops, double
 }
 SkfProfScope::~SkfProfScope() {
   if (idx_ >= 0) (void)hipEventRecord(g_prof[idx_].e1, st_);
+}
+void SkfProfScope::done(double flops_done, double bytes_done) {
+  if (idx_ < 0) return;
+  g_prof[idx_].flops_done = flops_done;
+  g_prof[idx_].bytes_done = bytes_done;
+}
+double skf_prof_list_fraction(const int* list) {
+  if (!list || !g_prof_on) return 1.0;
+  int h[2] = {0, 0};
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h, list, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess || h[1] <= 0) return 1.0;
+  return (double)h[0] / h[1];
+}
+double skf_prof_attention_fraction(const unsigned char* key_mask, int mask_ld, int causal, int B, int Lq, int Lk,
+                                   const int* q_live, int qtile, int ktile) {
+  if (!g_prof_on || (!key_mask && !q_live && !causal)) return 1.0;
+  if (hipDeviceSynchronize() != hipSuccess) return 1.0;
+  std::vector<unsigned char> km;
+  std::vector<int> ql;
+  if (key_mask) {
+    km.resize((size_t)B * mask_ld);
+    if (hipMemcpy(km.data(), key_mask, km.size(), hipMemcpyDeviceToHost) != hipSuccess) return 1.0;
+  }
+  if (q_live) {
+    ql.resize(B);
+    if (hipMemcpy(ql.data(), q_live, (size_t)B * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return 1.0;
+  }
+  const int nqt_all = (Lq + qtile - 1) / qtile, nkt_all = (Lk + ktile - 1) / ktile;
+  double visited = 0.0;
+  for (int b = 0; b < B; ++b) {
+    int nqt = nqt_all, nkt = nkt_all;
+    bool can_skip = causal != 0;
+    if (q_live) nqt = std::min(nqt_all, (std::max(ql[b], 0) + qtile - 1) / qtile);
+    if (key_mask) {
+      const unsigned char* m = km.data() + (size_t)b * mask_ld;
+      int lastk = -1;
+      for (int k = 0; k < Lk; ++k) if (!m[k]) lastk = k;
+      can_skip = can_skip && !m[0];
+      if (lastk >= 0 && (!causal || can_skip)) nkt = lastk / ktile + 1;
+    }
+    for (int qt = 0; qt < nqt; ++qt) {
+      // keys this query tile can see under the look-ahead rule, in key tiles
+      const int lim = can_skip ? std::min(nkt, ((qt + 1) * qtile - 1) / ktile + 1) : nkt;
+      visited += lim;
+    }
+  }
+  return visited / ((double)B * nqt_all * nkt_all);
 }
 
 extern "C" int skf_profiler_enable(int on) {
@@ -66,7 +113,7 @@ extern "C" int skf_profiler_enable(int on) {
 
 extern "C" int skf_profiler_report(char* buf_host, size_t len) {
   SKF_CHECK_ARG(buf_host && len > 2, "bad buffer");
-  struct Agg { int count = 0; double ms = 0, flops = 0, bytes = 0; };
+  struct Agg { int count = 0; double ms = 0, flops = 0, bytes = 0, flops_done = 0, bytes_done = 0; };
   std::vector<std::pair<std::string, Agg>> order;
   std::map<std::string, size_t> index;
   for (auto& r : g_prof) {
@@ -76,14 +123,14 @@ extern "C" int skf_profiler_report(char* buf_host, size_t len) {
     auto it = index.find(r.tag);
     if (it == index.end()) { index[r.tag] = order.size(); order.push_back({r.tag, Agg()}); it = index.find(r.tag); }
     Agg& a = order[it->second].second;
-    a.count += 1; a.ms += ms; a.flops += r.flops; a.bytes += r.bytes;
+    a.count += 1; a.ms += ms; a.flops += r.flops; a.bytes += r.bytes; a.flops_done += r.flops_done; a.bytes_done += r.bytes_done;
   }
   std::string out = "[";
   char line[384];
   for (size_t i = 0; i < order.size(); ++i) {
     const Agg& a = order[i].second;
-    snprintf(line, sizeof(line), "%s{\"tag\":\"%s\",\"count\":%d,\"ms\":%.6f,\"flops\":%.6e,\"bytes\":%.6e}", i ? "," : "",
-             order[i].first.c_str(), a.count, a.ms, a.flops, a.bytes);
+    snprintf(line, sizeof(line), "%s{\"tag\":\"%s\",\"count\":%d,\"ms\":%.6f,\"flops\":%.6e,\"bytes\":%.6e,\"flops_done\":%.6e,\"bytes_done\":%.6e}",
+             i ? "," : "", order[i].first.c_str(), a.count, a.ms, a.flops, a.bytes, a.flops_done, a.bytes_done);
     out += line;
   }
   out += "]";
@@ -837,6 +884,7 @@ int build_row_lists(SkfModel* M, hipStream_t s) {
 }
 
 int run_backward(SkfModel* M, hipStream_t s) {
+  M->live16 = M->live32 = nullptr; M->live_rows = 0;      // (set below for the decoder layers only; see reset_live_rows)
   M->next_event = 0;
   M->pending_readers.clear();
   M->side_used = false;
@@ -1212,9 +1260,15 @@ int prologue(SkfModel* M, hipStream_t s) {
                            c.seed, s);
 }
 
+// The live-row state is host-side and only valid while ONE backward is being issued: an early (error) return from a backward
+// must not leave it set for the next call on the model, whose batch has other live rows.
+inline void reset_live_rows(SkfModel* M) { M->live16 = M->live32 = nullptr; M->live_rows = 0; }
+
 int stage_inputs(SkfModel* M, const void* inp, const void* tar, int tar_ld, const long long* labels, hipStream_t s) {
   const SkfConfig& c = M->cfg;
   const Plan& P = M->plan;
+  reset_live_rows(M);
+  M->lists_built = false;
   SKF_CHECK_ARG(inp && tar, "null input");
   const size_t row = c.continuous ? (size_t)c.seq_len * 5 * sizeof(float) : (size_t)c.seq_len * 8;     // bytes per sample
   const size_t src_row = c.continuous ? (size_t)tar_ld * 5 * sizeof(float) : (size_t)tar_ld * 8;

@@ -127,8 +127,8 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* __restr
 //      Stability without a histogram per thread: wave w owns a contiguous range of rows and its own histogram [vocab] in
 //      LDS; an exclusive scan over the 16 waves gives each wave its base inside every id's segment, and inside a 64-row
 //      step the rank of a lane among the lanes with the same id comes from ballots (one per distinct id of the step).
-//      (vocab > kEmbOrderedVocab does not fit 16 histograms in LDS: the scatter falls back to an LDS-atomic cursor, whose
-//      order - and with it the summation order of ids with more than 64 positions - changes between runs.)
+//      (vocab > kEmbOrderedVocab does not fit 16 histograms in LDS: one count table, and a single wave walks all rows in order
+//      for the scatter - still stable.)
 //  (2) embed_bwd_sorted_kernel: one workgroup per chunk (a wave per 64 positions, summed through LDS in wave order) sums the
 //      dx rows of its positions (512-byte coalesced rows, dropout mask and sqrt(d) as in embed_bwd_kernel).  Single-chunk ids
 //      STORE the table row; the chunks of a split id (PAD, frequent tokens) leave partial rows in the workspace and whichever
@@ -137,22 +137,27 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* __restr
 constexpr int kEmbChunk = 256;   // positions per chunk = per workgroup of the gradient kernel (4 waves x 64)
 constexpr int kEmbOrderedVocab = 2032;   // 19 tables of vocab ints + the 8 KB of scan scratch must fit 160 KB of LDS
 constexpr int kEmbMaxD = 512;    // widest row the partial slab of the workspace is sized for
+constexpr int kEmbCursorBits = 25;   // ordered scatter: cursor bits of a (wave, id) word; the other 7 hold the step's group count (<= 64)
 struct EmbChunk { int id, first, count, n, j, pad; };   // n chunks of this id, this one is the j-th
 
-template <bool ORDERED>
+// NWH = number of per-wave histograms: 16 (vocab <= kEmbOrderedVocab: every wave scatters its own contiguous range of rows) or
+// 1 (larger vocabularies, e.g. the grid tokenizer's 10004 ids: 16 histograms do not fit in LDS, so all waves count into one table
+// and ONE wave walks the rows in order for the scatter - still stable, i.e. run-to-run deterministic; the cursor table reuses
+// the count table once the chunk descriptors are written).
+template <int NWH>
 __global__ __launch_bounds__(1024) void embed_sort_kernel(const long long* __restrict__ tok, int tok_ld, int Lrows, int rows,
                                                           int vocab, int* __restrict__ hdr, EmbChunk* __restrict__ chunks,
                                                           int* __restrict__ order, int* __restrict__ done) {
   extern __shared__ int smem_i[];
-  int* cnt = smem_i;                     // [vocab]      positions per id -> later the write cursor of the id
+  int* cnt = smem_i;                     // [vocab]      positions per id (NWH == 1: later the cursor table of the scatter)
   int* pst = smem_i + vocab;             // [vocab]      first position of the id in order[]
   int* cst = smem_i + 2 * vocab;         // [vocab + 1]  first chunk of the id (exclusive scan; [vocab] = number of chunks)
-  int* hist = cst + vocab + 1;           // ORDERED: [16][vocab] positions per (wave, id) -> the wave's cursor inside the id's segment
+  int* hist = NWH == 1 ? cnt : cst + vocab + 1;   // NWH == 16: [16][vocab] positions per (wave, id) -> the wave's cursor inside the id's segment
   __shared__ int part_tok[1024], part_chk[1024];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int RW = ((rows + 15) / 16 + 63) & ~63;      // rows per wave (ORDERED), a multiple of the 64-row step
+  const int RW = ((rows + 15) / 16 + 63) & ~63;      // rows per wave, a multiple of the 64-row step
   for (int v = tid; v < vocab; v += 1024) { cnt[v] = 0; done[v] = 0; }
-  if (ORDERED) for (int e = tid; e < 16 * vocab; e += 1024) hist[e] = 0;
+  if (NWH == 16) for (int e = tid; e < 16 * vocab; e += 1024) hist[e] = 0;
   __syncthreads();
   // token of row r, or -1 (row past the end / id out of range).  The passes below request TB steps of tokens before using
   // the first: one at a time, every 64-row step was a memory round trip of its own (2 x 25 of them at the cfg-2 size)
@@ -163,28 +168,24 @@ __global__ __launch_bounds__(1024) void embed_sort_kernel(const long long* __res
     return (t >= 0 && t < vocab) ? (int)t : -1;
   };
   const int rend = min(rows, (wave + 1) * RW);
-  if (ORDERED) {
-    for (int r0 = wave * RW; r0 < rend; r0 += 64 * TB) {
-      int tk[TB];
+  int* my_hist = NWH == 16 ? hist + wave * vocab : cnt;
+  for (int r0 = wave * RW; r0 < rend; r0 += 64 * TB) {
+    int tk[TB];
 #pragma unroll
-      for (int u = 0; u < TB; ++u) { const int r = r0 + 64 * u + lane; tk[u] = r < rend ? token_of(r) : -1; }
+    for (int u = 0; u < TB; ++u) { const int r = r0 + 64 * u + lane; tk[u] = r < rend ? token_of(r) : -1; }
 #pragma unroll
-      for (int u = 0; u < TB; ++u)
-        if (tk[u] >= 0) atomicAdd(&hist[wave * vocab + tk[u]], 1);
-    }
-    __syncthreads();
+    for (int u = 0; u < TB; ++u)
+      if (tk[u] >= 0) atomicAdd(&my_hist[tk[u]], 1);
+  }
+  __syncthreads();
+  if (NWH == 16) {
     for (int v = tid; v < vocab; v += 1024) {          // counts per id; hist -> exclusive prefix over the waves
       int run = 0;
       for (int w = 0; w < 16; ++w) { const int c = hist[w * vocab + v]; hist[w * vocab + v] = run; run += c; }
       cnt[v] = run;
     }
-  } else {
-    for (int r = tid; r < rows; r += 1024) {
-      const long long tk = tok[(size_t)(r / Lrows) * tok_ld + (r % Lrows)];
-      if (tk >= 0 && tk < vocab) atomicAdd(&cnt[(int)tk], 1);
-    }
+    __syncthreads();
   }
-  __syncthreads();
   // exclusive scans over ids: positions and chunks.  Thread t owns ids [t*per, (t+1)*per)
   const int per = (vocab + 1023) / 1024;
   int st = 0, sc = 0;
@@ -220,23 +221,29 @@ __global__ __launch_bounds__(1024) void embed_sort_kernel(const long long* __res
     chunks[ci] = EmbChunk{v, pst[v] + j * kEmbChunk, left < kEmbChunk ? (left > 0 ? left : 0) : kEmbChunk, cst[v + 1] - cst[v], j, 0};
   }
   __syncthreads();
-  if (ORDERED) {
-    // stable scatter: wave w walks its rows in order; inside a 64-row step the lanes with equal ids are ranked by lane
-    for (int rb = wave * RW; rb < rend; rb += 64 * TB) {
-     int tkb[TB];
+  if (NWH == 1) {                                                   // the counts are no longer needed: cursors start at 0
+    for (int v = tid; v < vocab; v += 1024) cnt[v] = 0;
+    __syncthreads();
+  }
+  // stable scatter: a scattering wave walks its rows in order; inside a 64-row step the lanes with equal ids are ranked by lane
+  const int sbeg = NWH == 16 ? wave * RW : 0, send = NWH == 16 ? rend : (wave == 0 ? rows : 0);
+  for (int rb = sbeg; rb < send; rb += 64 * TB) {
+    int tkb[TB];
 #pragma unroll
-     for (int u = 0; u < TB; ++u) { const int rr = rb + 64 * u + lane; tkb[u] = rr < rend ? token_of(rr) : -1; }
+    for (int u = 0; u < TB; ++u) { const int rr = rb + 64 * u + lane; tkb[u] = rr < send ? token_of(rr) : -1; }
 #pragma unroll
-     for (int u = 0; u < TB; ++u) {
+    for (int u = 0; u < TB; ++u) {
       const int r = rb + 64 * u + lane;
       const int tk = tkb[u];
-      // Size of the lane's group (lanes of the step with the same id) from ONE LDS atomic on the high half of the cursor word
+      // Size of the lane's group (lanes of the step with the same id) from ONE LDS atomic on the high bits of the cursor word
       // (only the count is used, not the order in which the adds land); ids that occur once - most of them - are done.  The
       // others (PAD, repeats) get their rank among the equal lanes from ballots, one round per such id.
-      const int slot = wave * vocab + (tk >= 0 ? tk : 0);
-      if (tk >= 0) atomicAdd(&hist[slot], 1 << 16);
-      const int wv = tk >= 0 ? reinterpret_cast<volatile int*>(hist)[slot] : 0;       // LDS operations of a wave execute in order
-      const int cur = wv & 0xffff, grp = wv >> 16;
+      // word = cursor (low 25 bits: after the scan over the waves it is the offset inside the id's WHOLE segment, i.e. up to
+      // rows - 1) | group count of the step (high 7 bits: at most 64 lanes)
+      const int slot = (NWH == 16 ? wave * vocab : 0) + (tk >= 0 ? tk : 0);
+      if (tk >= 0) atomicAdd(reinterpret_cast<unsigned*>(hist) + slot, 1u << kEmbCursorBits);
+      const unsigned wv = tk >= 0 ? reinterpret_cast<volatile unsigned*>(hist)[slot] : 0u;       // LDS operations of a wave execute in order
+      const int cur = (int)(wv & ((1u << kEmbCursorBits) - 1u)), grp = (int)(wv >> kEmbCursorBits);
       int rank = 0;
       bool lead = grp == 1;
       unsigned long long active = __ballot(grp > 1);
@@ -251,14 +258,6 @@ __global__ __launch_bounds__(1024) void embed_sort_kernel(const long long* __res
         order[pst[tk] + cur + rank] = r;
         if (lead) hist[slot] = cur + grp;                            // cursor advanced, count cleared
       }
-     }
-    }
-  } else {
-    for (int v = tid; v < vocab; v += 1024) cnt[v] = pst[v];      // counts -> write cursors
-    __syncthreads();
-    for (int r = tid; r < rows; r += 1024) {
-      const long long tk = tok[(size_t)(r / Lrows) * tok_ld + (r % Lrows)];
-      if (tk >= 0 && tk < vocab) order[atomicAdd(&cnt[(int)tk], 1)] = r;
     }
   }
 }
@@ -737,6 +736,85 @@ __global__ __launch_bounds__(256) void softmax_ce_reg_kernel(float* __restrict__
   }
 }
 
+// Same for wide rows (2048 < ncls <= 1024*NV4: the grid tokenizer's 10004 classes, utils/tokenizer.py:104-198): ONE WORKGROUP per
+// row keeps it in registers (NV4 float4 per thread), maximum / first argmax / sum / target logit folded over the four waves
+// through LDS - still one read and one write of the logits (1.02 GB at the cfg-2 size instead of four passes).
+template <int NV4>
+__global__ __launch_bounds__(256) void softmax_ce_wide_kernel(float* __restrict__ logits, int ld, int rows, int ncls,
+                                                              const long long* __restrict__ target, int tgt_ld, int tgt_cols,
+                                                              int tgt_off, int mask_pad, float scale,
+                                                              float* __restrict__ row_loss, float* __restrict__ row_hit,
+                                                              float* __restrict__ probs_out, int write_grad) {
+  __shared__ float r_mx[4], r_se[4], r_xt[4];
+  __shared__ int r_am[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n4 = ncls >> 2;
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    float* x = logits + (size_t)row * ld;
+    const long long tg = target[(size_t)(row / tgt_cols) * tgt_ld + (row % tgt_cols) + tgt_off];
+    f32x4 v[NV4];
+    float mx = -INFINITY; int am = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < NV4; ++k) {
+      const int j4 = tid + 256 * k;
+      v[k] = j4 < n4 ? *reinterpret_cast<const f32x4*>(x + 4 * j4) : (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (v[k][e] > mx) { mx = v[k][e]; am = 4 * j4 + e; }   // ascending index inside a thread: first maximum wins
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float om = __shfl_xor(mx, o, 64); const int oa = __shfl_xor(am, o, 64);
+      if (om > mx || (om == mx && oa < am)) { mx = om; am = oa; }
+    }
+    __syncthreads();                                  // (the previous row's readers are done with the slots)
+    if (lane == 0) { r_mx[wave] = mx; r_am[wave] = am; }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float om = r_mx[w]; const int oa = r_am[w];
+      if (om > mx || (om == mx && oa < am)) { mx = om; am = oa; }
+    }
+    float se = 0.f, xt = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV4; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if ((long long)(4 * (tid + 256 * k) + e) == tg) xt = v[k][e];
+        v[k][e] = __expf(v[k][e] - mx);            // exp(-inf) = 0 for the padding slots
+        se += v[k][e];
+      }
+    se = wave_sum(se);
+    xt = wave_sum(xt);                              // exactly one thread holds the target logit
+    if (lane == 0) { r_se[wave] = se; r_xt[wave] = xt; }
+    __syncthreads();
+    se = (r_se[0] + r_se[1]) + (r_se[2] + r_se[3]);
+    xt = (r_xt[0] + r_xt[1]) + (r_xt[2] + r_xt[3]);
+    const bool valid = tg >= 0 && tg < ncls;
+    const float lse = mx + __logf(se);
+    const float m = (mask_pad && tg == 0) ? 0.f : 1.f;
+    if (tid == 0) {
+      row_loss[row] = valid ? (lse - xt) * m : 0.f;
+      row_hit[row] = (am == (int)tg) ? 1.f : 0.f;
+    }
+    const float gs = m * scale, rse = 1.0f / se;
+#pragma unroll
+    for (int k = 0; k < NV4; ++k) {
+      const int j4 = tid + 256 * k;
+      if (j4 < n4) {
+        const f32x4 pj = v[k] * rse;
+        if (probs_out) *reinterpret_cast<f32x4*>(probs_out + (size_t)row * ncls + 4 * j4) = pj;
+        if (write_grad) {
+          f32x4 gq;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) gq[e] = (pj[e] - ((long long)(4 * j4 + e) == tg ? 1.f : 0.f)) * gs;
+          *reinterpret_cast<f32x4*>(x + 4 * j4) = gq;
+        }
+      }
+    }
+  }
+}
+
 // Step metrics + running Keras metrics (builders/keras_metrics.py:19-42).
 // metrics layout (floats): [0..4]  this step: recon_loss, recon_acc, class_loss, class_acc, total_loss
 //                          [8..12] running totals, [16..20] running counts
@@ -1040,20 +1118,21 @@ extern "C" int skf_embed_sort(const long long* tokens, int tok_ld, int B, int L,
   SKF_CHECK_ARG(vocab > 0 && vocab <= 12288, "vocabulary does not fit the sort kernel's LDS tables");
   const int rows = B * L;
   const EmbWs w = emb_ws_layout(ws, B, L, vocab);
-  const bool ordered = vocab <= kEmbOrderedVocab && rows / 16 + 64 < 65536;      // (a wave's cursor lives in 16 bits)
-  const size_t smem = ((size_t)3 * vocab + 1 + (ordered ? (size_t)16 * vocab : 0)) * sizeof(int);
+  SKF_CHECK_ARG(rows < (1 << kEmbCursorBits), "too many token positions for the scatter's cursor word");
+  const bool per_wave = vocab <= kEmbOrderedVocab;      // 16 histograms fit in LDS; otherwise one table and a one-wave scatter
+  const size_t smem = ((size_t)3 * vocab + 1 + (per_wave ? (size_t)16 * vocab : 0)) * sizeof(int);
   static bool attr_done = false;
   if (!attr_done) {
-    SKF_HIP(hipFuncSetAttribute((const void*)embed_sort_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (3 * 12288 + 1) * 4));
-    SKF_HIP(hipFuncSetAttribute((const void*)embed_sort_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (19 * kEmbOrderedVocab + 1) * 4));
+    SKF_HIP(hipFuncSetAttribute((const void*)embed_sort_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (3 * 12288 + 1) * 4));
+    SKF_HIP(hipFuncSetAttribute((const void*)embed_sort_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (19 * kEmbOrderedVocab + 1) * 4));
     attr_done = true;
   }
   SkfProfScope ps((hipStream_t)stream, "embed_sort", 0.0, 12.0 * rows);
-  if (ordered)
-    hipLaunchKernelGGL(embed_sort_kernel<true>, dim3(1), dim3(1024), smem, (hipStream_t)stream, tokens, tok_ld, L, rows, vocab, w.hdr, w.chunks,
+  if (per_wave)
+    hipLaunchKernelGGL(embed_sort_kernel<16>, dim3(1), dim3(1024), smem, (hipStream_t)stream, tokens, tok_ld, L, rows, vocab, w.hdr, w.chunks,
                        w.order, w.done);
   else
-    hipLaunchKernelGGL(embed_sort_kernel<false>, dim3(1), dim3(1024), smem, (hipStream_t)stream, tokens, tok_ld, L, rows, vocab, w.hdr, w.chunks,
+    hipLaunchKernelGGL(embed_sort_kernel<1>, dim3(1), dim3(1024), smem, (hipStream_t)stream, tokens, tok_ld, L, rows, vocab, w.hdr, w.chunks,
                        w.order, w.done);
   SKF_LAUNCH_CHECK();
   return SKF_OK;
@@ -1188,8 +1267,17 @@ extern "C" int skf_softmax_ce(float* logits, int ld, int rows, int ncls, const l
   SKF_CHECK_ARG(logits && target && row_loss && row_hit, "null operand");
   SKF_CHECK_ARG(rows > 0 && ncls > 0 && tgt_cols > 0, "empty problem");
   SkfProfScope ps((hipStream_t)stream, "softmax_ce", 0.0, 8.0 * rows * ncls);
-  const bool vec = (ncls & 3) == 0 && (ld & 3) == 0 && ((uintptr_t)logits & 15) == 0 && ncls <= 2048 &&
-                   (!probs_out || ((uintptr_t)probs_out & 15) == 0);
+  const bool al = (ncls & 3) == 0 && (ld & 3) == 0 && ((uintptr_t)logits & 15) == 0 && (!probs_out || ((uintptr_t)probs_out & 15) == 0);
+  const bool vec = al && ncls <= 2048;
+  if (al && ncls > 2048 && ncls <= 16384) {        // wide rows: one workgroup per row, the row in registers
+    int g = rows < 8192 ? rows : 8192;
+#define SKF_CE_WIDE(NV4) hipLaunchKernelGGL(softmax_ce_wide_kernel<NV4>, dim3(g), dim3(256), 0, (hipStream_t)stream, \
+    logits, ld, rows, ncls, target, tgt_ld, tgt_cols, tgt_off, mask_pad, scale, row_loss, row_hit, probs_out, write_grad)
+    if (ncls <= 4096) SKF_CE_WIDE(4); else if (ncls <= 8192) SKF_CE_WIDE(8); else if (ncls <= 12288) SKF_CE_WIDE(12); else SKF_CE_WIDE(16);
+#undef SKF_CE_WIDE
+    SKF_LAUNCH_CHECK();
+    return SKF_OK;
+  }
 #define SKF_CE_GO(NV4) hipLaunchKernelGGL(softmax_ce_reg_kernel<NV4>, dim3(grid_for_rows(rows)), dim3(256), 0, (hipStream_t)stream, \
     logits, ld, rows, ncls, target, tgt_ld, tgt_cols, tgt_off, mask_pad, scale, row_loss, row_hit, probs_out, write_grad)
   if (vec && ncls <= 256) SKF_CE_GO(1);

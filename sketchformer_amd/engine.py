@@ -377,6 +377,25 @@ class TrainEngine:
     def reset_metrics(self):
         self.metrics.zero_()
 
+    def fold_metric_accumulators_into_rank0(self):
+        """Data parallel, before a checkpoint: the running-metric (sum, count) accumulators of all ranks are summed into rank
+        0's buffer and zeroed elsewhere (collective).  Later reads still sum over the ranks, so nothing is counted twice, and
+        the file rank 0 writes carries every rank's history (restore: rank 0 loads it, the others start from zero)."""
+        if self.world_size <= 1:
+            return
+        with torch.cuda.stream(self.stream):
+            acc = torch.cat([self.metrics[8:13], self.metrics[16:21]]).contiguous()
+            torch.distributed.all_reduce(acc, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+            if self.rank == 0:
+                self.metrics[8:13], self.metrics[16:21] = acc[:5], acc[5:]
+            else:
+                self.zero_metric_accumulators()
+
+    def zero_metric_accumulators(self):
+        with torch.cuda.stream(self.stream):
+            self.metrics[8:13] = 0.0
+            self.metrics[16:21] = 0.0
+
     def metrics_snapshot(self):
         """Device copy of the 32 metric floats as they stand after the steps queued so far (no host sync): what
         ``train_on_batch`` hands back; ``resolve_metrics`` turns a list of them into floats with ONE read-back."""
@@ -384,15 +403,16 @@ class TrainEngine:
             snap = self.metrics.clone()
         return snap
 
-    def resolve_metrics(self, snaps):
+    def resolve_metrics(self, snaps, reduce=True):
         """[snapshot] -> [running-metric dict].  One device->host copy for the whole list; under data parallelism the
         (sum, count) accumulators are summed over the ranks first (all-reduce only when metrics are read),
-        so every rank must call this with the same number of snapshots."""
+        so every rank must call this with the same number of snapshots.  reduce=False: this rank's own running values,
+        no collective (what a rank-specific read such as ``if rank == 0: log(res['total_loss'])`` gets)."""
         if not snaps:
             return []
         with torch.cuda.stream(self.stream):
             m = torch.stack(list(snaps))
-            if self.world_size > 1:
+            if self.world_size > 1 and reduce:
                 acc = torch.cat([m[:, 8:13], m[:, 16:21]], dim=1).contiguous()
                 torch.distributed.all_reduce(acc, op=torch.distributed.ReduceOp.SUM, group=self.pg)
                 m = m.clone()

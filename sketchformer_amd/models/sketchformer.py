@@ -19,7 +19,9 @@ class DeferredMetrics(Mapping):
     (builders/keras_metrics.py:41-42); here the step only snapshots the 32 device floats, ``BaseModel.train`` resolves
     all pending snapshots with ONE copy when it prints (``log_every``), and a caller that indexes / iterates the mapping
     right away gets the same floats the reference would have returned (one sync, like the reference).  Under data
-    parallelism resolving all-reduces the (sum, count) accumulators, so every rank has to read the same steps."""
+    parallelism ``resolve_all`` (what ``BaseModel.train`` calls on EVERY rank) all-reduces the (sum, count) accumulators;
+    indexing / iterating / printing a single result never runs a collective - it reads this rank's own running values, so a
+    rank-specific read (``if rank == 0: log(res['total_loss'])``) cannot deadlock."""
 
     def __init__(self, engine, snapshot, drop):
         self._engine, self._snap, self._drop, self._vals = engine, snapshot, drop, None
@@ -30,7 +32,7 @@ class DeferredMetrics(Mapping):
 
     def _resolved(self):
         if self._vals is None:
-            self.resolve_with(self._engine.resolve_metrics([self._snap])[0])
+            self.resolve_with(self._engine.resolve_metrics([self._snap], reduce=False)[0])
         return self._vals
 
     @staticmethod
@@ -253,11 +255,16 @@ class Transformer(BaseModel, TransformerMetricsMixin):
         return {'params': e.params.cpu(), 'adam_m': e.adam_m.cpu(), 'adam_v': e.adam_v.cpu(), 'metrics': e.metrics.cpu(),
                 'iterations': e.iterations, 'entries': e.entries}
 
+    def prepare_metrics_for_save(self):
+        self.engine.fold_metric_accumulators_into_rank0()
+
     def load_state_dict(self, state):
         e = self.engine
         e.params.copy_(state['params'])
         e.adam_m.copy_(state['adam_m'])
         e.adam_v.copy_(state['adam_v'])
         e.metrics.copy_(state['metrics'])
+        if e.rank != 0:      # the file holds the accumulators of ALL ranks (folded into rank 0 before the save): one copy only
+            e.zero_metric_accumulators()
         e.state[0] = int(state['iterations'])
         e.assert_replicas_equal()

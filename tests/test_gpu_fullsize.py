@@ -1,7 +1,7 @@
 """Model-level oracle parity at the REAL BASELINE dimensions (SURVEY 8(c) "Acceptance on GPU"):
 
   cfg 1: 4L/8H/d128/dff512, L=200, V=1004, C=1      (models/sketchformer.py:27-52 defaults)
-  cfg 2: the same with C=345
+  cfg 2: the same with C=345; "cfg2grid": cfg 2 with the grid tokenizer's 10004-id vocabulary (utils/tokenizer.py:104-198)
   cfg 3: 6L/8H/d256/dff1024, L=200, continuous stroke-5 input (use_continuous_data=True), C=345
 
 with a small batch so that the float64 oracle costs seconds, in both Dense arithmetic modes (0 = fp32 MFMA,
@@ -29,6 +29,9 @@ CFGS = {
                          lowerdim=256), continuous=False),
     "cfg2": dict(kw=dict(seq_len=200, d_model=128, num_heads=8, dff=512, num_layers=4, vocab_size=1004, n_classes=345,
                          lowerdim=256), continuous=False),
+    # cfg 2 with the grid tokenizer's vocabulary (utils/tokenizer.py:104-198: 100 x 100 cells + 4 special ids)
+    "cfg2grid": dict(kw=dict(seq_len=200, d_model=128, num_heads=8, dff=512, num_layers=4, vocab_size=10004, n_classes=345,
+                             lowerdim=256), continuous=False),
     "cfg3": dict(kw=dict(seq_len=200, d_model=256, num_heads=8, dff=1024, num_layers=6, n_classes=345, lowerdim=256),
                  continuous=True),
 }
@@ -69,7 +72,7 @@ def _rel(got, want):
 
 
 @pytest.mark.parametrize("mode", [0, 6])
-@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg3"])
+@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg2grid", "cfg3"])
 def test_full_dims_forward_logits_argmax(name, mode):
     B = 4
     eng, ocfg = _build(name, B, mode)
@@ -95,7 +98,7 @@ def test_full_dims_forward_logits_argmax(name, mode):
 
 
 @pytest.mark.parametrize("mode", [0, 6])
-@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg3"])
+@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg2grid", "cfg3"])
 def test_full_dims_losses_and_all_gradients(name, mode):
     B = 4
     eng, ocfg = _build(name, B, mode)
@@ -126,7 +129,7 @@ def test_full_dims_losses_and_all_gradients(name, mode):
 
 
 @pytest.mark.parametrize("mode", [0, 6])
-@pytest.mark.parametrize("name", ["cfg2", "cfg3"])
+@pytest.mark.parametrize("name", ["cfg2", "cfg2grid", "cfg3"])
 def test_full_dims_adam_trajectory(name, mode):
     B = 4
     eng, ocfg = _build(name, B, mode, use_graph=(mode == 6))
@@ -152,3 +155,34 @@ def test_full_dims_adam_trajectory(name, mode):
     worst = max((np.abs(got[k] - st.params[k]).max(), k) for k in got if not k.endswith("wk/bias"))
     print("\n[%s mode %d] 3-step trajectory: worst parameter abs diff %.3e (%s)" % (name, mode, worst[0], worst[1]))
     assert worst[0] < 5e-4, worst
+
+
+def test_benchmarked_batch_forward_and_losses_at_B128():
+    """The exact workload bench.py times (cfg 2, B = 128, the seed-0 synthetic batch with its 58 % padding, bf16x6 arithmetic),
+    under the oracle: forward logits <= 1e-3 relative, token argmax identical wherever the top-2 margin exceeds 1e-4, and - through
+    forward_backward, i.e. with the live-row lists, the XCD remap and the grouped weight gradients of a 25.6 k-row step - the
+    losses.  The oracle runs in float32 here (forward only: seconds of CPU at this size)."""
+    B = 128
+    eng, ocfg = _build("cfg2", B, 6)
+    x, y = synthetic.token_batch(B, ocfg.seq_len, ocfg.vocab_size, ocfg.n_classes, seed=0)       # bench.py: make_batch(rank 0)
+    assert 0.5 < (x == 0).mean() < 0.65
+    P = {k: v.astype(np.float32) for k, v in eng.state_dict_numpy().items()}
+    losses, out, _ = oracle.loss_and_grads(P, ocfg, x, x, y, want_grads=False)
+    want = out["recon"].astype(np.float64)
+    eng.forward(x, training=False)
+    torch.cuda.synchronize()
+    logits = eng.buffer("logits").cpu().numpy().reshape(want.shape)
+    r = _rel(logits, want)
+    srt = np.sort(want, -1)
+    safe = (srt[..., -1] - srt[..., -2]) > 1e-4
+    print("\n[cfg2 B=128 bench batch] logits rel %.3e, argmax: %d of %d positions below the 1e-4 margin" % (r, (~safe).sum(), safe.size))
+    assert r < 1e-3
+    assert safe.mean() > 0.99
+    assert np.array_equal(logits.argmax(-1)[safe], want.argmax(-1)[safe])
+    eng.forward_backward(x, None, y)
+    torch.cuda.synchronize()
+    m = eng.step_metrics()
+    for k in ("recon_loss", "class_loss", "total_loss"):
+        assert abs(m[k] - losses[k]) < 2e-5 * max(1.0, abs(losses[k])), (k, m[k], losses[k])
+    g = eng.state_dict_numpy("grads")
+    assert all(np.isfinite(v).all() for v in g.values())

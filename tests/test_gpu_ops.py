@@ -464,11 +464,13 @@ def test_embed_bwd_sorted(ops, B, L, V, d, rate):
     _close(got, ref.cpu().numpy(), rtol=5e-5, name="embed bwd sorted vs atomic kernel")
 
 
-def test_embed_bwd_sorted_is_run_to_run_deterministic(ops):
+@pytest.mark.parametrize("V", [1004, 10004])
+def test_embed_bwd_sorted_is_run_to_run_deterministic(ops, V):
     """cfg-2 size with a PAD id of ~17k positions (68 chunks) and a few frequent ids: the stable counting sort and the in-order
     combination of a split id's chunks make the gradient bit-identical from run to run (round 1: LDS-atomic scatter + float
-    atomics, the PAD row changed in the last bits)."""
-    B, L, V, d = 128, 200, 1004, 128
+    atomics, the PAD row changed in the last bits).  V = 10004 (grid tokens, utils/tokenizer.py:104-198): the one-table sort
+    with a single scattering wave (round 2 fell back to an unordered scatter above 2032 ids)."""
+    B, L, d = 128, 200, 128
     rng = np.random.RandomState(11)
     tok = rng.randint(1, V, size=(B, L))
     tok[rng.rand(B, L) < 0.15] = 7                    # a frequent id: several chunks
@@ -496,6 +498,26 @@ def test_embed_bwd_sorted_is_run_to_run_deterministic(ops):
         again = ops.embed_bwd_sorted(tokd, dx, V, L=L, rate=0.1, site=2, state=st)
         assert torch.equal(first, again)
         del busy
+
+
+def test_embed_bwd_sorted_more_than_65535_positions_of_one_id(ops):
+    """B * L > 65536 rows with a PAD id of > 65536 positions: the ordered scatter's per-(wave, id) cursor is an offset inside the
+    id's whole segment (round 2 kept it in 16 bits: it overflowed into the group count and positions landed in wrong slots)."""
+    B, L, V, d = 320, 256, 1004, 64
+    rng = np.random.RandomState(3)
+    tok = rng.randint(1, V, size=(B, L))
+    lens = rng.randint(8, 48, size=B)
+    tok[np.arange(L)[None, :] >= lens[:, None]] = 0
+    assert (tok == 0).sum() > 65536
+    dx = rng.randn(B, L, d)
+    want = np.zeros((V, d))
+    np.add.at(want, tok.reshape(-1), (dx * np.sqrt(np.float64(d))).reshape(-1, d))
+    tokd, dxd = _dev(tok, torch.int64), _dev(dx)
+    got = ops.embed_bwd_sorted(tokd, dxd, V, L=L, rate=0.0, site=2)
+    assert torch.isfinite(got).all()
+    _close(got, want, rtol=5e-5, name="embed bwd sorted, 70k PAD positions")
+    for _ in range(3):
+        assert torch.equal(got, ops.embed_bwd_sorted(tokd, dxd, V, L=L, rate=0.0, site=2))
 
 
 @pytest.mark.parametrize("d,rate", [(128, 0.0), (128, 0.1), (256, 0.1), (64, 0.0), (512, 0.0)])

@@ -29,6 +29,10 @@ def test_train_loop_and_metric_contract(tmp_path, capsys):
     assert model.current_step == 8 and model.engine.iterations == 8
     out = capsys.readouterr().out
     assert "Epoch 0 Batch 4/8|recon_loss=" in out and "|total_loss=" in out
+    # end of epoch: the slow metrics are computed, plotted and appended to the log like in the reference (core/models.py:203-235)
+    assert "val-clas-acc=" in out and "sketch-reconstruction=" in out, out
+    # status_report returns the log string on every call, also on steps that print nothing
+    assert model.status_report().startswith("Epoch 1 Batch 0/8|recon_loss=")
     for name in ("recon_loss", "recon_acc", "class_loss", "class_acc", "total_loss"):
         h = model.quick_metrics[name].history
         assert len(h) == 8 and np.isfinite(h).all()
@@ -276,6 +280,7 @@ def _dp_plugin_worker(rank, world, port, outdir, backend):
     local = rank if backend == "nccl" else 0
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(local), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ["SKF_TRAIN_SLOW_METRICS"] = "0"          # (the end-of-epoch slow metrics are covered by the single-rank tests)
     import faulthandler
     faulthandler.dump_traceback_later(150, exit=True)
     import json
@@ -302,6 +307,14 @@ def _dp_plugin_worker(rank, world, port, outdir, backend):
                    dataset, outdir, "dp", process_group=pg)
     model2.restore_checkpoint_if_exists("latest")
     assert model2.current_step == 7 and model2.engine.iterations == 7, (model2.current_step, model2.engine.iterations)
+    # the file carries the running-metric accumulators of BOTH ranks (folded into rank 0 before the save): rank 0 restores
+    # them, the other rank starts from zero, and the reduced running mean equals what train() printed at that step
+    counts = model2.engine.metrics[16:21].cpu().numpy()
+    assert (counts.max() > 0) == (rank == 0), (rank, counts)
+    resumed = model2.engine.resolve_metrics([model2.engine.metrics_snapshot()])[0]
+    info["resumed_total_loss"] = resumed["total_loss"]
+    with open(os.path.join(outdir, "rank%d.json" % rank), "w") as f:
+        json.dump(info, f)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -325,5 +338,8 @@ def test_data_parallel_plugin_path(tmp_path, backend):
     assert r[0]["checksum"] == r[1]["checksum"] and r[0]["iters"] == r[1]["iters"] == 8
     assert r[0]["hist"] == r[1]["hist"]                              # metrics were reduced over the ranks before use
     assert all(len(h) == 8 and np.isfinite(h).all() for h in r[0]["hist"].values())
+    # ckpt-4.pt was written after train step 7 of 8: the restored, reduced running mean is the 7th history entry
+    assert abs(r[0]["resumed_total_loss"] - r[0]["hist"]["total_loss"][6]) < 1e-5 * abs(r[0]["hist"]["total_loss"][6]), r[0]
+    assert r[0]["resumed_total_loss"] == r[1]["resumed_total_loss"]
     w = sorted(p.name for p in (tmp_path / "sketch-transformer-tf2-dp" / "weights").iterdir())
     assert w == ["ckpt-3.pt", "ckpt-4.pt", "step7.pt"], w

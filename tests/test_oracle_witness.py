@@ -127,3 +127,33 @@ def test_finite_difference_spot():
         P[name][idx] = old
         fd = (lp - lm) / (2 * eps)
         assert abs(fd - G[name][idx]) < 1e-7 * max(1.0, abs(fd)), (name, fd, G[name][idx])
+
+
+def test_torch_restatement_train_step_matches_numpy_oracle():
+    """The PyTorch-CPU restatement bench.py times as the CPU baseline (oracle/torch_restatement.py: autograd backward, Keras-Adam
+    with the WarmupDecay schedule on the pre-increment counter) walks the same 3-step trajectory as the numpy oracle."""
+    import torch
+    from oracle import torch_restatement as tr
+    cfg = oracle.Config(seq_len=12, d_model=32, num_heads=4, dff=64, num_layers=2, vocab_size=20, n_classes=5, lowerdim=16,
+                        dropout_rate=0.1)
+    rng = np.random.RandomState(0)
+    P = oracle.init_params(cfg, 3, np.float64)
+    st_np = oracle.TrainState.create({k: v.copy() for k, v in P.items()})
+    st_t = tr.TorchTrainState(P, dtype=torch.float64)
+    st_np.iterations = st_t.iterations = 2000
+    for step in range(3):
+        x = rng.randint(1, cfg.vocab_size, size=(3, cfg.seq_len))
+        x[0, 7:] = 0
+        y = rng.randint(0, cfg.n_classes, size=(3, 1))
+        drops = {n: rng.rand(3, cfg.seq_len if t == "enc" else cfg.seq_len - 1, cfg.d_model) >= cfg.dropout_rate
+                 for n, t in oracle.dropout_sites(cfg)}
+        _, losses, _, _ = oracle.train_step(st_np, cfg, x, x, y, drops)
+        got = tr.train_step(st_t, cfg, x, x, y, drops)
+        # (the two restatements scale kept units by 1/(1-rate) in different association orders: ~1e-8 relative)
+        assert abs(got["total_loss"] - losses["total_loss"]) < 1e-7 * abs(losses["total_loss"])
+    assert st_t.iterations == st_np.iterations == 2003
+    for k in P:
+        if k.endswith("wk/bias"):          # analytically zero gradient: Adam amplifies rounding noise there
+            continue
+        moved = np.abs(st_np.params[k] - P[k]).max()
+        assert np.abs(st_t.P[k].detach().numpy() - st_np.params[k]).max() < 1e-4 * max(moved, 1e-12) + 1e-12, k
