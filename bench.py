@@ -54,6 +54,18 @@ WORKLOADS = {
 U, CN = 256, 345
 
 
+_T0 = time.perf_counter()
+
+
+def _progress(msg):
+    """phase log on stderr (the one JSON line goes to stdout): where a slow run spends its time"""
+    print("[bench %7.1f s] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+def _elapsed():
+    return time.perf_counter() - _T0
+
+
 def step_flops(B, L, d, dff, N, V, U, Cn, cont=False):
     """Algorithmic FLOPs of one train step, SURVEY.md section 8(d): F_step = 3 * F_fwd."""
     Le, Ld, Lk = L, L - 1, L
@@ -75,11 +87,11 @@ def step_bytes(B, L, d, dff, N, V, P, act_bytes):
     return 2 * A * act_bytes + 2 * P * act_bytes + 28 * P
 
 
-def cpu_baseline(seconds_budget=25.0):
+def cpu_baseline(seconds_budget=20.0):
     """The CPU restatement of the TF2 reference timed on this host at SURVEY 8(d)'s definition (TensorFlow itself cannot run here):
     the PyTorch-CPU eager restatement of the identical graph (oracle/torch_restatement.py: torch.nn.functional forward, autograd
     backward, Keras-Adam/WarmupDecay) in fp32 with torch.set_num_threads(os.cpu_count()), cfg 1 (4L/8H/d128/dff512, L=200,
-    V=1004, C=1), the full B=128 batch with dropout 0.1: 2 warm-up steps, then >= 5 timed steps (bounded to ~25 s).  The numpy
+    V=1004, C=1), the full B=128 batch with dropout 0.1: 2 warm-up steps, then >= 3 timed steps (bounded to ~25 s).  The numpy
     oracle (the parity checker) is timed beside it as `numpy_port` (one warm-up step, >= 1 timed step)."""
     import oracle
     from oracle import torch_restatement as tr
@@ -99,12 +111,13 @@ def cpu_baseline(seconds_budget=25.0):
         for _ in range(2):
             tr.train_step(state, cfg, x, x, y, drops)
         times = []
-        while len(times) < 5 or (len(times) < 20 and time.perf_counter() - t_start < seconds_budget):
+        while len(times) < 3 or (len(times) < 10 and time.perf_counter() - t_start < seconds_budget):
             t0 = time.perf_counter()
             tr.train_step(state, cfg, x, x, y, drops)
             times.append(time.perf_counter() - t0)
         med = float(np.median(times))
         threads = torch.get_num_threads()
+        _progress("cpu baseline: torch %.2f s/step on %d threads" % (med, threads))
     finally:
         torch.set_num_threads(old_threads)
     out = {"value": B * L / med, "unit": "stroke-tokens/sec", "cores": int(threads), "kind": "port",
@@ -417,6 +430,8 @@ def main():
     ap.add_argument("--full-length", action="store_true", help="all rows have n = L (worst case, no padding)")
     ap.add_argument("--allreduce", default="bucketed", choices=["bucketed", "single"],
                     help="data parallel: gradient buckets overlapped with backward / optimizer (default) or ONE all-reduce of the whole buffer")
+    ap.add_argument("--time-budget", type=float, default=420.0,
+                    help="seconds after which the optional legs (sub-records, their PMC passes, the plugin-path leg) are skipped and say so")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS),
                     help="cfg2 = the headline config (default); cfg3 = 6L/d256/dff1024 continuous; cfg5 = 8L/d512/dff2048 L=512 bf16")
     args = ap.parse_args()
@@ -500,6 +515,7 @@ def main():
     }
     single = rank == 0 and world == 1
     extras = single and not args.no_extras
+    _progress("headline: %.3f ms/step" % ms_per_step)
     if extras and not args.full_length:
         xf, yf = make_batch(synthetic, w, B, rank, True)
         e1 = timed(eng, torch.from_numpy(xf).cuda(), torch.from_numpy(yf).cuda(), args.steps, 5)
@@ -515,6 +531,7 @@ def main():
                                  "step_mfma_frac": f_step / (e1 / args.steps) / (PEAK_F32_MFMA_TFLOPS * 1e12)}
     del eng
     torch.cuda.empty_cache()
+    _progress("full-length / fp32-MFMA legs done")
     if rank == 0 and not args.no_profile:
         rows, _ = kernel_profile(engine, cfg_kwargs, x, y)
         rows.sort(key=lambda r: -r["ms"])
@@ -530,8 +547,10 @@ def main():
             out["attention_work_fraction"] = {"self_attention_key_tiles_visited": done / dense,
                                               "what": "share of (query, key) pairs in non-skipped 16-key tiles, encoder self-attention (the attn_* "
                                                       "`tflops` of the kernel tables already count visited tiles only; `tflops_dense_counted` does not)"}
+        _progress("per-kernel profile done")
         if extras:
             views = rocprof_views(args.workload)
+            _progress("rocprofv3 child runs (kernel trace + 2 PMC passes) done")
             apply_concurrent(roof, views)
             if views["kernels_concurrent"]:
                 out["kernels_concurrent"] = views["kernels_concurrent"]
@@ -549,15 +568,25 @@ def main():
             if roof["traffic"] is not None:
                 roof["traffic_source"] = "committed profiles/*pmc_traffic.json (rocprofv3 not runnable in this invocation)"
         out["roofline"] = roof
-    if extras and args.workload == "cfg2" and not args.graph:
-        out["plugin_path"] = plugin_path_record(args.steps, args.warmup, B)
-        for name, st, wu in (("cfg2grid", 20, 5), ("cfg3", 20, 5), ("cfg5", 8, 3)):
-            try:
-                out[name] = sub_record(engine, synthetic, name, 128, st, wu)
-            except Exception as e:      # a sub-record must never cost the headline line
-                out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
     if single and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
+        _progress("cpu baseline done")
+    if extras and args.workload == "cfg2" and not args.graph:
+        # optional legs, most informative first; each is skipped (and says so) once the time budget is spent, and the PMC child
+        # runs of a sub-record (~1 min) only while half of the budget is left
+        skipped = lambda: {"skipped": "time budget (%.0f s of --time-budget %.0f s spent)" % (_elapsed(), args.time_budget)}  # noqa: E731
+        for name, st, wu in (("cfg5", 8, 3), ("cfg3", 20, 5), ("cfg2grid", 20, 5)):
+            if _elapsed() > args.time_budget:
+                out[name] = skipped()
+                continue
+            try:
+                out[name] = sub_record(engine, synthetic, name, 128, st, wu,
+                                       traffic=name != "cfg2grid" and _elapsed() < 0.6 * args.time_budget)
+            except Exception as e:      # a sub-record must never cost the headline line
+                out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+            _progress("sub-record %s done" % name)
+        out["plugin_path"] = plugin_path_record(args.steps, args.warmup, B) if _elapsed() < args.time_budget else skipped()
+        _progress("plugin path done")
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

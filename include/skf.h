@@ -102,6 +102,18 @@ int skf_gemm_f32_rows(int a_kcontig, int b_kcontig, int M, int N, int K, const f
                       float* C, int ldc, const float* bias, int act, const float* relu_src, int ld_relu, int accumulate,
                       int splits, float* bias_grad, int bias_grad_accumulate, void* workspace, size_t workspace_bytes,
                       int precision, const int* row_blocks, int row_block_rows, skf_stream_t stream);
+/* ReLU sign bits (ffn: builders/layers/transformer.py:196-197 Dense(dff, relu) -> Dense(d); its tape gradient multiplies
+ * d(hidden) by relu'(hidden)).  A forward launch with act = relu can leave ONE BIT per output element ("> 0") in
+ * relu_bits_out, in the layout of its own tiles, and the input-gradient launch of the same (M, N, K) reads relu_bits_in
+ * instead of the hidden tensor (relu_src): identical results, 1/32 of the bytes.  Exists where the split-arithmetic
+ * weight-stationary kernel takes the launch: skf_gemm_relu_bits_bytes returns the buffer size (64-byte aligned buffer), or 0
+ * when the shape has no such path - then pass NULL / use relu_src; bits on an unsupported launch are an error. */
+size_t skf_gemm_relu_bits_bytes(int M, int N, int K, int precision);
+int skf_gemm_f32_bits(int a_kcontig, int b_kcontig, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                      float* C, int ldc, const float* bias, int act, const float* relu_src, int ld_relu, int accumulate,
+                      int splits, float* bias_grad, int bias_grad_accumulate, void* workspace, size_t workspace_bytes,
+                      int precision, const int* row_blocks, int row_block_rows, void* relu_bits_out, const void* relu_bits_in,
+                      skf_stream_t stream);
 int skf_gemm_wgrad_partial_rows(int M, int N, int K, const float* A, int lda, const float* B, int ldb, int splits,
                                 int with_bias_grad, float* slab, size_t slab_bytes, int* splits_used_host, int precision,
                                 const int* row_blocks, int row_block_rows, skf_stream_t stream);

@@ -521,7 +521,36 @@ extern "C" int skf_gemm_f32_rows(int a_kcontig, int b_kcontig, int M, int N, int
                                  int splits, float* bias_grad, int bias_grad_accumulate,
                                  void* workspace, size_t workspace_bytes, int precision, const int* row_blocks,
                                  int row_block_rows, skf_stream_t stream) {
+  return skf_gemm_f32_bits(a_kcontig, b_kcontig, M, N, K, A, lda, B, ldb, C, ldc, bias, act, relu_src, ld_relu, accumulate, splits,
+                           bias_grad, bias_grad_accumulate, workspace, workspace_bytes, precision, row_blocks, row_block_rows,
+                           nullptr, nullptr, stream);
+}
+
+// The sign-bit path exists where the split-arithmetic weight-stationary kernel takes the launch (skf_gemm_ws_dispatch +
+// ws_launch_one): A [M][K] with K in {128,256,384,512}, M >= 1024, a problem above the small-GEMM size, 32-bit byte offsets.
+static bool relu_bits_shape(int M, int N, int K, int precision) {
+  return precision != SKF_PREC_F32 && (K == 128 || K == 256 || K == 384 || K == 512) && M >= 1024 && (N & 3) == 0 &&
+         (double)M * N * K > 33554432.0 && (double)M * (N > K ? N : K) * 4 < 2147483648.0;
+}
+extern "C" size_t skf_gemm_relu_bits_bytes(int M, int N, int K, int precision) {
+  return relu_bits_shape(M, N, K, precision) ? skf_gemm_wsx_relu_bits_bytes(M, N, K) : 0;
+}
+
+extern "C" int skf_gemm_f32_bits(int a_kcontig, int b_kcontig, int M, int N, int K,
+                                 const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                                 const float* bias, int act, const float* relu_src, int ld_relu, int accumulate,
+                                 int splits, float* bias_grad, int bias_grad_accumulate,
+                                 void* workspace, size_t workspace_bytes, int precision, const int* row_blocks,
+                                 int row_block_rows, void* relu_bits_out, const void* relu_bits_in, skf_stream_t stream) {
   SKF_CHECK_ARG(M > 0 && N > 0 && K > 0, "empty problem");
+  if (relu_bits_out || relu_bits_in) {
+    SKF_CHECK_ARG(relu_bits_shape(M, N, K, precision) && a_kcontig && splits <= 1 && !bias_grad && lda == K && ldc == N &&
+                  (((uintptr_t)A | (uintptr_t)C | (uintptr_t)B) & 15) == 0 && (ldb & 3) == 0,
+                  "ReLU sign bits: not a launch of the split-arithmetic weight-stationary kernel (skf_gemm_relu_bits_bytes == 0)");
+    SKF_CHECK_ARG(!relu_bits_out || (act == 1 && !relu_src && !accumulate), "sign bits are written by a plain relu forward launch");
+    SKF_CHECK_ARG(!relu_bits_in || act == 0, "sign bits are read by an input-gradient launch (no activation)");
+    SKF_CHECK_ARG((((uintptr_t)relu_bits_out | (uintptr_t)relu_bits_in) & 63) == 0, "sign-bit buffers must be 64-byte aligned");
+  }
   SKF_CHECK_ARG(precision == SKF_PREC_F32 || precision == SKF_PREC_BF16X3 || precision == SKF_PREC_BF16X6, "precision must be 0 (fp32 MFMA), 6 (bf16x6) or 3 (bf16x3)");
   SKF_CHECK_ARG(A && B && C, "null operand");
   SKF_CHECK_ARG(act >= 0 && act <= 2, "bad activation");
@@ -534,6 +563,7 @@ extern "C" int skf_gemm_f32_rows(int a_kcontig, int b_kcontig, int M, int N, int
   SKF_CHECK_ARG(!row_blocks || (a_kcontig && row_block_rows > 0 && !bias && splits <= 1 && !bias_grad),
                 "a row-block list goes with the dgrad form: A [M][K], no bias, no split");
   p.row_blocks = row_blocks; p.row_block_rows = row_blocks ? row_block_rows : 0;
+  p.relu_bits_out = (unsigned long long*)relu_bits_out; p.relu_bits_in = (const unsigned long long*)relu_bits_in;
   p.a_vec = ((lda & 3) == 0) && (((uintptr_t)A & 15) == 0);
   p.b_vec = ((ldb & 3) == 0) && (((uintptr_t)B & 15) == 0);
   p.tiles_m = skf_cdiv(M, 128); p.tiles_n = skf_cdiv(N, 128);
@@ -550,6 +580,7 @@ extern "C" int skf_gemm_f32_rows(int a_kcontig, int b_kcontig, int M, int N, int
     int handled = 0;
     int rc = skf_gemm_ws_dispatch(p, a_kcontig, b_kcontig, st, &handled);
     if (rc != SKF_OK || handled) return rc;
+    if (relu_bits_out || relu_bits_in) { skf_set_error("skf_gemm_f32_bits: the weight-stationary path is switched off"); return SKF_EUNSUPPORTED; }
     // 64-row tiles when 128-row tiles would leave most CUs idle
     if (p.tiles_m * p.tiles_n < 400 && M > 64) {
       p.tiles_m = skf_cdiv(M, 64);

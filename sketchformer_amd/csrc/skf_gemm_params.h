@@ -30,12 +30,19 @@ struct GemmParams {
   const int* row_blocks;
   int row_block_rows;
   int ablate;              // generic kernel, diagnostics only (env SKF_GEMM_ABLATE): 1 no MFMA, 2 no C store, 3 no global reload
+  // ReLU sign bits (split-arithmetic weight-stationary kernels only; skf_gemm_relu_bits_bytes): a forward launch with
+  // act = relu leaves one bit per output element ("> 0") in the layout of its own tiles - word [tile][column wave][r * NB + nb]
+  // = ballot over the wave's lanes - and the input-gradient launch of the SAME (M, N, K) multiplies by them instead of
+  // re-reading the hidden tensor (52 MB per launch at the cfg-2 size -> 1.6 MB)
+  unsigned long long* relu_bits_out;
+  const unsigned long long* relu_bits_in;
 };
 
 // weight-stationary fast path; sets *handled when it launched the problem
 int skf_gemm_ws_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, hipStream_t st, int* handled);
 // the same problem on the bf16 matrix cores with split fp32 operands (pieces = 3: six products, 2: three products)
 int skf_gemm_wsx_launch(const GemmParams& p, int b_kcontig, int pieces, hipStream_t st);
+size_t skf_gemm_wsx_relu_bits_bytes(int M, int N, int K);
 // wgrad (X^T.dY) fast path writing the split-K slab; sets *handled when it launched the problem
 int skf_gemm_wgrad_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, int splits, hipStream_t st, int* handled);
 // several wgrad fast-path problems (k_chunk, slab, colsum_slab, row_blocks set as for skf_gemm_wgrad_dispatch) in one launch

@@ -208,16 +208,28 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
 
   vecn cprev[4], hsrc[4], oacc[4];
   int prev_tile = ntiles;
-  const bool has_relu = EXTRA && p.relu_src != nullptr;
+  const bool has_bits = EXTRA && p.relu_bits_in != nullptr;       // relu'(.) from the forward's sign bits instead of relu_src
+  const bool has_relu = EXTRA && p.relu_src != nullptr && !has_bits;
+  const int ncw = groups * 4, cwi = group * 4 + wave;             // column waves of the launch / this wave's index
+  unsigned long long mbits[EXTRA ? 4 * NB : 1];                   // sign-bit words of the tile whose C is stored next (uniform: SGPRs)
   auto store_prev = [&]() {
     const __amdgpu_buffer_rsrc_t rc = wsx_rows_rsrc(p.C, p.ldc, p.M, prev_tile * TR);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       vecn v = cprev[r];
       if (EXTRA) {
+        if (has_bits) {                       // wave-uniform branch, no memory operation inside
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            float sel;
+            asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(sel) : "v"(reinterpret_cast<const float*>(&v)[nb]), "s"(mbits[r * NB + nb]));
+            reinterpret_cast<float*>(&v)[nb] = sel;
+          }
+        } else {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
           reinterpret_cast<float*>(&v)[nb] = (!has_relu || reinterpret_cast<const float*>(&hsrc[r])[nb] > 0.f) ? reinterpret_cast<const float*>(&v)[nb] : 0.f;
+        }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) reinterpret_cast<float*>(&v)[nb] += reinterpret_cast<const float*>(&oacc[r])[nb];
       }
@@ -307,6 +319,14 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
           const __amdgpu_buffer_rsrc_t ro = wsx_rows_rsrc(p.C, p.ldc, p.accumulate ? p.M : 0, ptile * TR);
 #pragma unroll
           for (int r = 0; r < 4; ++r) oacc[r] = wsx_buf_load<NB>(ro, c_voff[r]);
+          // sign-bit words of this tile: one uniform (scalar) load per wave; without bits the words of tile 0 of some valid
+          // buffer are fetched and ignored (no branch around a memory operation in the loop)
+          // (constant address space: the words are never written by this launch, so a uniform address becomes ONE s_load)
+          typedef const __attribute__((address_space(4))) unsigned long long* const_u64p;
+          const const_u64p wp = (const_u64p)(has_bits ? p.relu_bits_in + ((size_t)(ptile < ntiles ? ptile : 0) * ncw + cwi) * (4 * NB)
+                                                      : reinterpret_cast<const unsigned long long*>(p.B));
+#pragma unroll
+          for (int j = 0; j < 4 * NB; ++j) mbits[j] = wp[j];
         }
         SKF_WSX_SCHED_BARRIER();
       }
@@ -345,6 +365,26 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) reinterpret_cast<float*>(&cprev[r])[nb] = __builtin_amdgcn_fmed3f(reinterpret_cast<float*>(&cprev[r])[nb], 0.f, __builtin_inff());   // one op (fmaxf = canonicalise + max)
+      if (!EXTRA) {
+        // sign bits for the input-gradient launch: word j = r * NB + nb is the ballot of "> 0" over the wave, stored by lane j
+        // (every lane executes the store: lanes >= 4 NB and launches without a bit buffer fall outside the descriptor)
+        unsigned long long w = 0;
+        if (p.relu_bits_out) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+              const unsigned long long bm = __ballot(reinterpret_cast<float*>(&cprev[r])[nb] > 0.f);
+              if (lane == r * NB + nb) w = bm;
+            }
+        }
+        const int ptile = phys(tile);
+        const bool wr = p.relu_bits_out != nullptr && ptile < ntiles;
+        const size_t woff = wr ? ((size_t)ptile * ncw + cwi) * (4 * NB) * 8 : 0;
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<char*>(wr ? (void*)p.relu_bits_out : (void*)p.C) + woff, 0, wr ? 4 * NB * 8 : 0, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, w), rb, (unsigned)lane * 8u, 0, 0);
+      }
     } else if (p.act == 2) {   // the bottleneck's tanh projection (one launch per step): a wave-uniform branch nobody else takes
 #pragma unroll
       for (int r = 0; r < 4; ++r)
@@ -446,6 +486,12 @@ int launch_wsx_k(const GemmParams& p, int b_kc, hipStream_t st) {
 }
 
 }  // namespace
+
+// bytes of the sign-bit buffer of an (M, N, K) launch: [16-row tile][column wave][4 * NB] 64-bit words (see GemmParams)
+size_t skf_gemm_wsx_relu_bits_bytes(int M, int N, int K) {
+  const int NB = K == 128 ? 2 : 1, CW = 16 * NB;
+  return (size_t)skf_cdiv(M, TR) * (size_t)skf_cdiv(N, 4 * CW) * 4 * (size_t)(4 * NB) * sizeof(unsigned long long);
+}
 
 // pieces = 3 (six products, fp32-equivalent) or 2 (three products); same applicability rules as skf_gemm_ws_dispatch
 int skf_gemm_wsx_launch(const GemmParams& p, int b_kcontig, int pieces, hipStream_t st) {

@@ -288,8 +288,8 @@ struct Bump {
   size_t take(size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; }
 };
 
-struct EncAct { size_t x_in, qkv, o, z1, st1, astats, x1, h, z2, st2, x2; };
-struct DecAct { size_t x_in, qkv, o1, z1, st1, astats1, out1, q2, kv2, o2, astats2, z2, st2, out2, h, z3, st3, out3; };
+struct EncAct { size_t x_in, qkv, o, z1, st1, astats, x1, h, z2, st2, x2, hbits; };
+struct DecAct { size_t x_in, qkv, o1, z1, st1, astats1, out1, q2, kv2, o2, astats2, z2, st2, out2, h, z3, st3, out3, hbits; };
 
 struct Plan {
   size_t bytes = 0;
@@ -335,6 +335,7 @@ Plan build_plan(const SkfConfig& c) {
     a.x_in = b.take(Me * d * f); a.qkv = b.take(Me * 3 * d * f); a.o = b.take(Me * d * f); a.z1 = b.take(Me * d * f);
     a.st1 = b.take(Me * 2 * f); a.astats = b.take(B * H * L * 2 * f); a.x1 = b.take(Me * d * f);
     a.h = b.take(Me * F * f); a.z2 = b.take(Me * d * f); a.st2 = b.take(Me * 2 * f);
+    a.hbits = b.take(skf_gemm_relu_bits_bytes((int)Me, (int)F, (int)d, c.gemm_precision));      // 0 bytes: no sign-bit path for this shape
     a.x2 = 0;
     P.enc.push_back(a);
   }
@@ -353,6 +354,7 @@ Plan build_plan(const SkfConfig& c) {
     a.q2 = b.take(Md * d * f); a.kv2 = b.take(Me * 2 * d * f); a.o2 = b.take(Md * d * f);   // kv2 = pre (Me,E) . Wkv (E,2d)
     a.astats2 = b.take(B * H * Ld * 2 * f); a.z2 = b.take(Md * d * f); a.st2 = b.take(Md * 2 * f);
     a.out2 = b.take(Md * d * f); a.h = b.take(Md * F * f); a.z3 = b.take(Md * d * f); a.st3 = b.take(Md * 2 * f);
+    a.hbits = b.take(skf_gemm_relu_bits_bytes((int)Md, (int)F, (int)d, c.gemm_precision));
     a.out3 = 0;
     P.dec.push_back(a);
   }
@@ -478,6 +480,18 @@ namespace {
 int dense_fwd(SkfModel* M, const DenseP& w, const float* x, int rows, float* y, int act, hipStream_t s) {
   return skf_gemm_f32(1, 0, rows, w.out, w.in, x, w.in, M->P(w.w), w.ld, y, w.out, M->P(w.b), act, nullptr, 0, 0, 1,
                       nullptr, 0, nullptr, 0, M->cfg.gemm_precision, s);
+}
+// sign-bit buffer of an ffn hidden tensor (rows x dff from d inputs), or null when the shape has no such path / SKF_NO_RELU_BITS=1
+void* hbits_of(SkfModel* M, size_t off, int rows) {
+  static const bool bits_off = getenv("SKF_NO_RELU_BITS") && getenv("SKF_NO_RELU_BITS")[0] == '1';
+  if (bits_off || !skf_gemm_relu_bits_bytes(rows, M->cfg.dff, M->cfg.d_model, M->cfg.gemm_precision)) return nullptr;
+  return M->at<char>(off);
+}
+// ffn dense1 (relu): also leaves the sign bits of the hidden tensor for the backward when the shape has that path (bits != null)
+int dense_fwd_relu_bits(SkfModel* M, const DenseP& w, const float* x, int rows, float* y, void* bits, hipStream_t s) {
+  if (!bits) return dense_fwd(M, w, x, rows, y, 1, s);
+  return skf_gemm_f32_bits(1, 0, rows, w.out, w.in, x, w.in, M->P(w.w), w.ld, y, w.out, M->P(w.b), 1, nullptr, 0, 0, 1,
+                           nullptr, 0, nullptr, 0, M->cfg.gemm_precision, nullptr, 0, bits, nullptr, s);
 }
 // strided-input variant (x has row stride ldx)
 int dense_fwd_ld(SkfModel* M, const DenseP& w, const float* x, int ldx, int rows, float* y, int ldy, int act, hipStream_t s) {
@@ -631,9 +645,12 @@ int flush_wgrads(SkfModel* M, hipStream_t s, int bucket, bool final) {
   return SKF_OK;
 }
 int dense_dgrad(SkfModel* M, const DenseP& w, const float* dy, int lddy, int rows, float* dx, int lddx, int accumulate,
-                const float* relu_src, int ld_relu, hipStream_t s) {
+                const float* relu_src, int ld_relu, hipStream_t s, const void* relu_bits = nullptr) {
   SKF_TRY(before_write(M, dx, s));
   const int* blocks = (M->live16 && rows == M->live_rows) ? M->live16 : nullptr;
+  if (relu_bits)      // relu'(hidden) from the sign bits the forward left (skf_gemm_f32_bits): the hidden tensor is not re-read
+    return skf_gemm_f32_bits(1, 1, rows, w.in, w.out, dy, lddy, M->P(w.w), w.ld, dx, lddx, nullptr, 0, nullptr, 0,
+                             accumulate, 1, nullptr, 0, nullptr, 0, M->cfg.gemm_precision, blocks, 16, nullptr, relu_bits, s);
   return skf_gemm_f32_rows(1, 1, rows, w.in, w.out, dy, lddy, M->P(w.w), w.ld, dx, lddx, nullptr, 0, relu_src, ld_relu,
                            accumulate, 1, nullptr, 0, nullptr, 0, M->cfg.gemm_precision, blocks, 16, s);
 }
@@ -716,7 +733,7 @@ int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s, bool 
     SKF_TRY(dense_fwd(M, w.mha.o, M->at<float>(a.o), Me, M->at<float>(a.z1), 0, s));
     SKF_TRY(skf_layernorm_residual_fwd(x, M->at<float>(a.z1), M->P(w.ln1.g), M->P(w.ln1.b), M->at<float>(a.x1),
                                        M->at<float>(a.st1), Me, d, rate, site_enc(i, 0), M->state, s));
-    SKF_TRY(dense_fwd(M, w.f1, M->at<float>(a.x1), Me, M->at<float>(a.h), 1, s));
+    SKF_TRY(dense_fwd_relu_bits(M, w.f1, M->at<float>(a.x1), Me, M->at<float>(a.h), hbits_of(M, a.hbits, Me), s));
     SKF_TRY(dense_fwd(M, w.f2, M->at<float>(a.h), Me, M->at<float>(a.z2), 0, s));
     SKF_TRY(skf_layernorm_residual_fwd(M->at<float>(a.x1), M->at<float>(a.z2), M->P(w.ln2.g), M->P(w.ln2.b),
                                        M->at<float>(a.x2), M->at<float>(a.st2), Me, d, rate, site_enc(i, 1), M->state, s));
@@ -787,7 +804,7 @@ int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s, bool 
     SKF_TRY(dense_fwd(M, w.mha2.o, M->at<float>(a.o2), Md, M->at<float>(a.z2), 0, s));
     SKF_TRY(skf_layernorm_residual_fwd(M->at<float>(a.out1), M->at<float>(a.z2), M->P(w.ln2.g), M->P(w.ln2.b),
                                        M->at<float>(a.out2), M->at<float>(a.st2), Md, d, rate, site_dec(N, i, 1), M->state, s));
-    SKF_TRY(dense_fwd(M, w.f1, M->at<float>(a.out2), Md, M->at<float>(a.h), 1, s));
+    SKF_TRY(dense_fwd_relu_bits(M, w.f1, M->at<float>(a.out2), Md, M->at<float>(a.h), hbits_of(M, a.hbits, Md), s));
     SKF_TRY(dense_fwd(M, w.f2, M->at<float>(a.h), Md, M->at<float>(a.z3), 0, s));
     SKF_TRY(skf_layernorm_residual_fwd(M->at<float>(a.out2), M->at<float>(a.z3), M->P(w.ln3.g), M->P(w.ln3.b),
                                        M->at<float>(a.out3), M->at<float>(a.st3), Md, d, rate, site_dec(N, i, 2), M->state, s));
@@ -826,9 +843,9 @@ int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s, bool 
 }
 
 int ffn_bwd(SkfModel* M, const DenseP& f1, const DenseP& f2, const float* x_in, const float* h, const float* dy,
-            float* dh, float* dx_acc, int rows, hipStream_t s) {
+            float* dh, float* dx_acc, int rows, hipStream_t s, const void* hbits) {
   SKF_TRY(dense_wgrad(M, f2, h, f2.in, dy, f2.out, rows, s));
-  SKF_TRY(dense_dgrad(M, f2, dy, f2.out, rows, dh, f2.in, 0, h, f2.in, s));
+  SKF_TRY(dense_dgrad(M, f2, dy, f2.out, rows, dh, f2.in, 0, h, f2.in, s, hbits));
   SKF_TRY(dense_wgrad(M, f1, x_in, f1.in, dh, f1.out, rows, s));
   SKF_TRY(dense_dgrad(M, f1, dh, f1.out, rows, dx_acc, f1.in, 1, nullptr, 0, s));
   return SKF_OK;
@@ -933,7 +950,7 @@ int run_backward(SkfModel* M, hipStream_t s) {
     float* dqkv = M->at<float>(gs.dqkv); float* dkv2 = M->at<float>(gs.dkv2); float* dq2 = M->at<float>(gs.dq2);
     // out3 = LN3(out2 + drop(ffn(out2)))
     SKF_TRY(ln_bwd(M, w.ln3, G, M->at<float>(a.z3), M->at<float>(a.st3), G2, dy3, Md, rate, site_dec(N, i, 2), s));
-    SKF_TRY(ffn_bwd(M, w.f1, w.f2, M->at<float>(a.out2), M->at<float>(a.h), dy3, M->at<float>(gs.dh), G2, Md, s));
+    SKF_TRY(ffn_bwd(M, w.f1, w.f2, M->at<float>(a.out2), M->at<float>(a.h), dy3, M->at<float>(gs.dh), G2, Md, s, hbits_of(M, a.hbits, Md)));
     // out2 = LN2(out1 + drop(mha2(pre, pre, out1)))
     SKF_TRY(ln_bwd(M, w.ln2, G2, M->at<float>(a.z2), M->at<float>(a.st2), G, dy2, Md, rate, site_dec(N, i, 1), s));
     SKF_TRY(dense_wgrad(M, w.mha2.o, M->at<float>(a.o2), d, dy2, d, Md, s));
@@ -1043,7 +1060,7 @@ int run_backward(SkfModel* M, hipStream_t s) {
     float* dy2 = M->at<float>(gs.dy[0]); float* dy1 = M->at<float>(gs.dy[1]);
     float* dqkv = M->at<float>(gs.dqkv);
     SKF_TRY(ln_bwd(M, w.ln2, G, M->at<float>(a.z2), M->at<float>(a.st2), G2, dy2, Me, rate, site_enc(i, 1), s));
-    SKF_TRY(ffn_bwd(M, w.f1, w.f2, M->at<float>(a.x1), M->at<float>(a.h), dy2, M->at<float>(gs.dh), G2, Me, s));
+    SKF_TRY(ffn_bwd(M, w.f1, w.f2, M->at<float>(a.x1), M->at<float>(a.h), dy2, M->at<float>(gs.dh), G2, Me, s, hbits_of(M, a.hbits, Me)));
     // last layer of the backward: nothing is left on the main stream to hide a whole layer's weight gradients behind
     // (only the embedding gradient follows), so they go out per sublayer - the step's tail before Adam is one wgrad, not four
     static const bool early_tail = !getenv("SKF_NO_EARLY_TAIL");

@@ -80,8 +80,14 @@ def row_blocks(live_len, rows_per_sample, granule):
     return out
 
 
+def relu_bits(M, N, K, device, precision=None):
+    """Zeroed sign-bit buffer for gemm(..., relu_bits_out= / relu_bits_in=), or None when the shape has no such path."""
+    n = _lib.load().skf_gemm_relu_bits_bytes(M, N, K, _prec(precision))
+    return torch.zeros(n // 8, dtype=torch.int64, device=device) if n else None
+
+
 def gemm(a, b, a_kcontig=True, b_kcontig=False, bias=None, act=0, relu_src=None, out=None, accumulate=False,
-         splits=1, bias_grad=None, precision=None, row_blocks=None, row_block_rows=0):
+         splits=1, bias_grad=None, precision=None, row_blocks=None, row_block_rows=0, relu_bits_out=None, relu_bits_in=None):
     """C[M,N] (+)= opA(a) . opB(b).  a: [M,K] (a_kcontig) or [K,M]; b: [K,N] or [N,K] (b_kcontig).
     precision: SKF_PREC_* (0 fp32 MFMA, 6 bf16x6, 3 bf16x3); None = _lib.default_precision().
     row_blocks: list from ``row_blocks()`` - dgrad form with 16-row blocks (dead rows of a are zero), or the weight
@@ -104,6 +110,12 @@ def gemm(a, b, a_kcontig=True, b_kcontig=False, bias=None, act=0, relu_src=None,
         _lib.call("skf_gemm_wgrad_partial_rows", M, N, K, _p(a), a.stride(0), _p(b), b.stride(0), splits,
                   int(bias_grad is not None), _p(ws), wsb, C.byref(used), _prec(precision), _p(row_blocks), row_block_rows, _stream())
         _lib.call("skf_splitk_reduce", _p(ws), used.value, M, N, _p(out), out.stride(0), int(accumulate), _p(bias_grad), 0, _stream())
+        return out
+    if relu_bits_out is not None or relu_bits_in is not None:
+        _lib.call("skf_gemm_f32_bits", int(a_kcontig), int(b_kcontig), M, N, K, _p(a), a.stride(0), _p(b), b.stride(0),
+                  _p(out), out.stride(0), _p(bias), act, _p(relu_src), relu_src.stride(0) if relu_src is not None else 0,
+                  int(accumulate), splits, _p(bias_grad), 0, _p(ws), wsb, _prec(precision), _p(row_blocks), row_block_rows,
+                  _p(relu_bits_out), _p(relu_bits_in), _stream())
         return out
     if row_blocks is not None:
         _lib.call("skf_gemm_f32_rows", int(a_kcontig), int(b_kcontig), M, N, K, _p(a), a.stride(0), _p(b), b.stride(0),

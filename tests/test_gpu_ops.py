@@ -54,6 +54,47 @@ def test_gemm_dgrad_relu_mask_accumulate(ops, M, N, K):
     _close(out, c0 + dy @ w.T, name="dgrad accumulate")
 
 
+@pytest.mark.parametrize("M,N,K", [(25600, 512, 128), (5000, 1024, 256), (3001, 132, 128), (4096, 512, 512)])
+def test_gemm_relu_sign_bits(ops, M, N, K):
+    """ffn backward without re-reading the hidden tensor: the relu forward launch leaves one sign bit per output element in the
+    layout of its own tiles (skf_gemm_f32_bits), the input-gradient launch of the same (M, N, K) multiplies by them - bit for
+    bit what the relu_src form computes, also over a live-row-block list and when accumulating."""
+    from sketchformer_amd import _lib
+    rng = np.random.RandomState(M + N + K)
+    x, w1, b1 = rng.randn(M, K), rng.randn(K, N) / np.sqrt(K), rng.randn(N)
+    dy, c0 = rng.randn(M, K), rng.randn(M, N)
+    bits = ops.relu_bits(M, N, K, "cuda")
+    assert bits is not None and bits.numel() * 8 == _lib.load().skf_gemm_relu_bits_bytes(M, N, K, _lib.default_precision())
+    h = ops.gemm(_dev(x), _dev(w1), bias=_dev(b1), act=1, relu_bits_out=bits)
+    _close(h, np.maximum(x @ w1 + b1, 0), name="relu forward with sign bits")
+    assert torch.equal(h, ops.gemm(_dev(x), _dev(w1), bias=_dev(b1), act=1))
+    w2t = _dev(rng.randn(N, K) / np.sqrt(K))              # dgrad form: B is [N][K]
+    want = ops.gemm(_dev(dy), w2t, a_kcontig=True, b_kcontig=True, relu_src=h)
+    got = ops.gemm(_dev(dy), w2t, a_kcontig=True, b_kcontig=True, relu_bits_in=bits)
+    assert torch.equal(got, want)
+    acc_w, acc_g = _dev(c0), _dev(c0)
+    ops.gemm(_dev(dy), w2t, a_kcontig=True, b_kcontig=True, relu_src=h, out=acc_w, accumulate=True)
+    ops.gemm(_dev(dy), w2t, a_kcontig=True, b_kcontig=True, relu_bits_in=bits, out=acc_g, accumulate=True)
+    assert torch.equal(acc_g, acc_w)
+    # live 16-row blocks: dead rows of dy are zero, their output rows come out as zeros
+    live = torch.full((M // 200 + 1,), 120, dtype=torch.int32, device="cuda")
+    rps = 200
+    Mr = (M // rps) * rps
+    if Mr >= 1024 and _lib.load().skf_gemm_relu_bits_bytes(Mr, N, K, _lib.default_precision()):
+        live = live[:Mr // rps].contiguous()
+        blocks = ops.row_blocks(live, rps, 16)
+        dyr = dy[:Mr].copy()
+        dyr.reshape(Mr // rps, rps, K)[:, 120:] = 0
+        bits_r = ops.relu_bits(Mr, N, K, "cuda")
+        hr = ops.gemm(_dev(x[:Mr]), _dev(w1), bias=_dev(b1), act=1, relu_bits_out=bits_r)
+        want = ops.gemm(_dev(dyr), w2t, a_kcontig=True, b_kcontig=True, relu_src=hr)
+        got = ops.gemm(_dev(dyr), w2t, a_kcontig=True, b_kcontig=True, relu_bits_in=bits_r, row_blocks=blocks, row_block_rows=16)
+        assert torch.equal(got, want)
+    # shapes without the path say so: size 0, and bits on such a launch are refused
+    assert _lib.load().skf_gemm_relu_bits_bytes(128, 64, 52, _lib.default_precision()) == 0
+    assert _lib.load().skf_gemm_relu_bits_bytes(M, N, K, 0) == 0
+
+
 @pytest.mark.parametrize("rows,inf,outf", [(25600, 128, 128), (25472, 128, 1004), (5000, 512, 128), (3000, 128, 384),
                                            (128, 128, 345), (999, 36, 52)])
 def test_gemm_wgrad_splitk_bias_grad(ops, rows, inf, outf):
