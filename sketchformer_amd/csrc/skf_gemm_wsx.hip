@@ -440,12 +440,12 @@ int launch_wsx(const GemmParams& p, int b_kc, hipStream_t st) {
   const size_t smem = (size_t)2 * P * TR * (2 * K + 32);
   dim3 grid(groups * workers), block(256);
   static const std::string tag = "gemm_wsx<K" + std::to_string(K) + ",CW" + std::to_string(CW) + ",bf16x" + std::to_string(P * (P + 1) / 2) + ">";
-  const bool extra = p.relu_src || p.accumulate;
+  const bool extra = p.relu_src || p.accumulate || p.relu_bits_in;
   GemmParams q = p;
   if (q.row_block_rows != TR) q.row_blocks = nullptr;       // the list's blocks must be this kernel's tiles
   // profiling: the dense figures, and the work of the live tiles only (A rows read / multiplied; every C row is still written)
   const double live = skf_prof_list_fraction(q.row_blocks);
-  const double a_c = (double)p.M * p.K + (double)p.M * p.N * ((p.accumulate ? 1 : 0) + (p.relu_src ? 1 : 0));
+  const double a_c = (double)p.M * p.K + (double)p.M * p.N * ((p.accumulate ? 1 : 0) + (p.relu_src && !p.relu_bits_in ? 1 : 0));
   SkfProfScope ps(st, tag.c_str(), 2.0 * p.M * p.N * p.K, 4.0 * (a_c + (double)p.K * p.N + (double)p.M * p.N));
   ps.done(2.0 * p.M * p.N * p.K * live, 4.0 * (a_c * live + (double)p.K * p.N + (double)p.M * p.N));
   // K >= 384 (N = 128): the two column groups of a worker read the same A tiles - XCD-contiguous ids keep the second read
