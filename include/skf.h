@@ -322,6 +322,14 @@ int skf_gemm_bf16_tile_rows(int M, int N, int K, int act);   /* 256 or 128: the 
 int skf_gemm_bf16_rows(int M, int N, int K, const void* A, int lda, const void* B_nk, int ldb, void* C, int ldc,
                        const float* bias, int act, const void* relu_src, int ld_relu, int accumulate, float* C_f32,
                        int ldc_f32, const int* row_list, int zero_dead, skf_stream_t stream);
+/* ReLU sign bits of the bf16 path (ffn: builders/layers/transformer.py:196-197): bit (n & 7) of byte [m][n >> 3] (row pitch
+ * ld_bits bytes) = "C[m][n] > 0".  A relu forward launch writes them (relu_bits_out), the input-gradient launch of the layer
+ * reads them (relu_bits_in) instead of the hidden tensor: same result, 1/16 of the bytes.  N must be a multiple of 8. */
+size_t skf_gemm_bf16_relu_bits_bytes(int M, int N);
+int skf_gemm_bf16_bits(int M, int N, int K, const void* A, int lda, const void* B_nk, int ldb, void* C, int ldc,
+                       const float* bias, int act, const void* relu_src, int ld_relu, int accumulate, float* C_f32, int ldc_f32,
+                       const int* row_list, int zero_dead, void* relu_bits_out, const void* relu_bits_in, int ld_bits,
+                       skf_stream_t stream);
 int skf_gemm_bf16_wgrad_partial_rows(int P, int Q, int R, const void* X, int ldx, const void* dY, int lddy, int splits,
                                      int with_bias_grad, float* slab, size_t slab_bytes, int* splits_used_host,
                                      const int* row_blocks_64, skf_stream_t stream);

@@ -124,6 +124,8 @@ SIGNATURES = {
     "skf_gemm_bf16": (_I, [_I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I, _P]),
     "skf_gemm_bf16_tile_rows": (_I, [_I, _I, _I, _I]),
     "skf_gemm_bf16_rows": (_I, [_I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I, _P, _I, _P]),
+    "skf_gemm_bf16_relu_bits_bytes": (_Z, [_I, _I]),
+    "skf_gemm_bf16_bits": (_I, [_I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I, _P, _I, _P, _P, _I, _P]),
     "skf_gemm_bf16_wgrad_rows": (_I, [_I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _Z, _P, _P]),
     "skf_gemm_bf16_wgrad_partial_rows": (_I, [_I, _I, _I, _P, _I, _P, _I, _I, _I, _P, _Z, _P, _P, _P]),
     "skf_gemm_bf16_wgrad_splits": (_I, [_I, _I, _I]),

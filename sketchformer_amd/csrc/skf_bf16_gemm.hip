@@ -39,7 +39,22 @@ struct NtParams {
   int wide_c;                   // C (and relu_src) rows are 16-byte aligned: the epilogue moves 16-byte pieces
   const int* row_blocks;        // live-ROW list (skf_row_blocks_build with granule 1: {n_live, M, live rows, dead rows, flags}) or null:
   int zero_dead;                //   the m tiles run over the compacted live rows; dead rows of C are zero-filled if zero_dead
+  // ReLU sign bits, row-major: bit (n & 7) of byte [m][n >> 3] (row pitch ld_bits bytes) = "C[m][n] > 0".  A relu forward launch
+  // writes them (bits_out), the input-gradient launch reads them (bits_in) instead of the 16-fold larger hidden tensor.
+  unsigned char* bits_out; const unsigned char* bits_in; int ld_bits;
 };
+
+// bit e of the result = element e of the 8 packed bf16 is > 0 (after a relu a stored value is +0 or positive)
+__device__ __forceinline__ unsigned nt_sign_byte(const uint4& w) {
+  const unsigned d[4] = {w.x, w.y, w.z, w.w};
+  unsigned m = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    m |= ((d[j] & 0x7fffu) != 0u && !(d[j] & 0x8000u)) ? (1u << (2 * j)) : 0u;
+    m |= ((d[j] & 0x7fff0000u) != 0u && !(d[j] & 0x80000000u)) ? (2u << (2 * j)) : 0u;
+  }
+  return m;
+}
 
 // ---- LDS images.  nt: a tile row = 64 bf16 = 128 B; two rows share a 256-byte super-row and the 16-byte chunk slot is
 // XOR-ed with the super-row index, so the 16 lanes of a ds_read_b128 group (16 consecutive rows, one logical chunk) hit
@@ -282,7 +297,11 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_bf16_nt_kernel(NtPara
     for (int it = 0; it < MT * 4; ++it) pr[it] = prow(m0 + wm * (MT * 32) + it * 8 + orow);
     if constexpr (EXTRA) {
       uint4 hv[MT * 4], ov[MT * 4];
-      if (p.relu_src) {
+      unsigned bv[MT * 4];
+      if (p.bits_in) {
+#pragma unroll
+        for (int it = 0; it < MT * 4; ++it) bv[it] = p.bits_in[(size_t)pr[it] * p.ld_bits + (n >> 3)];
+      } else if (p.relu_src) {
 #pragma unroll
         for (int it = 0; it < MT * 4; ++it) hv[it] = *reinterpret_cast<const uint4*>(p.relu_src + (size_t)pr[it] * p.ld_relu + n);
       }
@@ -295,7 +314,10 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_bf16_nt_kernel(NtPara
         uint4 w = *reinterpret_cast<const uint4*>(ew + (it * 8 + orow) * EP + och * 16);
         float v[8];
         skf_unpack8(w, v);
-        if (p.relu_src) {
+        if (p.bits_in) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = ((bv[it] >> e) & 1u) ? v[e] : 0.f;
+        } else if (p.relu_src) {
           float h[8]; skf_unpack8(hv[it], h);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = h[e] > 0.f ? v[e] : 0.f;
@@ -309,8 +331,11 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_bf16_nt_kernel(NtPara
       }
     } else {
 #pragma unroll
-      for (int it = 0; it < MT * 4; ++it)
-        *reinterpret_cast<uint4*>(p.C + (size_t)pr[it] * p.ldc + n) = *reinterpret_cast<const uint4*>(ew + (it * 8 + orow) * EP + och * 16);
+      for (int it = 0; it < MT * 4; ++it) {
+        const uint4 w = *reinterpret_cast<const uint4*>(ew + (it * 8 + orow) * EP + och * 16);
+        *reinterpret_cast<uint4*>(p.C + (size_t)pr[it] * p.ldc + n) = w;
+        if (p.bits_out) p.bits_out[(size_t)pr[it] * p.ld_bits + (n >> 3)] = (unsigned char)nt_sign_byte(w);
+      }
     }
     return;
   }
@@ -322,10 +347,15 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_bf16_nt_kernel(NtPara
     uint4 w = *reinterpret_cast<const uint4*>(ew + rloc * EP + och * 16);
     const bool full = n + 8 <= p.N;                      // else the chunk's first 4 columns only
     skf_bf16* cp = p.C + (size_t)pm * p.ldc + n;
+    if (!EXTRA && p.bits_out) p.bits_out[(size_t)pm * p.ld_bits + (n >> 3)] = (unsigned char)nt_sign_byte(w);   // (columns past N: relu(0 + 0) = 0)
     if constexpr (EXTRA) {
       float v[8];
       skf_unpack8(w, v);
-      if (p.relu_src) {
+      if (p.bits_in) {
+        const unsigned bvv = p.bits_in[(size_t)pm * p.ld_bits + (n >> 3)];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = ((bvv >> e) & 1u) ? v[e] : 0.f;
+      } else if (p.relu_src) {
         const skf_bf16* hp = p.relu_src + (size_t)pm * p.ld_relu + n;
         uint4 hv;
         if (wide && full) hv = *reinterpret_cast<const uint4*>(hp);
@@ -651,6 +681,21 @@ extern "C" int skf_gemm_bf16(int M, int N, int K, const void* A, int lda, const 
 extern "C" int skf_gemm_bf16_rows(int M, int N, int K, const void* A, int lda, const void* B_nk, int ldb, void* C, int ldc,
                                   const float* bias, int act, const void* relu_src, int ld_relu, int accumulate, float* C_f32,
                                   int ldc_f32, const int* row_list, int zero_dead, skf_stream_t stream) {
+  return skf_gemm_bf16_bits(M, N, K, A, lda, B_nk, ldb, C, ldc, bias, act, relu_src, ld_relu, accumulate, C_f32, ldc_f32, row_list, zero_dead,
+                            nullptr, nullptr, 0, stream);
+}
+
+extern "C" size_t skf_gemm_bf16_relu_bits_bytes(int M, int N) { return (N & 7) ? 0 : (size_t)M * (N >> 3); }
+
+extern "C" int skf_gemm_bf16_bits(int M, int N, int K, const void* A, int lda, const void* B_nk, int ldb, void* C, int ldc,
+                                  const float* bias, int act, const void* relu_src, int ld_relu, int accumulate, float* C_f32,
+                                  int ldc_f32, const int* row_list, int zero_dead, void* relu_bits_out, const void* relu_bits_in,
+                                  int ld_bits, skf_stream_t stream) {
+  if (relu_bits_out || relu_bits_in) {
+    SKF_CHECK_ARG((N & 7) == 0 && ld_bits >= (N >> 3), "ReLU sign bits: N must be a multiple of 8 and the row pitch >= N / 8 bytes");
+    SKF_CHECK_ARG(!relu_bits_out || (act == 1 && !relu_src && !accumulate && !C_f32), "sign bits are written by a plain relu forward launch");
+    SKF_CHECK_ARG(!relu_bits_in || (act == 0 && !C_f32), "sign bits are read by an input-gradient launch (no activation, no fp32 copy)");
+  }
   SKF_CHECK_ARG(!row_list || !bias, "a live-row list goes with the dgrad form (no bias: dead rows must come out as zeros)");
   SKF_CHECK_ARG(M > 0 && N > 0 && K > 0 && A && B_nk && C, "bad problem");
   SKF_CHECK_ARG(act >= 0 && act <= 2, "bad activation");
@@ -666,7 +711,8 @@ extern "C" int skf_gemm_bf16_rows(int M, int N, int K, const void* A, int lda, c
   p.bias = bias; p.act = act; p.relu_src = (const skf_bf16*)relu_src; p.ld_relu = ld_relu; p.accumulate = accumulate;
   p.C32 = C_f32; p.ldc32 = ldc_f32;
   hipStream_t st = (hipStream_t)stream;
-  const bool extra = relu_src || accumulate || C_f32;
+  p.bits_out = (unsigned char*)relu_bits_out; p.bits_in = (const unsigned char*)relu_bits_in; p.ld_bits = ld_bits;
+  const bool extra = relu_src || accumulate || C_f32 || relu_bits_in;
   // SKF_BF16_GEMM_DMA=0: register-staged tiles everywhere; SKF_BF16_GEMM_TILE=128: no 256 x 256 tiles (measurement knobs)
   static const bool dma_off = getenv("SKF_BF16_GEMM_DMA") && getenv("SKF_BF16_GEMM_DMA")[0] == '0';
   const bool dma = (K & 63) == 0 && !dma_off;
@@ -677,7 +723,7 @@ extern "C" int skf_gemm_bf16_rows(int M, int N, int K, const void* A, int lda, c
   p.wide_c = (ldc & 7) == 0 && ((uintptr_t)C & 15) == 0 && (!relu_src || ((ld_relu & 7) == 0 && ((uintptr_t)relu_src & 15) == 0));
   const size_t smem = big ? 8 * 128 * 144 : 65536;      // the epilogue's wave-private images (144-byte rows) exceed the 128 KB of tile buffers
   const double live = skf_prof_list_fraction(row_list);      // live rows of A that are loaded and multiplied (C is written in full)
-  const double a_c = (double)M * K + (double)M * N * ((accumulate ? 1 : 0) + (relu_src ? 1 : 0));
+  const double a_c = (double)M * K + (double)M * N * ((accumulate ? 1 : 0) + (relu_src && !relu_bits_in ? 1 : 0) + (relu_bits_in ? 1.0 / 16 : 0.0));
   SkfProfScope ps(st, "gemm_bf16_nt", 2.0 * M * N * K, 2.0 * (a_c + (double)N * K + (double)M * N));
   ps.done(2.0 * M * N * K * live, 2.0 * (a_c * live + (double)N * K + (double)M * N));
   int rc;
