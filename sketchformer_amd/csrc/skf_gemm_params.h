@@ -36,6 +36,11 @@ struct GemmParams {
   // re-reading the hidden tensor (52 MB per launch at the cfg-2 size -> 1.6 MB)
   unsigned long long* relu_bits_out;
   const unsigned long long* relu_bits_in;
+  // Last slice of a contraction that is not a multiple of the kernel's K (the logits input gradient: K = vocabulary = 1004 =
+  // 512 + 492): the launch runs with K = 512, weight elements k >= k_valid count as zeros and the A rows are read up to
+  // a_cut bytes short of the matrix end (the columns behind k_valid of a row are whatever follows it - the next row -
+  // multiplied by those zeros; behind the last row they are out of the descriptor's range and read as 0).  0 = plain launch.
+  int k_valid, a_cut;
 };
 
 // weight-stationary fast path; sets *handled when it launched the problem

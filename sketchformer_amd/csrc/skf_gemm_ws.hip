@@ -346,13 +346,32 @@ int skf_gemm_ws_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, hipS
   // accumulating into C - only without an epilogue that must see the complete sum (activation, relu mask)
   const bool single = p.K == 128 || p.K == 256 || p.K == 384 || p.K == 512;
   const bool chain = !single && p.K > 512 && p.K <= 2048 && (p.K & 127) == 0 && p.act == 0 && !p.relu_src;
-  if (!single && !chain) return SKF_OK;
+  // Input-gradient form with any K % 4 == 0 up to 2048 (the logits layer: K = vocabulary = 1004), split arithmetic only: 512-deep
+  // slices, the last one masked (GemmParams::k_valid).  SKF_NO_MASKED_CHAIN=1 keeps such shapes on the generic kernel.
+  static const bool masked_off = getenv("SKF_NO_MASKED_CHAIN") && getenv("SKF_NO_MASKED_CHAIN")[0] == '1';
+  const bool fits32m = (double)p.M * p.lda * 4 < 2147483648.0 && (double)p.M * p.ldc * 4 < 2147483648.0;
+  const bool chain_masked = !single && !chain && !masked_off && b_kcontig && p.precision != SKF_PREC_F32 && fits32m && p.K > 512 &&
+                            p.K <= 2048 && (p.K & 3) == 0 && p.act == 0 && !p.relu_src && !p.relu_bits_in && !p.relu_bits_out && !p.bias;
+  if (!single && !chain && !chain_masked) return SKF_OK;
   if ((p.N & 3) || (p.lda & 3) || (p.ldc & 3) || ((uintptr_t)p.A & 15) || ((uintptr_t)p.C & 15)) return SKF_OK;
   if (b_kcontig && ((p.ldb & 3) || ((uintptr_t)p.B & 15))) return SKF_OK;
   if (!b_kcontig && ((p.ldb & 1) || ((uintptr_t)p.B & 7))) return SKF_OK;   // NB-wide loads along n
   if (p.relu_src && ((p.ld_relu & 3) || ((uintptr_t)p.relu_src & 15))) return SKF_OK;
   *handled = 1;
   if (single) return ws_launch_one(p, b_kcontig, st);
+  if (chain_masked) {
+    for (int k0 = 0; k0 < p.K; k0 += 512) {
+      GemmParams q = p;
+      q.K = 512;
+      q.A = p.A + k0;
+      q.B = p.B + k0;
+      if (k0 > 0) q.accumulate = 1;
+      if (p.K - k0 < 512) { q.k_valid = p.K - k0; q.a_cut = k0 * 4; }
+      const int rc = skf_gemm_wsx_launch(q, 1, p.precision == 3 ? 2 : 3, st);
+      if (rc != SKF_OK) return rc;
+    }
+    return SKF_OK;
+  }
   for (int k0 = 0; k0 < p.K;) {
     const int left = p.K - k0, kc = left >= 512 ? 512 : left;       // left is a multiple of 128 below 512: 128 / 256 / 384
     GemmParams q = p;

@@ -50,9 +50,9 @@ template <> struct VecOfX<4> { typedef f32x4 type; typedef u32x4 utype; };
 // Descriptor over the rows [row0, M) of a row-major matrix.  The launcher guarantees M * ld * 4 < 2^31 (checked on the
 // host), so the byte counts are 32-bit SALU arithmetic: 8 scalar instructions per descriptor instead of 23 with the
 // 64-bit clamps (two to four descriptors per tile).
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t wsx_rows_rsrc(const float* base, int ld, int M, int row0) {
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wsx_rows_rsrc(const float* base, int ld, int M, int row0, int cut = 0) {
   const int rows_left = M - row0 > 0 ? M - row0 : 0;
-  const unsigned rem = (unsigned)rows_left * (unsigned)ld * 4u;
+  const unsigned rem = rows_left > 0 ? (unsigned)rows_left * (unsigned)ld * 4u - (unsigned)cut : 0u;
   const unsigned off = rows_left > 0 ? (unsigned)row0 * (unsigned)ld * 4u : 0u;   // empty descriptor: any valid base
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(base) + off), 0, rem, 0x00020000);
 }
@@ -75,11 +75,11 @@ template <int P> __device__ __forceinline__ void split2(float x, float y, unsign
 
 template <int K>
 __device__ __forceinline__ void wsx_load_tile(const float* __restrict__ A, int lda, int M, int tile,
-                                              const unsigned (&a_voff)[TR * K / 1024], f32x4 (&ra)[TR * K / 1024]) {
+                                              const unsigned (&a_voff)[TR * K / 1024], f32x4 (&ra)[TR * K / 1024], int cut = 0) {
 #ifdef SKF_WSX_ABLATE_LOAD   // diagnostics: every A tile load hits the same (cached) rows
   tile &= 7;
 #endif
-  const __amdgpu_buffer_rsrc_t r = wsx_rows_rsrc(A, lda, M, tile * TR);
+  const __amdgpu_buffer_rsrc_t r = wsx_rows_rsrc(A, lda, M, tile * TR, cut);
 #pragma unroll
   for (int v = 0; v < TR * K / 1024; ++v)
     ra[v] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, a_voff[v], 0, 0));
@@ -100,7 +100,7 @@ __device__ __forceinline__ void wsx_store_tile(char* __restrict__ dst, const f32
   }
 }
 
-template <int K, int NB, int P, bool B_KC, bool EXTRA>
+template <int K, int NB, int P, bool B_KC, bool EXTRA, bool KMASK = false>
 __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_kernel(GemmParams p, int groups, int workers) {
   constexpr int CW = 16 * NB;            // columns per wave
   constexpr int NKS = K / 32;            // MFMA k-steps per tile
@@ -162,8 +162,9 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
   // takes ~1.2k cycles, and a global load under a busy chip 3-4k.
   f32x4 ra[R][NV];
   int tile = worker;
+  const int a_cut = KMASK ? p.a_cut : 0;
 #pragma unroll
-  for (int j = 0; j < R; ++j) wsx_load_tile<K>(p.A, p.lda, p.M, phys(tile + j * workers), a_voff, ra[j]);
+  for (int j = 0; j < R; ++j) wsx_load_tile<K>(p.A, p.lda, p.M, phys(tile + j * workers), a_voff, ra[j], a_cut);
 
   // ---- weight slice -> split bf16 operands (once): bq[nb][s][q] = pieces q of B[k = 32s + 8g + e][n_lane + nb], e < 8
   u32x4 bq[NB][NKS][P];
@@ -175,7 +176,12 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
       for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(p.B + (size_t)(n_ld + nb) * p.ldb + 32 * s + 8 * g + 4 * h);
+          const int k4 = 32 * s + 8 * g + 4 * h;
+          // KMASK: k_valid is a multiple of 4, so a 4-vector is all in or all out; out ones re-read the last valid vector (no
+          // access behind the weight row) and count as zeros
+          const int kl = KMASK ? (k4 < p.k_valid ? k4 : p.k_valid - 4) : k4;
+          f32x4 v = *reinterpret_cast<const f32x4*>(p.B + (size_t)(n_ld + nb) * p.ldb + kl);
+          if (KMASK && k4 >= p.k_valid) v = (f32x4){0.f, 0.f, 0.f, 0.f};
           f[nb][4 * h + 0] = v[0]; f[nb][4 * h + 1] = v[1]; f[nb][4 * h + 2] = v[2]; f[nb][4 * h + 3] = v[3];
         }
     } else {
@@ -203,7 +209,7 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
   SKF_STAMP();   // weight slice loaded + split
   wsx_store_tile<K, P, PITCH>(As, ra[0], sel);
   __syncthreads();
-  wsx_load_tile<K>(p.A, p.lda, p.M, phys(tile + R * workers), a_voff, ra[0]);
+  wsx_load_tile<K>(p.A, p.lda, p.M, phys(tile + R * workers), a_voff, ra[0], a_cut);
   SKF_STAMP();   // first A tile in LDS
 
   vecn cprev[4], hsrc[4], oacc[4];
@@ -310,7 +316,7 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
       if (s == NKS / 2 - 1) {
         SKF_WSX_SCHED_BARRIER();
         wsx_store_tile<K, P, PITCH>(As + (cur ^ 1) * TILE_B, rn, sel);
-        wsx_load_tile<K>(p.A, p.lda, p.M, phys(tile + (R + 1) * workers), a_voff, rn);
+        wsx_load_tile<K>(p.A, p.lda, p.M, phys(tile + (R + 1) * workers), a_voff, rn, a_cut);
         if (EXTRA) {
           const int ptile = phys(tile);
           const __amdgpu_buffer_rsrc_t rh = wsx_rows_rsrc(has_relu ? p.relu_src : p.C, p.ld_relu, has_relu ? p.M : 0, ptile * TR);
@@ -464,6 +470,20 @@ int launch_wsx(const GemmParams& p, int b_kc, hipStream_t st) {
     }                                                                                                              \
     hipLaunchKernelGGL((gemm_wsx_kernel<K, NB, P, BKC, EX>), grid, block, smem, st, q, groups, workers);           \
   } while (0)
+  if constexpr (K == 512 && NB == 1) {
+    if (q.k_valid > 0) {       // masked last slice of a long contraction (dgrad form only: skf_gemm_ws_dispatch)
+      static bool attr_m[2] = {false, false};
+      if (!attr_m[extra ? 1 : 0]) {
+        if (extra) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wsx_kernel<K, NB, P, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wsx_kernel<K, NB, P, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_m[extra ? 1 : 0] = true;
+      }
+      if (extra) hipLaunchKernelGGL((gemm_wsx_kernel<K, NB, P, true, true, true>), grid, block, smem, st, q, groups, workers);
+      else hipLaunchKernelGGL((gemm_wsx_kernel<K, NB, P, true, false, true>), grid, block, smem, st, q, groups, workers);
+      SKF_LAUNCH_CHECK();
+      return SKF_OK;
+    }
+  }
   if (b_kc && extra) SKF_WSX_LAUNCH(true, true);
   else if (b_kc) SKF_WSX_LAUNCH(true, false);
   else if (extra) SKF_WSX_LAUNCH(false, true);

@@ -54,6 +54,31 @@ def test_gemm_dgrad_relu_mask_accumulate(ops, M, N, K):
     _close(out, c0 + dy @ w.T, name="dgrad accumulate")
 
 
+@pytest.mark.parametrize("M,N,K", [(25472, 128, 1004), (3000, 128, 1004), (2048, 256, 516), (1500, 128, 2044)])
+def test_gemm_dgrad_masked_last_slice(ops, M, N, K):
+    """Input gradient with a contraction that is no multiple of 128 (the logits layer: K = V = 1004): 512-deep slices on the
+    split-arithmetic weight-stationary kernel, the last one with its surplus weight columns counted as zeros and the A rows read
+    past their end (the next row's values times those zeros; nothing behind the last row).  Plain, accumulating, and over a
+    live-row-block list; a NaN-free neighbour is all the over-read needs."""
+    rng = np.random.RandomState(M + N + K)
+    dy, w, c0 = rng.randn(M, K), rng.randn(N, K) / np.sqrt(K), rng.randn(M, N)
+    got = ops.gemm(_dev(dy), _dev(w), a_kcontig=True, b_kcontig=True)
+    _close(got, dy @ w.T, name="dgrad K=%d" % K)
+    out = _dev(c0)
+    ops.gemm(_dev(dy), _dev(w), a_kcontig=True, b_kcontig=True, out=out, accumulate=True)
+    _close(out, c0 + dy @ w.T, name="dgrad K=%d accumulate" % K)
+    rps = 199
+    if M % rps == 0:
+        live = torch.from_numpy(rng.randint(8, rps, size=M // rps).astype(np.int32)).cuda()
+        blocks = ops.row_blocks(live, rps, 16)
+        dyr = dy.copy().reshape(M // rps, rps, K)
+        for b, n in enumerate(live.cpu().numpy()):
+            dyr[b, n:] = 0
+        dyr = dyr.reshape(M, K)
+        got = ops.gemm(_dev(dyr), _dev(w), a_kcontig=True, b_kcontig=True, row_blocks=blocks, row_block_rows=16)
+        _close(got, dyr @ w.T, name="dgrad K=%d over live row blocks" % K)
+
+
 @pytest.mark.parametrize("M,N,K", [(25600, 512, 128), (5000, 1024, 256), (3001, 132, 128), (4096, 512, 512)])
 def test_gemm_relu_sign_bits(ops, M, N, K):
     """ffn backward without re-reading the hidden tensor: the relu forward launch leaves one sign bit per output element in the
