@@ -563,8 +563,9 @@ int set_smem(K kfn, size_t bytes) {
   return SKF_OK;
 }
 
+inline bool mfma_head(int dh) { return dh == 16 || dh == 32 || dh == 64; }
 int check_common(const AttnParams& p, int dh) {
-  SKF_CHECK_ARG(dh == 16 || dh == 32 || dh == 64, "head dim must be 16, 32 or 64");
+  SKF_CHECK_ARG(mfma_head(dh) || skf_attention_any_supported(dh, p.Lq, p.Lk), "head dim must be 16, 32, 64 (MFMA kernels) or any size <= 128 with sequences <= 1024 (fallback)");
   SKF_CHECK_ARG(p.B > 0 && p.H > 0 && p.Lq > 0 && p.Lk > 0, "empty problem");
   SKF_CHECK_ARG((p.ldq & 3) == 0 && (p.ldk & 3) == 0 && (p.ldv & 3) == 0 && (p.ldo & 3) == 0, "row strides must be multiples of 4");
   SKF_CHECK_ARG(!p.causal || p.Lq == p.Lk, "causal attention needs Lq == Lk");
@@ -583,6 +584,7 @@ extern "C" int skf_attention_fwd(const float* Q, int ldq, const float* K, int ld
   int rc = check_common(p, dh);
   if (rc) return rc;
   SKF_CHECK_ARG(Q && K && V && O, "null operand");
+  if (!mfma_head(dh)) return skf_attention_fwd_any(p, dh, (hipStream_t)stream);
   SKF_CHECK_ARG(Lk <= 512, "Lk > 512 not supported");
   // S^T on the bf16 pipe follows the Dense arithmetic switch (SKF_ATTN_SPLIT=0 turns it off).  With padded 48-byte plane
   // rows it removed 26 % of the MFMA cycles and changed nothing (the forward is wait-bound: 45 % of the wave cycles parked,
@@ -641,6 +643,7 @@ extern "C" int skf_attention_bwd_rows(const float* Q, int ldq, const float* K, i
   if (rc) return rc;
   SKF_CHECK_ARG(Q && K && V && O && dO && stats && dQ && dK && dV, "null operand");
   SKF_CHECK_ARG((lddo & 3) == 0 && (lddq & 3) == 0 && (lddk & 3) == 0 && (lddv & 3) == 0, "row strides must be multiples of 4");
+  if (!mfma_head(dh)) return skf_attention_bwd_any(p, dh, (hipStream_t)stream);
   // head size 16 / 32 in the split arithmetic modes: the two-pass kernel on the bf16 matrix cores (skf_attention_bwd2.hip);
   // SKF_PREC_F32 keeps the fp32-MFMA kernel below (SKF_ATTN_BWD2=0 forces it)
   // Head size 16: only the causal (decoder self-attention) calls take it - measured at the cfg-2 shape, the one-pass kernel

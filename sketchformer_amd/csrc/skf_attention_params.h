@@ -23,3 +23,8 @@ struct AttnParams {
 
 // two-pass backward on the bf16 matrix cores with exactly split fp32 operands (head size 16 or 32); returns SKF_OK after launching
 int skf_attention_bwd2_launch(const AttnParams& p, int dh, hipStream_t st);
+
+// any head size <= 128 / sequence <= 1024 (skf_generic.hip): plain fp32 FMA kernels, the same semantics and statistics
+int skf_attention_any_supported(int dh, int Lq, int Lk);
+int skf_attention_fwd_any(const AttnParams& p, int dh, hipStream_t st);
+int skf_attention_bwd_any(const AttnParams& p, int dh, hipStream_t st);

@@ -104,6 +104,56 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
   if (lane < DH) p.O[(size_t)b * p.ldo + h * DH + lane] = mine;
 }
 
+// The same for any head size % 4 == 0 up to 128 (skf_generic.hip serves such models; every BASELINE config has 16 / 32 / 64):
+// query and probabilities in wave-private LDS, lanes over the keys for the scores and over the head columns for the output.
+__global__ __launch_bounds__(256) void attn_decode_any_kernel(AttnDecodeParams p, int DH) {
+  __shared__ float qs[4][128];
+  __shared__ float ps[4][512];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bh_ = blockIdx.x * 4 + wave;
+  const bool active = bh_ < p.B * p.H;
+  const int bh = active ? bh_ : 0;
+  const int b = bh / p.H, h = bh % p.H;
+  const int step = p.step_dev ? *p.step_dev : 0;
+  const int Lk = p.K_new ? step + 1 : p.Lk;
+  for (int c = lane; c < DH; c += 64) qs[wave][c] = p.Q[(size_t)b * p.ldq + h * DH + c];
+  const float* Kb = p.K + (size_t)b * p.kv_bs + h * DH;
+  const float* Vb = p.V + (size_t)b * p.kv_bs + h * DH;
+  int limit = p.key_limit ? p.key_limit[b] : (p.key_limit_all > 0 ? p.key_limit_all : 0x7fffffff);
+  if (p.limit_from_step && (!p.key_limit || limit < 0)) limit = step + 1;
+  const int jn = p.K_new ? Lk - 1 : -1;
+  const float* Kn = p.K_new ? p.K_new + (size_t)b * p.ld_new + h * DH : nullptr;
+  const float* Vn = p.V_new ? p.V_new + (size_t)b * p.ld_new + h * DH : nullptr;
+  if (active && p.K_new)
+    for (int c = lane; c < DH; c += 64) {
+      p.K_cache[(size_t)b * p.kv_bs + (size_t)jn * p.ld_kv + h * DH + c] = Kn[c];
+      p.V_cache[(size_t)b * p.kv_bs + (size_t)jn * p.ld_kv + h * DH + c] = Vn[c];
+    }
+  __syncthreads();
+  const float scale_div = sqrtf((float)DH);
+  float mx = -INFINITY;
+  for (int j = lane; j < Lk; j += 64) {
+    const float* kr = j == jn ? Kn : Kb + (size_t)j * p.ld_kv;
+    float dot = 0.f;
+    for (int c = 0; c < DH; ++c) dot += qs[wave][c] * kr[c];
+    const bool masked = (p.key_mask && p.key_mask[(size_t)b * p.key_mask_ld + j]) || j >= limit;
+    const float v = dot / scale_div + (masked ? -1e9f : 0.f);
+    ps[wave][j] = v;
+    mx = fmaxf(mx, v);
+  }
+  mx = wave_max(mx);
+  float se = 0.f;
+  for (int j = lane; j < Lk; j += 64) { const float e = __expf(ps[wave][j] - mx); ps[wave][j] = e; se += e; }
+  se = wave_sum(se);
+  const float rinv = 1.0f / se;
+  __syncthreads();
+  for (int c = lane; c < DH; c += 64) {
+    float acc = 0.f;
+    for (int j = 0; j < Lk; ++j) acc += ps[wave][j] * (j == jn ? Vn[c] : Vb[(size_t)j * p.ld_kv + c]);
+    if (active) p.O[(size_t)b * p.ldo + h * DH + c] = acc * rinv;
+  }
+}
+
 // Token mode, after step `step` produced the logits of position `step`:
 //   next = argmax (first index on ties, tf.argmax) -> tokens[b][step+1]; self-mask byte = (next == PAD);
 //   EOS flags are sticky; done_step = first step after which every one of the n_valid samples has emitted an EOS.
@@ -227,7 +277,7 @@ extern "C" int skf_attention_decode(const float* Q, int ldq, const float* K, con
                                     int limit_from_step, skf_stream_t stream) {
   SKF_CHECK_ARG(Q && K && V && O, "null operand");
   SKF_CHECK_ARG(B > 0 && H > 0 && Lk > 0 && Lk <= 512, "need 0 < Lk <= 512");
-  SKF_CHECK_ARG(dh == 16 || dh == 32 || dh == 64, "head size must be 16, 32 or 64");
+  SKF_CHECK_ARG(dh > 0 && dh <= 128 && (dh & 3) == 0, "head size must be a multiple of 4, at most 128");
   SKF_CHECK_ARG((ldq & 3) == 0 && (ld_kv & 3) == 0 && (kv_batch_stride & 3) == 0 &&
                 (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) == 0, "Q/K/V must allow 16-byte row loads");
   SKF_CHECK_ARG((K_new == nullptr) == (V_new == nullptr), "K_new and V_new go together");
@@ -242,7 +292,8 @@ extern "C" int skf_attention_decode(const float* Q, int ldq, const float* K, con
 #define SKF_AD(DHV)                                                                         \
   { if (Lk <= 256) hipLaunchKernelGGL((attn_decode_kernel<DHV, 4>), grid, block, 0, st, p);   \
     else hipLaunchKernelGGL((attn_decode_kernel<DHV, 8>), grid, block, 0, st, p); }
-  if (dh == 16) SKF_AD(16) else if (dh == 32) SKF_AD(32) else SKF_AD(64)
+  if (dh == 16) SKF_AD(16) else if (dh == 32) SKF_AD(32) else if (dh == 64) SKF_AD(64)
+  else hipLaunchKernelGGL(attn_decode_any_kernel, grid, block, 0, st, p, dh);
 #undef SKF_AD
   SKF_LAUNCH_CHECK();
   return SKF_OK;

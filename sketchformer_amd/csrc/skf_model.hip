@@ -393,7 +393,7 @@ Plan build_plan(const SkfConfig& c) {
   if (2 * B * L * f > s) s = 2 * B * L * f;
   if (c.continuous && skf_embed_continuous_bwd_workspace_bytes((int)Me, (int)d) > s) s = skf_embed_continuous_bwd_workspace_bytes((int)Me, (int)d);
   P.small_ws_bytes = s; P.small_ws = b.take(s);
-  if (!c.continuous && c.vocab_size <= 12288 && !getenv("SKF_NO_EMBED_SORT")) {
+  if (!c.continuous && c.vocab_size <= 12288 && c.d_model <= 512 && !getenv("SKF_NO_EMBED_SORT")) {   // (the sorted kernel's partial slab is sized for rows of <= 512 floats)
     P.emb_sort_bytes = (skf_embed_sort_workspace_bytes((int)B, (int)L, c.vocab_size) + 255) & ~(size_t)255;
     P.emb_sort[0] = b.take(P.emb_sort_bytes); P.emb_sort[1] = b.take(P.emb_sort_bytes);
   }
@@ -1331,17 +1331,21 @@ extern "C" int skf_config_validate(const SkfConfig* c) {
   SKF_CHECK_ARG(c->batch > 0 && c->seq_len > 1 && c->num_layers > 0, "bad sizes");
   SKF_CHECK_ARG(c->d_model % c->num_heads == 0, "d_model must be divisible by num_heads");
   const int dh = c->d_model / c->num_heads;
-  if (!(dh == 16 || dh == 32 || dh == 64)) { skf_set_error("head dim %d not in {16,32,64}", dh); return SKF_EUNSUPPORTED; }
-  if (!(c->d_model == 64 || c->d_model == 128 || c->d_model == 256 || c->d_model == 512)) {
-    skf_set_error("d_model %d not in {64,128,256,512}", c->d_model); return SKF_EUNSUPPORTED; }
+  // Any d_model % num_heads == 0 like the reference (builders/layers/transformer.py:150-152).  The MFMA kernels serve d_model in
+  // {64,128,256,512} with head sizes {16,32,64} (every BASELINE config); other shapes run on the plain fp32 kernels of
+  // skf_generic.hip (LayerNorm, expander, attention) and the generic GEMM.  Limits of those: d_model % 4 == 0 and
+  // head size % 4 == 0 (16-byte rows and head slices), d_model <= 1024, head size <= 128.
+  if ((c->d_model & 3) || c->d_model > 1024 || dh > 128 || (dh & 3)) {
+    skf_set_error("d_model %d / head size %d: need d_model %% 4 == 0, d_model <= 1024, head size %% 4 == 0, head size <= 128", c->d_model, dh);
+    return SKF_EUNSUPPORTED; }
   SKF_CHECK_ARG(c->attn_version == 1 || c->attn_version == 2, "attn_version must be 1 (SelfAttnV1) or 2 (SelfAttnV2)");
   SKF_CHECK_ARG(c->lowerdim >= 0, "lowerdim must be >= 0");
   // models/sketchformer.py:96-108,338: the class head only exists with a bottleneck; asking for it without one fails
   // in the reference too (the 'class' loss is never registered)
   SKF_CHECK_ARG(c->lowerdim > 0 || !c->do_classification, "do_classification needs lowerdim > 0");
   SKF_CHECK_ARG(c->do_reconstruction || (c->lowerdim > 0 && c->do_classification), "nothing to train: no decoder and no class head");
-  if (c->lowerdim > 0 && c->attn_version == 2 && !(c->lowerdim == 64 || c->lowerdim == 128 || c->lowerdim == 256 || c->lowerdim == 512)) {
-    skf_set_error("attn_version=2: lowerdim %d (the embedding width) not in {64,128,256,512}", c->lowerdim); return SKF_EUNSUPPORTED; }
+  if (c->lowerdim > 0 && c->attn_version == 2 && ((c->lowerdim & 3) || c->lowerdim > 1024)) {
+    skf_set_error("attn_version=2: lowerdim %d (the embedding width) must be a multiple of 4, at most 1024", c->lowerdim); return SKF_EUNSUPPORTED; }
   SKF_CHECK_ARG(c->class_buffer_layers >= 0 && c->class_buffer_layers <= 8, "class_buffer_layers must be in [0, 8]");
   SKF_CHECK_ARG(c->class_dropout >= 0.f && c->class_dropout < 1.f, "class_dropout out of range");
   SKF_CHECK_ARG(c->optimizer == 0 || c->optimizer == 1, "optimizer must be 0 (Adam) or 1 (SGD with momentum)");

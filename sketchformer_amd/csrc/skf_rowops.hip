@@ -25,6 +25,12 @@ __device__ __forceinline__ float2 skf_ld2(const skf_bf16* p, size_t i) {
 #ifndef SKF_LN_UR
 #define SKF_LN_UR 1            // row groups in flight per wave iteration (2 measured 0.3-0.5 us slower per launch in the step)
 #endif
+#ifndef SKF_LN_BWD_THREADS
+#define SKF_LN_BWD_THREADS 256 // threads per workgroup of the LayerNorm backward: more waves per workgroup = more bytes in flight per CU
+#endif                         // at the same number of dgamma / dbeta partial rows (one per workgroup)
+#ifndef SKF_LN_BWD_UR
+#define SKF_LN_BWD_UR SKF_LN_UR
+#endif
 constexpr int kMaxGrid = SKF_LN_FWD_GRID;
 constexpr int kLnBwdGrid = SKF_LN_BWD_GRID;    // workgroups of the LayerNorm backward (each leaves one [2][d] partial for the column sums)
 
@@ -526,13 +532,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 
 // Same, D = 4*LPR <= 256: 16-byte loads, 64/LPR rows per wave instruction, SKF_LN_UR groups in flight (see ln_fwd_v4_kernel).
 template <int LPR>
-__global__ __launch_bounds__(256) void ln_bwd_v4_kernel(const float* __restrict__ dout, const float* __restrict__ z,
+__global__ __launch_bounds__(SKF_LN_BWD_THREADS) void ln_bwd_v4_kernel(const float* __restrict__ dout, const float* __restrict__ z,
                                                         const float* __restrict__ stats, const float* __restrict__ gamma,
                                                         float* __restrict__ dz, float* __restrict__ dy,
                                                         float* __restrict__ part, int rows, float rate, uint32_t site,
                                                         const SkfStepState* st, const int* __restrict__ live_len, int rps) {
-  constexpr int D = 4 * LPR, RPW = 64 / LPR, UR = SKF_LN_UR;
-  __shared__ float red[4][2][D];
+  constexpr int D = 4 * LPR, RPW = 64 / LPR, UR = SKF_LN_BWD_UR, NWV = SKF_LN_BWD_THREADS / 64;
+  __shared__ float red[NWV][2][D];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane % LPR, rsel = lane / LPR;
   const uint32_t thresh = skf_drop_thresh(rate);
@@ -540,8 +546,8 @@ __global__ __launch_bounds__(256) void ln_bwd_v4_kernel(const float* __restrict_
   const uint32_t sk = rate > 0.f ? skf_site_key(st->drop_key, site) : 0u;
   const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + 4 * sub);
   f32x4 dg = {0.f, 0.f, 0.f, 0.f}, db = dg;
-  const int stride = gridDim.x * 4 * RPW * UR;
-  for (int row0 = (blockIdx.x * 4 + wave) * RPW * UR; row0 < rows; row0 += stride) {
+  const int stride = gridDim.x * NWV * RPW * UR;
+  for (int row0 = (blockIdx.x * NWV + wave) * RPW * UR; row0 < rows; row0 += stride) {
     f32x4 dv[UR], zv[UR];
     float mean[UR], rstd[UR];
     size_t off[UR];
@@ -596,9 +602,12 @@ __global__ __launch_bounds__(256) void ln_bwd_v4_kernel(const float* __restrict_
     *reinterpret_cast<f32x4*>(&red[wave][1][4 * sub]) = db;
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < 2 * D; e += 256) {
+  for (int e = threadIdx.x; e < 2 * D; e += SKF_LN_BWD_THREADS) {
     const int w = e / D, c = e % D;
-    part[(size_t)blockIdx.x * 2 * D + e] = red[0][w][c] + red[1][w][c] + red[2][w][c] + red[3][w][c];
+    float t = red[0][w][c];
+#pragma unroll
+    for (int k = 1; k < NWV; ++k) t += red[k][w][c];
+    part[(size_t)blockIdx.x * 2 * D + e] = t;
   }
 }
 
@@ -1077,6 +1086,15 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
     y[i] = rate > 0.f ? x[i] * (skf_keep(sk, (uint32_t)i, thresh) ? inv_keep : 0.f) : x[i];
 }
 
+}  // namespace
+// any-width fallbacks (skf_generic.hip)
+int skf_ln_fwd_any(const float* x, float* y_z, const float* gamma, const float* beta, float* out, float* stats, int rows, int d, float rate,
+                   unsigned site, const void* st, int grid, hipStream_t s);
+int skf_ln_bwd_any(const float* dout, const float* z, const float* stats, const float* gamma, float* dz, float* dy, float* part, int rows, int d,
+                   float rate, unsigned site, const void* st, int grid, hipStream_t s);
+int skf_expander_bwd_any(const float* dpre, const float* emb, const float* w, int B, int L, int d, float* demb, int demb_accumulate, float* p1,
+                         float* p2, hipStream_t s);
+namespace {
 int grid_for_rows(int rows) { int g = skf_cdiv(rows, 4); return g > kMaxGrid ? kMaxGrid : g; }
 
 }  // namespace
@@ -1217,7 +1235,7 @@ extern "C" int skf_layernorm_residual_fwd(const float* x, float* y_inout_z, cons
     case 256: hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, block, 0, s, x, y_inout_z, gamma, beta, out, stats, rows, rate, site, st); break;
     case 512: hipLaunchKernelGGL(ln_fwd_kernel<8>, grid, block, 0, s, x, y_inout_z, gamma, beta, out, stats, rows, rate, site, st); break;
     case 64:  hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, block, 0, s, x, y_inout_z, gamma, beta, out, stats, rows, rate, site, st); break;
-    default: skf_set_error("skf_layernorm_residual_fwd: d_model %d not in {64,128,256,512}", d); return SKF_EUNSUPPORTED;
+    default: return skf_ln_fwd_any(x, y_inout_z, gamma, beta, out, stats, rows, d, rate, site, st, grid_for_rows(rows), s);   // any other width (skf_generic.hip)
   }
   SKF_LAUNCH_CHECK();
   return SKF_OK;
@@ -1254,16 +1272,17 @@ extern "C" int skf_layernorm_residual_bwd_rows(const float* dout, const float* z
   SkfProfScope ps(s, "ln_bwd", 0.0, (rate > 0.f ? 16.0 : 12.0) * rows * d);
   static const bool v4 = !(getenv("SKF_LN_V4") && getenv("SKF_LN_V4")[0] == '0');
   const bool al = ((((uintptr_t)dout | (uintptr_t)z | (uintptr_t)dz | (uintptr_t)dyp | (uintptr_t)gamma) & 15) == 0);
-  if (v4 && al && d == 64) hipLaunchKernelGGL(ln_bwd_v4_kernel<16>, grid, block, 0, s, dout, z, stats, gamma, dz, dyp, part, rows, rate, site, st, live_len, rows_per_sample);
-  else if (v4 && al && d == 128) hipLaunchKernelGGL(ln_bwd_v4_kernel<32>, grid, block, 0, s, dout, z, stats, gamma, dz, dyp, part, rows, rate, site, st, live_len, rows_per_sample);
-  else if (v4 && al && d == 256) hipLaunchKernelGGL(ln_bwd_v4_kernel<64>, grid, block, 0, s, dout, z, stats, gamma, dz, dyp, part, rows, rate, site, st, live_len, rows_per_sample);
+  const dim3 block4(SKF_LN_BWD_THREADS);
+  if (v4 && al && d == 64) hipLaunchKernelGGL(ln_bwd_v4_kernel<16>, grid, block4, 0, s, dout, z, stats, gamma, dz, dyp, part, rows, rate, site, st, live_len, rows_per_sample);
+  else if (v4 && al && d == 128) hipLaunchKernelGGL(ln_bwd_v4_kernel<32>, grid, block4, 0, s, dout, z, stats, gamma, dz, dyp, part, rows, rate, site, st, live_len, rows_per_sample);
+  else if (v4 && al && d == 256) hipLaunchKernelGGL(ln_bwd_v4_kernel<64>, grid, block4, 0, s, dout, z, stats, gamma, dz, dyp, part, rows, rate, site, st, live_len, rows_per_sample);
   else
   switch (d) {
     case 128: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, 0, s, dout, z, stats, gamma, dz, dyp, part, rows, rate, site, st); break;
     case 256: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, s, dout, z, stats, gamma, dz, dyp, part, rows, rate, site, st); break;
     case 512: hipLaunchKernelGGL(ln_bwd_kernel<8>, grid, block, 0, s, dout, z, stats, gamma, dz, dyp, part, rows, rate, site, st); break;
     case 64:  hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, 0, s, dout, z, stats, gamma, dz, dyp, part, rows, rate, site, st); break;
-    default: skf_set_error("skf_layernorm_residual_bwd: d_model %d not in {64,128,256,512}", d); return SKF_EUNSUPPORTED;
+    default: { const int rc = skf_ln_bwd_any(dout, z, stats, gamma, dz, dyp, part, rows, d, rate, site, st, g, s); if (rc) return rc; }   // skf_generic.hip
   }
   SKF_LAUNCH_CHECK();
   // part is [g][2][d] : columns 0..d-1 = dgamma, d..2d-1 = dbeta
@@ -1376,7 +1395,7 @@ extern "C" int skf_expander_bwd(const float* dpre, const float* emb, const float
     case 128: hipLaunchKernelGGL(expander_bwd_kernel<2>, dim3(B), dim3(1024), 0, s, dpre, emb, w, L, demb, demb_accumulate, p1, p2); break;
     case 256: hipLaunchKernelGGL(expander_bwd_kernel<4>, dim3(B), dim3(1024), 0, s, dpre, emb, w, L, demb, demb_accumulate, p1, p2); break;
     case 512: hipLaunchKernelGGL(expander_bwd_kernel<8>, dim3(B), dim3(1024), 0, s, dpre, emb, w, L, demb, demb_accumulate, p1, p2); break;
-    default: skf_set_error("skf_expander_bwd: d_model %d not in {64,128,256,512}", d); return SKF_EUNSUPPORTED;
+    default: { const int rc = skf_expander_bwd_any(dpre, emb, w, B, L, d, demb, demb_accumulate, p1, p2, s); if (rc) return rc; }   // skf_generic.hip
   }
   hipLaunchKernelGGL(colsum_kernel, dim3(skf_cdiv(L, 64)), dim3(1024), 0, s, p1, B, L, L, dw, 0);
   hipLaunchKernelGGL(colsum_kernel, dim3(skf_cdiv(L, 64)), dim3(1024), 0, s, p2, B, L, L, dbias, 0);

@@ -105,9 +105,17 @@ def test_unsupported_configs_fail_loudly(lib):
     assert lib.skf_config_validate(C.byref(engine.make_config(batch=4, lowerdim=0, do_classification=False))) == 0
     assert lib.skf_config_validate(C.byref(engine.make_config(batch=4, do_reconstruction=False))) == 0
     assert lib.skf_config_validate(C.byref(engine.make_config(batch=4, do_reconstruction=False, do_classification=False))) == -1
-    assert lib.skf_config_validate(C.byref(engine.make_config(batch=4, d_model=96))) == -2        # unsupported width
+    # any d_model % num_heads == 0 like the reference (MFMA kernels for the BASELINE widths, skf_generic.hip for the others), within
+    # d_model % 4 == 0, head size % 4 == 0, d_model <= 1024, head size <= 128
+    assert lib.skf_config_validate(C.byref(engine.make_config(batch=4, d_model=96))) == 0         # 8 heads of 12
+    assert lib.skf_config_validate(C.byref(engine.make_config(batch=4, d_model=80, num_heads=2))) == 0
+    assert lib.skf_config_validate(C.byref(engine.make_config(batch=4, d_model=100, num_heads=8))) == -1      # not divisible by the heads
+    assert lib.skf_config_validate(C.byref(engine.make_config(batch=4, d_model=72, num_heads=4))) == -2       # head size 18
+    assert b"head size" in lib.skf_last_error()
+    assert lib.skf_config_validate(C.byref(engine.make_config(batch=4, d_model=2048, num_heads=32))) == -2
     assert lib.skf_config_validate(C.byref(engine.make_config(batch=4, attn_version=3))) == -1
-    assert lib.skf_config_validate(C.byref(engine.make_config(batch=4, attn_version=2, lowerdim=100))) == -2
+    assert lib.skf_config_validate(C.byref(engine.make_config(batch=4, attn_version=2, lowerdim=100))) == 0
+    assert lib.skf_config_validate(C.byref(engine.make_config(batch=4, attn_version=2, lowerdim=102))) == -2
     assert lib.skf_config_validate(C.byref(engine.make_config(batch=4, attn_version=2, class_buffer_layers=2, optimizer="sgd"))) == 0
     with pytest.raises(ValueError):
         engine.make_config(batch=4, optimizer="rmsprop")
