@@ -457,7 +457,11 @@ struct SkfModel {
   hipEvent_t new_event() {
     if (next_event == events.size()) {
       hipEvent_t e = nullptr;
-      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+      // Events that only order the library's own two streams on ONE device: a device-scope release is all the waiter needs
+      // (the default system-scope fence of hipEventRecord writes caches back for host / peer visibility).  SKF_EVENT_SCOPE=system
+      // restores the default for A/B measurements.  (The gradient-bucket events handed to the caller keep the default.)
+      static const bool sys_scope = getenv("SKF_EVENT_SCOPE") && getenv("SKF_EVENT_SCOPE")[0] == 's';
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming | (sys_scope ? 0u : hipEventReleaseToDevice)) != hipSuccess) return nullptr;
       events.push_back(e);
     }
     return events[next_event++];

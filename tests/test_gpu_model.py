@@ -510,6 +510,31 @@ def test_any_width_and_head_size(kw, rate, blind):
     assert np.isfinite(eng.step_metrics()["total_loss"])
 
 
+def test_host_batches_are_staged_before_the_step_reads_them():
+    """train_step on HOST arrays that differ from step to step, with the caller's stream kept busy so that the host-to-device
+    copies land late: the step must be ordered behind them (round 3: a single stream hand-over per step was first taken BEFORE
+    the copies were enqueued - steps then read the previous batch; found by the two-rank test)."""
+    B = 8
+    eng, ocfg = _mk(B, rate=0.0)
+    ref, _ = _mk(B, rate=0.0)
+    eng.state[0] = 3000
+    ref.state[0] = 3000
+    batches = [synthetic.token_batch(B, ocfg.seq_len, ocfg.vocab_size, ocfg.n_classes, seed=40 + s) for s in range(6)]
+    a = torch.randn(4096, 4096, device="cuda")
+    for x, y in batches:
+        for _ in range(4):
+            a = (a @ a).clamp_(-1, 1)                  # ~ms of work on the caller's stream in front of the copies
+        eng.train_step(x, y)
+    for x, y in batches:
+        xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+        torch.cuda.synchronize()
+        ref.train_step(xd, yd)
+        torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    assert eng.iterations == ref.iterations == 3006
+    assert torch.equal(eng.params, ref.params)
+
+
 def test_sgd_momentum_trajectory_matches_oracle():
     """optimizer='sgd' (models/sketchformer.py:124-126): Keras SGD(schedule, momentum=0.9); the schedule is evaluated on
     the pre-increment step, so the very first update is a no-op here too."""

@@ -75,7 +75,14 @@ def test_two_ranks_equal_one_engine_at_double_batch(tmp_path, backend, use_graph
     for x, y in _batches(world):
         ref.train_step(x, y)
     torch.cuda.synchronize()
+    assert ref.iterations == START + STEPS, ref.iterations
     want = ref.params.detach().cpu().numpy()
+    ref2 = engine.TrainEngine(engine.make_config(batch=B_LOCAL * world, **KW), init_seed=1)      # the reference itself is reproducible
+    ref2.state[0] = START
+    for x, y in _batches(world):
+        ref2.train_step(x, y)
+    torch.cuda.synchronize()
+    assert np.array_equal(want, ref2.params.detach().cpu().numpy()), "the single-engine reference differs between two runs"
     moved = np.abs(want - engine.keras_init(ref.entries, ref.n_floats, 1)).max()
     assert moved > 1e-3                                                     # the optimizer really moved the weights
     # wk biases have an analytically zero gradient; Adam turns their rounding noise into +-lr steps (see

@@ -133,28 +133,26 @@ class TrainEngine:
         self.n_floats = int(self.lib.skf_model_param_floats(C.byref(cfg)))
         flat = keras_init(self.entries, self.n_floats, init_seed)
         dev = self.device
-        self._params = torch.from_numpy(flat).to(dev)
-        self._grads = torch.zeros(self.n_floats, dtype=torch.float32, device=dev)
-        self._adam_m = torch.zeros_like(self._grads)
-        self._adam_v = torch.zeros_like(self._grads)
+        self.params = torch.from_numpy(flat).to(dev)
+        self.grads = torch.zeros(self.n_floats, dtype=torch.float32, device=dev)
+        self.adam_m = torch.zeros_like(self.grads)
+        self.adam_v = torch.zeros_like(self.grads)
         self.pos = torch.from_numpy(positional_encoding(cfg.max_pos, cfg.d_model)).to(dev)
-        self._metrics = torch.zeros(32, dtype=torch.float32, device=dev)
-        self._state = torch.zeros(int(self.lib.skf_step_state_bytes()) // 8 + 1, dtype=torch.int64, device=dev)
+        self.metrics = torch.zeros(32, dtype=torch.float32, device=dev)
+        self.state = torch.zeros(int(self.lib.skf_step_state_bytes()) // 8 + 1, dtype=torch.int64, device=dev)
         ws_bytes = int(self.lib.skf_model_workspace_bytes(C.byref(cfg)))
-        self._workspace = torch.empty(ws_bytes + 256, dtype=torch.uint8, device=dev)
-        off = (-self._workspace.data_ptr()) % 256
-        self._ws_ptr = self._workspace.data_ptr() + off
+        self.workspace = torch.empty(ws_bytes + 256, dtype=torch.uint8, device=dev)
+        off = (-self.workspace.data_ptr()) % 256
+        self._ws_ptr = self.workspace.data_ptr() + off
         self._ws_bytes = ws_bytes
         handle = C.c_void_p()
         _lib.call("skf_model_create", C.byref(cfg), C.byref(handle))
         self.handle = handle
-        _lib.call("skf_model_bind", handle, self._p(self._params), self._p(self._grads), self._p(self._adam_m),
-                  self._p(self._adam_v), self._p(self.pos), C.c_void_p(self._ws_ptr), ws_bytes, self._p(self._metrics),
-                  self._p(self._state))
+        _lib.call("skf_model_bind", handle, self._p(self.params), self._p(self.grads), self._p(self.adam_m),
+                  self._p(self.adam_v), self._p(self.pos), C.c_void_p(self._ws_ptr), ws_bytes, self._p(self.metrics),
+                  self._p(self.state))
         # a dedicated non-default stream: hipGraph capture is illegal on the legacy default stream
         self.stream = torch.cuda.Stream(device=dev)
-        self._depth = 0
-        self._dirty = False
         self._comm = None                # communication stream of the data-parallel gradient buckets
         self.pg = process_group
         self.world_size = torch.distributed.get_world_size(process_group) if process_group is not None else 1
@@ -163,27 +161,6 @@ class TrainEngine:
         # backward / the optimizer sweep of the previous piece); "single": ONE all-reduce of the whole buffer after
         # backward (the literal north-star schedule) - bench.py --allreduce single|bucketed A/Bs the two
         self.dp_mode = "bucketed"
-
-    # The buffers live on the engine's stream.  A step no longer makes the caller's stream wait for it (that hand-over, and the
-    # one back at the start of the next step, were two cross-stream hops = ~25-40 us of idle GPU between steps,
-    # profiles/r03l_gaps.txt): it only marks the results unpublished, and whoever READS a buffer through the attributes below
-    # (or any accessor of this class) first orders the current stream behind the engine's.
-    def _publish(self):
-        if self._dirty:
-            torch.cuda.current_stream(self.device).wait_stream(self.stream)
-            self._dirty = False
-
-    def _published(self, t):
-        self._publish()
-        return t
-
-    params = property(lambda self: self._published(self._params))
-    grads = property(lambda self: self._published(self._grads))
-    adam_m = property(lambda self: self._published(self._adam_m))
-    adam_v = property(lambda self: self._published(self._adam_v))
-    metrics = property(lambda self: self._published(self._metrics))
-    state = property(lambda self: self._published(self._state))
-    workspace = property(lambda self: self._published(self._workspace))
 
     def __del__(self):
         h = getattr(self, "handle", None)
@@ -201,18 +178,12 @@ class TrainEngine:
         return C.c_void_p(self.stream.cuda_stream)
 
     def _enter(self):
-        # order after whatever the caller queued on its current stream (H2D copies of the batch, set()).  Nested calls (train_step
-        # brackets forward_backward + apply_gradients) hand over once: every hand-over is a cross-stream event pair, and the one
-        # that used to sit between the backward and the optimizer was ~40 us of idle GPU per step (profiles/r03l_gaps.txt)
-        if self._depth == 0:
-            self.stream.wait_stream(torch.cuda.current_stream(self.device))
-        self._depth += 1
+        # order after whatever the caller queued on its current stream (H2D copies of the batch, set())
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
 
     def _leave(self):
         # let the caller's stream observe the step's results
-        self._depth -= 1
-        if self._depth == 0:
-            self._dirty = True               # published lazily (see _publish)
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
 
     def synchronize(self):
         self.stream.synchronize()
@@ -262,14 +233,6 @@ class TrainEngine:
             raise ValueError("continuous mode expects (B, L, 5) stroke-5 input")
         return t.to(self.device, dtype=torch.float32, non_blocking=True).contiguous()
 
-    def _hold(self, *tensors):
-        """The engine's stream reads these caller-owned tensors asynchronously: tell the caching allocator, so that a tensor the
-        caller drops right after the call is not handed out again (and overwritten from the caller's stream) before the step has
-        staged it (the step used to make the caller's stream wait instead: see _publish)."""
-        for t in tensors:
-            if isinstance(t, torch.Tensor) and t.is_cuda:
-                t.record_stream(self.stream)
-
     def _ld(self, t):
         return t.stride(0) // 5 if self.cfg.continuous else t.stride(0)
 
@@ -278,22 +241,16 @@ class TrainEngine:
         inp = self._dev_input(inp)
         tar = inp if tar is None else self._dev_input(tar)
         self._enter()
-        try:
-            self._hold(inp, tar)
-            _lib.call("skf_model_forward", self.handle, self._p(inp), self._p(tar), self._ld(tar), int(training), self._stream())
-        finally:
-            self._leave()
+        _lib.call("skf_model_forward", self.handle, self._p(inp), self._p(tar), self._ld(tar), int(training), self._stream())
+        self._leave()
 
     def encode(self, inp):
         """encode_from_seq (models/sketchformer.py:162-168): encoder + bottleneck + classifier, dropout off.
         Results in the buffers 'embedding', 'class_probs', 'enc_output'."""
         inp = self._dev_input(inp)
         self._enter()
-        try:
-            self._hold(inp)
-            _lib.call("skf_model_encode", self.handle, self._p(inp), self._stream())
-        finally:
-            self._leave()
+        _lib.call("skf_model_encode", self.handle, self._p(inp), self._stream())
+        self._leave()
 
     def greedy_decode(self, embedding=None, expected_len=None, n_valid=None, sos=0, eos=0, max_steps=None):
         """predict_from_embedding (models/sketchformer.py:255-311) with a K/V cache.  embedding: (B,d) array / tensor
@@ -326,35 +283,22 @@ class TrainEngine:
             out = torch.zeros(B, max_steps + 1, dtype=torch.int64, device=self.device)
         n_out = C.c_int(0)
         self._enter()
-        try:
-            _lib.call("skf_model_greedy_decode", self.handle, emb_ptr, lim, n_valid, int(sos), int(eos), max_steps, self._p(out),
-                      C.byref(n_out), self._stream())
-        finally:
-            self._leave()
+        _lib.call("skf_model_greedy_decode", self.handle, emb_ptr, lim, n_valid, int(sos), int(eos), max_steps, self._p(out),
+                  C.byref(n_out), self._stream())
+        self._leave()
         self.synchronize()
         res = out[:n_valid, :n_out.value].cpu().numpy()
         return res if self.cfg.continuous else res.astype(np.int32)
 
-    def _stage(self, inp, tar, labels):
-        """caller-side arguments -> device tensors (enqueued on the CALLER's stream: must precede _enter)"""
+    def forward_backward(self, inp, tar, labels):
         inp = self._dev_input(inp)
         tar = inp if tar is None else self._dev_input(tar)
         labels = self._dev_tokens(labels, self.cfg.n_classes if self.cfg.do_classification and self.cfg.lowerdim else None,
                                   "class label")
-        return inp, tar, labels
-
-    def _forward_backward_staged(self, inp, tar, labels):
-        self._hold(inp, tar, labels)
+        self._enter()
         _lib.call("skf_model_forward_backward", self.handle, self._p(inp), self._p(tar), self._ld(tar), self._p(labels),
                   self._stream())
-
-    def forward_backward(self, inp, tar, labels):
-        staged = self._stage(inp, tar, labels)
-        self._enter()
-        try:
-            self._forward_backward_staged(*staged)
-        finally:
-            self._leave()
+        self._leave()
 
     def grad_buckets(self):
         """[(offset, count)] slices of the flat gradient buffer in the order they become final during backward."""
@@ -373,46 +317,40 @@ class TrainEngine:
         if bucketed is None:
             bucketed = self.world_size > 1 and self.dp_mode == "bucketed"
         self._enter()
-        try:
-            if not bucketed:
-                scale = 1.0
-                if self.world_size > 1:       # one all-reduce of the whole flat buffer, ordered after backward on the step's stream
-                    with torch.cuda.stream(self.stream):
-                        scale = parallel.allreduce_flat_gradients(self._grads, self.pg)
-                _lib.call("skf_model_apply_gradients", self.handle, scale, self._stream())
-                return
-            if self._comm is None:
-                self._comm = torch.cuda.Stream(device=self.device)
-            buckets = self.grad_buckets()
-            scale = 1.0 / max(self.world_size, 1)
-            works = []
-            if self.cfg.use_graph:
-                # a step replayed from a hipGraph records no per-bucket events (one bucket): the communication stream must be
-                # ordered after the whole captured forward/backward, or the all-reduce would race with the gradient writes
-                self._comm.wait_stream(self.stream)
-            for i, (off, cnt) in enumerate(buckets):
-                _lib.call("skf_model_wait_grad_bucket", self.handle, i, C.c_void_p(self._comm.cuda_stream))
-                with torch.cuda.stream(self._comm):
-                    works.append(parallel.allreduce_bucket(self._grads[off:off + cnt], self.pg))
-            for i, (off, cnt) in enumerate(buckets):
+        if not bucketed:
+            scale = 1.0
+            if self.world_size > 1:       # one all-reduce of the whole flat buffer, ordered after backward on the step's stream
                 with torch.cuda.stream(self.stream):
-                    if works[i] is not None:
-                        works[i].wait()                      # engine stream waits for this bucket's all-reduce
-                    else:
-                        self.stream.wait_stream(self._comm)
-                _lib.call("skf_model_apply_gradients_range", self.handle, off, cnt, scale, int(i == len(buckets) - 1), self._stream())
-        finally:
+                    scale = parallel.allreduce_flat_gradients(self.grads, self.pg)
+            _lib.call("skf_model_apply_gradients", self.handle, scale, self._stream())
             self._leave()
+            return
+        if self._comm is None:
+            self._comm = torch.cuda.Stream(device=self.device)
+        buckets = self.grad_buckets()
+        scale = 1.0 / max(self.world_size, 1)
+        works = []
+        if self.cfg.use_graph:
+            # a step replayed from a hipGraph records no per-bucket events (one bucket): the communication stream must be
+            # ordered after the whole captured forward/backward, or the all-reduce would race with the gradient writes
+            self._comm.wait_stream(self.stream)
+        for i, (off, cnt) in enumerate(buckets):
+            _lib.call("skf_model_wait_grad_bucket", self.handle, i, C.c_void_p(self._comm.cuda_stream))
+            with torch.cuda.stream(self._comm):
+                works.append(parallel.allreduce_bucket(self.grads[off:off + cnt], self.pg))
+        for i, (off, cnt) in enumerate(buckets):
+            with torch.cuda.stream(self.stream):
+                if works[i] is not None:
+                    works[i].wait()                      # engine stream waits for this bucket's all-reduce
+                else:
+                    self.stream.wait_stream(self._comm)
+            _lib.call("skf_model_apply_gradients_range", self.handle, off, cnt, scale, int(i == len(buckets) - 1), self._stream())
+        self._leave()
 
     def train_step(self, inp, labels, tar=None):
         """model_trainer(inp, tar, lab) (models/sketchformer.py:325-349); no host sync."""
-        staged = self._stage(inp, tar, labels)       # host-to-device copies of the batch go to the caller's stream FIRST:
-        self._enter()                                # the hand-over below is what orders the step behind them
-        try:
-            self._forward_backward_staged(*staged)
-            self.apply_gradients()
-        finally:
-            self._leave()
+        self.forward_backward(inp, tar, labels)
+        self.apply_gradients()
 
     def buffer(self, name):
         """(rows, cols) view of an internal activation.  fp32 models: a float32 view of the workspace; bf16 models keep
@@ -446,23 +384,23 @@ class TrainEngine:
         if self.world_size <= 1:
             return
         with torch.cuda.stream(self.stream):
-            acc = torch.cat([self._metrics[8:13], self._metrics[16:21]]).contiguous()
+            acc = torch.cat([self.metrics[8:13], self.metrics[16:21]]).contiguous()
             torch.distributed.all_reduce(acc, op=torch.distributed.ReduceOp.SUM, group=self.pg)
             if self.rank == 0:
-                self._metrics[8:13], self._metrics[16:21] = acc[:5], acc[5:]
+                self.metrics[8:13], self.metrics[16:21] = acc[:5], acc[5:]
             else:
                 self.zero_metric_accumulators()
 
     def zero_metric_accumulators(self):
         with torch.cuda.stream(self.stream):
-            self._metrics[8:13] = 0.0
-            self._metrics[16:21] = 0.0
+            self.metrics[8:13] = 0.0
+            self.metrics[16:21] = 0.0
 
     def metrics_snapshot(self):
         """Device copy of the 32 metric floats as they stand after the steps queued so far (no host sync): what
         ``train_on_batch`` hands back; ``resolve_metrics`` turns a list of them into floats with ONE read-back."""
         with torch.cuda.stream(self.stream):
-            snap = self._metrics.clone()
+            snap = self.metrics.clone()
         return snap
 
     def resolve_metrics(self, snaps, reduce=True):
