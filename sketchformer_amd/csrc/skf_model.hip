@@ -433,14 +433,20 @@ struct SkfModel {
   hipStream_t side = nullptr;
   std::vector<hipEvent_t> events;
   size_t next_event = 0;
-  std::map<const void*, hipEvent_t> pending_readers;   // buffer -> completion event of its last side-stream reader
+  // Side-stream events carry a sequence number (their record order on the in-order side stream): once the main stream has
+  // waited for event k, every event <= k is complete too - later waits for those are dropped (a decoder layer's seven dY
+  // buffers share one `done` event: one barrier packet on the main stream instead of seven, ~5 us each)
+  struct SideEvent { hipEvent_t e; long seq; };
+  long side_seq = 0, side_waited = 0;
+  bool no_wait_dedupe = getenv("SKF_NO_WAIT_DEDUPE") && getenv("SKF_NO_WAIT_DEDUPE")[0] == '1';     // A/B knob
+  std::map<const void*, SideEvent> pending_readers;    // buffer -> completion event of its last side-stream reader
   // kind 0: dW = X^T dY (+ bias grad); kind 1: an input gradient nobody on the main stream needs soon (dx (+)= dY W^T)
   struct QueuedWgrad { DenseP w; const float* x; int ldx; const float* dy; int lddy; int rows; int kind = 0; float* dx = nullptr; int lddx = 0; int accumulate = 0; const int* blocks32 = nullptr; };
   // Live row blocks of the decoder-side backward (skf_row_blocks.hip): set while the decoder layers' gradients are issued,
   // consulted by dense_dgrad / dense_wgrad for problems with exactly `live_rows` rows; null = every row is visited
   const int* live16 = nullptr; const int* live32 = nullptr; int live_rows = 0;
   bool lists_built = false;             // this step's lists are in P.live16 / P.live32 (issued, not necessarily complete)
-  std::map<const void*, hipEvent_t> pending_writers;   // buffers a side-stream dgrad still writes
+  std::map<const void*, SideEvent> pending_writers;    // buffers a side-stream dgrad still writes
   std::vector<QueuedWgrad> wq;                         // wgrads of the current layer, not yet issued
   bool side_used = false;
   std::vector<SkfReduceDesc> descs;     // one per wgrad of the step, in launch order
@@ -515,7 +521,10 @@ int before_write(SkfModel* M, const void* buf, hipStream_t s) {
     if (q.dy == buf || q.x == buf) { SKF_TRY(issue_wgrads(M, s)); break; }
   auto it = M->pending_readers.find(buf);
   if (it == M->pending_readers.end()) return SKF_OK;
-  SKF_HIP(hipStreamWaitEvent(s, it->second, 0));
+  if (it->second.seq > M->side_waited || M->no_wait_dedupe) {
+    SKF_HIP(hipStreamWaitEvent(s, it->second.e, 0));
+    M->side_waited = std::max(M->side_waited, it->second.seq);
+  }
   M->pending_readers.erase(it);
   return SKF_OK;
 }
@@ -533,7 +542,10 @@ int before_read(SkfModel* M, const void* buf, hipStream_t s) {
     if (q.kind == 1 && q.dx == buf) { SKF_TRY(issue_wgrads(M, s)); break; }
   auto it = M->pending_writers.find(buf);
   if (it == M->pending_writers.end()) return SKF_OK;
-  SKF_HIP(hipStreamWaitEvent(s, it->second, 0));
+  if (it->second.seq > M->side_waited || M->no_wait_dedupe) {
+    SKF_HIP(hipStreamWaitEvent(s, it->second.e, 0));
+    M->side_waited = std::max(M->side_waited, it->second.seq);
+  }
   M->pending_writers.erase(it);
   return SKF_OK;
 }
@@ -556,7 +568,8 @@ int issue_wgrads(SkfModel* M, hipStream_t s) {
                          q.accumulate, 1, nullptr, 0, nullptr, 0, M->cfg.gemm_precision, M->side));
     if (!dgrad_done) { dgrad_done = M->new_event(); SKF_CHECK_ARG(dgrad_done, "event allocation failed"); }
   }
-  if (dgrad_done) SKF_HIP(hipEventRecord(dgrad_done, M->side));
+  long dgrad_seq = 0;
+  if (dgrad_done) { SKF_HIP(hipEventRecord(dgrad_done, M->side)); dgrad_seq = ++M->side_seq; }
   // the large problems of the group: partial tiles by ONE grouped launch (up to 8 problems each); every slab of the phase is
   // reduced by one launch in flush_wgrads()
   std::vector<SkfWgradProblem> probs;
@@ -602,10 +615,11 @@ int issue_wgrads(SkfModel* M, hipStream_t s) {
     M->desc_cursor += 1;
   }
   SKF_HIP(hipEventRecord(done, M->side));
+  const long done_seq = ++M->side_seq;
   for (const auto& q : group) {
-    M->pending_readers[q.dy] = done;
-    if (q.x) M->pending_readers[q.x] = done;
-    if (q.kind == 1) M->pending_writers[q.dx] = dgrad_done;
+    M->pending_readers[q.dy] = SkfModel::SideEvent{done, done_seq};
+    if (q.x) M->pending_readers[q.x] = SkfModel::SideEvent{done, done_seq};
+    if (q.kind == 1) M->pending_writers[q.dx] = SkfModel::SideEvent{dgrad_done, dgrad_seq};
   }
   M->side_used = true;
   return SKF_OK;
@@ -624,6 +638,17 @@ int flush_wgrads(SkfModel* M, hipStream_t s, int bucket, bool final) {
     }
     // LayerNorm partials and the embedding gradients of this bucket were written by the main stream: the batched
     // reduction (wgrad slabs + LayerNorm partials) and the bucket-ready event are ordered after both streams
+    static const bool tail_on_main = !(getenv("SKF_TAIL_REDUCE_SIDE") && getenv("SKF_TAIL_REDUCE_SIDE")[0] == '1');
+    if (final && tail_on_main) {
+      // end of the backward: the optimizer waits for this reduction anyway, so it runs on the MAIN stream behind ONE hop
+      // (side -> main after the last weight gradient) instead of two (main -> side for the partials, side -> main for the result)
+      hipEvent_t e = M->new_event();
+      SKF_CHECK_ARG(e, "event allocation failed");
+      SKF_HIP(hipEventRecord(e, M->side));
+      SKF_HIP(hipStreamWaitEvent(s, e, 0));
+      SKF_TRY(skf_splitk_reduce_batch(M->at<SkfReduceDesc>(M->plan.descs) + begin, (int)(end - begin), M->reduce_blocks, s));
+      ready_on = s;
+    } else {
     hipEvent_t em = M->new_event();
     SKF_CHECK_ARG(em, "event allocation failed");
     SKF_HIP(hipEventRecord(em, s));
@@ -637,6 +662,7 @@ int flush_wgrads(SkfModel* M, hipStream_t s, int bucket, bool final) {
       SKF_HIP(hipStreamWaitEvent(s, e, 0));
       ready_on = s;
     }
+    }
   }
   if (M->bucket_ready[bucket]) SKF_HIP(hipEventRecord(M->bucket_ready[bucket], ready_on));
   M->phase_desc_begin = end;
@@ -645,6 +671,7 @@ int flush_wgrads(SkfModel* M, hipStream_t s, int bucket, bool final) {
     M->pending_readers.clear();
     M->pending_writers.clear();
     M->side_used = false;
+    M->side_waited = M->side_seq;        // the main stream has joined the side stream: every event recorded so far is behind it
   }
   return SKF_OK;
 }
@@ -1079,6 +1106,9 @@ int run_backward(SkfModel* M, hipStream_t s) {
                               M->at<float>(a.astats), emask, Le, 0, B, H, Le, Le, dh, dqkv, 3 * d, dqkv + d, 3 * d,
                               dqkv + 2 * d, 3 * d, M->cfg.gemm_precision, s));
     SKF_TRY(dense_wgrad(M, w.mha.qkv, M->at<float>(a.x_in), d, dqkv, 3 * d, Me, s));
+    // last layer of the backward: the weight gradient only needs dqkv, so it goes out BEFORE the input-gradient GEMM - the hop
+    // to the side stream and the kernel itself then run under that GEMM and the embedding gradient instead of behind them
+    if (i == 0 && early_tail) SKF_TRY(issue_wgrads(M, s));
     SKF_TRY(dense_dgrad(M, w.mha.qkv, dqkv, 3 * d, Me, G, d, 1, nullptr, 0, s));
     SKF_TRY(issue_wgrads(M, s));
   }
