@@ -114,6 +114,18 @@ int skf_gemm_f32_bits(int a_kcontig, int b_kcontig, int M, int N, int K, const f
                       int splits, float* bias_grad, int bias_grad_accumulate, void* workspace, size_t workspace_bytes,
                       int precision, const int* row_blocks, int row_block_rows, void* relu_bits_out, const void* relu_bits_in,
                       skf_stream_t stream);
+/* Dense + residual + dropout + LayerNorm in ONE launch: the reference's `layernorm1(x + dropout1(attn_output))`
+ * (builders/layers/transformer.py:216-224 EncoderLayer.call, :258-272 DecoderLayer.call) where attn_output is the MultiHeadAttention
+ * output projection `self.dense(concat_attention)` (:186):
+ *   z = x + dropout(A[M,K] . W[K,N] + bias, rate, site);  out = (z - mean) * rstd * gamma + beta;  stats[row] = (mean, rstd)
+ * with the arithmetic, the dropout mask and the epsilon (1e-6) of skf_gemm_f32 followed by skf_layernorm_residual_fwd (z is
+ * bit-identical to that pair's; mean / rstd are summed in a different order).  z, out and x are row-major with pitch N.  Exists where
+ * one workgroup of the split-arithmetic weight-stationary kernel owns whole output rows: skf_gemm_ln_residual_supported
+ * (K = N = 128, precision != SKF_PREC_F32); anything else is an error - use the two calls. */
+int skf_gemm_ln_residual_supported(int M, int N, int K, int precision);
+int skf_gemm_ln_residual_f32(int M, int N, int K, const float* A, int lda, const float* W, int ldw, const float* bias,
+                             const float* x, const float* gamma, const float* beta, float* z, float* out, float* stats,
+                             float rate, unsigned site, const void* step_state, int precision, skf_stream_t stream);
 int skf_gemm_wgrad_partial_rows(int M, int N, int K, const float* A, int lda, const float* B, int ldb, int splits,
                                 int with_bias_grad, float* slab, size_t slab_bytes, int* splits_used_host, int precision,
                                 const int* row_blocks, int row_block_rows, skf_stream_t stream);

@@ -118,9 +118,13 @@ __host__ __device__ __forceinline__ uint32_t skf_hash32(uint32_t x) {
 __host__ __device__ __forceinline__ uint32_t skf_site_key(uint32_t key, uint32_t site) {
   return skf_hash32(key ^ (0x9e3779b9U * (site + 1)));
 }
+constexpr uint32_t kSkfKeepStride = 0x9e3779b1U;   // hash argument of element idx = idx * kSkfKeepStride + site_key
+// the same decision from the hash argument itself: kernels that walk idx in fixed steps add multiples of kSkfKeepStride
+// instead of multiplying per element (v_mul_lo_u32 is a quarter-rate instruction)
+__host__ __device__ __forceinline__ bool skf_keep_arg(uint32_t arg, uint32_t thresh) { return skf_hash32(arg) >= thresh; }
 __host__ __device__ __forceinline__ bool skf_keep(uint32_t site_key, uint32_t idx, uint32_t thresh) {
   // keep iff u >= rate  (tf.nn.dropout: random_uniform >= rate)
-  return skf_hash32(idx * 0x9e3779b1U + site_key) >= thresh;
+  return skf_keep_arg(idx * kSkfKeepStride + site_key, thresh);
 }
 __host__ __device__ __forceinline__ uint32_t skf_drop_thresh(float rate) {
   double t = (double)rate * 4294967296.0;

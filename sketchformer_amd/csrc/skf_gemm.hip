@@ -526,6 +526,30 @@ extern "C" int skf_gemm_f32_rows(int a_kcontig, int b_kcontig, int M, int N, int
                            nullptr, nullptr, stream);
 }
 
+// Dense + residual + dropout + LayerNorm in one launch (the attention output projection of every layer): exists where one
+// workgroup of the split-arithmetic weight-stationary kernel owns whole output rows, i.e. K = N = 128.
+extern "C" int skf_gemm_ln_residual_supported(int M, int N, int K, int precision) {
+  return precision != SKF_PREC_F32 && K == 128 && N == 128 && M > 0 && (double)M * 128 * 4 < 2147483648.0;
+}
+extern "C" int skf_gemm_ln_residual_f32(int M, int N, int K, const float* A, int lda, const float* W, int ldw, const float* bias,
+                                        const float* x, const float* gamma, const float* beta, float* z, float* out, float* stats,
+                                        float rate, unsigned site, const void* step_state, int precision, skf_stream_t stream) {
+  SKF_CHECK_ARG(skf_gemm_ln_residual_supported(M, N, K, precision), "skf_gemm_ln_residual_f32: K = N = 128 in a split-arithmetic mode only (skf_gemm_ln_residual_supported)");
+  SKF_CHECK_ARG(A && W && x && gamma && beta && z && out && stats, "null operand");
+  SKF_CHECK_ARG(rate >= 0.f && rate < 1.f && (rate == 0.f || step_state), "dropout needs 0 <= rate < 1 and the step state");
+  SKF_CHECK_ARG((lda & 3) == 0 && lda >= K && (ldw & 1) == 0 && ldw >= N, "bad pitch");
+  SKF_CHECK_ARG((((uintptr_t)A | (uintptr_t)x | (uintptr_t)z | (uintptr_t)out) & 15) == 0 && (((uintptr_t)W | (uintptr_t)stats) & 7) == 0, "operands must be 16-byte aligned");
+  SKF_CHECK_ARG((double)M * lda * 4 < 2147483648.0, "A exceeds 32-bit byte offsets");
+  GemmParams p{};
+  p.A = A; p.B = W; p.C = z; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldw; p.ldc = N; p.bias = bias;
+  p.precision = precision;
+  p.a_vec = 1; p.b_vec = ((ldw & 3) == 0) && (((uintptr_t)W & 15) == 0);
+  p.ln_x = x; p.ln_gamma = gamma; p.ln_beta = beta; p.ln_out = out; p.ln_stats = stats;
+  p.ln_rate = rate; p.ln_site = site; p.ln_state = step_state;
+  { const char* db = getenv("SKF_GEMM_DBG"); p.dbg = db ? (long long*)strtoull(db, nullptr, 0) : nullptr; }
+  return skf_gemm_wsx_launch(p, 0, precision == SKF_PREC_BF16X3 ? 2 : 3, (hipStream_t)stream);
+}
+
 // The sign-bit path exists where the split-arithmetic weight-stationary kernel takes the launch (skf_gemm_ws_dispatch +
 // ws_launch_one): A [M][K] with K in {128,256,384,512}, M >= 1024, a problem above the small-GEMM size, 32-bit byte offsets.
 static bool relu_bits_shape(int M, int N, int K, int precision) {

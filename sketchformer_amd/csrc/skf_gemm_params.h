@@ -41,6 +41,12 @@ struct GemmParams {
   // a_cut bytes short of the matrix end (the columns behind k_valid of a row are whatever follows it - the next row -
   // multiplied by those zeros; behind the last row they are out of the descriptor's range and read as 0).  0 = plain launch.
   int k_valid, a_cut;
+  // Residual + dropout + LayerNorm epilogue (split-arithmetic weight-stationary kernel, K = N = 128: one workgroup owns whole
+  // output rows; skf_gemm_ln_residual_f32): C = z = ln_x + dropout(A.B + bias), ln_out = LayerNorm(z) * gamma + beta,
+  // ln_stats[row] = (mean, rstd).  ln_out == null: plain launch.
+  const float* ln_x; const float* ln_gamma; const float* ln_beta;
+  float* ln_out; float* ln_stats;
+  float ln_rate; unsigned ln_site; const void* ln_state;   // dropout of the product (SkfStepState*, read on the device)
 };
 
 // weight-stationary fast path; sets *handled when it launched the problem

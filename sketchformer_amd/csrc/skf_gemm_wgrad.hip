@@ -184,7 +184,10 @@ __device__ __forceinline__ void wgrad_x_body(const GemmParams& p, const int bid,
   constexpr int RI = 32 * NW;                       // rows per iteration of the workgroup
   // With a row-block list (32-row blocks) the contraction runs over the LIVE blocks only: split z takes the list entries
   // [z * per, (z + 1) * per), wave w every NW-th of them - the rows of a dead block are zero in dY, so leaving them out is exact.
-  const int* blk = p.row_blocks;
+  // (constant address space: written by an earlier launch, wave-uniform indices -> s_load instead of global_load + s_waitcnt vmcnt(0),
+  //  which also drained the operand rows requested a step ahead)
+  typedef const __attribute__((address_space(4))) int* const_i32p;
+  const const_i32p blk = (const_i32p)p.row_blocks;
   int eb = 0, ee = 0;
   if (blk) {
     const int nlive = blk[0], per = (nlive + nblocks / ntile - 1) / (nblocks / ntile);

@@ -100,12 +100,28 @@ __device__ __forceinline__ void wsx_store_tile(char* __restrict__ dst, const f32
   }
 }
 
-template <int K, int NB, int P, bool B_KC, bool EXTRA, bool KMASK = false>
+// sum over the 16 lanes of a DPP row (the lanes that share g): every lane of the row ends up with the total
+__device__ __forceinline__ float wsx_row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));   // row_mirror
+  return v;
+}
+
+// LNF (K = 128, NB = 2, one column group: the workgroup's four waves hold the 128 columns of a tile's 16 rows): the epilogue is
+// z = x + dropout(A.B + bias), out = LayerNorm(z) - builders/layers/transformer.py:221-224 / 262-272 `layernorm(x + dropout(sublayer))` -
+// in the launch that produces the sublayer output.  Per tile: the residual rows are requested in the middle of the MFMA stream;
+// behind it every wave forms z for its 32 columns, their mean and centred square sum (two passes in registers, DPP row sums) and
+// leaves the pair in LDS; the tile's closing barrier publishes them; the four pairs of a row are combined (Chan's update: as
+// accurate as two passes over the whole row) when the tile is stored, under the next tile's MFMAs.
+template <int K, int NB, int P, bool B_KC, bool EXTRA, bool KMASK = false, bool LNF = false>
 __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_kernel(GemmParams p, int groups, int workers) {
   constexpr int CW = 16 * NB;            // columns per wave
   constexpr int NKS = K / 32;            // MFMA k-steps per tile
   constexpr int NF = NKS * P;            // A fragments (ds_read_b128) per tile
-  constexpr bool EARLY = K == 128 && (P == 2 || NB == 4 || SKF_WSX_EARLY3);   // every fragment of a tile in registers: barrier inside the MFMA stream
+  static_assert(!LNF || (K == 128 && NB == 2 && !EXTRA && !KMASK), "LayerNorm epilogue: K = 128, two columns per lane, plain launch");
+  constexpr bool EARLY = !LNF && K == 128 && (P == 2 || NB == 4 || SKF_WSX_EARLY3);   // every fragment of a tile in registers: barrier inside the MFMA stream
   constexpr int PF = EARLY ? NF : (NF < 6 ? NF : 6);
   constexpr int NCH = NB == 1 ? 2 : 1;   // accumulator chains per column block
   constexpr int PITCH = 2 * K + 32;      // bytes per LDS row.  ds_read_b128 is served in four groups of 16 lanes that MIX the lane
@@ -132,10 +148,28 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
   // Row-block list (16-row blocks = tiles): the loop below walks list POSITIONS [0, nlive); phys() maps a position to its
   // tile (positions past the live ones map past the matrix: empty descriptors, nothing loaded or stored).  The dead
   // tiles' output rows are zero-filled at the end.
-  const int* blk = p.row_blocks;
+  // (constant address space: the list is written by an earlier launch, never by this one, and every index is wave-uniform - the
+  //  entries arrive through s_load.  As plain global loads each lookup was `global_load_dword; s_waitcnt vmcnt(0)`: a full memory
+  //  round trip per tile that also drained the A tiles requested ahead)
+  typedef const __attribute__((address_space(4))) int* const_i32p;
+  const const_i32p blk = (const_i32p)p.row_blocks;
   const int nlive = blk ? blk[0] : ntiles;
   auto phys = [&](int pos) -> int { return pos < nlive ? (blk ? blk[2 + pos] : pos) : ntiles; };
 
+  // LNF: the epilogue's operands are requested before everything else (the dropout key is two dependent loads away)
+  float* lnst = reinterpret_cast<float*>(smem_x + 2 * TILE_B);   // [2 tile parities][TR rows][4 waves] (mean, centred square sum)
+  float ln_g[NB], ln_b[NB], ln_inv_keep = 1.f;
+  uint32_t ln_key = 0u, ln_thresh = 0u;
+  if constexpr (LNF) {
+    if (p.ln_rate > 0.f) {
+      typedef const __attribute__((address_space(4))) uint32_t* const_u32p;   // written by the step prologue launch: a scalar load, waited for at its use
+      ln_key = *(const_u32p)&reinterpret_cast<const SkfStepState*>(p.ln_state)->drop_key;
+      ln_thresh = skf_drop_thresh(p.ln_rate);
+      ln_inv_keep = 1.0f / (1.0f - p.ln_rate);
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) { ln_g[nb] = p.ln_gamma[n_ld + nb]; ln_b[nb] = p.ln_beta[n_ld + nb]; }
+  }
   long long* dbg = (p.dbg && lane == 0 && wave == 0 && (blockIdx.x % 64) == 0 && blockIdx.x / 64 < 8) ? p.dbg + (blockIdx.x / 64) * 32 : nullptr;   // same XCD: comparable clocks
   int dbi = 0;
 #if SKF_WS_STAMPS   // per-phase s_memtime stamps (tools/ws_timeline.py); off by default
@@ -206,6 +240,7 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) bias_r[nb] = p.bias ? p.bias[n_ld + nb] : 0.f;
 
+  const uint32_t ln_sk = (LNF && p.ln_rate > 0.f) ? skf_site_key(ln_key, p.ln_site) : 0u;
   SKF_STAMP();   // weight slice loaded + split
   wsx_store_tile<K, P, PITCH>(As, ra[0], sel);
   __syncthreads();
@@ -213,13 +248,37 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
   SKF_STAMP();   // first A tile in LDS
 
   vecn cprev[4], hsrc[4], oacc[4];
-  int prev_tile = ntiles;
+  vecn xresA[LNF ? 4 : 1], xresB[LNF ? 4 : 1];                    // LNF: residual rows of this tile and of the next one (requested a tile ahead:
+                                                                  // a load issued inside the tile that consumes it stalls ~2.5k cycles per tile)
+  int prev_tile = ntiles, prev_par = 0;
   const bool has_bits = EXTRA && p.relu_bits_in != nullptr;       // relu'(.) from the forward's sign bits instead of relu_src
   const bool has_relu = EXTRA && p.relu_src != nullptr && !has_bits;
   const int ncw = groups * 4, cwi = group * 4 + wave;             // column waves of the launch / this wave's index
   unsigned long long mbits[EXTRA ? 4 * NB : 1];                   // sign-bit words of the tile whose C is stored next (uniform: SGPRs)
   auto store_prev = [&]() {
     const __amdgpu_buffer_rsrc_t rc = wsx_rows_rsrc(p.C, p.ldc, p.M, prev_tile * TR);
+    if constexpr (LNF) {
+      const __amdgpu_buffer_rsrc_t ro = wsx_rows_rsrc(p.ln_out, p.ldc, p.M, prev_tile * TR);
+      const __amdgpu_buffer_rsrc_t rs = wsx_rows_rsrc(p.ln_stats, 2, p.M, prev_tile * TR);
+      const float* sp = lnst + prev_par * TR * 8;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(sp + (4 * g + r) * 8), b = *reinterpret_cast<const f32x4*>(sp + (4 * g + r) * 8 + 4);
+        const float mean = 0.25f * ((a[0] + a[2]) + (b[0] + b[2]));
+        const float d0 = a[0] - mean, d1 = a[2] - mean, d2 = b[0] - mean, d3 = b[2] - mean;
+        const float m2 = ((a[1] + a[3]) + (b[1] + b[3])) + (float)CW * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+        const float rstd = rsqrtf(m2 * (1.0f / (4 * CW)) + 1e-6f);
+        vecn o;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          reinterpret_cast<float*>(&o)[nb] = (reinterpret_cast<const float*>(&cprev[r])[nb] - mean) * rstd * ln_g[nb] + ln_b[nb];
+        wsx_buf_store<NB>(cprev[r], rc, c_voff[r]);
+        wsx_buf_store<NB>(o, ro, c_voff[r]);
+        __builtin_amdgcn_raw_buffer_store_b64((u32x2){__builtin_bit_cast(unsigned, mean), __builtin_bit_cast(unsigned, rstd)}, rs,
+                                              (wave == 0 && i == 0) ? (unsigned)(4 * g + r) * 8u : OOB, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       vecn v = cprev[r];
@@ -253,7 +312,12 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
     for (int f = 0; f < PF; ++f) afA[f] = *reinterpret_cast<const u32x4*>(As + (f % P) * TR * PITCH + frag_off + 64 * (f / P));
   }
 
-  auto do_tile = [&](int cur, f32x4 (&rn)[NV], u32x4 (&af)[PF], u32x4 (&afn)[PF]) {
+  if constexpr (LNF) {
+    const __amdgpu_buffer_rsrc_t rx = wsx_rows_rsrc(p.ln_x, p.ldc, p.M, phys(tile) * TR);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xresA[r] = wsx_buf_load<NB>(rx, c_voff[r]);
+  }
+  auto do_tile = [&](int cur, f32x4 (&rn)[NV], u32x4 (&af)[PF], u32x4 (&afn)[PF], vecn (&xres)[LNF ? 4 : 1], vecn (&xnext)[LNF ? 4 : 1]) {
     const char* At = As + cur * TILE_B + frag_off;
     if (!EARLY) {
 #pragma unroll
@@ -317,6 +381,11 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
         SKF_WSX_SCHED_BARRIER();
         wsx_store_tile<K, P, PITCH>(As + (cur ^ 1) * TILE_B, rn, sel);
         wsx_load_tile<K>(p.A, p.lda, p.M, phys(tile + (R + 1) * workers), a_voff, rn, a_cut);
+        if constexpr (LNF) {
+          const __amdgpu_buffer_rsrc_t rx = wsx_rows_rsrc(p.ln_x, p.ldc, p.M, phys(tile + workers) * TR);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) xnext[r] = wsx_buf_load<NB>(rx, c_voff[r]);
+        }
         if (EXTRA) {
           const int ptile = phys(tile);
           const __amdgpu_buffer_rsrc_t rh = wsx_rows_rsrc(has_relu ? p.relu_src : p.C, p.ld_relu, has_relu ? p.M : 0, ptile * TR);
@@ -366,6 +435,30 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
         if (NCH == 2) v += acc[nb][1][r];
         reinterpret_cast<float*>(&cprev[r])[nb] = v;
       }
+    if constexpr (LNF) {
+      const uint32_t karg0 = ((uint32_t)(phys(tile) * TR + 4 * g) * (uint32_t)(4 * CW) + (uint32_t)n_lane) * kSkfKeepStride + ln_sk;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float* zr = reinterpret_cast<float*>(&cprev[r]);
+        const float* xr = reinterpret_cast<const float*>(&xres[r]);
+        float sum = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          float y = zr[nb];
+          // element (row0 + r, n_lane + nb) of the (rows, 128) tensor: its hash argument is karg0 plus a compile-time multiple of the stride
+          if (p.ln_rate > 0.f) y *= skf_keep_arg(karg0 + (uint32_t)(r * 4 * CW + nb) * kSkfKeepStride, ln_thresh) ? ln_inv_keep : 0.f;
+          zr[nb] = xr[nb] + y;
+          sum += zr[nb];
+        }
+        const float mw = wsx_row16_sum(sum) * (1.0f / CW);
+        float sq = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) { const float c = zr[nb] - mw; sq += c * c; }
+        sq = wsx_row16_sum(sq);
+        if (i == 0) *reinterpret_cast<float2*>(lnst + ((cur * TR + 4 * g + r) * 4 + wave) * 2) = make_float2(mw, sq);
+      }
+      prev_par = cur;
+    }
     if (p.act == 1) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
@@ -405,8 +498,8 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
                                            // a break is not unrolled and would index the ring dynamically)
 #define SKF_WSX_STEP(u)                                              \
   {                                                                  \
-    if ((u) & 1) do_tile(1, ra[((u) + 1) % R], afB, afA);            \
-    else do_tile(0, ra[((u) + 1) % R], afA, afB);                    \
+    if ((u) & 1) do_tile(1, ra[((u) + 1) % R], afB, afA, xresB, xresA); \
+    else do_tile(0, ra[((u) + 1) % R], afA, afB, xresA, xresB);      \
     tile += workers;                                                 \
     if (tile >= nlive) break;                                        \
   }
@@ -452,8 +545,10 @@ int launch_wsx(const GemmParams& p, int b_kc, hipStream_t st) {
   // profiling: the dense figures, and the work of the live tiles only (A rows read / multiplied; every C row is still written)
   const double live = skf_prof_list_fraction(q.row_blocks);
   const double a_c = (double)p.M * p.K + (double)p.M * p.N * ((p.accumulate ? 1 : 0) + (p.relu_src && !p.relu_bits_in ? 1 : 0));
-  SkfProfScope ps(st, tag.c_str(), 2.0 * p.M * p.N * p.K, 4.0 * (a_c + (double)p.K * p.N + (double)p.M * p.N));
-  ps.done(2.0 * p.M * p.N * p.K * live, 4.0 * (a_c * live + (double)p.K * p.N + (double)p.M * p.N));
+  static const std::string tag_ln = tag + "+ln";      // its own line in the kernel table: C, the residual and the LayerNorm output move too
+  const double ln_c = p.ln_out ? 2.0 * p.M * p.N : 0.0;
+  SkfProfScope ps(st, p.ln_out ? tag_ln.c_str() : tag.c_str(), 2.0 * p.M * p.N * p.K, 4.0 * (a_c + ln_c + (double)p.K * p.N + (double)p.M * p.N));
+  ps.done(2.0 * p.M * p.N * p.K * live, 4.0 * (a_c * live + ln_c + (double)p.K * p.N + (double)p.M * p.N));
   // K >= 384 (N = 128): the two column groups of a worker read the same A tiles - XCD-contiguous ids keep the second read
   // in the L2 (PMC: 132 -> ~80 MB per launch); with one or two groups of short tiles (K <= 256) the remap only costs
   // K = 128 with three or more column groups (N = 384 / 512 / 1004): round-robin ids put the group-mates of a worker on
@@ -470,6 +565,20 @@ int launch_wsx(const GemmParams& p, int b_kc, hipStream_t st) {
     }                                                                                                              \
     hipLaunchKernelGGL((gemm_wsx_kernel<K, NB, P, BKC, EX>), grid, block, smem, st, q, groups, workers);           \
   } while (0)
+  if constexpr (K == 128 && NB == 2) {
+    if (q.ln_out) {            // residual + dropout + LayerNorm epilogue (skf_gemm_ln_residual_f32 checked the shape)
+      if (groups != 1 || extra || q.row_blocks || b_kc || q.act != 0) { skf_set_error("gemm_wsx: LayerNorm epilogue on an unsupported launch"); return SKF_EUNSUPPORTED; }
+      const size_t smem_ln = smem + (size_t)2 * TR * 4 * 2 * sizeof(float);
+      static bool attr_ln = false;
+      if (!attr_ln) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wsx_kernel<K, NB, P, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_ln);
+        attr_ln = true;
+      }
+      hipLaunchKernelGGL((gemm_wsx_kernel<K, NB, P, false, false, false, true>), grid, block, smem_ln, st, q, groups, workers);
+      SKF_LAUNCH_CHECK();
+      return SKF_OK;
+    }
+  }
   if constexpr (K == 512 && NB == 1) {
     if (q.k_valid > 0) {       // masked last slice of a long contraction (dgrad form only: skf_gemm_ws_dispatch)
       static bool attr_m[2] = {false, false};

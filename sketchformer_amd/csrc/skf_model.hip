@@ -491,6 +491,17 @@ int dense_fwd(SkfModel* M, const DenseP& w, const float* x, int rows, float* y, 
   return skf_gemm_f32(1, 0, rows, w.out, w.in, x, w.in, M->P(w.w), w.ld, y, w.out, M->P(w.b), act, nullptr, 0, 0, 1,
                       nullptr, 0, nullptr, 0, M->cfg.gemm_precision, s);
 }
+// y = Dense(a); z = x + dropout(y); out = LayerNorm(z): one launch where the fused kernel exists (the attention output projection
+// at d_model = 128 in the split-arithmetic modes), else the Dense launch followed by the LayerNorm launch.  SKF_NO_LN_FUSE=1: A/B knob.
+int dense_ln_fwd(SkfModel* M, const DenseP& w, const float* a, int rows, const float* x, float* z, const LnP& ln, float* out,
+                 float* stats, float rate, unsigned site, hipStream_t s) {
+  static const bool fuse_off = getenv("SKF_NO_LN_FUSE") && getenv("SKF_NO_LN_FUSE")[0] == '1';
+  if (!fuse_off && skf_gemm_ln_residual_supported(rows, w.out, w.in, M->cfg.gemm_precision))
+    return skf_gemm_ln_residual_f32(rows, w.out, w.in, a, w.in, M->P(w.w), w.ld, M->P(w.b), x, M->P(ln.g), M->P(ln.b), z, out, stats,
+                                    rate, site, M->state, M->cfg.gemm_precision, s);
+  SKF_TRY(dense_fwd(M, w, a, rows, z, 0, s));
+  return skf_layernorm_residual_fwd(x, z, M->P(ln.g), M->P(ln.b), out, stats, rows, w.out, rate, site, M->state, s);
+}
 // sign-bit buffer of an ffn hidden tensor (rows x dff from d inputs), or null when the shape has no such path / SKF_NO_RELU_BITS=1
 void* hbits_of(SkfModel* M, size_t off, int rows) {
   static const bool bits_off = getenv("SKF_NO_RELU_BITS") && getenv("SKF_NO_RELU_BITS")[0] == '1';
@@ -761,9 +772,8 @@ int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s, bool 
     SKF_TRY(dense_fwd(M, w.mha.qkv, x, Me, qkv, 0, s));
     SKF_TRY(skf_attention_fwd(qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, emask, Le, 0, B, H, Le, Le, dh,
                               M->at<float>(a.o), d, M->at<float>(a.astats), M->cfg.gemm_precision, s));
-    SKF_TRY(dense_fwd(M, w.mha.o, M->at<float>(a.o), Me, M->at<float>(a.z1), 0, s));
-    SKF_TRY(skf_layernorm_residual_fwd(x, M->at<float>(a.z1), M->P(w.ln1.g), M->P(w.ln1.b), M->at<float>(a.x1),
-                                       M->at<float>(a.st1), Me, d, rate, site_enc(i, 0), M->state, s));
+    SKF_TRY(dense_ln_fwd(M, w.mha.o, M->at<float>(a.o), Me, x, M->at<float>(a.z1), w.ln1, M->at<float>(a.x1), M->at<float>(a.st1), rate,
+                         site_enc(i, 0), s));
     SKF_TRY(dense_fwd_relu_bits(M, w.f1, M->at<float>(a.x1), Me, M->at<float>(a.h), hbits_of(M, a.hbits, Me), s));
     SKF_TRY(dense_fwd(M, w.f2, M->at<float>(a.h), Me, M->at<float>(a.z2), 0, s));
     SKF_TRY(skf_layernorm_residual_fwd(M->at<float>(a.x1), M->at<float>(a.z2), M->P(w.ln2.g), M->P(w.ln2.b),
@@ -823,18 +833,16 @@ int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s, bool 
     SKF_TRY(dense_fwd(M, w.mha1.qkv, x, Md, qkv, 0, s));
     SKF_TRY(skf_attention_fwd(qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, dmask, Ld, 1, B, H, Ld, Ld, dh,
                               M->at<float>(a.o1), d, M->at<float>(a.astats1), M->cfg.gemm_precision, s));
-    SKF_TRY(dense_fwd(M, w.mha1.o, M->at<float>(a.o1), Md, M->at<float>(a.z1), 0, s));
-    SKF_TRY(skf_layernorm_residual_fwd(x, M->at<float>(a.z1), M->P(w.ln1.g), M->P(w.ln1.b), M->at<float>(a.out1),
-                                       M->at<float>(a.st1), Md, d, rate, site_dec(N, i, 0), M->state, s));
+    SKF_TRY(dense_ln_fwd(M, w.mha1.o, M->at<float>(a.o1), Md, x, M->at<float>(a.z1), w.ln1, M->at<float>(a.out1), M->at<float>(a.st1),
+                         rate, site_dec(N, i, 0), s));
     float* kv2 = M->at<float>(a.kv2);
     SKF_TRY(dense_fwd(M, w.mha2.q, M->at<float>(a.out1), Md, M->at<float>(a.q2), 0, s));
     if (!kv_done) SKF_TRY(dense_fwd(M, w.mha2.kv, pre, Me, kv2, 0, s));
     else if (i == 0) SKF_HIP(hipStreamWaitEvent(s, kv_done, 0));
     SKF_TRY(skf_attention_fwd(M->at<float>(a.q2), d, kv2, 2 * d, kv2 + d, 2 * d, cross_mask, Le, 0, B, H, Ld, Le, dh,
                               M->at<float>(a.o2), d, M->at<float>(a.astats2), M->cfg.gemm_precision, s));
-    SKF_TRY(dense_fwd(M, w.mha2.o, M->at<float>(a.o2), Md, M->at<float>(a.z2), 0, s));
-    SKF_TRY(skf_layernorm_residual_fwd(M->at<float>(a.out1), M->at<float>(a.z2), M->P(w.ln2.g), M->P(w.ln2.b),
-                                       M->at<float>(a.out2), M->at<float>(a.st2), Md, d, rate, site_dec(N, i, 1), M->state, s));
+    SKF_TRY(dense_ln_fwd(M, w.mha2.o, M->at<float>(a.o2), Md, M->at<float>(a.out1), M->at<float>(a.z2), w.ln2, M->at<float>(a.out2),
+                         M->at<float>(a.st2), rate, site_dec(N, i, 1), s));
     SKF_TRY(dense_fwd_relu_bits(M, w.f1, M->at<float>(a.out2), Md, M->at<float>(a.h), hbits_of(M, a.hbits, Md), s));
     SKF_TRY(dense_fwd(M, w.f2, M->at<float>(a.h), Md, M->at<float>(a.z3), 0, s));
     SKF_TRY(skf_layernorm_residual_fwd(M->at<float>(a.out2), M->at<float>(a.z3), M->P(w.ln3.g), M->P(w.ln3.b),

@@ -221,6 +221,20 @@ def layernorm_residual_fwd(x, y, gamma, beta, rate=0.0, site=0, state=None):
     return out, z, stats
 
 
+def gemm_ln_residual(a, w, bias, x, gamma, beta, rate=0.0, site=0, state=None, precision=None):
+    """One launch: z = x + dropout(a . w + bias), out = LayerNorm(z) -> out, z, stats (skf_gemm_ln_residual_f32;
+    K = N = 128 in a split-arithmetic mode only)."""
+    _f32(a, "a"); _f32(w, "w"); _f32(x, "x")
+    M, K = a.shape
+    N = w.shape[1]
+    z = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    out = torch.empty_like(z)
+    stats = torch.empty(M, 2, dtype=torch.float32, device=a.device)
+    _lib.call("skf_gemm_ln_residual_f32", M, N, K, _p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(x), _p(gamma), _p(beta),
+              _p(z), _p(out), _p(stats), rate, site, _p(state), _prec(precision), _stream())
+    return out, z, stats
+
+
 def layernorm_residual_bwd(dout, z, stats, gamma, rate=0.0, site=0, state=None):
     d = dout.shape[-1]
     rows = dout.numel() // d

@@ -610,6 +610,55 @@ def test_layernorm_residual_fwd_bwd(ops, d, rate):
     _close(gb, db, rtol=5e-5, name="ln dbeta")
 
 
+@pytest.mark.parametrize("rows,rate", [(25600, 0.1), (1031, 0.1), (25472, 0.0), (7, 0.1)])
+def test_gemm_ln_residual_one_launch(ops, rows, rate):
+    """Dense + residual + dropout + LayerNorm in one launch (the attention output projection, K = N = 128) against the oracle,
+    and against the two launches it replaces: z bit-identical, out / stats to rounding."""
+    d = 128
+    rng = np.random.RandomState(rows)
+    a, x = rng.randn(rows, d), rng.randn(rows, d)
+    x[rows // 2] = 100.0 + 1e-3 * rng.randn(d)               # a row whose mean dwarfs its spread: the centred sums must hold
+    w, b = rng.randn(d, d) / np.sqrt(d), 0.1 * rng.randn(d)
+    gamma, beta = 1 + 0.1 * rng.randn(d), 0.1 * rng.randn(d)
+    st = ops.new_step_state("cuda", iterations=3)
+    ops.step_prologue(st, seed=5)
+    keep = np.ones((rows, d), bool)
+    if rate > 0:
+        keep = ops.dropout_keep_mask(ops.read_step_state(st)["drop_key"], 4, rate, rows * d).reshape(rows, d)
+    z = x + oracle.dropout_fwd(a @ w + b, keep, rate)
+    want, cache = oracle.layernorm_fwd(z, gamma, beta)
+    A, X, W, Bv, G, Be = _dev(a), _dev(x), _dev(w), _dev(b), _dev(gamma), _dev(beta)
+    out, zz, stats = ops.gemm_ln_residual(A, W, Bv, X, G, Be, rate=rate, site=4, state=st, precision=6)
+    _close(zz, z, name="fused z")
+    _close(out, want, rtol=2e-5, name="fused ln out")
+    mean, var = z.mean(-1), z.var(-1)
+    _close(stats[:, 0], mean, rtol=2e-5, name="fused mean")
+    _close(stats[:, 1], 1.0 / np.sqrt(var + 1e-6), rtol=2e-5, name="fused rstd")
+    if rows > 2048:                                            # below that the plain call takes the small fp32 kernel
+        y = ops.gemm(A, W, bias=Bv, precision=6)
+        out2, z2, stats2 = ops.layernorm_residual_fwd(X, y, G, Be, rate=rate, site=4, state=st)
+        assert torch.equal(zz, z2), "z differs from the Dense + LayerNorm launch pair"
+        assert (out - out2).abs().max().item() <= 2e-5 * max(1.0, out2.abs().max().item())
+        assert (stats - stats2).abs().max().item() <= 2e-5 * max(1.0, stats2.abs().max().item())
+    # the backward consumes (z, stats) exactly as the LayerNorm launch leaves them
+    dout = rng.randn(rows, d)
+    dz, dg, db = oracle.layernorm_bwd(dout, cache)
+    gz, gy, gg, gb = ops.layernorm_residual_bwd(_dev(dout), zz, stats, G, rate=rate, site=4, state=st)
+    _close(gz, dz, rtol=5e-5, name="ln dz from fused stats")
+    _close(gg, dg, rtol=5e-5, name="ln dgamma from fused stats")
+
+
+def test_gemm_ln_residual_refuses_other_shapes(ops):
+    lib = ops._lib.load()
+    assert lib.skf_gemm_ln_residual_supported(25600, 128, 128, 6) == 1
+    assert lib.skf_gemm_ln_residual_supported(25600, 128, 128, 0) == 0      # fp32-MFMA mode: two launches
+    assert lib.skf_gemm_ln_residual_supported(25600, 128, 512, 6) == 0
+    assert lib.skf_gemm_ln_residual_supported(25600, 256, 256, 6) == 0
+    a = torch.zeros(64, 256, device="cuda"); w = torch.zeros(256, 256, device="cuda"); v = torch.zeros(256, device="cuda")
+    with pytest.raises(RuntimeError):
+        ops.gemm_ln_residual(a, w, v, a, v, v, precision=6)
+
+
 # ------------------------------------------------------------------ loss heads
 @pytest.mark.parametrize("V", [1004, 52, 10004])
 def test_recon_softmax_ce(ops, V):
