@@ -17,6 +17,7 @@
 // Small products go to their own accumulator (added to the a0.b0 sum at the end).
 #include "skf_common.h"
 #include "skf_gemm_params.h"
+#include <set>
 
 namespace {
 
@@ -73,24 +74,24 @@ __device__ __forceinline__ void wsx_buf_store(typename VecOfX<NB>::type v, __amd
 
 template <int P> __device__ __forceinline__ void split2(float x, float y, unsigned (&out)[P], const SkfSplitSel& sel) { skf_split2<P>(x, y, out, sel); }
 
-template <int K>
+template <int K, int KS = 1>
 __device__ __forceinline__ void wsx_load_tile(const float* __restrict__ A, int lda, int M, int tile,
-                                              const unsigned (&a_voff)[TR * K / 1024], f32x4 (&ra)[TR * K / 1024], int cut = 0) {
+                                              const unsigned (&a_voff)[TR * K / (1024 * KS)], f32x4 (&ra)[TR * K / (1024 * KS)], int cut = 0) {
 #ifdef SKF_WSX_ABLATE_LOAD   // diagnostics: every A tile load hits the same (cached) rows
   tile &= 7;
 #endif
   const __amdgpu_buffer_rsrc_t r = wsx_rows_rsrc(A, lda, M, tile * TR, cut);
 #pragma unroll
-  for (int v = 0; v < TR * K / 1024; ++v)
+  for (int v = 0; v < TR * K / (1024 * KS); ++v)
     ra[v] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, a_voff[v], 0, 0));
 }
 
 // one A tile (registers, fp32) -> P bf16 planes in LDS; PITCH = bytes per row
-template <int K, int P, int PITCH>
-__device__ __forceinline__ void wsx_store_tile(char* __restrict__ dst, const f32x4 (&ra)[TR * K / 1024], const SkfSplitSel& sel) {
+template <int K, int P, int PITCH, int KS = 1>
+__device__ __forceinline__ void wsx_store_tile(char* __restrict__ dst, const f32x4 (&ra)[TR * K / (1024 * KS)], const SkfSplitSel& sel) {
 #pragma unroll
-  for (int v = 0; v < TR * K / 1024; ++v) {
-    const int e = threadIdx.x + v * 256, row = e / (K / 4), c4 = (e % (K / 4)) * 4;
+  for (int v = 0; v < TR * K / (1024 * KS); ++v) {
+    const int e = threadIdx.x + v * 256 * KS, row = e / (K / 4), c4 = (e % (K / 4)) * 4;
     unsigned lo[P], hi[P];
     split2<P>(ra[v][0], ra[v][1], lo, sel);
     split2<P>(ra[v][2], ra[v][3], hi, sel);
@@ -115,11 +116,16 @@ __device__ __forceinline__ float wsx_row16_sum(float v) {
 // behind it every wave forms z for its 32 columns, their mean and centred square sum (two passes in registers, DPP row sums) and
 // leaves the pair in LDS; the tile's closing barrier publishes them; the four pairs of a row are combined (Chan's update: as
 // accurate as two passes over the whole row) when the tile is stored, under the next tile's MFMAs.
-template <int K, int NB, int P, bool B_KC, bool EXTRA, bool KMASK = false, bool LNF = false>
-__global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_kernel(GemmParams p, int groups, int workers) {
+// KS = 2 (K >= 256, no activation): 512 threads, the contraction is split between two waves of each 16-column block - waves 0-3
+// take k < K/2 and own the output, waves 4-7 take the rest and hand their partial sums over through LDS behind the tile's closing
+// barrier (added when the tile is stored, under the next tile's MFMAs).  Half the weight registers per wave (96 instead of 192 at
+// K = 512) = two waves per SIMD instead of one: K = 512 ran at one wave per SIMD with 1536 MFMA cycles in a ~4100-cycle tile.
+template <int K, int NB, int P, bool B_KC, bool EXTRA, bool KMASK = false, bool LNF = false, int KS = 1>
+__global__ __launch_bounds__(256 * KS, (KS == 2 || (K <= 256 && NB <= 2) ? 2 : 1)) void gemm_wsx_kernel(GemmParams p, int groups, int workers) {
   constexpr int CW = 16 * NB;            // columns per wave
-  constexpr int NKS = K / 32;            // MFMA k-steps per tile
+  constexpr int NKS = K / (32 * KS);     // MFMA k-steps per tile (of this wave)
   constexpr int NF = NKS * P;            // A fragments (ds_read_b128) per tile
+  static_assert(KS == 1 || (KS == 2 && K >= 256 && !LNF), "contraction split: two halves, K >= 256");
   static_assert(!LNF || (K == 128 && NB == 2 && !EXTRA && !KMASK), "LayerNorm epilogue: K = 128, two columns per lane, plain launch");
   constexpr bool EARLY = !LNF && K == 128 && (P == 2 || NB == 4 || SKF_WSX_EARLY3);   // every fragment of a tile in registers: barrier inside the MFMA stream
   constexpr int PF = EARLY ? NF : (NF < 6 ? NF : 6);
@@ -128,7 +134,7 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
                                          // groups g (lanes {0-3,12-15,20-27}, ...): with quad(i, g) = 2i + g (pitch = 32 mod 256) every
                                          // group hits 16 different bank quads; +16 (quad = i + g) had a 2-way conflict in each group
   constexpr int TILE_B = P * TR * PITCH; // bytes per LDS tile buffer
-  constexpr int NV = TR * K / 1024;      // float4 per thread per A tile
+  constexpr int NV = TR * K / (1024 * KS);   // float4 per thread per A tile
   constexpr int R = (K == 128 && !EARLY) ? 4 : 2;   // A tiles in flight in registers
   constexpr unsigned OOB = 0x7ffffff0u;
   typedef typename VecOfX<NB>::type vecn;
@@ -137,7 +143,9 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
 
   const SkfSplitSel sel = skf_split_sel();
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = wave_all & 3, kh = wave_all >> 2;        // column block of the wave, its half of the contraction (0 when KS = 1)
+  const int s0 = kh * NKS;                                  // first k-step of this wave
   const int i = lane & 15, g = lane >> 4;
   const int logical = p.xcd_remap ? skf_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   const int group = logical % groups, worker = logical / groups;
@@ -170,7 +178,7 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) { ln_g[nb] = p.ln_gamma[n_ld + nb]; ln_b[nb] = p.ln_beta[n_ld + nb]; }
   }
-  long long* dbg = (p.dbg && lane == 0 && wave == 0 && (blockIdx.x % 64) == 0 && blockIdx.x / 64 < 8) ? p.dbg + (blockIdx.x / 64) * 32 : nullptr;   // same XCD: comparable clocks
+  long long* dbg = (p.dbg && lane == 0 && wave_all == 0 && (blockIdx.x % 64) == 0 && blockIdx.x / 64 < 8) ? p.dbg + (blockIdx.x / 64) * 32 : nullptr;   // same XCD: comparable clocks
   int dbi = 0;
 #if SKF_WS_STAMPS   // per-phase s_memtime stamps (tools/ws_timeline.py); off by default
 #define SKF_STAMP() do { if (dbg && dbi < 30) dbg[dbi++] = clock64(); } while (0)
@@ -184,7 +192,7 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
   unsigned a_voff[NV], c_voff[4], h_voff[4];
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
-    const int e = tid + v * 256, row = e / (K / 4), c4 = (e % (K / 4)) * 4;
+    const int e = tid + v * 256 * KS, row = e / (K / 4), c4 = (e % (K / 4)) * 4;
     a_voff[v] = (unsigned)(row * p.lda + c4) * 4u;
   }
 #pragma unroll
@@ -198,7 +206,7 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
   int tile = worker;
   const int a_cut = KMASK ? p.a_cut : 0;
 #pragma unroll
-  for (int j = 0; j < R; ++j) wsx_load_tile<K>(p.A, p.lda, p.M, phys(tile + j * workers), a_voff, ra[j], a_cut);
+  for (int j = 0; j < R; ++j) wsx_load_tile<K, KS>(p.A, p.lda, p.M, phys(tile + j * workers), a_voff, ra[j], a_cut);
 
   // ---- weight slice -> split bf16 operands (once): bq[nb][s][q] = pieces q of B[k = 32s + 8g + e][n_lane + nb], e < 8
   u32x4 bq[NB][NKS][P];
@@ -210,7 +218,7 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
       for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const int k4 = 32 * s + 8 * g + 4 * h;
+          const int k4 = 32 * (s0 + s) + 8 * g + 4 * h;
           // KMASK: k_valid is a multiple of 4, so a 4-vector is all in or all out; out ones re-read the last valid vector (no
           // access behind the weight row) and count as zeros
           const int kl = KMASK ? (k4 < p.k_valid ? k4 : p.k_valid - 4) : k4;
@@ -221,7 +229,7 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
     } else {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const vecn v = *reinterpret_cast<const vecn*>(p.B + (size_t)(32 * s + 8 * g + e) * p.ldb + n_ld);
+        const vecn v = *reinterpret_cast<const vecn*>(p.B + (size_t)(32 * (s0 + s) + 8 * g + e) * p.ldb + n_ld);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) f[nb][e] = reinterpret_cast<const float*>(&v)[nb];
       }
@@ -238,13 +246,13 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
   }
   float bias_r[NB];
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) bias_r[nb] = p.bias ? p.bias[n_ld + nb] : 0.f;
+  for (int nb = 0; nb < NB; ++nb) bias_r[nb] = (p.bias && kh == 0) ? p.bias[n_ld + nb] : 0.f;
 
   const uint32_t ln_sk = (LNF && p.ln_rate > 0.f) ? skf_site_key(ln_key, p.ln_site) : 0u;
   SKF_STAMP();   // weight slice loaded + split
-  wsx_store_tile<K, P, PITCH>(As, ra[0], sel);
+  wsx_store_tile<K, P, PITCH, KS>(As, ra[0], sel);
   __syncthreads();
-  wsx_load_tile<K>(p.A, p.lda, p.M, phys(tile + R * workers), a_voff, ra[0], a_cut);
+  wsx_load_tile<K, KS>(p.A, p.lda, p.M, phys(tile + R * workers), a_voff, ra[0], a_cut);
   SKF_STAMP();   // first A tile in LDS
 
   vecn cprev[4], hsrc[4], oacc[4];
@@ -255,8 +263,16 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
   const bool has_relu = EXTRA && p.relu_src != nullptr && !has_bits;
   const int ncw = groups * 4, cwi = group * 4 + wave;             // column waves of the launch / this wave's index
   unsigned long long mbits[EXTRA ? 4 * NB : 1];                   // sign-bit words of the tile whose C is stored next (uniform: SGPRs)
+  // KS = 2: partial sums of the upper contraction half, [2 tile parities][4 column waves][64 lanes] x vecn[4]
+  vecn* xch = reinterpret_cast<vecn*>(smem_x + 2 * TILE_B);
   auto store_prev = [&]() {
+    if (KS == 2 && kh != 0) return;                              // the upper half's waves own no output
     const __amdgpu_buffer_rsrc_t rc = wsx_rows_rsrc(p.C, p.ldc, p.M, prev_tile * TR);
+    if constexpr (KS == 2) {
+      const vecn* part = xch + ((prev_par * 4 + wave) * 64 + lane) * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cprev[r] += part[r];
+    }
     if constexpr (LNF) {
       const __amdgpu_buffer_rsrc_t ro = wsx_rows_rsrc(p.ln_out, p.ldc, p.M, prev_tile * TR);
       const __amdgpu_buffer_rsrc_t rs = wsx_rows_rsrc(p.ln_stats, 2, p.M, prev_tile * TR);
@@ -305,7 +321,7 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
     }
   };
 
-  const int frag_off = i * PITCH + 16 * g;   // byte offset of this lane's fragment inside (plane, step 0)
+  const int frag_off = i * PITCH + 16 * g + 64 * s0;   // byte offset of this lane's fragment inside (plane, first step of the wave)
   u32x4 afA[PF], afB[PF];
   if (EARLY) {
 #pragma unroll
@@ -344,7 +360,7 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
     };
     // K <= 256: all small products of the tile first, its a0.b0 products last (their A fragments stay in registers);
     // longer K: the a0.b0 product closes each k-step (no room to keep K/32 fragments, and no second LDS read).
-    constexpr bool TWO_PHASE = K <= 256;
+    constexpr bool TWO_PHASE = K / KS <= 256;
     u32x4 a0keep[TWO_PHASE ? NKS : 1];
     int c = 0;
 #pragma unroll
@@ -379,14 +395,14 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
       }
       if (s == NKS / 2 - 1) {
         SKF_WSX_SCHED_BARRIER();
-        wsx_store_tile<K, P, PITCH>(As + (cur ^ 1) * TILE_B, rn, sel);
-        wsx_load_tile<K>(p.A, p.lda, p.M, phys(tile + (R + 1) * workers), a_voff, rn, a_cut);
+        wsx_store_tile<K, P, PITCH, KS>(As + (cur ^ 1) * TILE_B, rn, sel);
+        wsx_load_tile<K, KS>(p.A, p.lda, p.M, phys(tile + (R + 1) * workers), a_voff, rn, a_cut);
         if constexpr (LNF) {
           const __amdgpu_buffer_rsrc_t rx = wsx_rows_rsrc(p.ln_x, p.ldc, p.M, phys(tile + workers) * TR);
 #pragma unroll
           for (int r = 0; r < 4; ++r) xnext[r] = wsx_buf_load<NB>(rx, c_voff[r]);
         }
-        if (EXTRA) {
+        if (EXTRA && (KS == 1 || kh == 0)) {
           const int ptile = phys(tile);
           const __amdgpu_buffer_rsrc_t rh = wsx_rows_rsrc(has_relu ? p.relu_src : p.C, p.ld_relu, has_relu ? p.M : 0, ptile * TR);
 #pragma unroll
@@ -435,6 +451,14 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
         if (NCH == 2) v += acc[nb][1][r];
         reinterpret_cast<float*>(&cprev[r])[nb] = v;
       }
+    if constexpr (KS == 2) {
+      if (kh != 0) {
+        vecn* part = xch + ((cur * 4 + wave) * 64 + lane) * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[r] = cprev[r];
+      }
+      prev_par = cur;
+    }
     if constexpr (LNF) {
       const uint32_t karg0 = ((uint32_t)(phys(tile) * TR + 4 * g) * (uint32_t)(4 * CW) + (uint32_t)n_lane) * kSkfKeepStride + ln_sk;
 #pragma unroll
@@ -459,7 +483,7 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
       }
       prev_par = cur;
     }
-    if (p.act == 1) {
+    if (KS == 1 && p.act == 1) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -484,7 +508,7 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
             reinterpret_cast<char*>(wr ? (void*)p.relu_bits_out : (void*)p.C) + woff, 0, wr ? 4 * NB * 8 : 0, 0x00020000);
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, w), rb, (unsigned)lane * 8u, 0, 0);
       }
-    } else if (p.act == 2) {   // the bottleneck's tanh projection (one launch per step): a wave-uniform branch nobody else takes
+    } else if (KS == 1 && p.act == 2) {   // the bottleneck's tanh projection (one launch per step): a wave-uniform branch nobody else takes
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -510,7 +534,7 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
   }
 #undef SKF_WSX_STEP
   store_prev();
-  if (blk && !p.accumulate) {                        // rows of dead tiles: zeros (an accumulating call leaves them as they are)
+  if (blk && !p.accumulate && kh == 0) {             // rows of dead tiles: zeros (an accumulating call leaves them as they are)
     vecn zero;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) reinterpret_cast<float*>(&zero)[nb] = 0.f;
@@ -527,18 +551,18 @@ __global__ __launch_bounds__(256, (K <= 256 && NB <= 2 ? 2 : 1)) void gemm_wsx_k
 #undef SKF_STAMP
 }
 
-template <int K, int NB, int P>
+template <int K, int NB, int P, int KS = 1>
 int launch_wsx(const GemmParams& p, int b_kc, hipStream_t st) {
   constexpr int CW = 16 * NB;
   const int groups = skf_cdiv(p.N, 4 * CW);
-  static const int wg_target = getenv("SKF_WS_WGS") ? atoi(getenv("SKF_WS_WGS")) : (K <= 256 && NB <= 2 ? 512 : 256);
+  static const int wg_target = getenv("SKF_WS_WGS") ? atoi(getenv("SKF_WS_WGS")) : (KS == 1 && K <= 256 && NB <= 2 ? 512 : 256);
   int workers = wg_target / groups;
   if (workers < 1) workers = 1;
   const int ntiles = skf_cdiv(p.M, TR);
   if (workers > ntiles) workers = ntiles;
-  const size_t smem = (size_t)2 * P * TR * (2 * K + 32);
-  dim3 grid(groups * workers), block(256);
-  static const std::string tag = "gemm_wsx<K" + std::to_string(K) + ",CW" + std::to_string(CW) + ",bf16x" + std::to_string(P * (P + 1) / 2) + ">";
+  const size_t smem = (size_t)2 * P * TR * (2 * K + 32) + (KS == 2 ? (size_t)2 * 4 * 64 * 4 * NB * sizeof(float) : 0);
+  dim3 grid(groups * workers), block(256 * KS);
+  static const std::string tag = "gemm_wsx<K" + std::to_string(K) + ",CW" + std::to_string(CW) + ",bf16x" + std::to_string(P * (P + 1) / 2) + (KS == 2 ? ",ksplit" : "") + ">";
   const bool extra = p.relu_src || p.accumulate || p.relu_bits_in;
   GemmParams q = p;
   if (q.row_block_rows != TR) q.row_blocks = nullptr;       // the list's blocks must be this kernel's tiles
@@ -547,7 +571,13 @@ int launch_wsx(const GemmParams& p, int b_kc, hipStream_t st) {
   const double a_c = (double)p.M * p.K + (double)p.M * p.N * ((p.accumulate ? 1 : 0) + (p.relu_src && !p.relu_bits_in ? 1 : 0));
   static const std::string tag_ln = tag + "+ln";      // its own line in the kernel table: C, the residual and the LayerNorm output move too
   const double ln_c = p.ln_out ? 2.0 * p.M * p.N : 0.0;
-  SkfProfScope ps(st, p.ln_out ? tag_ln.c_str() : tag.c_str(), 2.0 * p.M * p.N * p.K, 4.0 * (a_c + ln_c + (double)p.K * p.N + (double)p.M * p.N));
+  // SKF_PROF_FINE=1 (analysis only): one table line per output width and epilogue
+  static const bool fine = getenv("SKF_PROF_FINE") && getenv("SKF_PROF_FINE")[0] == '1';
+  static std::set<std::string> fine_tags;           // the profiler keeps the pointer: interned
+  const char* ftag = nullptr;
+  if (fine) ftag = fine_tags.insert(tag + "[N" + std::to_string(p.N) + (b_kc ? ",dgrad" : "") + (p.relu_bits_in ? ",bits" : "") + (p.relu_src ? ",relu_src" : "") +
+                   (p.accumulate ? ",acc" : "") + (q.row_blocks ? ",list" : "") + (p.act ? ",act" : "") + (p.ln_out ? ",ln" : "") + "]").first->c_str();
+  SkfProfScope ps(st, fine ? ftag : p.ln_out ? tag_ln.c_str() : tag.c_str(), 2.0 * p.M * p.N * p.K, 4.0 * (a_c + ln_c + (double)p.K * p.N + (double)p.M * p.N));
   ps.done(2.0 * p.M * p.N * p.K * live, 4.0 * (a_c * live + ln_c + (double)p.K * p.N + (double)p.M * p.N));
   // K >= 384 (N = 128): the two column groups of a worker read the same A tiles - XCD-contiguous ids keep the second read
   // in the L2 (PMC: 132 -> ~80 MB per launch); with one or two groups of short tiles (K <= 256) the remap only costs
@@ -559,13 +589,13 @@ int launch_wsx(const GemmParams& p, int b_kc, hipStream_t st) {
   do {                                                                                                             \
     static bool attr_done = false;                                                                                 \
     if (!attr_done) {                                                                                              \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wsx_kernel<K, NB, P, BKC, EX>),                    \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wsx_kernel<K, NB, P, BKC, EX, false, false, KS>),  \
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                                  \
       attr_done = true;                                                                                            \
     }                                                                                                              \
-    hipLaunchKernelGGL((gemm_wsx_kernel<K, NB, P, BKC, EX>), grid, block, smem, st, q, groups, workers);           \
+    hipLaunchKernelGGL((gemm_wsx_kernel<K, NB, P, BKC, EX, false, false, KS>), grid, block, smem, st, q, groups, workers); \
   } while (0)
-  if constexpr (K == 128 && NB == 2) {
+  if constexpr (K == 128 && NB == 2 && KS == 1) {
     if (q.ln_out) {            // residual + dropout + LayerNorm epilogue (skf_gemm_ln_residual_f32 checked the shape)
       if (groups != 1 || extra || q.row_blocks || b_kc || q.act != 0) { skf_set_error("gemm_wsx: LayerNorm epilogue on an unsupported launch"); return SKF_EUNSUPPORTED; }
       const size_t smem_ln = smem + (size_t)2 * TR * 4 * 2 * sizeof(float);
@@ -583,12 +613,12 @@ int launch_wsx(const GemmParams& p, int b_kc, hipStream_t st) {
     if (q.k_valid > 0) {       // masked last slice of a long contraction (dgrad form only: skf_gemm_ws_dispatch)
       static bool attr_m[2] = {false, false};
       if (!attr_m[extra ? 1 : 0]) {
-        if (extra) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wsx_kernel<K, NB, P, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wsx_kernel<K, NB, P, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (extra) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wsx_kernel<K, NB, P, true, true, true, false, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wsx_kernel<K, NB, P, true, false, true, false, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_m[extra ? 1 : 0] = true;
       }
-      if (extra) hipLaunchKernelGGL((gemm_wsx_kernel<K, NB, P, true, true, true>), grid, block, smem, st, q, groups, workers);
-      else hipLaunchKernelGGL((gemm_wsx_kernel<K, NB, P, true, false, true>), grid, block, smem, st, q, groups, workers);
+      if (extra) hipLaunchKernelGGL((gemm_wsx_kernel<K, NB, P, true, true, true, false, KS>), grid, block, smem, st, q, groups, workers);
+      else hipLaunchKernelGGL((gemm_wsx_kernel<K, NB, P, true, false, true, false, KS>), grid, block, smem, st, q, groups, workers);
       SKF_LAUNCH_CHECK();
       return SKF_OK;
     }
@@ -610,7 +640,12 @@ int launch_wsx_k(const GemmParams& p, int b_kc, hipStream_t st) {
     case 128: return launch_wsx<128, 2, P>(p, b_kc, st);
     case 256: return launch_wsx<256, 1, P>(p, b_kc, st);
     case 384: return launch_wsx<384, 1, P>(p, b_kc, st);
-    default:  return launch_wsx<512, 1, P>(p, b_kc, st);
+    default: {
+      // K = 512 without an activation: the contraction split between wave pairs (two waves per SIMD); SKF_WSX_KSPLIT=0: A/B knob
+      static const bool ks_off = getenv("SKF_WSX_KSPLIT") && getenv("SKF_WSX_KSPLIT")[0] == '0';
+      if (!ks_off && p.act == 0) return launch_wsx<512, 1, P, 2>(p, b_kc, st);
+      return launch_wsx<512, 1, P>(p, b_kc, st);
+    }
   }
 }
 
