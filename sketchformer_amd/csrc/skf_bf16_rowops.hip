@@ -424,9 +424,18 @@ __global__ __launch_bounds__(256) void cast_weight_kernel(const float* __restric
 // i (the ~90 images of a step were 90 launches of a few microseconds each)
 __global__ __launch_bounds__(256) void cast_weight_batch_kernel(const SkfCastDesc* __restrict__ descs, int n) {
   __shared__ float tile[32][33];
-  int i = 0;
-  while (i + 1 < n && descs[i + 1].block_begin <= (int)blockIdx.x) ++i;      // wave-uniform scan of a short table
-  const SkfCastDesc d = descs[i];
+  // binary search over scalar loads (constant address space: the table is uploaded once, no kernel writes it); the linear scan over
+  // plain global loads was up to ~90 dependent memory round trips for the last workgroups
+  typedef const __attribute__((address_space(4))) SkfCastDesc* const_descp;
+  const const_descp cd = (const_descp)descs;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (cd[mid].block_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  SkfCastDesc d;                                         // (member-wise: no copy constructor across address spaces)
+  d.src = cd[lo].src; d.dst = cd[lo].dst; d.dst_t = cd[lo].dst_t; d.R = cd[lo].R; d.C = cd[lo].C; d.ld_src = cd[lo].ld_src;
+  d.ld_dst = cd[lo].ld_dst; d.ld_t = cd[lo].ld_t; d.block_begin = cd[lo].block_begin; d.blocks_x = cd[lo].blocks_x; d.pad = 0;
   const int local = blockIdx.x - d.block_begin;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int r0 = (local / d.blocks_x) * 32, c0 = (local % d.blocks_x) * 32;

@@ -359,9 +359,19 @@ extern "C" int skf_gemm_default_splits(int M, int N, int K) {
 namespace {
 __global__ __launch_bounds__(256) void splitk_reduce_batch_kernel(const SkfReduceDesc* __restrict__ descs, int ndesc) {
   __shared__ f32x4 red[4][64];
-  int di = 0;
-  while (di + 1 < ndesc && (int)blockIdx.x >= descs[di + 1].block_begin) ++di;    // ndesc is small (tens)
-  const SkfReduceDesc d = descs[di];
+  // descriptor of this workgroup: the last one with block_begin <= blockIdx.x.  Binary search over scalar loads (constant address
+  // space: the table is uploaded once and never written by a kernel) - the linear scan over plain global loads was up to ~50
+  // DEPENDENT memory round trips (`global_load_dword; s_waitcnt vmcnt(0)`) before a late workgroup issued its first slab load
+  typedef const __attribute__((address_space(4))) SkfReduceDesc* const_descp;
+  const const_descp cd = (const_descp)descs;
+  int lo = 0, hi = ndesc - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int)blockIdx.x >= cd[mid].block_begin) lo = mid; else hi = mid - 1;
+  }
+  SkfReduceDesc d;
+  d.slab = cd[lo].slab; d.C = cd[lo].C; d.bias_grad = cd[lo].bias_grad;
+  d.splits = cd[lo].splits; d.M = cd[lo].M; d.N = cd[lo].N; d.ldc = cd[lo].ldc; d.block_begin = cd[lo].block_begin; d.pad = 0;
   const int M = d.M, N = d.N, splits = d.splits;
   const size_t total = (size_t)M * N, total4 = (total + N + 3) / 4;
   const int zg = threadIdx.x >> 6;
@@ -374,6 +384,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_batch_kernel(const SkfReduc
     const float* src = in_tiles ? d.slab + base : (colsum_slab ? colsum_slab + (base - total) : nullptr);
     const size_t zstride = in_tiles ? total : (size_t)N;
     if (src) {
+      // (measured: all <= 16 slabs of a wave group requested before the first add - one round trip instead of four - made the launch
+      //  SLOWER, 95 vs 52 us for ~95 MB: the slabs of one output tile lie 64-262 KB apart, and more strided requests in flight
+      //  only deepen the translation / DRAM-page misses; the cure would be a [tile][split] slab layout)
       int z = zg;
       for (; z + 12 < splits; z += 16) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(src + (size_t)z * zstride);

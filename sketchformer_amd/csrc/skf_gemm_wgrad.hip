@@ -204,6 +204,9 @@ __device__ __forceinline__ void wgrad_x_body(const GemmParams& p, const int bid,
     } else {
       r0 = kb + RI * it + 32 * wave; r1 = ke;
     }
+#ifdef SKF_WG_ABLATE_LOAD   // diagnostics: every step re-reads the first rows of its split (cache hits; wrong results)
+    if (r0 < p.K) { r0 = kb + 32 * wave; r1 = ke; }
+#endif
     const __amdgpu_buffer_rsrc_t rx = wg_rows_rsrc(p.A, p.lda, r0, r1);
     const __amdgpu_buffer_rsrc_t ry = wg_rows_rsrc(p.B, p.ldb, r0, r1);
 #pragma unroll
