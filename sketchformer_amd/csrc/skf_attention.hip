@@ -27,6 +27,7 @@
 // fp32-MFMA mode, head size 64 and long sequences.
 #include <stdlib.h>
 #include "skf_common.h"
+#include <type_traits>
 #include "skf_attention_params.h"
 
 namespace {
@@ -94,35 +95,54 @@ __global__ __launch_bounds__(256, MAXT <= 13 ? 4 : 1) void attn_fwd_kernel(AttnP
     }
   };
   load_q((wave + bh) & 3, qnext);
-  // ---- stage K, V^T (zero-filled tail rows) and the key mask
-  for (int e = tid; e < nkt * 16 * (DH / 4); e += 256) {
-    const int row = e / (DH / 4), c4 = (e % (DH / 4)) * 4;
-    float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-    if (row < p.Lk) {
-      kv = *reinterpret_cast<const float4*>(p.K + (size_t)(b * p.Lk + row) * p.ldk + h * DH + c4);
-      vv = *reinterpret_cast<const float4*>(p.V + (size_t)(b * p.Lk + row) * p.ldv + h * DH + c4);
-    }
-    if constexpr (SPLIT) {
-      unsigned lo[3], hi[3];
-      skf_split2<3>(kv.x, kv.y, lo, sel);
-      skf_split2<3>(kv.z, kv.w, hi, sel);
-      char* kp = reinterpret_cast<char*>(Ks);
+  // ---- stage K, V^T (zero-filled tail rows) and the key mask.  All global loads of the prologue are issued before the first wait
+  // (clamped, always valid addresses; rows past Lk zeroed afterwards): the guarded form - `if (row < Lk) load` inside a 256-element
+  // loop, then the mask bytes - was one serialised memory round trip per loop iteration, five before the first MFMA at L = 200.
+  const int last_key = p.Lk - 1;
+  const unsigned char* kmp = p.key_mask ? p.key_mask + (size_t)b * p.key_mask_ld
+                                        : reinterpret_cast<const unsigned char*>(p.K + (size_t)b * p.Lk * p.ldk);   // no mask: readable bytes, ignored
+  const unsigned char mk0 = kmp[min(tid, last_key)];
+  constexpr int SB = 4;                                  // staging loads in flight per thread (K and V: 2 x SB float4)
+  const int stage_total = nkt * 16 * (DH / 4);
+  for (int e0 = tid; e0 < stage_total; e0 += 256 * SB) {
+    float4 kvb[SB], vvb[SB];
 #pragma unroll
-      for (int q = 0; q < 3; ++q)
-        *reinterpret_cast<attn_u32x2*>(kp + (size_t)q * nkt * 16 * KPP + row * KPP + c4 * 2) = (attn_u32x2){lo[q], hi[q]};
-    } else {
-      *reinterpret_cast<float4*>(&Ks[row * LD + c4]) = kv;
+    for (int u = 0; u < SB; ++u) {
+      const int e = e0 + u * 256, rc = min(e / (DH / 4), last_key), c4 = (e % (DH / 4)) * 4;
+      kvb[u] = *reinterpret_cast<const float4*>(p.K + (size_t)(b * p.Lk + rc) * p.ldk + h * DH + c4);
+      vvb[u] = *reinterpret_cast<const float4*>(p.V + (size_t)(b * p.Lk + rc) * p.ldv + h * DH + c4);
     }
-    Vt[(c4 + 0) * VP + row] = vv.x; Vt[(c4 + 1) * VP + row] = vv.y; Vt[(c4 + 2) * VP + row] = vv.z; Vt[(c4 + 3) * VP + row] = vv.w;
+#pragma unroll
+    for (int u = 0; u < SB; ++u) {
+      const int e = e0 + u * 256, row = e / (DH / 4), c4 = (e % (DH / 4)) * 4;
+      if (e >= stage_total) continue;
+      float4 kv = kvb[u], vv = vvb[u];
+      if (row >= p.Lk) { kv = make_float4(0.f, 0.f, 0.f, 0.f); vv = kv; }
+      if constexpr (SPLIT) {
+        unsigned lo[3], hi[3];
+        skf_split2<3>(kv.x, kv.y, lo, sel);
+        skf_split2<3>(kv.z, kv.w, hi, sel);
+        char* kp = reinterpret_cast<char*>(Ks);
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          *reinterpret_cast<attn_u32x2*>(kp + (size_t)q * nkt * 16 * KPP + row * KPP + c4 * 2) = (attn_u32x2){lo[q], hi[q]};
+      } else {
+        *reinterpret_cast<float4*>(&Ks[row * LD + c4]) = kv;
+      }
+      Vt[(c4 + 0) * VP + row] = vv.x; Vt[(c4 + 1) * VP + row] = vv.y; Vt[(c4 + 2) * VP + row] = vv.z; Vt[(c4 + 3) * VP + row] = vv.w;
+    }
   }
   {
     int lv = -1;
-    for (int key = tid; key < nkt * 16; key += 256) {
+    auto mask_key = [&](int key, unsigned char mb) {
       float mv = -INFINITY;
-      if (key < p.Lk) mv = (p.key_mask && p.key_mask[(size_t)b * p.key_mask_ld + key]) ? -1e9f : 0.f;
+      if (key < p.Lk) mv = (p.key_mask && mb) ? -1e9f : 0.f;
       Ms[key] = mv;
       if (mv == 0.f) lv = key;             // keys ascend within a thread
-    }
+    };
+    if (tid < nkt * 16) mask_key(tid, mk0);
+    if constexpr (MAXT * 16 > 256)
+      for (int key = tid + 256; key < nkt * 16; key += 256) mask_key(key, kmp[min(key, last_key)]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) lv = max(lv, __shfl_xor(lv, o, 64));
     if (lane == 0) last_valid[wave] = lv;
@@ -154,6 +174,10 @@ __global__ __launch_bounds__(256, MAXT <= 13 ? 4 : 1) void attn_fwd_kernel(AttnP
   const char* ka3 = kp + (g < 2 ? plane_b : 0) + lane_k;
   const char* ka2 = kp + (g < 2 ? plane_b : 2 * plane_b) + lane_k;
   const char* ka1 = kp + lane_k;
+  // output rows / row statistics of this (sample, head): 32-bit byte offsets inside the sample (Lq * ldo * 4 < 2^31, checked on the host)
+  const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.O + (size_t)b * p.Lq * p.ldo, 0, (unsigned)(p.Lq * p.ldo) * 4u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t st_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.stats ? p.stats + (size_t)bh * p.Lq * 2 : p.O, 0,
+                                                                           p.stats ? (unsigned)p.Lq * 8u : 0u, 0x00020000);
   for (int qt = (wave + bh) & 3; qt < nqt; qt += 4) {
     const int q0 = qt * 16, qrow = q0 + i;
     const bool qok = qrow < p.Lq;
@@ -242,16 +266,17 @@ __global__ __launch_bounds__(256, MAXT <= 13 ? 4 : 1) void attn_fwd_kernel(AttnP
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     const float rinv = 1.0f / sum;
-    if (qok) {
+    // Stores through buffer descriptors, issued by every lane on every path (rows past Lq / lanes without a statistic fall outside
+    // the descriptor): behind `if (qok)` the compiler cannot count them, and the wait for the NEXT tile's query rows at the top of
+    // the loop became s_waitcnt vmcnt(0) - i.e. every tile also waited for the stores it had just issued.
 #pragma unroll
-      for (int c = 0; c < NC; ++c)
-        *reinterpret_cast<float4*>(p.O + (size_t)(b * p.Lq + qrow) * p.ldo + h * DH + c * 16 + g * 4) =
-            make_float4(o[c][0] * rinv, o[c][1] * rinv, o[c][2] * rinv, o[c][3] * rinv);
-      if (g == 0 && p.stats) {
-        float2* st = reinterpret_cast<float2*>(p.stats) + ((size_t)bh * p.Lq + qrow);
-        *st = make_float2(mx, rinv);
-      }
+    for (int c = 0; c < NC; ++c) {
+      const f32x4 ov = {o[c][0] * rinv, o[c][1] * rinv, o[c][2] * rinv, o[c][3] * rinv};
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(attn_u32x4, ov), o_rsrc,
+                                             qok ? (unsigned)(qrow * p.ldo + h * DH + c * 16 + g * 4) * 4u : 0x7ffffff0u, 0, 0);
     }
+    __builtin_amdgcn_raw_buffer_store_b64((attn_u32x2){__builtin_bit_cast(unsigned, mx), __builtin_bit_cast(unsigned, rinv)}, st_rsrc,
+                                          (qok && g == 0) ? (unsigned)qrow * 8u : 0x7ffffff0u, 0, 0);
   }
 }
 
@@ -362,35 +387,54 @@ __global__ __launch_bounds__(256, SKF_ATTN_BWD_WAVES) void attn_bwd_kernel(AttnP
   // key-tile ownership rotates with the workgroup id (see forward): the wave with the most key tiles (padding- and
   // causal-skipping make the load uneven) lands on a different SIMD for each of the co-resident workgroups
   const int wv = (wave + bh) & 3;
-  for (int kg = 0; kg < nkt; kg += 4 * KTW) {
+  // One pass over the query tiles per group of 4 KTW key tiles.  The first pass STORES dQ, later ones (Lk > 64 KTW) add to it: as a
+  // run-time `kg == 0 ? v : *dst + v` the conditional load sat in the query-tile loop of every launch, and the waits the compiler
+  // scatters for a load that may be pending (register reuse) are s_waitcnt vmcnt(n) on the dQ STORES when it is not.
+  auto kg_pass = [&](const int kg, auto first_tag) {
+    constexpr bool FIRST = decltype(first_tag)::value;
     const int kt0 = kg + wv;                   // smallest key tile of this wave in this group
-    const bool share = !CAUSAL && kg == 0 && KTW > 1 && nkt == 4 * (KTW - 1) + 1;
+    const bool share = !CAUSAL && FIRST && KTW > 1 && nkt == 4 * (KTW - 1) + 1;
     // B-operand fragments (lane = key i, contraction d = 16c+4g+s) and
     // A-operand (transposed) fragments (lane = d 16c+i, contraction key = k0+4g+s)
     float4 kb[KTW][NC], vb[KTW][NC];
     float kT[KTW][NC][4];
     float kadd[KTW];
     f32x4 dKt[KTW][NC], dVt[KTW][NC];
+    // Every global load of the wave's key tiles is issued before the first use, from clamped (always valid) addresses, and rows
+    // past Lk are zeroed afterwards: written as guarded loads (`kr < Lk ? K[..] : 0`) each of the 4 KTW NC transposed elements and
+    // each mask byte became its own `global_load; s_waitcnt vmcnt(0)` - ~22 serialised memory round trips per workgroup.
+    const int last_row = p.Lk - 1;
+    const unsigned char* kmp = km ? km : reinterpret_cast<const unsigned char*>(p.K + (size_t)b * p.Lk * p.ldk);   // no mask: any readable bytes, ignored
+    unsigned char mkb[KTW];
+    float kraw[KTW][NC][4];
+#pragma unroll
+    for (int j = 0; j < KTW; ++j) {
+      const int ktj = (share && j == KTW - 1) ? nkt - 1 : kt0 + 4 * j;
+      const int k0 = ktj * 16;
+      const int krc = min(k0 + i, last_row);
+      mkb[j] = kmp[krc];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        kb[j][c] = *reinterpret_cast<const float4*>(p.K + (size_t)(b * p.Lk + krc) * p.ldk + h * DH + c * 16 + g * 4);
+        vb[j][c] = *reinterpret_cast<const float4*>(p.V + (size_t)(b * p.Lk + krc) * p.ldv + h * DH + c * 16 + g * 4);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          kraw[j][c][s] = p.K[(size_t)(b * p.Lk + min(k0 + g * 4 + s, last_row)) * p.ldk + h * DH + c * 16 + i];
+      }
+    }
 #pragma unroll
     for (int j = 0; j < KTW; ++j) {
       const int ktj = (share && j == KTW - 1) ? nkt - 1 : kt0 + 4 * j;
       const int k0 = ktj * 16, krow = k0 + i;
       const bool kok = krow < p.Lk;
       // keys past Lk get -inf (never -1e9): with a fully padded sample the row max itself is -1e9 and exp(x - max) would overflow
-      kadd[j] = kok ? ((km && km[krow]) ? -1e9f : 0.f) : -INFINITY;
+      kadd[j] = kok ? ((km && mkb[j]) ? -1e9f : 0.f) : -INFINITY;
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        kb[j][c] = make_float4(0.f, 0.f, 0.f, 0.f); vb[j][c] = kb[j][c];
-        if (kok) {
-          kb[j][c] = *reinterpret_cast<const float4*>(p.K + (size_t)(b * p.Lk + krow) * p.ldk + h * DH + c * 16 + g * 4);
-          vb[j][c] = *reinterpret_cast<const float4*>(p.V + (size_t)(b * p.Lk + krow) * p.ldv + h * DH + c * 16 + g * 4);
-        }
+        if (!kok) { kb[j][c] = make_float4(0.f, 0.f, 0.f, 0.f); vb[j][c] = kb[j][c]; }
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const int kr = k0 + g * 4 + s;
-          // pre-scaled by 1/sqrt(dh): dQ = (P o (dP - delta)) . K / sqrt(dh) without a multiply per score
-          kT[j][c][s] = kr < p.Lk ? p.K[(size_t)(b * p.Lk + kr) * p.ldk + h * DH + c * 16 + i] * inv_sqrt : 0.f;
-        }
+        for (int s = 0; s < 4; ++s)   // pre-scaled by 1/sqrt(dh): dQ = (P o (dP - delta)) . K / sqrt(dh) without a multiply per score
+          kT[j][c][s] = k0 + g * 4 + s < p.Lk ? kraw[j][c][s] * inv_sqrt : 0.f;
         dKt[j][c] = (f32x4){0.f, 0.f, 0.f, 0.f}; dVt[j][c] = dKt[j][c];
       }
     }
@@ -495,7 +539,7 @@ __global__ __launch_bounds__(256, SKF_ATTN_BWD_WAVES) void attn_bwd_kernel(AttnP
             const float v = base[qq * RLD + dd] + base[16 * RLD + qq * RLD + dd] + base[2 * 16 * RLD + qq * RLD + dd] +
                             base[3 * 16 * RLD + qq * RLD + dd];
             float* dst = p.dQ + (size_t)(b * p.Lq + q0 + qq) * p.lddq + h * DH + dd;
-            *dst = kg == 0 ? v : *dst + v;
+            *dst = FIRST ? v : *dst + v;
           }
         }
       }
@@ -518,7 +562,9 @@ __global__ __launch_bounds__(256, SKF_ATTN_BWD_WAVES) void attn_bwd_kernel(AttnP
         }
       }
     }
-  }
+  };
+  kg_pass(0, std::true_type());
+  for (int kg = 4 * KTW; kg < nkt; kg += 4 * KTW) kg_pass(kg, std::false_type());
   SKF_STAMP();   // wave done
   __syncthreads();
   SKF_STAMP();   // all waves done
@@ -586,6 +632,7 @@ extern "C" int skf_attention_fwd(const float* Q, int ldq, const float* K, int ld
   SKF_CHECK_ARG(Q && K && V && O, "null operand");
   if (!mfma_head(dh)) return skf_attention_fwd_any(p, dh, (hipStream_t)stream);
   SKF_CHECK_ARG(Lk <= 512, "Lk > 512 not supported");
+  SKF_CHECK_ARG((double)Lq * ldo * 4 < 2147483648.0, "one sample's output rows exceed 32-bit byte offsets");
   // S^T on the bf16 pipe follows the Dense arithmetic switch (SKF_ATTN_SPLIT=0 turns it off).  With padded 48-byte plane
   // rows it removed 26 % of the MFMA cycles and changed nothing (the forward is wait-bound: 45 % of the wave cycles parked,
   // and the planes cost the fourth resident workgroup per CU); with unpadded rows (four workgroups per CU again, 2-way bank
