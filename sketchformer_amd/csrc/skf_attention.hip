@@ -319,6 +319,43 @@ __global__ __launch_bounds__(256, SKF_ATTN_BWD_WAVES) void attn_bwd_kernel(AttnP
   int dbi = 0;
 #define SKF_STAMP() do { if (dbg && dbi < 32) dbg[dbi++] = clock64(); } while (0)
   SKF_STAMP();
+  // Everything the prologue reads from global memory is requested before its first wait: the key fragments of the first pass,
+  // this thread's mask byte and row statistics, then the Q / dO / O rows (four serialised round trips before: rows, mask scan,
+  // statistics, fragments - 8.4k + 3.9k cycles of a ~40k-cycle workgroup at one or two waves per SIMD).
+  const unsigned char* km = p.key_mask ? p.key_mask + (size_t)b * p.key_mask_ld : nullptr;
+  const int last_row = p.Lk - 1;
+  const unsigned char* kmp = km ? km : reinterpret_cast<const unsigned char*>(p.K + (size_t)b * p.Lk * p.ldk);   // no mask: any readable bytes, ignored
+  // key-tile ownership rotates with the workgroup id (see forward): the wave with the most key tiles (padding- and
+  // causal-skipping make the load uneven) lands on a different SIMD for each of the co-resident workgroups
+  const int wv = (wave + bh) & 3;
+  // B-operand fragments (lane = key i, contraction d = 16c+4g+s), the raw elements of the A-operand (transposed) fragments
+  // (lane = d 16c+i, contraction key = k0+4g+s) and the mask bytes of the wave's key tiles; from clamped (always valid) addresses,
+  // rows past Lk are zeroed when they are consumed: written as guarded loads (`kr < Lk ? K[..] : 0`) each transposed element and
+  // each mask byte became its own `global_load; s_waitcnt vmcnt(0)` - ~22 serialised memory round trips per workgroup.
+  float4 kb[KTW][NC], vb[KTW][NC];
+  float kraw[KTW][NC][4];
+  unsigned char mkb[KTW];
+  auto load_frags = [&](const int kg, const bool share) {
+    const int kt0 = kg + wv;
+#pragma unroll
+    for (int j = 0; j < KTW; ++j) {
+      const int ktj = (share && j == KTW - 1) ? nkt - 1 : kt0 + 4 * j;
+      const int k0 = ktj * 16;
+      const int krc = min(k0 + i, last_row);
+      mkb[j] = kmp[krc];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        kb[j][c] = *reinterpret_cast<const float4*>(p.K + (size_t)(b * p.Lk + krc) * p.ldk + h * DH + c * 16 + g * 4);
+        vb[j][c] = *reinterpret_cast<const float4*>(p.V + (size_t)(b * p.Lk + krc) * p.ldv + h * DH + c * 16 + g * 4);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          kraw[j][c][s] = p.K[(size_t)(b * p.Lk + min(k0 + g * 4 + s, last_row)) * p.ldk + h * DH + c * 16 + i];
+      }
+    }
+  };
+  load_frags(0, !CAUSAL && KTW > 1 && nkt == 4 * (KTW - 1) + 1);
+  const unsigned char mk0 = kmp[min(tid, last_row)];
+  const float2 st0 = reinterpret_cast<const float2*>(p.stats)[(size_t)bh * p.Lq + min(tid, p.Lq - 1)];
   // Staging: all global loads of a batch are issued before the first LDS store (one HBM latency per batch of
   // 4 float4 x 3 arrays instead of one per element), delta = sum_d dO*O is reduced over the DH/4 lanes of a row.
   {
@@ -355,15 +392,16 @@ __global__ __launch_bounds__(256, SKF_ATTN_BWD_WAVES) void attn_bwd_kernel(AttnP
   int* last_valid = reinterpret_cast<int*>(Tr + 4 * KTW * 16 * TLD);   // [4]: per-wave index of the last un-padded key
   {
     int lv = -1;
-    for (int key = tid; key < p.Lk; key += 256)
-      if (!(p.key_mask && p.key_mask[(size_t)b * p.key_mask_ld + key])) lv = key;
+    if (tid < p.Lk && !(km && mk0)) lv = tid;
+    for (int key = tid + 256; key < p.Lk; key += 256)
+      if (!(km && km[key])) lv = key;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) lv = max(lv, __shfl_xor(lv, o, 64));
     if (lane == 0) last_valid[wave] = lv;
   }
   for (int row = tid; row < nqt * 16; row += 256) {
     float2 st = make_float2(0.f, 0.f);
-    if (row < p.Lq) st = reinterpret_cast<const float2*>(p.stats)[(size_t)bh * p.Lq + row];
+    if (row < p.Lq) st = row == tid ? st0 : reinterpret_cast<const float2*>(p.stats)[(size_t)bh * p.Lq + row];
     Mx[row] = st.x; Ri[row] = st.y;
   }
   // dQ of the dead query tiles: zeros (their tiles are never visited below)
@@ -371,7 +409,6 @@ __global__ __launch_bounds__(256, SKF_ATTN_BWD_WAVES) void attn_bwd_kernel(AttnP
   __syncthreads();
   SKF_STAMP();   // staging done
 
-  const unsigned char* km = p.key_mask ? p.key_mask + (size_t)b * p.key_mask_ld : nullptr;
   // skipping fully look-ahead-masked tiles is exact only if key 0 is visible (see forward)
   const bool can_skip = CAUSAL && !(km && km[0]);      // CAUSAL == p.causal (dispatch)
   // trailing all-padding key tiles have P == 0 exactly: their dK/dV are 0 and they add nothing to dQ (see forward)
@@ -384,9 +421,6 @@ __global__ __launch_bounds__(256, SKF_ATTN_BWD_WAVES) void attn_bwd_kernel(AttnP
 #pragma unroll
   for (int c = 0; c < NC; ++c) { dK_shared[c] = (f32x4){0.f, 0.f, 0.f, 0.f}; dV_shared[c] = dK_shared[c]; }
 
-  // key-tile ownership rotates with the workgroup id (see forward): the wave with the most key tiles (padding- and
-  // causal-skipping make the load uneven) lands on a different SIMD for each of the co-resident workgroups
-  const int wv = (wave + bh) & 3;
   // One pass over the query tiles per group of 4 KTW key tiles.  The first pass STORES dQ, later ones (Lk > 64 KTW) add to it: as a
   // run-time `kg == 0 ? v : *dst + v` the conditional load sat in the query-tile loop of every launch, and the waits the compiler
   // scatters for a load that may be pending (register reuse) are s_waitcnt vmcnt(n) on the dQ STORES when it is not.
@@ -394,34 +428,10 @@ __global__ __launch_bounds__(256, SKF_ATTN_BWD_WAVES) void attn_bwd_kernel(AttnP
     constexpr bool FIRST = decltype(first_tag)::value;
     const int kt0 = kg + wv;                   // smallest key tile of this wave in this group
     const bool share = !CAUSAL && FIRST && KTW > 1 && nkt == 4 * (KTW - 1) + 1;
-    // B-operand fragments (lane = key i, contraction d = 16c+4g+s) and
-    // A-operand (transposed) fragments (lane = d 16c+i, contraction key = k0+4g+s)
-    float4 kb[KTW][NC], vb[KTW][NC];
     float kT[KTW][NC][4];
     float kadd[KTW];
     f32x4 dKt[KTW][NC], dVt[KTW][NC];
-    // Every global load of the wave's key tiles is issued before the first use, from clamped (always valid) addresses, and rows
-    // past Lk are zeroed afterwards: written as guarded loads (`kr < Lk ? K[..] : 0`) each of the 4 KTW NC transposed elements and
-    // each mask byte became its own `global_load; s_waitcnt vmcnt(0)` - ~22 serialised memory round trips per workgroup.
-    const int last_row = p.Lk - 1;
-    const unsigned char* kmp = km ? km : reinterpret_cast<const unsigned char*>(p.K + (size_t)b * p.Lk * p.ldk);   // no mask: any readable bytes, ignored
-    unsigned char mkb[KTW];
-    float kraw[KTW][NC][4];
-#pragma unroll
-    for (int j = 0; j < KTW; ++j) {
-      const int ktj = (share && j == KTW - 1) ? nkt - 1 : kt0 + 4 * j;
-      const int k0 = ktj * 16;
-      const int krc = min(k0 + i, last_row);
-      mkb[j] = kmp[krc];
-#pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        kb[j][c] = *reinterpret_cast<const float4*>(p.K + (size_t)(b * p.Lk + krc) * p.ldk + h * DH + c * 16 + g * 4);
-        vb[j][c] = *reinterpret_cast<const float4*>(p.V + (size_t)(b * p.Lk + krc) * p.ldv + h * DH + c * 16 + g * 4);
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-          kraw[j][c][s] = p.K[(size_t)(b * p.Lk + min(k0 + g * 4 + s, last_row)) * p.ldk + h * DH + c * 16 + i];
-      }
-    }
+    if (!FIRST) load_frags(kg, false);         // (the first pass's fragments were requested at the top of the kernel)
 #pragma unroll
     for (int j = 0; j < KTW; ++j) {
       const int ktj = (share && j == KTW - 1) ? nkt - 1 : kt0 + 4 * j;
