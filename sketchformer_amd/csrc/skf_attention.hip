@@ -288,6 +288,10 @@ __global__ __launch_bounds__(256, MAXT <= 13 ? 4 : 1) void attn_fwd_kernel(AttnP
 #ifndef SKF_ATTN_BWD_WAVES
 #define SKF_ATTN_BWD_WAVES 2   // waves per SIMD the register allocation aims at (3 = 168 VGPRs)
 #endif
+#ifndef SKF_ATTN_BWD_TRP
+#define SKF_ATTN_BWD_TRP 0     // transpose patches per wave: 0 = one per key tile of the wave (KTW); 1 = one shared patch (20 -> 5 KB of LDS at dh = 16:
+                               // three workgroups per CU instead of two when SKF_ATTN_BWD_WAVES = 3)
+#endif
 template <int DH, int KTW, bool CAUSAL>
 __global__ __launch_bounds__(256, SKF_ATTN_BWD_WAVES) void attn_bwd_kernel(AttnParams p) {
   constexpr int NC = DH / 16;
@@ -389,7 +393,7 @@ __global__ __launch_bounds__(256, SKF_ATTN_BWD_WAVES) void attn_bwd_kernel(AttnP
       }
     }
   }
-  int* last_valid = reinterpret_cast<int*>(Tr + 4 * KTW * 16 * TLD);   // [4]: per-wave index of the last un-padded key
+  int* last_valid = reinterpret_cast<int*>(Tr + 4 * (SKF_ATTN_BWD_TRP ? SKF_ATTN_BWD_TRP : KTW) * 16 * TLD);   // [4]: per-wave index of the last un-padded key
   {
     int lv = -1;
     if (tid < p.Lk && !(km && mk0)) lv = tid;
@@ -416,7 +420,7 @@ __global__ __launch_bounds__(256, SKF_ATTN_BWD_WAVES) void attn_bwd_kernel(AttnP
   const int nkt_eff = (lastk >= 0 && (!CAUSAL || can_skip)) ? (lastk >> 4) + 1 : nkt;
   const float inv_sqrt = 1.0f / sqrtf((float)DH);
   const float c2 = 1.44269504088896340736f / sqrtf((float)DH);
-  float* tr0 = Tr + wave * KTW * 16 * TLD;
+  float* tr0 = Tr + wave * (SKF_ATTN_BWD_TRP ? SKF_ATTN_BWD_TRP : KTW) * 16 * TLD;
   f32x4 dK_shared[NC], dV_shared[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) { dK_shared[c] = (f32x4){0.f, 0.f, 0.f, 0.f}; dV_shared[c] = dK_shared[c]; }
@@ -518,7 +522,7 @@ __global__ __launch_bounds__(256, SKF_ATTN_BWD_WAVES) void attn_bwd_kernel(AttnP
             dKt[j][c] = mfma16(qT[c][r], ds[r], dKt[j][c]);
           }
         // transpose dS through the wave-private scratch: write [q][k], read [q=i][k=4g..4g+3]
-        float* tr = tr0 + j * 16 * TLD;
+        float* tr = tr0 + (SKF_ATTN_BWD_TRP ? j % SKF_ATTN_BWD_TRP : j) * 16 * TLD;
 #pragma unroll
         for (int r = 0; r < 4; ++r) tr[(g * 4 + r) * TLD + i] = ds[r];
         // (no fence: the LDS executes one wave's instructions in order, and the patch is private to (wave, j))
@@ -610,7 +614,7 @@ size_t fwd_smem(int DH, int Lk, bool split) {
 }
 size_t bwd_smem(int DH, int Lq) {
   const size_t QR = (size_t)(Lq + 15) / 16 * 16;
-  return (2 * QR * (DH + 4) + (size_t)2 * 4 * 16 * (DH + 1) + 3 * QR + (size_t)4 * (64 / DH) * 16 * 20 + 4) * sizeof(float);
+  return (2 * QR * (DH + 4) + (size_t)2 * 4 * 16 * (DH + 1) + 3 * QR + (size_t)4 * (SKF_ATTN_BWD_TRP ? SKF_ATTN_BWD_TRP : 64 / DH) * 16 * 20 + 4) * sizeof(float);
 }
 
 template <typename K>

@@ -1218,7 +1218,6 @@ extern "C" int skf_layernorm_residual_fwd(const float* x, float* y_inout_z, cons
   const SkfStepState* st = (const SkfStepState*)step_state;
   dim3 grid(grid_for_rows(rows)), block(256);
   hipStream_t s = (hipStream_t)stream;
-  { static const bool abl = getenv("SKF_ABLATE_LN_FWD") && getenv("SKF_ABLATE_LN_FWD")[0] == '1'; if (abl) return SKF_OK; }   // TEMP measurement
   SkfProfScope ps(s, "ln_fwd", 0.0, 16.0 * rows * d);
   static const bool v4 = !(getenv("SKF_LN_V4") && getenv("SKF_LN_V4")[0] == '0');
   const bool al = ((((uintptr_t)x | (uintptr_t)y_inout_z | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0);
