@@ -566,7 +566,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_big_kernel(TnParams p) {
   const int p0 = tp * 256, q0 = tq * 256;
   // contraction steps of this split: 64-row steps of [rbeg, rend), or (with a live-block list) the entries [eb, ee) of the
   // list - the dead 64-row blocks hold zeros in B (= dY), leaving them out is exact
-  const int* blk = p.row_blocks;
+  // (constant address space: the list is written by an earlier launch and every index is wave-uniform -> s_load; as plain global loads
+  //  each step's lookup was `global_load_dword; s_waitcnt vmcnt(0)`, which also drained the tile DMA in flight)
+  typedef const __attribute__((address_space(4))) int* const_i32p;
+  const const_i32p blk = (const_i32p)p.row_blocks;
   int rbeg = z * p.r_chunk, nk = (min(p.R, rbeg + p.r_chunk) - rbeg) >> 6, eb = 0;
   if (blk) {
     const int nlive = blk[0], per = (nlive + p.splits - 1) / p.splits;
