@@ -639,7 +639,11 @@ int launch_wsx_k(const GemmParams& p, int b_kc, hipStream_t st) {
     // (four columns per lane = 64 per wave, one workgroup per CU, was measured for N >= 256: 30.8 vs 28.7 us at N = 512 -
     //  one wave per SIMD loses more to exposed waits than the doubled MFMA : overhead ratio wins)
     case 128: return launch_wsx<128, 2, P>(p, b_kc, st);
-    case 256: return launch_wsx<256, 1, P>(p, b_kc, st);
+    case 256: {
+      static const bool ks_on2 = getenv("SKF_WSX_KSPLIT256") && getenv("SKF_WSX_KSPLIT256")[0] == '1';   // measurement knob
+      if (ks_on2 && p.act == 0) return launch_wsx<256, 1, P, 2>(p, b_kc, st);
+      return launch_wsx<256, 1, P>(p, b_kc, st);
+    }
     case 384: {
       static const bool ks_off3 = (getenv("SKF_WSX_KSPLIT") && getenv("SKF_WSX_KSPLIT")[0] == '0') || (getenv("SKF_WSX_KSPLIT384") && getenv("SKF_WSX_KSPLIT384")[0] == '0');
       if (!ks_off3 && p.act == 0) return launch_wsx<384, 1, P, 2>(p, b_kc, st);

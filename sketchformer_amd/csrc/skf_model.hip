@@ -675,7 +675,7 @@ int flush_wgrads(SkfModel* M, hipStream_t s, int bucket, bool final) {
     }
     }
   }
-  if (M->bucket_ready[bucket]) SKF_HIP(hipEventRecord(M->bucket_ready[bucket], ready_on));
+  if (bucket >= 0 && M->bucket_ready[bucket]) SKF_HIP(hipEventRecord(M->bucket_ready[bucket], ready_on));   // bucket < 0: an intermediate reduction
   M->phase_desc_begin = end;
   M->reduce_blocks = 0;                 // block numbering of the next batch starts again at 0
   if (final) {
@@ -1119,6 +1119,10 @@ int run_backward(SkfModel* M, hipStream_t s) {
     if (i == 0 && early_tail) SKF_TRY(issue_wgrads(M, s));
     SKF_TRY(dense_dgrad(M, w.mha.qkv, dqkv, 3 * d, Me, G, d, 1, nullptr, 0, s));
     SKF_TRY(issue_wgrads(M, s));
+    // half-way through the encoder: the slabs and LayerNorm partials finished so far are reduced on the side stream now, under the
+    // remaining layers - the final reduction, which the optimizer waits for on the main stream, shrinks to the last layers' share
+    static const bool mid_flush = !(getenv("SKF_MID_FLUSH") && getenv("SKF_MID_FLUSH")[0] == '0');
+    if (mid_flush && M->side && N >= 2 && i == N / 2) SKF_TRY(flush_wgrads(M, s, -1, false));
   }
   if (c.continuous) {
     SKF_TRY(skf_embed_continuous_bwd(M->at<float>(P.inp), Le, B, Le, G, d, M->G(L.enc_embd.w), M->G(L.enc_embd.b), rate,
