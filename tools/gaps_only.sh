@@ -5,6 +5,6 @@ R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_$tag -- python $R/bench.py "$@" --steps 20 --warmup 5 --no-profile --no-cpu-baseline --no-extras > /dev/null 2>&1
 f=$(find /tmp/kt_$tag -name "*kernel_trace.csv" | head -1)
-python $R/tools/step_gaps.py $f 15 > $R/gpurun_out/${tag}_step_gaps.txt
+python $R/tools/step_gaps.py $f 15 gaps > $R/gpurun_out/${tag}_step_gaps.txt
 python $R/tools/ktrace_stats_csv.py $f $R/gpurun_out/${tag}_kernel_stats.csv
 head -50 $R/gpurun_out/${tag}_step_gaps.txt
