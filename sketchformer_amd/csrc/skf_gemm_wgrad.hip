@@ -21,6 +21,9 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 }
 
 constexpr int UN = 4;    // 4-row steps per unrolled iteration (per wave): 16 rows
+#ifndef SKF_WGRAD_PIPE
+#define SKF_WGRAD_PIPE 0 // 1: software-pipelined split-arithmetic step (see wgrad_x_body) - measured SLOWER, kept as a build-time experiment
+#endif
 
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // [4 waves][64][64] + [4][64] column sums
@@ -241,6 +244,79 @@ __device__ __forceinline__ void wgrad_x_body(const GemmParams& p, const int bid,
                                                                 __builtin_bit_cast(bf16x8, by[f][d - qa]), acc[e][f], 0, 0, 0);
     }
   };
+#if SKF_WGRAD_PIPE
+  // MEASURED SLOWER (round 3: 34.5 / 33.2 / 29.4 / 18.1 us against 28.5 / 28.3 / 24.5 / 16.0 for 128x512 / 512x128 / 128x384 / 128x128,
+  // 4.40 vs 4.15 ms/step): with every MFMA followed by 1-3 v_perm / v_dot2c the step is longer than with the compiler's own
+  // arrangement (a VALU phase, then the MFMAs back to back) - 338 registers (82 of them AGPRs reached through v_accvgpr moves) and a
+  // hazard s_nop at most MFMA <-> VALU transitions cost more than the overlap returns.  Off by default (-DSKF_WGRAD_PIPE=1 builds it).
+  // Software-pipelined step (P = 3): the 112 VALU of the NEXT step's X split sit under the MFMAs of dY columns 2 and 3 of this step
+  // (28 + 56 and 56 VALU for 24 MFMAs each, the interleave pinned with sched_group_barrier), the rows of step it + 2 are requested
+  // in column 3, when both halves of their register set are dead.  Without it the step was 190 VALU, then 12 MFMAs with 3 VALU each,
+  // 50 VALU, 78 MFMAs back to back = 1536 cycles of MFMA + ~1000 of VALU one after the other (tools/micro/valu_rates.hip: v_perm /
+  // v_dot2c issue in ~4.5 cycles; tools/micro/mfma_bf16_valu_overlap.hip: about half of the VALU time hides under interleaved MFMAs).
+  auto mfma_col = [&](const u32x4 (&ax)[4][P], const u32x4 (&byf)[P], int f) {
+#pragma unroll
+    for (int d = P - 1; d >= 0; --d)
+#pragma unroll
+      for (int qa = 0; qa <= d; ++qa)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          acc[e][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ax[e][qa]), __builtin_bit_cast(bf16x8, byf[d - qa]), acc[e][f], 0, 0, 0);
+  };
+  // yb / xfree: the register set of this step (dY rows; its X rows were split a step ago and are the target of the loads for it + 2);
+  // xn: X rows of step it + 1; ax: split X of this step; axn: receives the split X of step it + 1
+  // pins a split result inside the scheduling region it was written in: instruction selection otherwise sinks the (side-effect free)
+  // split next to its first use, i.e. behind the sched_barrier into the next step
+  auto pin = [&](u32x4 (&v)[P]) {
+#pragma unroll
+    for (int q = 0; q < P; ++q) asm volatile("" : "+v"(v[q]));
+  };
+  auto pstep = [&](int it, f32x4 (&yb)[8], f32x4 (&xfree)[8], const f32x4 (&xn)[8], const u32x4 (&ax)[4][P], u32x4 (&axn)[4][P]) {
+    if (do_colsum) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) csum += yb[j];
+    }
+    u32x4 by[4][P];
+    wg_split_col<P>(yb, 0, by[0], sel);
+    __builtin_amdgcn_sched_barrier(0);
+    wg_split_col<P>(yb, 1, by[1], sel);
+    mfma_col(ax, by[0], 0);
+#pragma unroll
+    for (int k = 0; k < 24; ++k) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 1, 0); }
+    __builtin_amdgcn_sched_barrier(0);
+    wg_split_col<P>(yb, 2, by[2], sel);
+    mfma_col(ax, by[1], 1);
+#pragma unroll
+    for (int k = 0; k < 24; ++k) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 1, 0); }
+    __builtin_amdgcn_sched_barrier(0);
+    wg_split_col<P>(yb, 3, by[3], sel);
+    wg_split_col<P>(xn, 0, axn[0], sel);
+    wg_split_col<P>(xn, 1, axn[1], sel);
+    mfma_col(ax, by[2], 2);
+    pin(by[3]); pin(axn[0]); pin(axn[1]);
+#pragma unroll
+    for (int k = 0; k < 24; ++k) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); }
+    __builtin_amdgcn_sched_barrier(0);
+    load_step(it + 2, xfree, yb);                    // both halves of this set are dead now; past the end: empty descriptor, zeros
+    wg_split_col<P>(xn, 2, axn[2], sel);
+    wg_split_col<P>(xn, 3, axn[3], sel);
+    mfma_col(ax, by[3], 3);
+    pin(axn[2]); pin(axn[3]);
+#pragma unroll
+    for (int k = 0; k < 24; ++k) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  u32x4 axA[4][P], axB[4][P];
+  load_step(0, xa0, yb0);
+  load_step(1, xa1, yb1);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) wg_split_col<P>(xa0, e, axA[e], sel);
+  for (int it = 0; it < niter; it += 2) {
+    pstep(it, yb0, xa0, xa1, axA, axB);
+    if (it + 1 >= niter) break;
+    pstep(it + 1, yb1, xa1, xa0, axB, axA);
+  }
+#else
   load_step(0, xa0, yb0);
   for (int it = 0; it < niter; it += 2) {
     load_step(it + 1, xa1, yb1);                     // past the end: empty descriptor, zeros
@@ -249,6 +325,7 @@ __device__ __forceinline__ void wgrad_x_body(const GemmParams& p, const int bid,
     load_step(it + 2, xa0, yb0);
     step(xa1, yb1);
   }
+#endif
 
   float* mine = smem + wave * 4096;
 #pragma unroll
