@@ -640,7 +640,10 @@ int launch_wsx_k(const GemmParams& p, int b_kc, hipStream_t st) {
     //  one wave per SIMD loses more to exposed waits than the doubled MFMA : overhead ratio wins)
     case 128: return launch_wsx<128, 2, P>(p, b_kc, st);
     case 256: {
-      static const bool ks_on2 = getenv("SKF_WSX_KSPLIT256") && getenv("SKF_WSX_KSPLIT256")[0] == '1';   // measurement knob
+      // K = 256: only for N <= 128 (one or two column groups, 256 workgroups either way); with more column groups the 512-thread form
+      // was 4 % slower at cfg 3 (N = 256 ... 1024).  SKF_WSX_KSPLIT256=1 forces it for every N, =0 turns it off (measurement)
+      static const char* ks2 = getenv("SKF_WSX_KSPLIT256");
+      const bool ks_on2 = ks2 ? ks2[0] == '1' : (p.N <= 128 && !(getenv("SKF_WSX_KSPLIT") && getenv("SKF_WSX_KSPLIT")[0] == '0'));
       if (ks_on2 && p.act == 0) return launch_wsx<256, 1, P, 2>(p, b_kc, st);
       return launch_wsx<256, 1, P>(p, b_kc, st);
     }
