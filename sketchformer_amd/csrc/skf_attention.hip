@@ -712,7 +712,10 @@ extern "C" int skf_attention_bwd_rows(const float* Q, int ldq, const float* K, i
   // with the dead query tiles left out by q_live it also wins on padded batches); SKF_ATTN_BWD2=1 forces the two-pass kernel.
   static const char* bwd2_env = getenv("SKF_ATTN_BWD2");
   const bool bwd2_off = bwd2_env && bwd2_env[0] == '0', bwd2_all = bwd2_env && bwd2_env[0] == '1';
-  const bool bwd2_shape = (dh == 16 && (causal || bwd2_all)) || (dh == 32 && Lk <= 256 && Lq <= 256);
+  // (round 3: with its prologue loads batched the one-pass kernel also wins the causal dh = 16 calls - 4.134 vs 4.149 ms/step padded,
+  //  4.777 vs 4.774 full-length at cfg 2 - so head size 16 takes the two-pass kernel only when forced; head size 32 keeps it:
+  //  15.9 vs 17.2 ms/step at cfg 3)
+  const bool bwd2_shape = (dh == 16 && bwd2_all) || (dh == 32 && Lk <= 256 && Lq <= 256);
   if (bwd2_shape && precision != SKF_PREC_F32 && !bwd2_off && Lk <= 512 && Lq <= 512)
     return skf_attention_bwd2_launch(p, dh, (hipStream_t)stream);
   const size_t smem = bwd_smem(dh, Lq);

@@ -450,6 +450,17 @@ def test_attention_padding_tile_skipping_is_exact(ops, causal):
     assert float(gk[2, 32:].abs().max()) == 0.0 and float(gv[2, 32:].abs().max()) == 0.0     # skipped tiles: exact zeros
 
 
+def test_attention_two_pass_backward_head_size_16_in_a_fresh_process():
+    """Head size 16 takes the one-pass backward by default since round 3; the two-pass kernel (`attn_bwd2<1, *>`, still the head-size-32
+    default) is kept for that size behind SKF_ATTN_BWD2=1, which is read once per process: its oracle tests run in a child."""
+    import os, subprocess, sys
+    env = dict(os.environ, SKF_ATTN_BWD2="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k",
+                        "test_attention_fwd_bwd or test_attention_bwd_live_query_counts_is_exact or test_attention_padding_tile_skipping_is_exact"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_attention_strided_qkv(ops):
     """q/k/v as column slices of one (B,L,3d) projection buffer, as the train step uses them."""
     B, H, L, dh = 2, 8, 50, 16
