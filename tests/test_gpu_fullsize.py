@@ -226,3 +226,48 @@ def test_benchmarked_batch_all_gradients_at_B128():
           (worst[0], worst[1], np.median(list(rel.values())), len(rel)))
     assert worst[0] < 1e-3, worst
     assert np.median(list(rel.values())) < 1e-4
+
+
+def test_benchmarked_batch_adam_trajectory_at_B128():
+    """Three train steps (forward, backward, Keras Adam / WarmupDecay from iterations = 3000) on bench.py's batches at B = 128 against the
+    float64 PyTorch-CPU witness: losses per step and every parameter afterwards (attention key biases excluded: analytically zero
+    gradient, see the B = 4 trajectory test)."""
+    from oracle import torch_restatement as witness
+    B = 128
+    eng, ocfg = _build("cfg2", B, 6)
+    st = witness.TorchTrainState({k: v.astype(np.float64) for k, v in eng.state_dict_numpy().items()}, dtype=torch.float64)
+    st.iterations = 3000
+    eng.state[0] = 3000
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    try:
+        for step in range(3):
+            x, y = synthetic.token_batch(B, ocfg.seq_len, ocfg.vocab_size, ocfg.n_classes, seed=step)
+            eng.train_step(x, y)
+            torch.cuda.synchronize()
+            losses = witness.train_step(st, ocfg, x, x, y)
+            m = eng.step_metrics()
+            assert abs(m["total_loss"] - losses["total_loss"]) < 1e-3 * abs(losses["total_loss"]), (step, m, losses)
+    finally:
+        torch.set_num_threads(nthreads)
+    assert eng.iterations == 3003
+    got = eng.state_dict_numpy()
+    # From zero moments the first Adam steps move every element by ~lr * sign(g) whatever |g| is, so a gradient element that is zero up
+    # to rounding (a dense1 column of a ReLU unit on the kink, with no branch hand-off at this size) may land 1-2 steps of lr = 7.5e-4
+    # away: the differences are COUNTED by size instead of bounded by their maximum
+    lr = 7.5e-4
+    n_all = 0
+    n_over = {1e-5: 0, 1e-4: 0, 5e-4: 0}
+    for k in got:
+        if k.endswith("wk/bias"):
+            continue
+        diff = np.abs(got[k] - st.P[k].detach().numpy().reshape(got[k].shape))
+        n_all += diff.size
+        for t in n_over:
+            n_over[t] += int((diff > t).sum())
+        assert diff.max() < 3.2 * lr, (k, diff.max())
+    print("\n[cfg2 B=128 bench batches] 3-step trajectory: of %d parameters %d / %d / %d differ by more than 1e-5 / 1e-4 / 5e-4"
+          % (n_all, n_over[1e-5], n_over[1e-4], n_over[5e-4]))
+    # measured (round 3): 6 / 106 / 3932 of 2,314,581 - m / sqrt(v) from zero moments turns the rounding noise of the smallest gradient
+    # elements into fractions of a step; bars: one in 10^5 / 10^4 / 200
+    assert n_over[5e-4] <= max(1, n_all // 100000) and n_over[1e-4] <= n_all // 10000 and n_over[1e-5] <= n_all // 200, n_over
