@@ -190,8 +190,8 @@ def test_benchmarked_batch_forward_and_losses_at_B128():
     assert all(np.isfinite(v).all() for v in g.values())
 
 
-@pytest.mark.parametrize("rate", [0.0, 0.1])
-def test_benchmarked_batch_all_gradients_at_B128(rate):
+@pytest.mark.parametrize("name,rate", [("cfg2", 0.0), ("cfg2", 0.1), ("cfg2grid", 0.1), ("cfg3", 0.1)])
+def test_benchmarked_batch_all_gradients_at_B128(name, rate):
     """Every gradient tensor of the benchmarked step (cfg 2, B = 128, the seed-0 bench batch with its 58 % padding, bf16x6 arithmetic, i.e.
     with the live-row lists, the wave-pair Dense kernels, the grouped weight gradients and the fused projection + LayerNorm launches
     of a 25.6 k-row step) against the float64 PyTorch-CPU witness of the reference (oracle/torch_restatement.py; ~20 s of CPU): the same
@@ -200,8 +200,12 @@ def test_benchmarked_batch_all_gradients_at_B128(rate):
     from oracle import torch_restatement as witness
     from test_gpu_model import _drops_from_engine
     B = 128
-    eng, ocfg = _build("cfg2", B, 6, rate=rate)                  # rate = 0.1 is what bench.py runs: the witness gets the device's masks
-    x, y = synthetic.token_batch(B, ocfg.seq_len, ocfg.vocab_size, ocfg.n_classes, seed=0)
+    eng, ocfg = _build(name, B, 6, rate=rate)                    # rate = 0.1 is what bench.py runs: the witness gets the device's masks
+    if name == "cfg2":
+        x, y = synthetic.token_batch(B, ocfg.seq_len, ocfg.vocab_size, ocfg.n_classes, seed=0)      # bench.py's batch
+        xo = x
+    else:                                                        # the other single-GPU workloads of bench.py (sub-records), same size
+        x, y, xo = _batch(name, B, ocfg, seed=0)
     P = {k: v.astype(np.float64) for k, v in eng.state_dict_numpy().items()}
     eng.forward_backward(x, None, y)
     torch.cuda.synchronize()
@@ -209,7 +213,7 @@ def test_benchmarked_batch_all_gradients_at_B128(rate):
     nthreads = torch.get_num_threads()
     torch.set_num_threads(min(16, os.cpu_count() or 1))          # one thread per logical core is pathological for eager PyTorch on the GPU box
     try:
-        losses, _, G = witness.loss_and_grads(P, ocfg, x, x, y, drops)
+        losses, _, G = witness.loss_and_grads(P, ocfg, xo, xo, y, drops)
     finally:
         torch.set_num_threads(nthreads)
     m = eng.step_metrics()
@@ -225,8 +229,8 @@ def test_benchmarked_batch_all_gradients_at_B128(rate):
     rel = {k: np.abs(got[k].astype(np.float64) - G[k].reshape(got[k].shape)).max() / max(np.abs(G[k]).max(), floor) for k in G
            if not k.endswith("wk/bias")}
     worst = max((v, k) for k, v in rel.items())
-    print("\n[cfg2 B=128 bench batch, dropout %.1f] worst gradient rel %.3e (%s), median %.3e over %d tensors" %
-          (rate, worst[0], worst[1], np.median(list(rel.values())), len(rel)))
+    print("\n[%s B=128, dropout %.1f] worst gradient rel %.3e (%s), median %.3e over %d tensors" %
+          (name, rate, worst[0], worst[1], np.median(list(rel.values())), len(rel)))
     assert worst[0] < 1e-3, worst
     assert np.median(list(rel.values())) < 1e-4
 
