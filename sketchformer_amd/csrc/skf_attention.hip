@@ -522,7 +522,8 @@ __global__ __launch_bounds__(256, SKF_ATTN_BWD_WAVES) void attn_bwd_kernel(AttnP
             dKt[j][c] = mfma16(qT[c][r], ds[r], dKt[j][c]);
           }
         // transpose dS through the wave-private scratch: write [q][k], read [q=i][k=4g..4g+3]
-        float* tr = tr0 + (SKF_ATTN_BWD_TRP ? j % SKF_ATTN_BWD_TRP : j) * 16 * TLD;
+        constexpr int TRP = SKF_ATTN_BWD_TRP ? SKF_ATTN_BWD_TRP : KTW;     // patches per wave
+        float* tr = tr0 + (j % TRP) * 16 * TLD;
 #pragma unroll
         for (int r = 0; r < 4; ++r) tr[(g * 4 + r) * TLD + i] = ds[r];
         // (no fence: the LDS executes one wave's instructions in order, and the patch is private to (wave, j))
