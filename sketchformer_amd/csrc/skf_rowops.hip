@@ -547,49 +547,83 @@ __global__ __launch_bounds__(SKF_LN_BWD_THREADS) void ln_bwd_v4_kernel(const flo
   const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + 4 * sub);
   f32x4 dg = {0.f, 0.f, 0.f, 0.f}, db = dg;
   const int stride = gridDim.x * NWV * RPW * UR;
-  for (int row0 = (blockIdx.x * NWV + wave) * RPW * UR; row0 < rows; row0 += stride) {
-    f32x4 dv[UR], zv[UR];
-    float mean[UR], rstd[UR];
-    size_t off[UR];
-    bool ok[UR];
+  const int first = (blockIdx.x * NWV + wave) * RPW * UR;
+  // The loop is software-pipelined: the rows of iteration k + 1 are requested before iteration k is computed, and the live flags of
+  // the first PRE iterations (row t of sample b with t >= live_len[b]: dout is exactly zero, skf_target_live_len - neither it nor z is
+  // read) come from ONE batch of live_len loads in front of the loop.  Before, every iteration was two dependent memory round trips
+  // (live_len[b], then the rows it gates) followed by the arithmetic: ~5 iterations x 2 x 1.5 us of a 15-18 us launch.
+  constexpr int PRE = 8;
+  unsigned lvmask = 0xffffffffu;
+  if (live_len) {
+    int ll[PRE][UR], tt[PRE][UR];
+#pragma unroll
+    for (int k = 0; k < PRE; ++k)
+#pragma unroll
+      for (int u = 0; u < UR; ++u) {
+        const int row = first + k * stride + u * RPW + rsel, rr = row < rows ? row : rows - 1, b = rr / rps;
+        tt[k][u] = rr - b * rps;
+        ll[k][u] = live_len[b];
+      }
+    lvmask = 0u;
+#pragma unroll
+    for (int k = 0; k < PRE; ++k)
+#pragma unroll
+      for (int u = 0; u < UR; ++u) lvmask |= (tt[k][u] < ll[k][u] ? 1u : 0u) << (k * UR + u);
+  }
+  struct Rows { f32x4 dv[UR], zv[UR]; float mean[UR], rstd[UR], keep[UR]; size_t off[UR]; bool ok[UR]; };
+  auto fetch = [&](int row0, int k, Rows& r) {
 #pragma unroll
     for (int u = 0; u < UR; ++u) {
       const int row = row0 + u * RPW + rsel;
-      ok[u] = row < rows;
-      const int rr = ok[u] ? row : rows - 1;
-      off[u] = (size_t)rr * D + 4 * sub;
-      mean[u] = stats[2 * (size_t)rr]; rstd[u] = stats[2 * (size_t)rr + 1];
-      // row t of sample b with t >= live_len[b]: dout is exactly zero (skf_target_live_len) - neither it nor z is read, the
-      // arithmetic below then yields the zeros that are stored
-      bool lv = true;
-      if (live_len) { const int b = rr / rps; lv = rr - b * rps < live_len[b]; }
-      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-      dv[u] = lv ? *reinterpret_cast<const f32x4*>(dout + off[u]) : zero;
-      zv[u] = lv ? *reinterpret_cast<const f32x4*>(z + off[u]) : zero;
+      r.ok[u] = row < rows;
+      const int rr = r.ok[u] ? row : rows - 1;
+      r.off[u] = (size_t)rr * D + 4 * sub;
+      r.mean[u] = stats[2 * (size_t)rr]; r.rstd[u] = stats[2 * (size_t)rr + 1];
+      // dead rows re-read the first row of the tensors (a cache hit) and are zeroed: EVERY lane issues both loads on every path, so
+      // the compiler can count them (guarded loads forced s_waitcnt vmcnt(0) right behind the prefetch); beyond PRE sweeps of the grid
+      // (very long inputs) every row is read - dout of a dead row is exactly zero, so that is only slower, not different
+      const bool lv = k < PRE ? ((lvmask >> (k * UR + u)) & 1u) != 0u : true;
+      const size_t src = lv ? r.off[u] : (size_t)(4 * sub);
+      r.dv[u] = *reinterpret_cast<const f32x4*>(dout + src);
+      r.zv[u] = *reinterpret_cast<const f32x4*>(z + src);
+      r.keep[u] = lv ? 1.f : 0.f;                                 // applied when the rows are consumed, not here: nothing may touch the loads yet
     }
+  };
+  // dz / dy leave through buffer descriptors (rows past the end fall outside; no dy: an empty descriptor) and the prefetch runs on
+  // every iteration (clamped rows): with nothing conditional between a row's loads and its use the compiler waits with a counted
+  // vmcnt instead of vmcnt(0), which had put the wait for the PREFETCHED rows in front of the arithmetic of the current ones
+  typedef unsigned lnb_u32x4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t dz_rsrc = __builtin_amdgcn_make_buffer_rsrc(dz, 0, (unsigned)rows * (unsigned)D * 4u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t dy_rsrc = __builtin_amdgcn_make_buffer_rsrc(dy ? dy : dz, 0, dy ? (unsigned)rows * (unsigned)D * 4u : 0u, 0x00020000);
+  Rows cur, nxt;
+  fetch(first, 0, cur);
+  int k = 0;
+  for (int row0 = first; row0 < rows; row0 += stride, ++k) {
+    fetch(row0 + stride, k + 1, nxt);
 #pragma unroll
     for (int u = 0; u < UR; ++u) {
-      const float live = ok[u] ? 1.f : 0.f;                 // rows past the end: loads were clamped, contribute nothing
-      const f32x4 xh = (zv[u] - mean[u]) * rstd[u];
-      const f32x4 gg = dv[u] * gm;
-      dg += (dv[u] * xh) * live;
-      db += dv[u] * live;
+      const float live = cur.ok[u] ? 1.f : 0.f;             // rows past the end: loads were clamped, contribute nothing
+      const f32x4 dvu = cur.dv[u] * cur.keep[u], zvu = cur.zv[u] * cur.keep[u];
+      const f32x4 xh = (zvu - cur.mean[u]) * cur.rstd[u];
+      const f32x4 gg = dvu * gm;
+      dg += (dvu * xh) * live;
+      db += dvu * live;
       float s1 = (gg[0] + gg[1]) + (gg[2] + gg[3]);
       float s2 = (gg[0] * xh[0] + gg[1] * xh[1]) + (gg[2] * xh[2] + gg[3] * xh[3]);
 #pragma unroll
       for (int o = LPR / 2; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
       s1 *= (1.0f / D); s2 *= (1.0f / D);
-      const f32x4 g = rstd[u] * (gg - s1 - xh * s2);
-      if (ok[u]) {
-        *reinterpret_cast<f32x4*>(dz + off[u]) = g;
-        if (dy) {
-          f32x4 gy;
+      const f32x4 g = cur.rstd[u] * (gg - s1 - xh * s2);
+      const unsigned voff = cur.ok[u] ? (unsigned)cur.off[u] * 4u : 0x7ffffff0u;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(lnb_u32x4, g), dz_rsrc, voff, 0, 0);
+      f32x4 gy = g;
+      if (rate > 0.f) {                                           // (uniform; dy != null exactly when rate > 0)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) gy[e] = g[e] * (skf_keep(sk, (uint32_t)off[u] + e, thresh) ? inv_keep : 0.f);
-          *reinterpret_cast<f32x4*>(dy + off[u]) = gy;
-        }
+        for (int e = 0; e < 4; ++e) gy[e] = g[e] * (skf_keep(sk, (uint32_t)cur.off[u] + e, thresh) ? inv_keep : 0.f);
       }
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(lnb_u32x4, gy), dy_rsrc, voff, 0, 0);
     }
+    cur = nxt;
   }
   // fold the 64/LPR row groups of the wave, then the 4 waves
 #pragma unroll
@@ -1271,7 +1305,8 @@ extern "C" int skf_layernorm_residual_bwd_rows(const float* dout, const float* z
   float* dyp = (dy && (rate > 0.f || dy != dz)) ? dy : nullptr;   // rate 0 with a separate dy buffer: dy = dz
   SkfProfScope ps(s, "ln_bwd", 0.0, (rate > 0.f ? 16.0 : 12.0) * rows * d);
   static const bool v4 = !(getenv("SKF_LN_V4") && getenv("SKF_LN_V4")[0] == '0');
-  const bool al = ((((uintptr_t)dout | (uintptr_t)z | (uintptr_t)dz | (uintptr_t)dyp | (uintptr_t)gamma) & 15) == 0);
+  const bool al = ((((uintptr_t)dout | (uintptr_t)z | (uintptr_t)dz | (uintptr_t)dyp | (uintptr_t)gamma) & 15) == 0) &&
+                  (double)rows * d * 4 < 2147483648.0;             // (the v4 kernel stores through 32-bit buffer offsets)
   const dim3 block4(SKF_LN_BWD_THREADS);
   if (v4 && al && d == 64) hipLaunchKernelGGL(ln_bwd_v4_kernel<16>, grid, block4, 0, s, dout, z, stats, gamma, dz, dyp, part, rows, rate, site, st, live_len, rows_per_sample);
   else if (v4 && al && d == 128) hipLaunchKernelGGL(ln_bwd_v4_kernel<32>, grid, block4, 0, s, dout, z, stats, gamma, dz, dyp, part, rows, rate, site, st, live_len, rows_per_sample);
