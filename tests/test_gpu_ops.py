@@ -621,6 +621,28 @@ def test_layernorm_residual_fwd_bwd(ops, d, rate):
     _close(gb, db, rtol=5e-5, name="ln dbeta")
 
 
+@pytest.mark.parametrize("N,K,acc", [(256, 768, False), (256, 256, True), (256, 1024, False), (256, 512, True), (128, 256, True), (128, 128, True),
+                                     (128, 384, True), (768, 256, True), (1024, 256, True), (512, 128, True)])
+def test_gemm_dgrad_accumulate_and_chains_at_full_rows_are_deterministic(ops, N, K, acc):
+    """The accumulate / chained input-gradient launches at the benchmark's row count (M = 25600: every template variant of the
+    weight-stationary kernel the cfg 2 / cfg 3 steps dispatch for them), against float64 and run against run.  Added after an
+    'accumulate only' variant of one instantiation produced run-to-run different results that no small-M test could see."""
+    M = 25600
+    g = torch.Generator(device="cuda").manual_seed(N * 7919 + K)
+    x = torch.randn(M, K, device="cuda", generator=g)
+    wt = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
+    c0 = torch.randn(M, N, device="cuda", generator=g)
+    ref = x.double() @ wt.double().t() + (c0.double() if acc else 0)
+    outs = []
+    for _ in range(3):
+        out = c0.clone()
+        ops.gemm(x, wt, b_kcontig=True, out=out, accumulate=acc, precision=6)
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "run-to-run different results"
+    err = (outs[0].double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 2e-6, err
+
+
 @pytest.mark.parametrize("rows,rate", [(25600, 0.1), (1031, 0.1), (25472, 0.0), (7, 0.1)])
 def test_gemm_ln_residual_one_launch(ops, rows, rate):
     """Dense + residual + dropout + LayerNorm in one launch (the attention output projection, K = N = 128) against the oracle,
