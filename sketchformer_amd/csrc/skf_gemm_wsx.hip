@@ -580,7 +580,11 @@ int launch_wsx(const GemmParams& p, int b_kc, hipStream_t st) {
   //  produced wrong, run-to-run different results for N >= 256 (tools/tmp-style determinism check over 8 shapes; the other kind-1
   //  instantiations passed it, and the kernel text is the general form minus the relu_src loads) - unexplained, so every accumulating
   //  launch keeps the general form.  Kind 2 passed the same check and the full-size gradient tests.)
-  const int extra = p.relu_src ? 3 : p.relu_bits_in ? (p.accumulate ? 3 : 2) : p.accumulate ? 3 : 0;
+#ifndef SKF_WSX_KIND1
+#define SKF_WSX_KIND1 0       // build-time experiment: 1 = dispatch the accumulate-only kind everywhere, 2 = only where K = 128 or KS = 2
+#endif
+  constexpr bool kind1_here = SKF_WSX_KIND1 == 1 || (SKF_WSX_KIND1 == 2 && (K == 128 || KS == 2));
+  const int extra = p.relu_src ? 3 : p.relu_bits_in ? (p.accumulate ? 3 : 2) : p.accumulate ? (kind1_here ? 1 : 3) : 0;
   GemmParams q = p;
   if (q.row_block_rows != TR) q.row_blocks = nullptr;       // the list's blocks must be this kernel's tiles
   // profiling: the dense figures, and the work of the live tiles only (A rows read / multiplied; every C row is still written)
@@ -643,6 +647,9 @@ int launch_wsx(const GemmParams& p, int b_kc, hipStream_t st) {
   }
   // (the forward form [K][N] only ever carries the general epilogue: relu_src / accumulate there are test-only combinations)
   if (b_kc && extra == 2) SKF_WSX_LAUNCH(true, 2);
+#if SKF_WSX_KIND1
+  else if (b_kc && extra == 1) SKF_WSX_LAUNCH(true, 1);
+#endif
   else if (b_kc && extra) SKF_WSX_LAUNCH(true, 3);
   else if (b_kc) SKF_WSX_LAUNCH(true, 0);
   else if (extra) SKF_WSX_LAUNCH(false, 3);
