@@ -577,9 +577,12 @@ int launch_wsx(const GemmParams& p, int b_kc, hipStream_t st) {
   static const std::string tag = "gemm_wsx<K" + std::to_string(K) + ",CW" + std::to_string(CW) + ",bf16x" + std::to_string(P * (P + 1) / 2) + (KS == 2 ? ",ksplit" : "") + ">";
   // epilogue kind (see the kernel): 1 accumulate only, 2 sign bits only, 3 anything else that needs epilogue operands
   // (kind 1 - accumulate only, no relu_src requests - is NOT dispatched: the instantiation <K = 256, one column per lane, kind 1>
-  //  produced wrong, run-to-run different results for N >= 256 (tools/tmp-style determinism check over 8 shapes; the other kind-1
-  //  instantiations passed it, and the kernel text is the general form minus the relu_src loads) - unexplained, so every accumulating
-  //  launch keeps the general form.  Kind 2 passed the same check and the full-size gradient tests.)
+  //  produced wrong, run-to-run different results (tools/gemm_determinism.py; the other kind-1 instantiations passed it, and the kernel
+  //  text is the general form minus the relu_src loads).  What is known (profiles/r03x_ab_stream_experiments.txt, item 8): only with two
+  //  workgroups per CU and >= 3 column groups; only in a workgroup's LAST tile; the bad cells are rows 12 / 14 of the tile x the 16
+  //  columns of one wave (lanes 48-63 of the first / third old-C load) and hold the product WITHOUT the old C; `s_waitcnt vmcnt(0)`
+  //  straight behind those loads, or in front of the final store, changes nothing.  Unexplained - every accumulating launch keeps the
+  //  general form.  Kind 2 passed the same check and the full-size gradient tests.)
 #ifndef SKF_WSX_KIND1
 #define SKF_WSX_KIND1 0       // build-time experiment: 1 = dispatch the accumulate-only kind everywhere, 2 = only where K = 128 or KS = 2
 #endif
