@@ -142,6 +142,8 @@ def cpu_baseline(seconds_budget=20.0):
                      "(4L/8H/d128/dff512, L=200, V=1004, C=1), B=128, dropout 0.1, median of %d full train steps after the warm-up ladder "
                      "(%.2f s each), torch.set_num_threads(%d) = the fastest of the ladder %s (threads, s/step) on %d logical cores "
                      "(one thread per logical core is pathological for eager PyTorch on this host)" % (len(times), med, int(threads), trials, ncpu)}
+    out["sample_short"] = ("torch-CPU fp32 port of the TF2 step, cfg1 B=128 L=200 dropout 0.1, median of %d steps (%.2f s each), %d threads "
+                           "(best of ladder) on %d logical cores" % (len(times), med, int(threads), ncpu))
     # the numpy oracle (what the parity tests check against), for continuity with rounds 1-2
     nstate = oracle.TrainState.create(oracle.init_params(cfg, 0, np.float32))
     rng = np.random.RandomState(0)
@@ -435,6 +437,84 @@ def plugin_path_record(steps, warmup, B):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def _r(v, sig=5):
+    """floats to `sig` significant digits (the compact line is read by people and by the driver, not used for arithmetic)"""
+    if isinstance(v, float):
+        return float("%.*g" % (sig, v)) if np.isfinite(v) else None
+    return v
+
+
+def _pick(d, keys, sig=5):
+    return {k: _r(d[k], sig) for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def detail_paths():
+    """where the full record (kernel tables, sub-records, every roofline side figure) goes: next to the script, and under
+    gpurun_out/ when that exists so that it travels back from a GPU box"""
+    paths = [os.path.join(ROOT, "bench_detail.json")]
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        paths.append(os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
+    return paths
+
+
+COMPACT_LIMIT = 4000
+
+
+def compact_line(out):
+    """The ONE stdout line the driver parses: the contract keys + `roofline` + `cpu_baseline` and a one-level summary of the
+    optional legs, kept under COMPACT_LIMIT bytes (round 3's 20.9 KB line could not be parsed: BENCH_r03.parsed = null).
+    Kernel tables, sub-record detail and the long `sample` / `timing` strings live in bench_detail.json."""
+    line = {k: _r(out[k], 8) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                    "vs_baseline", "dtype", "data") if k in out}
+    cfg = dict(out.get("config") or {})
+    for k in ("dense_gemm_arithmetic",):
+        if isinstance(cfg.get(k), str) and len(cfg[k]) > 60:
+            cfg[k] = cfg[k][:57] + "..."
+    if isinstance(cfg.get("workload"), str) and len(cfg["workload"]) > 140:
+        cfg["workload"] = cfg["workload"][:137] + "..."
+    line["config"] = {k: _r(v) for k, v in cfg.items()}
+    roof = out.get("roofline")
+    if roof:
+        line["roofline"] = _pick(roof, ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us", "launches_per_step",
+                                        "per_step_ms", "frac_dense_counted", "frac_of_executing_pipe", "algorithmic_per_launch",
+                                        "avg_launch_us_concurrent", "frac_hip_events"))
+        line["roofline"].setdefault("traffic", None)
+        if roof.get("timing"):
+            line["roofline"]["timing"] = "rocprofv3 kernel trace" if roof["timing"].startswith("rocprofv3") else "HIP events"
+    cpu = out.get("cpu_baseline")
+    if cpu:
+        line["cpu_baseline"] = _pick(cpu, ("value", "unit", "cores", "kind"))
+        sample = cpu.get("sample_short") or cpu.get("sample") or ""
+        line["cpu_baseline"]["sample"] = sample if len(sample) <= 200 else sample[:197] + "..."
+    line.update(_pick(out, ("step_mfma_frac", "step_tflops", "achieved_hbm", "kernels_per_step", "rocprof_wall_per_step_us", "rccl_ranks",
+                            "final_total_loss")))
+    for leg in ("full_length", "fp32_mfma_mode", "plugin_path", "hip_graph_mode"):
+        if isinstance(out.get(leg), dict):
+            line[leg] = _pick(out[leg], ("ms_per_step", "value", "step_mfma_frac", "skipped", "error"), 4)
+    for leg in ("cfg3", "cfg5", "cfg2grid"):
+        rec = out.get(leg)
+        if isinstance(rec, dict):
+            s = _pick(rec, ("ms_per_step", "value", "step_mfma_frac", "skipped"), 4)
+            if isinstance(rec.get("full_length"), dict):
+                s["full_length_ms"] = _r(rec["full_length"].get("ms_per_step"), 4)
+            if isinstance(rec.get("padded"), dict):
+                s["pad_fraction"] = _r(rec["padded"].get("pad_fraction"), 3)
+            if "error" in rec:
+                s["error"] = str(rec["error"])[:80]
+            line[leg] = s
+    line["detail"] = "bench_detail.json"
+    text = json.dumps(line, separators=(",", ":"))
+    # belt and braces: drop optional legs (least important first) rather than ever exceed the limit
+    for leg in ("cfg2grid", "cfg3", "cfg5", "plugin_path", "fp32_mfma_mode", "hip_graph_mode", "full_length", "final_total_loss",
+                "rocprof_wall_per_step_us", "kernels_per_step"):
+        if len(text) <= COMPACT_LIMIT:
+            break
+        line.pop(leg, None)
+        text = json.dumps(line, separators=(",", ":"))
+    assert len(text) <= COMPACT_LIMIT and "\n" not in text, len(text)
+    return text
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -470,12 +550,18 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         pg = dist.group.WORLD
+    rccl_ranks = None
 
     from sketchformer_amd import build, engine, synthetic, _lib
     if rank == 0:
         build.build_library(verbose=False)
     if world > 1:
         dist.barrier()
+        # the rank count the RCCL communicator itself reports after a real collective (not the env's WORLD_SIZE)
+        ones = torch.ones(1, device="cuda")
+        dist.all_reduce(ones)
+        rccl_ranks = int(ones.item())
+        assert rccl_ranks == dist.get_world_size() == world, (rccl_ranks, dist.get_world_size(), world)
 
     w = WORKLOADS[args.workload]
     B, L, d, dff, N, V = args.batch, w["L"], w["d"], w["dff"], w["N"], w["V"]
@@ -606,7 +692,15 @@ def main():
         out["plugin_path"] = plugin_path_record(args.steps, args.warmup, B) if _elapsed() < args.time_budget else skipped()
         _progress("plugin path done")
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        out["rccl_ranks"] = rccl_ranks
+        for path in detail_paths():
+            try:
+                with open(path, "w") as f:
+                    json.dump(out, f, indent=1)
+                _progress("full record -> %s" % path)
+            except OSError as e:
+                _progress("could not write %s: %s" % (path, e))
+        print(compact_line(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
