@@ -14,6 +14,8 @@
  *  - launches are asynchronous on `stream` (a hipStream_t cast to void*), re-entrant,
  *    and keep no global state besides a thread-local error string (the opt-in launch
  *    profiler below is a measurement facility of the calling process, off by default).
+ *    The library reads no environment variable: tuning / ablation knobs exist only in
+ *    -DSKF_MEASURE=1 builds (csrc/skf_common.h: skf_knob), never in the shipped .so.
  *  - return 0 on success, negative on error (never throws across the ABI);
  *    skf_last_error() describes the last failure on the calling thread.
  */
@@ -67,6 +69,10 @@ int skf_profiler_report(char* buf_host, size_t len);
 #define SKF_PREC_F32 0
 #define SKF_PREC_BF16X3 3
 #define SKF_PREC_BF16X6 6
+/* May be OR'ed into the `precision` argument of skf_attention_bwd / skf_attention_bwd_rows: take the two-pass backward
+ * (skf_attention_bwd2.hip: a dQ pass over query tiles, a dK/dV pass over key tiles, bf16 matrix cores) wherever it is built
+ * (head sizes 16 and 32, Lq, Lk <= 512, split modes) even where the dispatch would pick the one-pass kernel (head size 16). */
+#define SKF_ATTN_TWO_PASS 0x100
 size_t skf_gemm_workspace_bytes(int M, int N, int K, int splits, int with_bias_grad);
 int skf_gemm_default_splits(int M, int N, int K);
 int skf_gemm_f32(int a_kcontig, int b_kcontig, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
@@ -415,6 +421,10 @@ int skf_cast_bf16_to_f32(const void* src, float* dst, size_t n, skf_stream_t str
 /* ------------------------------------------------------------------ the train step
  * Transformer.build_model / call / model_trainer, models/sketchformer.py:63-147, 313-349. */
 typedef struct SkfConfig {
+  /* sizeof(SkfConfig) as the CALLER compiled / declared it.  skf_config_validate (and with it every entry that takes a
+   * config) refuses any other value: a binding that is a field short or long is an error, never a read of heap garbage.
+   * skf_config_size() returns the library's figure. */
+  uint32_t struct_size;
   int32_t batch, seq_len, d_model, num_heads, dff, num_layers;
   int32_t vocab_size, n_classes, lowerdim, attn_version;
   int32_t continuous, blind_decoder_mask, max_pos;
@@ -449,6 +459,7 @@ typedef struct SkfParamEntry {
 
 typedef struct SkfModel SkfModel;
 
+size_t skf_config_size(void);                                   /* sizeof(SkfConfig) of this build of the library */
 int skf_config_validate(const SkfConfig* cfg);
 size_t skf_model_param_floats(const SkfConfig* cfg);            /* length of the flat buffers */
 int skf_model_param_entries(const SkfConfig* cfg, SkfParamEntry* out_host, int max_entries); /* returns count */
@@ -456,6 +467,11 @@ size_t skf_model_workspace_bytes(const SkfConfig* cfg);
 
 int skf_model_create(const SkfConfig* cfg, SkfModel** out);
 void skf_model_destroy(SkfModel* m);
+/* Per-model switches (state of THIS model object, not of the library).  SKF_MODEL_DECODE_LAYERWISE: skf_model_greedy_decode
+ * runs the layer-by-layer path (one launch per operator, the form the oracle tests pinned first) instead of the one launch
+ * per position of skf_decode_fused.hip - same tokens, kept as the cross-check of the fused kernel. */
+#define SKF_MODEL_DECODE_LAYERWISE 1u
+int skf_model_set_flags(SkfModel* m, uint32_t flags);
 /* params/grads/adam_m/adam_v: skf_model_param_floats floats each; pos: (max_pos, d_model) table
  * (builders/utils.py:17-32, computed by the host in float64 like the reference);
  * metrics: 32 floats; step_state: skf_step_state_bytes bytes.  All device memory owned by the caller. */

@@ -30,8 +30,15 @@ class SkfError(RuntimeError):
     pass
 
 
+ATTN_TWO_PASS = 0x100                                 # SKF_ATTN_TWO_PASS
+MODEL_DECODE_LAYERWISE = 1                            # SKF_MODEL_DECODE_LAYERWISE
+
+
 class SkfConfig(C.Structure):
+    """include/skf.h: struct SkfConfig, field for field (tests/test_cabi_cpu.py parses the header and compares).  struct_size is
+    filled in by the constructor; the library refuses a config whose struct_size is not ITS sizeof(SkfConfig)."""
     _fields_ = [
+        ("struct_size", C.c_uint32),
         ("batch", C.c_int32), ("seq_len", C.c_int32), ("d_model", C.c_int32), ("num_heads", C.c_int32),
         ("dff", C.c_int32), ("num_layers", C.c_int32),
         ("vocab_size", C.c_int32), ("n_classes", C.c_int32), ("lowerdim", C.c_int32), ("attn_version", C.c_int32),
@@ -47,6 +54,11 @@ class SkfConfig(C.Structure):
         ("do_classification", C.c_int32), ("do_reconstruction", C.c_int32),
         ("gemm_precision", C.c_int32), ("act_dtype", C.c_int32),
     ]
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        if not self.struct_size:
+            self.struct_size = C.sizeof(SkfConfig)
 
 
 class SkfParamEntry(C.Structure):
@@ -110,6 +122,8 @@ SIGNATURES = {
     "skf_pool_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _Z, _P]),
     "skf_expander_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
     "skf_expander_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _Z, _P]),
+    "skf_config_size": (_Z, []),
+    "skf_model_set_flags": (_I, [_P, C.c_uint32]),
     "skf_step_state_bytes": (_Z, []),
     "skf_step_prologue": (_I, [_P, _I, _F, _F, _F, _F, _F, _F, _U, _P]),
     "skf_step_epilogue": (_I, [_P, _P]),

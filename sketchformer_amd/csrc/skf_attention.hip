@@ -321,7 +321,11 @@ __global__ __launch_bounds__(256, SKF_ATTN_BWD_WAVES) void attn_bwd_kernel(AttnP
 
   long long* dbg = (p.dbg && lane == 0 && (blockIdx.x % 131) == 0 && blockIdx.x / 131 < 8) ? p.dbg + ((blockIdx.x / 131) * 4 + wave) * 32 : nullptr;
   int dbi = 0;
+#if SKF_MEASURE     // clock stamps of a few workgroups (tools/attn_timeline.py): measurement builds only
 #define SKF_STAMP() do { if (dbg && dbi < 32) dbg[dbi++] = clock64(); } while (0)
+#else
+#define SKF_STAMP() do { (void)dbg; (void)dbi; } while (0)
+#endif
   SKF_STAMP();
   // Everything the prologue reads from global memory is requested before its first wait: the key fragments of the first pass,
   // this thread's mask byte and row statistics, then the Q / dO / O rows (four serialised round trips before: rows, mask scan,
@@ -641,7 +645,7 @@ extern "C" int skf_attention_fwd(const float* Q, int ldq, const float* K, int ld
   AttnParams p{};
   p.Q = Q; p.K = K; p.V = V; p.O = O; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
   p.key_mask = key_mask; p.key_mask_ld = key_mask_ld; p.causal = causal; p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.stats = stats;
-  { const char* e = getenv("SKF_ATTN_XCD"); p.xcd_remap = !(e && e[0] == '0'); }
+  { const char* e = skf_knob("SKF_ATTN_XCD"); p.xcd_remap = !(e && e[0] == '0'); }
   int rc = check_common(p, dh);
   if (rc) return rc;
   SKF_CHECK_ARG(Q && K && V && O, "null operand");
@@ -652,7 +656,7 @@ extern "C" int skf_attention_fwd(const float* Q, int ldq, const float* K, int ld
   // rows it removed 26 % of the MFMA cycles and changed nothing (the forward is wait-bound: 45 % of the wave cycles parked,
   // and the planes cost the fourth resident workgroup per CU); with unpadded rows (four workgroups per CU again, 2-way bank
   // conflicts) it is 4-11 % faster than the fp32-MFMA tiles: 36.4 / 29.0 / 42.1 vs 39.2 / 30.2 / 47.2 us.
-  static const bool split_off = getenv("SKF_ATTN_SPLIT") && getenv("SKF_ATTN_SPLIT")[0] == '0';
+  static const bool split_off = skf_knob("SKF_ATTN_SPLIT") && skf_knob("SKF_ATTN_SPLIT")[0] == '0';
   const bool split = dh == 16 && !split_off && precision != SKF_PREC_F32;
   const size_t smem = fwd_smem(dh, Lk, split);
   SKF_CHECK_ARG(smem <= 160 * 1024, "K/V of one head do not fit in LDS");
@@ -692,14 +696,18 @@ extern "C" int skf_attention_bwd_rows(const float* Q, int ldq, const float* K, i
                                       const unsigned char* key_mask, int key_mask_ld, int causal, int B, int H, int Lq, int Lk,
                                       int dh, float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv, int precision,
                                       const int* q_live_len, skf_stream_t stream) {
+  const bool two_pass = (precision & SKF_ATTN_TWO_PASS) != 0;
+  precision &= ~SKF_ATTN_TWO_PASS;
   AttnParams p{};
   p.q_live = q_live_len;
   p.Q = Q; p.K = K; p.V = V; p.O = const_cast<float*>(O); p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
   p.key_mask = key_mask; p.key_mask_ld = key_mask_ld; p.causal = causal; p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk;
   p.stats = const_cast<float*>(stats);
-  { const char* ab = getenv("SKF_ATTN_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }
-  { const char* e = getenv("SKF_ATTN_XCD"); p.xcd_remap = !(e && e[0] == '0'); }
-  { const char* db = getenv("SKF_ATTN_DBG"); p.dbg = db ? (long long*)strtoull(db, nullptr, 0) : nullptr; }
+  { const char* ab = skf_knob("SKF_ATTN_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }
+  { const char* e = skf_knob("SKF_ATTN_XCD"); p.xcd_remap = !(e && e[0] == '0'); }
+#if SKF_MEASURE
+  { const char* db = skf_knob("SKF_ATTN_DBG"); p.dbg = db ? (long long*)strtoull(db, nullptr, 0) : nullptr; }
+#endif
   p.dO = dO; p.lddo = lddo; p.dQ = dQ; p.dK = dK; p.dV = dV; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
   int rc = check_common(p, dh);
   if (rc) return rc;
@@ -711,8 +719,8 @@ extern "C" int skf_attention_bwd_rows(const float* Q, int ldq, const float* K, i
   // Head size 16: only the causal (decoder self-attention) calls take it - measured at the cfg-2 shape, the one-pass kernel
   // below is faster without a look-ahead mask (encoder self 89 vs 95 us; cross 101 vs 124 us with every dO row live, and
   // with the dead query tiles left out by q_live it also wins on padded batches); SKF_ATTN_BWD2=1 forces the two-pass kernel.
-  static const char* bwd2_env = getenv("SKF_ATTN_BWD2");
-  const bool bwd2_off = bwd2_env && bwd2_env[0] == '0', bwd2_all = bwd2_env && bwd2_env[0] == '1';
+  static const char* bwd2_env = skf_knob("SKF_ATTN_BWD2");       // measurement builds only
+  const bool bwd2_off = bwd2_env && bwd2_env[0] == '0', bwd2_all = (bwd2_env && bwd2_env[0] == '1') || two_pass;
   // (round 3: with its prologue loads batched the one-pass kernel also wins the causal dh = 16 calls - 4.134 vs 4.149 ms/step padded,
   //  4.777 vs 4.774 full-length at cfg 2 - so head size 16 takes the two-pass kernel only when forced; head size 32 keeps it:
   //  15.9 vs 17.2 ms/step at cfg 3)

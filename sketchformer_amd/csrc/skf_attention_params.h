@@ -13,7 +13,7 @@ struct AttnParams {
   // backward only
   int xcd_remap;                  // XCD-contiguous (sample, head) ids (default on; env SKF_ATTN_XCD=0 turns it off)
   int ablate;                     // diagnostics (env SKF_ATTN_ABLATE): 1 = no dQ atomics
-  long long* dbg;                 // diagnostics: s_memtime stamps of a few workgroups (env SKF_ATTN_DBG)
+  long long* dbg;                 // diagnostics: s_memtime stamps of a few workgroups (-DSKF_MEASURE=1 builds only, env SKF_ATTN_DBG; always null in the shipped library)
   const float* dO; int lddo;
   float* dQ; float* dK; float* dV;
   int lddq, lddk, lddv;

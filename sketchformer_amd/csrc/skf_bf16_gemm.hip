@@ -653,7 +653,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_big_kernel(TnParams p) {
 }
 
 __host__ inline bool tn_use_big(int P, int Q, int R) {
-  static const int tile_env = getenv("SKF_BF16_GEMM_TILE") ? atoi(getenv("SKF_BF16_GEMM_TILE")) : 0;
+  static const int tile_env = skf_knob("SKF_BF16_GEMM_TILE") ? atoi(skf_knob("SKF_BF16_GEMM_TILE")) : 0;
   return tile_env != 128 && (R & 63) == 0 && P >= 256 && Q >= 256 && R >= 16384;
 }
 
@@ -667,8 +667,8 @@ int set_smem(K kfn, size_t bytes) {
 
 // rows per output tile the launcher will use for this problem (a live-row block list must be built for that height)
 extern "C" int skf_gemm_bf16_tile_rows(int M, int N, int K, int act) {
-  static const bool dma_off = getenv("SKF_BF16_GEMM_DMA") && getenv("SKF_BF16_GEMM_DMA")[0] == '0';
-  static const int tile_env = getenv("SKF_BF16_GEMM_TILE") ? atoi(getenv("SKF_BF16_GEMM_TILE")) : 0;
+  static const bool dma_off = skf_knob("SKF_BF16_GEMM_DMA") && skf_knob("SKF_BF16_GEMM_DMA")[0] == '0';
+  static const int tile_env = skf_knob("SKF_BF16_GEMM_TILE") ? atoi(skf_knob("SKF_BF16_GEMM_TILE")) : 0;
   const bool dma = (K & 63) == 0 && !dma_off;
   // the 256 x 256 tile: one workgroup per CU, so only where there are enough tiles to fill the chip
   const bool big = dma && tile_env != 128 && act != 2 && N >= 256 && ((long)skf_cdiv(M, 256) * skf_cdiv(N, 256) >= 256 || tile_env == 256);
@@ -717,7 +717,7 @@ extern "C" int skf_gemm_bf16_bits(int M, int N, int K, const void* A, int lda, c
   p.bits_out = (unsigned char*)relu_bits_out; p.bits_in = (const unsigned char*)relu_bits_in; p.ld_bits = ld_bits;
   const bool extra = relu_src || accumulate || C_f32 || relu_bits_in;
   // SKF_BF16_GEMM_DMA=0: register-staged tiles everywhere; SKF_BF16_GEMM_TILE=128: no 256 x 256 tiles (measurement knobs)
-  static const bool dma_off = getenv("SKF_BF16_GEMM_DMA") && getenv("SKF_BF16_GEMM_DMA")[0] == '0';
+  static const bool dma_off = skf_knob("SKF_BF16_GEMM_DMA") && skf_knob("SKF_BF16_GEMM_DMA")[0] == '0';
   const bool dma = (K & 63) == 0 && !dma_off;
   const bool big = skf_gemm_bf16_tile_rows(M, N, K, act) == 256;
   const int tile = big ? 256 : 128;

@@ -10,6 +10,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define SKF_WAVE 64
 
+// The shipped library reads NO environment variable and keeps no configuration state (include/skf.h): the A/B, ablation and
+// timeline knobs of tools/ exist only in measurement builds (SKF_EXTRA_HIPCC_FLAGS=-DSKF_MEASURE=1 python -m
+// sketchformer_amd.build --force); in the default build skf_knob() is a constant null and every branch on it folds away.
+#ifndef SKF_MEASURE
+#define SKF_MEASURE 0
+#endif
+#if SKF_MEASURE
+#include <stdlib.h>
+static inline const char* skf_knob(const char* name) { return getenv(name); }
+#else
+static inline const char* skf_knob(const char*) { return nullptr; }
+#endif
+
 void skf_set_error(const char* fmt, ...);
 
 #define SKF_CHECK_ARG(cond, msg)                                   \

@@ -348,7 +348,7 @@ extern "C" size_t skf_gemm_workspace_bytes(int M, int N, int K, int splits, int 
 extern "C" int skf_gemm_default_splits(int M, int N, int K) {
   const int tiles = skf_cdiv(M, 64) * skf_cdiv(N, 64);
   if (K <= 512) return 1;
-  static const int wgs = getenv("SKF_WGRAD_WGS") ? atoi(getenv("SKF_WGRAD_WGS")) : 256;
+  static const int wgs = skf_knob("SKF_WGRAD_WGS") ? atoi(skf_knob("SKF_WGRAD_WGS")) : 256;
   int splits = wgs / tiles;
   const int max_splits = skf_cdiv(K, 8 * BK);   // at least 8 slabs per split
   if (splits > max_splits) splits = max_splits;
@@ -559,7 +559,9 @@ extern "C" int skf_gemm_ln_residual_f32(int M, int N, int K, const float* A, int
   p.a_vec = 1; p.b_vec = ((ldw & 3) == 0) && (((uintptr_t)W & 15) == 0);
   p.ln_x = x; p.ln_gamma = gamma; p.ln_beta = beta; p.ln_out = out; p.ln_stats = stats;
   p.ln_rate = rate; p.ln_site = site; p.ln_state = step_state;
-  { const char* db = getenv("SKF_GEMM_DBG"); p.dbg = db ? (long long*)strtoull(db, nullptr, 0) : nullptr; }
+#if SKF_MEASURE
+  { const char* db = skf_knob("SKF_GEMM_DBG"); p.dbg = db ? (long long*)strtoull(db, nullptr, 0) : nullptr; }
+#endif
   return skf_gemm_wsx_launch(p, 0, precision == SKF_PREC_BF16X3 ? 2 : 3, (hipStream_t)stream);
 }
 
@@ -604,9 +606,11 @@ extern "C" int skf_gemm_f32_bits(int a_kcontig, int b_kcontig, int M, int N, int
   p.a_vec = ((lda & 3) == 0) && (((uintptr_t)A & 15) == 0);
   p.b_vec = ((ldb & 3) == 0) && (((uintptr_t)B & 15) == 0);
   p.tiles_m = skf_cdiv(M, 128); p.tiles_n = skf_cdiv(N, 128);
-  { const char* ab = getenv("SKF_GEMM_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }
-  { const char* xr = getenv("SKF_WS_XCD"); p.xcd_remap = xr ? atoi(xr) : 0; }
-  { const char* db = getenv("SKF_GEMM_DBG"); p.dbg = db ? (long long*)strtoull(db, nullptr, 0) : nullptr; }
+  { const char* ab = skf_knob("SKF_GEMM_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }
+  { const char* xr = skf_knob("SKF_WS_XCD"); p.xcd_remap = xr ? atoi(xr) : 0; }
+#if SKF_MEASURE
+  { const char* db = skf_knob("SKF_GEMM_DBG"); p.dbg = db ? (long long*)strtoull(db, nullptr, 0) : nullptr; }
+#endif
   SKF_CHECK_ARG(!bias_grad || !b_kcontig, "bias_grad needs B as [K][N]");
   {
     int handled = 0;

@@ -19,7 +19,7 @@ struct GemmParams {
   float* slab;             // [splits][M][N] raw partial tiles (split-K only)
   float* colsum_slab;      // [splits][N] partial column sums of B (bias grad), or null
   int tiles_m, tiles_n;
-  long long* dbg;          // diagnostics only: per-phase s_memtime stamps of a few workgroups (env SKF_GEMM_DBG)
+  long long* dbg;          // diagnostics only: per-phase s_memtime stamps of a few workgroups (-DSKF_MEASURE=1 builds only, env SKF_GEMM_DBG; always null in the shipped library)
   int xcd_remap;           // ws kernel: XCD-contiguous logical ids (env SKF_WS_XCD, A/B knob)
   int precision;           // SKF_PREC_*: 0 fp32 MFMA, 6 / 3 = split fp32 operands on the bf16 matrix cores
   // Row-block list (skf_row_blocks_build): {n_live, n_blocks, live block ids ..., dead block ids ...} over blocks of

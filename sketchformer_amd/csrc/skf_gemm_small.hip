@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(SmallParams p) {
 int skf_gemm_small_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, float* bias_grad, int bias_grad_accumulate,
                             hipStream_t st, int* handled) {
   *handled = 0;
-  const char* off = getenv("SKF_GEMM_NO_SMALL");
+  const char* off = skf_knob("SKF_GEMM_NO_SMALL");
   if (off && off[0] == '1') return SKF_OK;
   if ((double)p.M * p.N * p.K > 33554432.0) return SKF_OK;
   // a long contraction over few outputs (weight gradient of a narrow layer over the B*L rows, e.g. Dense(d -> 5) of the

@@ -392,7 +392,7 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_x_group_kernel(WgradGroup gr
 // (the caller runs the slab reduction).  p.k_chunk must already be set (multiple of 64).
 int skf_gemm_wgrad_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, int splits, hipStream_t st, int* handled) {
   *handled = 0;
-  const char* off = getenv("SKF_GEMM_NO_WGRAD");
+  const char* off = skf_knob("SKF_GEMM_NO_WGRAD");
   if (off && off[0] == '1') return SKF_OK;
   if (a_kcontig || b_kcontig) return SKF_OK;
   if ((p.M & 3) || (p.N & 3) || (p.lda & 3) || (p.ldb & 3) || ((uintptr_t)p.A & 15) || ((uintptr_t)p.B & 15)) return SKF_OK;
@@ -440,8 +440,8 @@ int skf_gemm_wgrad_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, i
 // (split arithmetic, aligned, 32-bit offsets); *handled = 0 when any is not (the caller then issues them one by one).
 int skf_gemm_wgrad_group_dispatch(const GemmParams* ps, const int* splits, int n, hipStream_t st, int* handled) {
   *handled = 0;
-  const char* off = getenv("SKF_GEMM_NO_WGRAD");
-  static const bool group_off = getenv("SKF_NO_WGRAD_GROUP") && getenv("SKF_NO_WGRAD_GROUP")[0] == '1';
+  const char* off = skf_knob("SKF_GEMM_NO_WGRAD");
+  static const bool group_off = skf_knob("SKF_NO_WGRAD_GROUP") && skf_knob("SKF_NO_WGRAD_GROUP")[0] == '1';
   if ((off && off[0] == '1') || group_off || n < 2 || n > kWgradGroupMax) return SKF_OK;
   WgradGroup grp{};
   grp.n = n;

@@ -299,7 +299,7 @@ int launch_ws(const GemmParams& p, int b_kc, hipStream_t st) {
   constexpr int CW = 16 * NB;
   const int groups = skf_cdiv(p.N, 4 * CW);
   // two workgroups per CU where the register budget allows it (K*NB <= 512), else one
-  static const int wg_target = getenv("SKF_WS_WGS") ? atoi(getenv("SKF_WS_WGS")) : (K * NB <= 512 ? 512 : 256);
+  static const int wg_target = skf_knob("SKF_WS_WGS") ? atoi(skf_knob("SKF_WS_WGS")) : (K * NB <= 512 ? 512 : 256);
   int workers = wg_target / groups;
   if (workers < 1) workers = 1;
   const int ntiles = skf_cdiv(p.M, TR);
@@ -338,7 +338,7 @@ static int ws_launch_one(const GemmParams& p, int b_kcontig, hipStream_t st) {
 
 int skf_gemm_ws_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, hipStream_t st, int* handled) {
   *handled = 0;
-  const char* off = getenv("SKF_GEMM_NO_WS");
+  const char* off = skf_knob("SKF_GEMM_NO_WS");
   if (off && off[0] == '1') return SKF_OK;
   if (!a_kcontig || p.M < 1024) return SKF_OK;
   // K in {128,256,384,512} = one launch; longer K (a multiple of 128 up to 2048: dff = 1024 / 2048, the 3d-wide qkv dgrad
@@ -348,7 +348,7 @@ int skf_gemm_ws_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, hipS
   const bool chain = !single && p.K > 512 && p.K <= 2048 && (p.K & 127) == 0 && p.act == 0 && !p.relu_src;
   // Input-gradient form with any K % 4 == 0 up to 2048 (the logits layer: K = vocabulary = 1004), split arithmetic only: 512-deep
   // slices, the last one masked (GemmParams::k_valid).  SKF_NO_MASKED_CHAIN=1 keeps such shapes on the generic kernel.
-  static const bool masked_off = getenv("SKF_NO_MASKED_CHAIN") && getenv("SKF_NO_MASKED_CHAIN")[0] == '1';
+  static const bool masked_off = skf_knob("SKF_NO_MASKED_CHAIN") && skf_knob("SKF_NO_MASKED_CHAIN")[0] == '1';
   const bool fits32m = (double)p.M * p.lda * 4 < 2147483648.0 && (double)p.M * p.ldc * 4 < 2147483648.0;
   const bool chain_masked = !single && !chain && !masked_off && b_kcontig && p.precision != SKF_PREC_F32 && fits32m && p.K > 512 &&
                             p.K <= 2048 && (p.K & 3) == 0 && p.act == 0 && !p.relu_src && !p.relu_bits_in && !p.relu_bits_out && !p.bias;

@@ -120,8 +120,8 @@ __device__ __forceinline__ float wsx_row16_sum(float v) {
 // take k < K/2 and own the output, waves 4-7 take the rest and hand their partial sums over through LDS behind the tile's closing
 // barrier (added when the tile is stored, under the next tile's MFMAs).  Half the weight registers per wave (96 instead of 192 at
 // K = 512) = two waves per SIMD instead of one: K = 512 ran at one wave per SIMD with 1536 MFMA cycles in a ~4100-cycle tile.
-// EXTRA = epilogue operands of the launch: 0 none, 1 accumulate only (C += ...; written, not dispatched - see launch_wsx), 2 ReLU sign
-// bits only, 3 the general form (relu_src and / or any combination).  The kinds exist so that a launch issues only the loads it uses:
+// EXTRA = epilogue operands of the launch: 0 none, 2 ReLU sign bits only, 3 the general form (relu_src, old C, any combination).
+// (Kind 1, "accumulate only", existed in round 3 and was removed in round 4: see the note in launch_wsx.)  The kinds exist so that a launch issues only the loads it uses:
 // in the general form every tile requests the relu_src rows AND the old C rows through (possibly empty) descriptors - eight VMEM
 // instructions per tile and wave for nothing in the bits-only ffn input gradient.
 template <int K, int NB, int P, bool B_KC, int EXTRA, bool KMASK = false, bool LNF = false, int KS = 1>
@@ -129,6 +129,7 @@ __global__ __launch_bounds__(256 * KS, (KS == 2 || (K <= 256 && NB <= 2) ? 2 : 1
   constexpr int CW = 16 * NB;            // columns per wave
   constexpr int NKS = K / (32 * KS);     // MFMA k-steps per tile (of this wave)
   constexpr int NF = NKS * P;            // A fragments (ds_read_b128) per tile
+  static_assert(EXTRA == 0 || EXTRA == 2 || EXTRA == 3, "epilogue kinds: none, sign bits only, general");
   static_assert(KS == 1 || (KS == 2 && K >= 256 && !LNF), "contraction split: two halves, K >= 256");
   static_assert(!LNF || (K == 128 && NB == 2 && !EXTRA && !KMASK), "LayerNorm epilogue: K = 128, two columns per lane, plain launch");
   constexpr bool EARLY = !LNF && K == 128 && (P == 2 || NB == 4 || SKF_WSX_EARLY3);   // every fragment of a tile in registers: barrier inside the MFMA stream
@@ -567,7 +568,7 @@ template <int K, int NB, int P, int KS = 1>
 int launch_wsx(const GemmParams& p, int b_kc, hipStream_t st) {
   constexpr int CW = 16 * NB;
   const int groups = skf_cdiv(p.N, 4 * CW);
-  static const int wg_target = getenv("SKF_WS_WGS") ? atoi(getenv("SKF_WS_WGS")) : (KS == 1 && K <= 256 && NB <= 2 ? 512 : 256);
+  static const int wg_target = skf_knob("SKF_WS_WGS") ? atoi(skf_knob("SKF_WS_WGS")) : (KS == 1 && K <= 256 && NB <= 2 ? 512 : 256);
   int workers = wg_target / groups;
   if (workers < 1) workers = 1;
   const int ntiles = skf_cdiv(p.M, TR);
@@ -575,19 +576,17 @@ int launch_wsx(const GemmParams& p, int b_kc, hipStream_t st) {
   const size_t smem = (size_t)2 * P * TR * (2 * K + 32) + (KS == 2 ? (size_t)2 * 4 * 64 * 4 * NB * sizeof(float) : 0);
   dim3 grid(groups * workers), block(256 * KS);
   static const std::string tag = "gemm_wsx<K" + std::to_string(K) + ",CW" + std::to_string(CW) + ",bf16x" + std::to_string(P * (P + 1) / 2) + (KS == 2 ? ",ksplit" : "") + ">";
-  // epilogue kind (see the kernel): 1 accumulate only, 2 sign bits only, 3 anything else that needs epilogue operands
-  // (kind 1 - accumulate only, no relu_src requests - is NOT dispatched: the instantiation <K = 256, one column per lane, kind 1>
-  //  produced wrong, run-to-run different results (tools/gemm_determinism.py; the other kind-1 instantiations passed it, and the kernel
-  //  text is the general form minus the relu_src loads).  What is known (profiles/r03x_ab_stream_experiments.txt, item 8): only with two
-  //  workgroups per CU and >= 3 column groups; only in a workgroup's LAST tile; the bad cells are rows 12 / 14 of the tile x the 16
-  //  columns of one wave (lanes 48-63 of the first / third old-C load) and hold the product WITHOUT the old C; `s_waitcnt vmcnt(0)`
-  //  straight behind those loads, or in front of the final store, changes nothing.  Unexplained - every accumulating launch keeps the
-  //  general form.  Kind 2 passed the same check and the full-size gradient tests.)
-#ifndef SKF_WSX_KIND1
-#define SKF_WSX_KIND1 0       // build-time experiment: 1 = dispatch the accumulate-only kind everywhere, 2 = only where K = 128 or KS = 2
-#endif
-  constexpr bool kind1_here = SKF_WSX_KIND1 == 1 || (SKF_WSX_KIND1 == 2 && (K == 128 || KS == 2));
-  const int extra = p.relu_src ? 3 : p.relu_bits_in ? (p.accumulate ? 3 : 2) : p.accumulate ? (kind1_here ? 1 : 3) : 0;
+  // epilogue kind (see the kernel): 2 sign bits only, 3 anything else that needs epilogue operands.
+  // There is no "accumulate only" kind.  Round 3 had one (the general form minus the relu_src requests, +0.5 % on the step) whose
+  // instantiation <K = 256, one column per lane> gave run-to-run different results.  Round 4 bisected it on the hardware
+  // (profiles/r04b_kind1_bisect.txt): with only the old-C add left in the epilogue the compiler fuses the four adds of a lane into
+  // v_pk_add_f32 with CROSSED operand selects (op_sel:[0,1] op_sel_hi:[1,0]) in the kernel's exit block; the wrong cells (rows 12 / 14
+  // of a workgroup's last tile = lanes 48-63 of the first and third add) are exactly the low halves of those instructions.  Draining
+  // VMEM and 16 wait states in front of them changed nothing (not an s_waitcnt count), zero-initialised epilogue registers changed
+  // nothing (not an undefined value), the same adds forced to four v_add_f32 were bit-reproducible over 210 runs.  The general form
+  // never lets the compiler build that instruction (its select sits between the product and the add): tools/isa_pk_opsel.py
+  // counts crossed-select packed-fp32 instructions per kernel (0 in this file, checked by tests/test_cabi_cpu.py).
+  const int extra = p.relu_src ? 3 : p.relu_bits_in ? (p.accumulate ? 3 : 2) : p.accumulate ? 3 : 0;
   GemmParams q = p;
   if (q.row_block_rows != TR) q.row_blocks = nullptr;       // the list's blocks must be this kernel's tiles
   // profiling: the dense figures, and the work of the live tiles only (A rows read / multiplied; every C row is still written)
@@ -595,7 +594,7 @@ int launch_wsx(const GemmParams& p, int b_kc, hipStream_t st) {
   const double a_c = (double)p.M * p.K + (double)p.M * p.N * ((p.accumulate ? 1 : 0) + (p.relu_src && !p.relu_bits_in ? 1 : 0));
   const double ln_c = p.ln_out ? 2.0 * p.M * p.N : 0.0;
   // SKF_PROF_FINE=1 (analysis only): one table line per output width and epilogue
-  static const bool fine = getenv("SKF_PROF_FINE") && getenv("SKF_PROF_FINE")[0] == '1';
+  static const bool fine = skf_knob("SKF_PROF_FINE") && skf_knob("SKF_PROF_FINE")[0] == '1';
   static std::set<std::string> fine_tags;           // the profiler keeps the pointer: interned
   const char* ftag = nullptr;
   if (fine) ftag = fine_tags.insert(tag + "[N" + std::to_string(p.N) + (b_kc ? ",dgrad" : "") + (p.relu_bits_in ? ",bits" : "") + (p.relu_src ? ",relu_src" : "") +
@@ -608,7 +607,7 @@ int launch_wsx(const GemmParams& p, int b_kc, hipStream_t st) {
   // in the L2 (PMC: 132 -> ~80 MB per launch); with one or two groups of short tiles (K <= 256) the remap only costs
   // K = 128 with three or more column groups (N = 384 / 512 / 1004): round-robin ids put the group-mates of a worker on
   // different XCDs, i.e. every A tile is fetched into `groups` L2s (PMC, round 1: 1.55x the algorithmic bytes)
-  static const char* xcd_env = getenv("SKF_WS_XCD");     // "0" / "1" force it (measurement)
+  static const char* xcd_env = skf_knob("SKF_WS_XCD");     // "0" / "1" force it (measurement)
   q.xcd_remap = xcd_env ? xcd_env[0] == '1' : (groups > 1 && (K >= 384 || groups >= 3));
 #define SKF_WSX_LAUNCH(BKC, EX)                                                                                    \
   do {                                                                                                             \
@@ -650,9 +649,6 @@ int launch_wsx(const GemmParams& p, int b_kc, hipStream_t st) {
   }
   // (the forward form [K][N] only ever carries the general epilogue: relu_src / accumulate there are test-only combinations)
   if (b_kc && extra == 2) SKF_WSX_LAUNCH(true, 2);
-#if SKF_WSX_KIND1
-  else if (b_kc && extra == 1) SKF_WSX_LAUNCH(true, 1);
-#endif
   else if (b_kc && extra) SKF_WSX_LAUNCH(true, 3);
   else if (b_kc) SKF_WSX_LAUNCH(true, 0);
   else if (extra) SKF_WSX_LAUNCH(false, 3);
@@ -671,19 +667,19 @@ int launch_wsx_k(const GemmParams& p, int b_kc, hipStream_t st) {
     case 256: {
       // K = 256: only for N <= 128 (one or two column groups, 256 workgroups either way); with more column groups the 512-thread form
       // was 4 % slower at cfg 3 (N = 256 ... 1024).  SKF_WSX_KSPLIT256=1 forces it for every N, =0 turns it off (measurement)
-      static const char* ks2 = getenv("SKF_WSX_KSPLIT256");
-      const bool ks_on2 = ks2 ? ks2[0] == '1' : (p.N <= 128 && !(getenv("SKF_WSX_KSPLIT") && getenv("SKF_WSX_KSPLIT")[0] == '0'));
+      static const char* ks2 = skf_knob("SKF_WSX_KSPLIT256");
+      const bool ks_on2 = ks2 ? ks2[0] == '1' : (p.N <= 128 && !(skf_knob("SKF_WSX_KSPLIT") && skf_knob("SKF_WSX_KSPLIT")[0] == '0'));
       if (ks_on2 && p.act == 0) return launch_wsx<256, 1, P, 2>(p, b_kc, st);
       return launch_wsx<256, 1, P>(p, b_kc, st);
     }
     case 384: {
-      static const bool ks_off3 = (getenv("SKF_WSX_KSPLIT") && getenv("SKF_WSX_KSPLIT")[0] == '0') || (getenv("SKF_WSX_KSPLIT384") && getenv("SKF_WSX_KSPLIT384")[0] == '0');
+      static const bool ks_off3 = (skf_knob("SKF_WSX_KSPLIT") && skf_knob("SKF_WSX_KSPLIT")[0] == '0') || (skf_knob("SKF_WSX_KSPLIT384") && skf_knob("SKF_WSX_KSPLIT384")[0] == '0');
       if (!ks_off3 && p.act == 0) return launch_wsx<384, 1, P, 2>(p, b_kc, st);
       return launch_wsx<384, 1, P>(p, b_kc, st);
     }
     default: {
       // K = 512 without an activation: the contraction split between wave pairs (two waves per SIMD); SKF_WSX_KSPLIT=0: A/B knob
-      static const bool ks_off = getenv("SKF_WSX_KSPLIT") && getenv("SKF_WSX_KSPLIT")[0] == '0';
+      static const bool ks_off = skf_knob("SKF_WSX_KSPLIT") && skf_knob("SKF_WSX_KSPLIT")[0] == '0';
       if (!ks_off && p.act == 0) return launch_wsx<512, 1, P, 2>(p, b_kc, st);
       return launch_wsx<512, 1, P>(p, b_kc, st);
     }

@@ -42,6 +42,7 @@ namespace {
 struct ProfRec { const char* tag; double flops, bytes, flops_done, bytes_done; hipEvent_t e0, e1; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
+thread_local int g_capturing = 0;      // > 0 while this thread records a step into a hipGraph (capture_or_run)
 }  // namespace
 
 SkfProfScope::SkfProfScope(hipStream_t st, const char* tag, double flops, double bytes) : st_(st), idx_(-1) {
@@ -63,14 +64,15 @@ void SkfProfScope::done(double flops_done, double bytes_done) {
   g_prof[idx_].bytes_done = bytes_done;
 }
 double skf_prof_list_fraction(const int* list) {
-  if (!list || !g_prof_on) return 1.0;
+  // (never inside a stream capture: a device synchronisation there invalidates the capture - hipErrorStreamCaptureUnsupported)
+  if (!list || !g_prof_on || g_capturing) return 1.0;
   int h[2] = {0, 0};
   if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h, list, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess || h[1] <= 0) return 1.0;
   return (double)h[0] / h[1];
 }
 double skf_prof_attention_fraction(const unsigned char* key_mask, int mask_ld, int causal, int B, int Lq, int Lk,
                                    const int* q_live, int qtile, int ktile) {
-  if (!g_prof_on || (!key_mask && !q_live && !causal)) return 1.0;
+  if (!g_prof_on || g_capturing || (!key_mask && !q_live && !causal)) return 1.0;
   if (hipDeviceSynchronize() != hipSuccess) return 1.0;
   std::vector<unsigned char> km;
   std::vector<int> ql;
@@ -393,7 +395,7 @@ Plan build_plan(const SkfConfig& c) {
   if (2 * B * L * f > s) s = 2 * B * L * f;
   if (c.continuous && skf_embed_continuous_bwd_workspace_bytes((int)Me, (int)d) > s) s = skf_embed_continuous_bwd_workspace_bytes((int)Me, (int)d);
   P.small_ws_bytes = s; P.small_ws = b.take(s);
-  if (!c.continuous && c.vocab_size <= 12288 && c.d_model <= 512 && !getenv("SKF_NO_EMBED_SORT")) {   // (the sorted kernel's partial slab is sized for rows of <= 512 floats)
+  if (!c.continuous && c.vocab_size <= 12288 && c.d_model <= 512 && !skf_knob("SKF_NO_EMBED_SORT")) {   // (the sorted kernel's partial slab is sized for rows of <= 512 floats)
     P.emb_sort_bytes = (skf_embed_sort_workspace_bytes((int)B, (int)L, c.vocab_size) + 255) & ~(size_t)255;
     P.emb_sort[0] = b.take(P.emb_sort_bytes); P.emb_sort[1] = b.take(P.emb_sort_bytes);
   }
@@ -418,6 +420,8 @@ Plan build_plan(const SkfConfig& c) {
 
 struct SkfModel {
   SkfConfig cfg;
+  uint32_t flags = 0;                // skf_model_set_flags
+  bool no_ln_fuse = false, no_relu_bits = false;   // a fused entry answered SKF_EUNSUPPORTED once: this model takes the general pair
   Layout lay;
   Plan plan;
   Plan16 p16;                        // bf16 path (cfg.act_dtype == SKF_ACT_BF16): its own workspace plan
@@ -438,7 +442,7 @@ struct SkfModel {
   // buffers share one `done` event: one barrier packet on the main stream instead of seven, ~5 us each)
   struct SideEvent { hipEvent_t e; long seq; };
   long side_seq = 0, side_waited = 0;
-  bool no_wait_dedupe = getenv("SKF_NO_WAIT_DEDUPE") && getenv("SKF_NO_WAIT_DEDUPE")[0] == '1';     // A/B knob
+  bool no_wait_dedupe = skf_knob("SKF_NO_WAIT_DEDUPE") && skf_knob("SKF_NO_WAIT_DEDUPE")[0] == '1';     // A/B knob
   std::map<const void*, SideEvent> pending_readers;    // buffer -> completion event of its last side-stream reader
   // kind 0: dW = X^T dY (+ bias grad); kind 1: an input gradient nobody on the main stream needs soon (dx (+)= dY W^T)
   struct QueuedWgrad { DenseP w; const float* x; int ldx; const float* dy; int lddy; int rows; int kind = 0; float* dx = nullptr; int lddx = 0; int accumulate = 0; const int* blocks32 = nullptr; };
@@ -466,7 +470,7 @@ struct SkfModel {
       // Events that only order the library's own two streams on ONE device: a device-scope release is all the waiter needs
       // (the default system-scope fence of hipEventRecord writes caches back for host / peer visibility).  SKF_EVENT_SCOPE=system
       // restores the default for A/B measurements.  (The gradient-bucket events handed to the caller keep the default.)
-      static const bool sys_scope = getenv("SKF_EVENT_SCOPE") && getenv("SKF_EVENT_SCOPE")[0] == 's';
+      static const bool sys_scope = skf_knob("SKF_EVENT_SCOPE") && skf_knob("SKF_EVENT_SCOPE")[0] == 's';
       if (hipEventCreateWithFlags(&e, hipEventDisableTiming | (sys_scope ? 0u : hipEventReleaseToDevice)) != hipSuccess) return nullptr;
       events.push_back(e);
     }
@@ -495,24 +499,33 @@ int dense_fwd(SkfModel* M, const DenseP& w, const float* x, int rows, float* y, 
 // at d_model = 128 in the split-arithmetic modes), else the Dense launch followed by the LayerNorm launch.  SKF_NO_LN_FUSE=1: A/B knob.
 int dense_ln_fwd(SkfModel* M, const DenseP& w, const float* a, int rows, const float* x, float* z, const LnP& ln, float* out,
                  float* stats, float rate, unsigned site, hipStream_t s) {
-  static const bool fuse_off = getenv("SKF_NO_LN_FUSE") && getenv("SKF_NO_LN_FUSE")[0] == '1';
-  if (!fuse_off && skf_gemm_ln_residual_supported(rows, w.out, w.in, M->cfg.gemm_precision))
-    return skf_gemm_ln_residual_f32(rows, w.out, w.in, a, w.in, M->P(w.w), w.ld, M->P(w.b), x, M->P(ln.g), M->P(ln.b), z, out, stats,
-                                    rate, site, M->state, M->cfg.gemm_precision, s);
+  static const bool fuse_off = skf_knob("SKF_NO_LN_FUSE") && skf_knob("SKF_NO_LN_FUSE")[0] == '1';
+  if (!fuse_off && !M->no_ln_fuse && skf_gemm_ln_residual_supported(rows, w.out, w.in, M->cfg.gemm_precision)) {
+    const int rc = skf_gemm_ln_residual_f32(rows, w.out, w.in, a, w.in, M->P(w.w), w.ld, M->P(w.b), x, M->P(ln.g), M->P(ln.b), z, out, stats,
+                                            rate, site, M->state, M->cfg.gemm_precision, s);
+    // the shape test above does not see pitches / alignment: a launch the fused entry declines takes the general pair (from now on)
+    if (rc != SKF_EUNSUPPORTED) return rc;
+    M->no_ln_fuse = true;
+  }
   SKF_TRY(dense_fwd(M, w, a, rows, z, 0, s));
   return skf_layernorm_residual_fwd(x, z, M->P(ln.g), M->P(ln.b), out, stats, rows, w.out, rate, site, M->state, s);
 }
 // sign-bit buffer of an ffn hidden tensor (rows x dff from d inputs), or null when the shape has no such path / SKF_NO_RELU_BITS=1
 void* hbits_of(SkfModel* M, size_t off, int rows) {
-  static const bool bits_off = getenv("SKF_NO_RELU_BITS") && getenv("SKF_NO_RELU_BITS")[0] == '1';
-  if (bits_off || !skf_gemm_relu_bits_bytes(rows, M->cfg.dff, M->cfg.d_model, M->cfg.gemm_precision)) return nullptr;
+  static const bool bits_off = skf_knob("SKF_NO_RELU_BITS") && skf_knob("SKF_NO_RELU_BITS")[0] == '1';
+  if (bits_off || M->no_relu_bits || !skf_gemm_relu_bits_bytes(rows, M->cfg.dff, M->cfg.d_model, M->cfg.gemm_precision)) return nullptr;
   return M->at<char>(off);
 }
 // ffn dense1 (relu): also leaves the sign bits of the hidden tensor for the backward when the shape has that path (bits != null)
 int dense_fwd_relu_bits(SkfModel* M, const DenseP& w, const float* x, int rows, float* y, void* bits, hipStream_t s) {
   if (!bits) return dense_fwd(M, w, x, rows, y, 1, s);
-  return skf_gemm_f32_bits(1, 0, rows, w.out, w.in, x, w.in, M->P(w.w), w.ld, y, w.out, M->P(w.b), 1, nullptr, 0, 0, 1,
-                           nullptr, 0, nullptr, 0, M->cfg.gemm_precision, nullptr, 0, bits, nullptr, s);
+  const int rc = skf_gemm_f32_bits(1, 0, rows, w.out, w.in, x, w.in, M->P(w.w), w.ld, y, w.out, M->P(w.b), 1, nullptr, 0, 0, 1,
+                                   nullptr, 0, nullptr, 0, M->cfg.gemm_precision, nullptr, 0, bits, nullptr, s);
+  if (rc != SKF_EUNSUPPORTED) return rc;
+  // the weight-stationary dispatch declined (pitch / alignment): the general kernels, and the backward of this and every later
+  // step reads the hidden tensor (relu_src) instead of sign bits nobody wrote - hbits_of() answers null from here on
+  M->no_relu_bits = true;
+  return dense_fwd(M, w, x, rows, y, 1, s);
 }
 // strided-input variant (x has row stride ldx)
 int dense_fwd_ld(SkfModel* M, const DenseP& w, const float* x, int ldx, int rows, float* y, int ldy, int act, hipStream_t s) {
@@ -649,7 +662,7 @@ int flush_wgrads(SkfModel* M, hipStream_t s, int bucket, bool final) {
     }
     // LayerNorm partials and the embedding gradients of this bucket were written by the main stream: the batched
     // reduction (wgrad slabs + LayerNorm partials) and the bucket-ready event are ordered after both streams
-    static const bool tail_on_main = !(getenv("SKF_TAIL_REDUCE_SIDE") && getenv("SKF_TAIL_REDUCE_SIDE")[0] == '1');
+    static const bool tail_on_main = !(skf_knob("SKF_TAIL_REDUCE_SIDE") && skf_knob("SKF_TAIL_REDUCE_SIDE")[0] == '1');
     if (final && tail_on_main) {
       // end of the backward: the optimizer waits for this reduction anyway, so it runs on the MAIN stream behind ONE hop
       // (side -> main after the last weight gradient) instead of two (main -> side for the partials, side -> main for the result)
@@ -702,7 +715,7 @@ int dense_dgrad(SkfModel* M, const DenseP& w, const float* dy, int lddy, int row
 // before_read(dx).  Successive deferred writers of one dx stay in order (one side stream).
 int dense_dgrad_deferred(SkfModel* M, const DenseP& w, const float* dy, int lddy, int rows, float* dx, int lddx, int accumulate,
                          hipStream_t s) {
-  static const bool off = getenv("SKF_NO_DEFERRED_DGRAD") != nullptr;
+  static const bool off = skf_knob("SKF_NO_DEFERRED_DGRAD") != nullptr;
   if (!M->side || off) return dense_dgrad(M, w, dy, lddy, rows, dx, lddx, accumulate, nullptr, 0, s);
   SkfModel::QueuedWgrad q{w, nullptr, 0, dy, lddy, rows};
   q.kind = 1; q.dx = dx; q.lddx = lddx; q.accumulate = accumulate;
@@ -928,7 +941,7 @@ int ln_bwd(SkfModel* M, const LnP& ln, const float* dout, const float* z, const 
 int build_row_lists(SkfModel* M, hipStream_t s) {
   const SkfConfig& c = M->cfg;
   const Plan& P = M->plan;
-  static const bool rows_off = getenv("SKF_NO_ROW_BLOCKS") && getenv("SKF_NO_ROW_BLOCKS")[0] == '1';
+  static const bool rows_off = skf_knob("SKF_NO_ROW_BLOCKS") && skf_knob("SKF_NO_ROW_BLOCKS")[0] == '1';
   M->lists_built = false;
   if (c.continuous || rows_off || !do_recon(c) || c.gemm_precision == SKF_PREC_F32) return SKF_OK;
   const int B = c.batch, Le = c.seq_len, Ld = c.seq_len - 1;
@@ -1102,7 +1115,7 @@ int run_backward(SkfModel* M, hipStream_t s) {
     SKF_TRY(ffn_bwd(M, w.f1, w.f2, M->at<float>(a.x1), M->at<float>(a.h), dy2, M->at<float>(gs.dh), G2, Me, s, hbits_of(M, a.hbits, Me)));
     // last layer of the backward: nothing is left on the main stream to hide a whole layer's weight gradients behind
     // (only the embedding gradient follows), so they go out per sublayer - the step's tail before Adam is one wgrad, not four
-    static const bool early_tail = !getenv("SKF_NO_EARLY_TAIL");
+    static const bool early_tail = !skf_knob("SKF_NO_EARLY_TAIL");
     if (i == 0 && early_tail) SKF_TRY(issue_wgrads(M, s));
     SKF_TRY(ln_bwd(M, w.ln1, G2, M->at<float>(a.z1), M->at<float>(a.st1), G, dy1, Me, rate, site_enc(i, 0), s));
     SKF_TRY(dense_wgrad(M, w.mha.o, M->at<float>(a.o), d, dy1, d, Me, s));
@@ -1121,7 +1134,7 @@ int run_backward(SkfModel* M, hipStream_t s) {
     SKF_TRY(issue_wgrads(M, s));
     // half-way through the encoder: the slabs and LayerNorm partials finished so far are reduced on the side stream now, under the
     // remaining layers - the final reduction, which the optimizer waits for on the main stream, shrinks to the last layers' share
-    static const bool mid_flush = !(getenv("SKF_MID_FLUSH") && getenv("SKF_MID_FLUSH")[0] == '0');
+    static const bool mid_flush = !(skf_knob("SKF_MID_FLUSH") && skf_knob("SKF_MID_FLUSH")[0] == '0');
     if (mid_flush && M->side && N >= 2 && i == N / 2) SKF_TRY(flush_wgrads(M, s, -1, false));
   }
   if (c.continuous) {
@@ -1237,9 +1250,8 @@ int run_greedy_decode(SkfModel* M, const float* embedding, const int* expected_l
     return skf_decode_select_tokens(logits, Vout, B, Vout, 0, 0, 0, tokens, Ti, selfmask, Le + 1, eos_seen, done_step,
                                     step_dev, dyn, s);
   };
-  // One launch per position (skf_decode_fused.hip) unless SKF_DECODE_FUSED=0 asks for the layer-by-layer path above
-  const char* fused_env = getenv("SKF_DECODE_FUSED");       // read per call: the tests compare the two paths in one process
-  const bool fused_off = fused_env && fused_env[0] == '0';
+  // One launch per position (skf_decode_fused.hip) unless SKF_MODEL_DECODE_LAYERWISE (skf_model_set_flags) asks for the layer-by-layer path above
+  const bool fused_off = (M->flags & SKF_MODEL_DECODE_LAYERWISE) != 0;
   const bool fused = !fused_off && skf_decode_fused_supported(d, H, F, Le, N, Vout);
   SkfDecodeFused fp{};
   if (fused) {
@@ -1266,7 +1278,7 @@ int run_greedy_decode(SkfModel* M, const float* embedding, const int* expected_l
     fp.dyn = dyn; fp.limit = limit;
     SKF_HIP(hipMemsetAsync(fp.ticket, 0, sizeof(int), s));
   }
-  static const bool use_graph = !(getenv("SKF_DECODE_GRAPH") && getenv("SKF_DECODE_GRAPH")[0] == '0');
+  static const bool use_graph = !(skf_knob("SKF_DECODE_GRAPH") && skf_knob("SKF_DECODE_GRAPH")[0] == '0');
   if (fused) {
     for (int i = 0; i < max_steps; ++i) {
       SKF_TRY(skf_decode_fused_launch(fp, s));
@@ -1353,7 +1365,9 @@ int capture_or_run(SkfModel* M, hipGraphExec_t* exec, hipStream_t s, F body) {
   if (!*exec) {
     hipGraph_t graph = nullptr;
     SKF_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    ++g_capturing;
     int rc = body();
+    --g_capturing;
     hipError_t e = hipStreamEndCapture(s, &graph);
     if (rc != SKF_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     if (e != hipSuccess) { skf_set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return SKF_EHIP; }
@@ -1372,8 +1386,22 @@ int capture_or_run(SkfModel* M, hipGraphExec_t* exec, hipStream_t s, F body) {
 #undef SKF_BF16_PART
 
 // =========================================================================== C ABI
+extern "C" size_t skf_config_size(void) { return sizeof(SkfConfig); }
+
+extern "C" int skf_model_set_flags(SkfModel* M, uint32_t flags) {
+  SKF_CHECK_ARG(M, "null model");
+  SKF_CHECK_ARG((flags & ~SKF_MODEL_DECODE_LAYERWISE) == 0, "unknown flag bits");
+  M->flags = flags;
+  return SKF_OK;
+}
+
 extern "C" int skf_config_validate(const SkfConfig* c) {
   SKF_CHECK_ARG(c, "null config");
+  if (c->struct_size != sizeof(SkfConfig)) {
+    skf_set_error("SkfConfig.struct_size is %u, this library's SkfConfig has %zu bytes: the caller's declaration of the struct does not "
+                  "match include/skf.h (set struct_size = sizeof(SkfConfig))", c->struct_size, sizeof(SkfConfig));
+    return SKF_EINVAL;
+  }
   SKF_CHECK_ARG(c->batch > 0 && c->seq_len > 1 && c->num_layers > 0, "bad sizes");
   SKF_CHECK_ARG(c->d_model % c->num_heads == 0, "d_model must be divisible by num_heads");
   const int dh = c->d_model / c->num_heads;
@@ -1487,7 +1515,7 @@ extern "C" int skf_model_create(const SkfConfig* cfg, SkfModel** out) {
   reg("dec_embed_out", P.dec[0].x_in, B * Ld, d);
   // measured on MI355X: eager launches + a wgrad side stream beat hipGraph replay (graph nodes of different
   // streams do not overlap, 7.50 vs 7.72 ms/step), so the side stream is only used on the eager path
-  if (!cfg->use_graph && !(getenv("SKF_NO_SIDE_STREAM") && getenv("SKF_NO_SIDE_STREAM")[0] == '1'))
+  if (!cfg->use_graph && !(skf_knob("SKF_NO_SIDE_STREAM") && skf_knob("SKF_NO_SIDE_STREAM")[0] == '1'))
     SKF_HIP(hipStreamCreateWithFlags(&M->side, hipStreamNonBlocking));
   if (!cfg->use_graph) {     // events cannot be recorded for outside waiters inside a captured graph: one bucket there
     M->n_buckets = do_recon(*cfg) ? 2 : 1;

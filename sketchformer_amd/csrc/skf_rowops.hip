@@ -1253,7 +1253,7 @@ extern "C" int skf_layernorm_residual_fwd(const float* x, float* y_inout_z, cons
   dim3 grid(grid_for_rows(rows)), block(256);
   hipStream_t s = (hipStream_t)stream;
   SkfProfScope ps(s, "ln_fwd", 0.0, 16.0 * rows * d);
-  static const bool v4 = !(getenv("SKF_LN_V4") && getenv("SKF_LN_V4")[0] == '0');
+  static const bool v4 = !(skf_knob("SKF_LN_V4") && skf_knob("SKF_LN_V4")[0] == '0');
   const bool al = ((((uintptr_t)x | (uintptr_t)y_inout_z | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0);
   if (v4 && al && (d == 64 || d == 128 || d == 256)) {
     const int rpi = (64 / (d / 4)) * SKF_LN_UR * 4;               // rows per workgroup iteration
@@ -1304,7 +1304,7 @@ extern "C" int skf_layernorm_residual_bwd_rows(const float* dout, const float* z
   float* part = (float*)workspace;
   float* dyp = (dy && (rate > 0.f || dy != dz)) ? dy : nullptr;   // rate 0 with a separate dy buffer: dy = dz
   SkfProfScope ps(s, "ln_bwd", 0.0, (rate > 0.f ? 16.0 : 12.0) * rows * d);
-  static const bool v4 = !(getenv("SKF_LN_V4") && getenv("SKF_LN_V4")[0] == '0');
+  static const bool v4 = !(skf_knob("SKF_LN_V4") && skf_knob("SKF_LN_V4")[0] == '0');
   const bool al = ((((uintptr_t)dout | (uintptr_t)z | (uintptr_t)dz | (uintptr_t)dyp | (uintptr_t)gamma) & 15) == 0) &&
                   (double)rows * d * 4 < 2147483648.0;             // (the v4 kernel stores through 32-bit buffer offsets)
   const dim3 block4(SKF_LN_BWD_THREADS);

@@ -250,7 +250,17 @@ class TrainEngine:
                                  "does not match the model (vocab_size / n_classes)" % (what, lo, hi, limit))
         if t.dtype != torch.int64:
             t = t.to(torch.int64)
-        return t.to(self.device, non_blocking=True).contiguous()
+        return self._own(t, t.to(self.device, non_blocking=True).contiguous())
+
+    @staticmethod
+    def _own(given, staged):
+        """The step reads its inputs asynchronously on the engine's stream and no longer makes the caller's stream wait for it
+        (_publish): a device tensor the caller passes in - and may refill IN PLACE for the next batch - is therefore copied here,
+        on the caller's stream (the hand-over of _enter orders the step behind the copy).  Host inputs already became fresh device
+        copies.  ~2 us of copy kernels on the caller's stream, nothing on the engine's."""
+        if torch.is_tensor(given) and given.is_cuda and staged.data_ptr() == given.data_ptr():
+            return staged.clone()
+        return staged
 
     def _dev_input(self, x):
         """(B,L) int64 tokens, or (B,L,5) float32 stroke-5 rows in continuous mode (the reference casts the
@@ -260,7 +270,7 @@ class TrainEngine:
         t = torch.as_tensor(x)
         if t.dim() != 3 or t.shape[-1] != 5:
             raise ValueError("continuous mode expects (B, L, 5) stroke-5 input")
-        return t.to(self.device, dtype=torch.float32, non_blocking=True).contiguous()
+        return self._own(t, t.to(self.device, dtype=torch.float32, non_blocking=True).contiguous())
 
     def _hold(self, *tensors):
         """The engine's stream reads these caller-owned tensors asynchronously: tell the caching allocator, so that a tensor the
@@ -283,6 +293,10 @@ class TrainEngine:
             _lib.call("skf_model_forward", self.handle, self._p(inp), self._p(tar), self._ld(tar), int(training), self._stream())
         finally:
             self._leave()
+
+    def set_flags(self, flags):
+        """skf_model_set_flags: per-model switches (``_lib.MODEL_DECODE_LAYERWISE``)."""
+        _lib.check(self.lib.skf_model_set_flags(self.handle, int(flags)), "skf_model_set_flags")
 
     def encode(self, inp):
         """encode_from_seq (models/sketchformer.py:162-168): encoder + bottleneck + classifier, dropout off.
@@ -445,18 +459,26 @@ class TrainEngine:
         the file rank 0 writes carries every rank's history (restore: rank 0 loads it, the others start from zero)."""
         if self.world_size <= 1:
             return
-        with torch.cuda.stream(self.stream):
-            acc = torch.cat([self._metrics[8:13], self._metrics[16:21]]).contiguous()
-            torch.distributed.all_reduce(acc, op=torch.distributed.ReduceOp.SUM, group=self.pg)
-            if self.rank == 0:
-                self._metrics[8:13], self._metrics[16:21] = acc[:5], acc[5:]
-            else:
-                self.zero_metric_accumulators()
+        self._enter()               # after whatever the caller's stream wrote into the buffer (load_state_dict); marks it unpublished
+        try:
+            with torch.cuda.stream(self.stream):
+                acc = torch.cat([self._metrics[8:13], self._metrics[16:21]]).contiguous()
+                torch.distributed.all_reduce(acc, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+                if self.rank == 0:
+                    self._metrics[8:13], self._metrics[16:21] = acc[:5], acc[5:]
+                else:
+                    self.zero_metric_accumulators()
+        finally:
+            self._leave()
 
     def zero_metric_accumulators(self):
-        with torch.cuda.stream(self.stream):
-            self._metrics[8:13] = 0.0
-            self._metrics[16:21] = 0.0
+        self._enter()
+        try:
+            with torch.cuda.stream(self.stream):
+                self._metrics[8:13] = 0.0
+                self._metrics[16:21] = 0.0
+        finally:
+            self._leave()
 
     def metrics_snapshot(self):
         """Device copy of the 32 metric floats as they stand after the steps queued so far (no host sync): what

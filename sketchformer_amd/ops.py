@@ -155,8 +155,10 @@ def attention_decode(q, k, v, num_heads, n_keys=None, key_mask=None, key_limit=N
     return o
 
 
-def attention_bwd(q, k, v, o, do, stats, num_heads, key_mask=None, causal=False, precision=None, q_live_len=None):
-    """q_live_len: optional int32 (B,) - query rows at or behind it have do == 0 exactly (``target_live_len``)."""
+def attention_bwd(q, k, v, o, do, stats, num_heads, key_mask=None, causal=False, precision=None, q_live_len=None, two_pass=False):
+    """q_live_len: optional int32 (B,) - query rows at or behind it have do == 0 exactly (``target_live_len``).
+    two_pass: OR SKF_ATTN_TWO_PASS into the precision argument (the two-pass kernel of skf_attention_bwd2.hip also where the
+    dispatch would take the one-pass kernel: head size 16)."""
     B, Lq, d = q.shape
     Lk = k.shape[1]
     dq = torch.full((B, Lq, d), float("nan"), dtype=torch.float32, device=q.device)
@@ -165,7 +167,7 @@ def attention_bwd(q, k, v, o, do, stats, num_heads, key_mask=None, causal=False,
     _lib.call("skf_attention_bwd_rows", _p(q), q.stride(1), _p(k), k.stride(1), _p(v), v.stride(1), _p(o), o.stride(1),
               _p(do), do.stride(1), _p(stats), _p(key_mask), key_mask.stride(0) if key_mask is not None else 0,
               int(causal), B, num_heads, Lq, Lk, d // num_heads, _p(dq), dq.stride(1), _p(dk), dk.stride(1),
-              _p(dv), dv.stride(1), _prec(precision), _p(q_live_len), _stream())
+              _p(dv), dv.stride(1), _prec(precision) | (_lib.ATTN_TWO_PASS if two_pass else 0), _p(q_live_len), _stream())
     return dq, dk, dv
 
 

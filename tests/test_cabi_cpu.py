@@ -35,6 +35,115 @@ def test_binding_table_matches_header(lib):
     assert sorted(_lib.SIGNATURES) == _declared()
 
 
+_CTYPE_OF = {"int32_t": "c_int32", "uint32_t": "c_uint32", "float": "c_float", "int64_t": "c_int64", "char": "c_char"}
+
+
+def _header_struct_fields(name):
+    """[(field, ctypes type name)] of `typedef struct <name> {...}` as include/skf.h declares it, in order."""
+    text = open(os.path.join(ROOT, "include", "skf.h")).read()
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), text, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    out = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        m = re.match(r"(?:const\s+)?(\w+)\s*(\*?)\s*(.*)$", decl, flags=re.S)
+        ctype, star, names = m.group(1), m.group(2), m.group(3)
+        for n in names.split(","):
+            n = n.strip()
+            arr = re.match(r"(\w+)\[(\d+)\]$", n)
+            if arr:
+                out.append((arr.group(1), "%s*%s" % (_CTYPE_OF[ctype], arr.group(2))))
+            else:
+                out.append((n.lstrip("*").strip(), "c_void_p" if (star or n.startswith("*")) else _CTYPE_OF[ctype]))
+    return out
+
+
+def _canon(pairs):
+    """(field, type name) -> (field, ctypes type object) so that aliases (c_int32 is c_int) compare equal"""
+    out = []
+    for n, t in pairs:
+        if "*" in t:
+            base, length = t.split("*")
+            out.append((n, (getattr(C, base), int(length))))
+        else:
+            out.append((n, getattr(C, t)))
+    return out
+
+
+def _ctypes_fields(struct):
+    return [(n, (t._type_, t._length_) if hasattr(t, "_length_") else t) for n, t in struct._fields_]
+
+
+def test_config_struct_layout_matches_header_binding_and_integration_doc(lib):
+    """Field for field, in order: include/skf.h == sketchformer_amd/_lib.py == the binding INTEGRATION.md shows a maintainer
+    (round 3's document was two fields short: a struct copied from it handed the library heap garbage)."""
+    from sketchformer_amd import _lib
+    header = _header_struct_fields("SkfConfig")
+    assert header[0] == ("struct_size", "c_uint32") and len(header) >= 35
+    assert _ctypes_fields(_lib.SkfConfig) == _canon(header)
+    assert C.sizeof(_lib.SkfConfig) == lib.skf_config_size() == 4 * len(header)
+    assert _ctypes_fields(_lib.SkfParamEntry) == _canon(_header_struct_fields("SkfParamEntry"))
+    # INTEGRATION.md section 1: the `_fields_ = [...]` block of its SkfConfig
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = re.search(r"class SkfConfig\(C\.Structure\):.*?_fields_ = \[(.*?)\n    \]", doc, flags=re.S).group(1)
+    doc_fields = re.findall(r'\("(\w+)",\s*C\.(c_\w+)\)', block)
+    assert _canon(doc_fields) == _canon(header)
+    assert "struct_size=C.sizeof(SkfConfig)" in doc
+
+
+def test_config_struct_size_guard(lib):
+    """A config whose struct_size is not the library's sizeof(SkfConfig) is refused by every entry that takes one."""
+    from sketchformer_amd import engine
+    cfg = engine.make_config(batch=4)
+    assert cfg.struct_size == C.sizeof(type(cfg)) and lib.skf_config_validate(C.byref(cfg)) == 0
+    for bad in (0, cfg.struct_size - 8, cfg.struct_size + 4):
+        cfg.struct_size = bad
+        assert lib.skf_config_validate(C.byref(cfg)) == -1
+        assert b"struct_size" in lib.skf_last_error()
+        assert lib.skf_model_param_floats(C.byref(cfg)) == 0 and lib.skf_model_workspace_bytes(C.byref(cfg)) == 0
+        h = C.c_void_p()
+        assert lib.skf_model_create(C.byref(cfg), C.byref(h)) == -1 and not h.value
+
+
+def test_shipped_library_reads_no_environment():
+    """include/skf.h: 'no global state'.  The default build must not call getenv at all (A/B and ablation knobs live behind
+    -DSKF_MEASURE=1, skf_common.h: skf_knob), and no source may turn an environment string into a device pointer outside it."""
+    import glob
+    import subprocess
+    csrc = os.path.join(ROOT, "sketchformer_amd", "csrc")
+    for path in glob.glob(os.path.join(csrc, "*")):
+        text = open(path).read()
+        if path.endswith("skf_common.h"):
+            assert text.count("getenv(") == 1          # the one inside `#if SKF_MEASURE`
+            continue
+        assert "getenv(" not in text, path
+        for m in re.finditer(r"strtoull\(", text):
+            before = text[:m.start()]
+            assert before.rfind("#if SKF_MEASURE") > before.rfind("#endif"), "%s: strtoull outside an SKF_MEASURE block" % path
+    from sketchformer_amd import build
+    if "-DSKF_MEASURE=1" in build.FLAGS:
+        pytest.skip("measurement build")
+    syms = subprocess.run(["nm", "-D", "--undefined-only", os.path.join(ROOT, "sketchformer_amd", "libskf.so")],
+                          capture_output=True, text=True, check=True).stdout
+    assert not re.search(r"\bU (secure_)?getenv\b", syms), "libskf.so imports getenv"
+
+
+def test_gemm_wsx_isa_has_no_crossed_select_packed_fp32():
+    """Round 4 bisected the run-to-run wrong results of round 3's 'accumulate only' epilogue kind to a compiler-formed
+    v_pk_add_f32 with crossed operand selects in gemm_wsx_kernel's exit block (skf_gemm_wsx.hip: launch_wsx).  The kind is gone; this
+    keeps the dominant kernel family free of the instruction form (a new epilogue that lets the compiler pair adds again shows up
+    here, on the CPU, before it shows up as a flaky gradient on the GPU)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_pk_opsel", os.path.join(ROOT, "tools", "isa_pk_opsel.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    path, hits = mod.scan(os.path.join(ROOT, "sketchformer_amd", "csrc", "skf_gemm_wsx.hip"), [])
+    assert hits is not None, "skf_gemm_wsx.hip did not compile"
+    assert hits == {}, hits
+
+
 def test_host_only_entry_points(lib):
     from sketchformer_amd import _lib, engine
     assert lib.skf_version() >= 100

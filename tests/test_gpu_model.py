@@ -407,7 +407,7 @@ def test_greedy_decode_continuous_matches_oracle():
     assert got.shape == want.shape and np.abs(got - want).max() < 2e-4 * max(1.0, np.abs(want).max())
 
 
-def test_greedy_decode_one_launch_path_equals_layer_by_layer_at_full_size(monkeypatch):
+def test_greedy_decode_one_launch_path_equals_layer_by_layer_at_full_size():
     """cfg-2 dimensions (4L/8H/d128/dff512, L=200, V=1004): the one-launch-per-position kernel (skf_decode_fused.hip) and the
     layer-by-layer path it replaces (51 launches per position, the one the oracle tests above pinned in round 1) emit the
     same tokens; random weights never emit EOS, so all 200 positions are compared."""
@@ -417,10 +417,12 @@ def test_greedy_decode_one_launch_path_equals_layer_by_layer_at_full_size(monkey
                                                 n_classes=345, lowerdim=128, dropout_rate=0.0, use_graph=False, seed=1), init_seed=2)
     x, _ = synthetic.token_batch(B, L, V, 345, seed=5)
     eng.encode(x)
-    monkeypatch.delenv("SKF_DECODE_FUSED", raising=False)
+    from sketchformer_amd import _lib
     fused = eng.greedy_decode(None, sos=V - 2, eos=V - 1)
-    monkeypatch.setenv("SKF_DECODE_FUSED", "0")
+    eng.set_flags(_lib.MODEL_DECODE_LAYERWISE)
     ref = eng.greedy_decode(None, sos=V - 2, eos=V - 1)
+    eng.set_flags(0)
+    assert np.array_equal(eng.greedy_decode(None, sos=V - 2, eos=V - 1), fused)
     assert fused.shape == ref.shape == (B, L + 1)
     assert np.array_equal(fused, ref)
 
