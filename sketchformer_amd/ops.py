@@ -307,6 +307,29 @@ def adam_step(w, g, m, v, state, grad_scale=1.0, beta1=0.9, beta2=0.98, eps=1e-9
     _lib.call("skf_adam_step", _p(w), _p(g), _p(m), _p(v), w.numel(), _p(state), grad_scale, beta1, beta2, eps, _stream())
 
 
+def dropout(x, rate, site=0, state=None):
+    """Inverted dropout (tf.keras.layers.Dropout in training mode) with the kernels' counter-based mask of (step key, site, element):
+    skf_dropout.  rate 0 or no state = the input itself."""
+    if rate <= 0.0 or state is None:
+        return x
+    _f32(x, "x")
+    y = torch.empty_like(x)
+    _lib.call("skf_dropout", _p(x), _p(y), x.numel(), float(rate), int(site), _p(state), _stream())
+    return y
+
+
+def embed_continuous_fwd(x, W, bias, pos, L=None, rate=0.0, site=0, state=None):
+    """Encoder / Decoder embed stage in continuous mode (builders/layers/transformer.py:276,288-296): Dense(5 -> d) of the stroke-5
+    rows, * sqrt(d), + pos[:L], dropout.  x (B, ld, 5) float32."""
+    _f32(x, "x")
+    B, ld = x.shape[0], x.shape[1]
+    L = L or ld
+    d = W.shape[1]
+    out = torch.empty(B, L, d, dtype=torch.float32, device=x.device)
+    _lib.call("skf_embed_continuous_fwd", _p(x), ld, B, L, _p(W), _p(bias), d, _p(pos), _p(out), float(rate), int(site), _p(state), _stream())
+    return out
+
+
 def dropout_keep_mask(drop_key, site, rate, n):
     """Host replica of the kernels' counter-based keep mask (for parity tests)."""
     import numpy as np

@@ -171,8 +171,80 @@ def test_builders_front_ends_against_oracle():
     want_x, _ = oracle.sketchformer_oracle.encoder_layer_fwd(P, "encoder/layer0", x0, oe.astype(np.float64), 4, 0.0, {})
     got_x = enc(tok, False, enc_m)
     assert np.abs(got_x.cpu().numpy() - want_x).max() < 1e-4
-    with pytest.raises(NotImplementedError):
-        enc(tok, True, enc_m)
+    # training=True (round 4): inverted dropout at the reference's three sites of this stack (Encoder.dropout, dropout1, dropout2,
+    # builders/layers/transformer.py:212-213,286), masks = the kernels' counter-based ones - the oracle is handed the same masks
+    from sketchformer_amd import ops
+    got_t = enc(tok, True, enc_m)
+    key = ops.read_step_state(enc.drop.state)["drop_key"]
+    keep = lambda site: ops.dropout_keep_mask(key, site, 0.1, B * L * 64).reshape(B, L, 64)     # noqa: E731
+    x0d, _ = oracle.sketchformer_oracle._embed_fwd(P, "encoder/embedding", tok, ocfg, pos, 0.1, keep(enc.site0))
+    drops = {"encoder/layer0/dropout1": keep(lay.site1), "encoder/layer0/dropout2": keep(lay.site2)}
+    want_t, _ = oracle.sketchformer_oracle.encoder_layer_fwd(P, "encoder/layer0", x0d, oe.astype(np.float64), 4, 0.1, drops)
+    assert np.abs(got_t.cpu().numpy() - want_t).max() < 1e-4
+    assert np.abs(got_t.cpu().numpy() - want_x).max() > 1e-2                      # it did drop something
+    again = enc(tok, True, enc_m)                                                 # a new call draws new masks
+    assert np.abs(again.cpu().numpy() - got_t.cpu().numpy()).max() > 1e-2
+    assert np.abs(enc(tok, False, enc_m).cpu().numpy() - want_x).max() < 1e-4     # and inference is unchanged
+
+
+def test_builders_layer_variants_against_oracle():
+    """The layer front-ends the reference defines beside the defaults (round 3 refused them): SelfAttnV2 (transformer.py:80-137),
+    use_continuous_input=True (:267-296: the embedding is Dense(5 -> d)), DenseExpander(feat_dim_out) (:354-376), and a Decoder that
+    returns the reference's attention_weights dictionary keys."""
+    from sketchformer_amd import builders
+    T = builders.layers.transformer
+    rng = np.random.RandomState(1)
+    B, L, d = 3, 20, 64
+    f64 = lambda t: t.detach().cpu().numpy().astype(np.float64)        # noqa: E731
+    # SelfAttnV2 with and without the Dense(units) after the pooling
+    x = rng.randn(B, L, d)
+    for units in (32, None):
+        sa = T.SelfAttnV2(units)
+        o, a = sa(torch.as_tensor(x, dtype=torch.float32).cuda())
+        P = {"bottleneck/W_attn": f64(sa.W), "bottleneck/b_attn": f64(sa.b), "bottleneck/V_attn": f64(sa.V)}
+        assert sa.W.shape == (d, d) and sa.V.shape == (d, 1)
+        if units:
+            P["bottleneck/embeding_layer/kernel"], P["bottleneck/embeding_layer/bias"] = f64(sa.embeding_layer.kernel), f64(sa.embeding_layer.bias)
+            want, wa, _ = oracle.sketchformer_oracle.self_attn_v2_fwd(P, x)
+        else:
+            want, wa, _ = oracle.sketchformer_oracle.self_attn_v1_fwd(P, x)
+        assert o.shape == (B, units or d) == sa.compute_output_shape((B, L, d)) and a.shape == (B, L, 1)
+        assert np.abs(f64(o) - want).max() < 1e-5 and np.abs(f64(a) - wa).max() < 1e-6
+    # continuous input: stroke-5 rows through Dense(5 -> d), * sqrt(d), + pos
+    s5 = rng.randn(B, L, 5).astype(np.float32)
+    enc = T.Encoder(1, d, 4, 128, None, rate=0.0, use_continuous_input=True)
+    assert enc.embedding.kernel.shape == (5, d)
+    ocfg = oracle.Config(num_layers=1, d_model=d, dff=128, num_heads=4, seq_len=L, continuous=True)
+    pos = oracle.positional_encoding(1000, d).astype(np.float64)
+    P = {"encoder/embedding/kernel": f64(enc.embedding.kernel), "encoder/embedding/bias": f64(enc.embedding.bias)}
+    lay = enc.enc_layers[0]
+    for n, dn in (("mha/wq", lay.mha.wq), ("mha/wk", lay.mha.wk), ("mha/wv", lay.mha.wv), ("mha/dense", lay.mha.dense),
+                  ("ffn/dense1", lay.ffn.d1), ("ffn/dense2", lay.ffn.d2)):
+        P["encoder/layer0/%s/kernel" % n], P["encoder/layer0/%s/bias" % n] = f64(dn.kernel), f64(dn.bias)
+    for n in ("layernorm1", "layernorm2"):
+        P["encoder/layer0/%s/gamma" % n] = np.ones(d); P["encoder/layer0/%s/beta" % n] = np.zeros(d)
+    x0, _ = oracle.sketchformer_oracle._embed_fwd(P, "encoder/embedding", s5.astype(np.float64), ocfg, pos, 0.0, None)
+    want_x, _ = oracle.sketchformer_oracle.encoder_layer_fwd(P, "encoder/layer0", x0, np.zeros((B, 1, 1, L)), 4, 0.0, {})
+    got_x = enc(torch.as_tensor(s5).cuda(), False, None)
+    assert np.abs(f64(got_x) - want_x).max() < 1e-4
+    # DenseExpander with the relu projection in front
+    emb = rng.randn(B, d)
+    ex = T.DenseExpander(L, feat_dim_out=48)
+    pre = ex(torch.as_tensor(emb, dtype=torch.float32).cuda())
+    proj = np.maximum(emb @ f64(ex.project_layer.kernel) + f64(ex.project_layer.bias), 0)
+    want_pre = proj[:, None, :] * f64(ex.kernel)[0][None, :, None] + f64(ex.bias)[None, :, None]
+    assert pre.shape == (B, L, 48) == ex.compute_output_shape((B, d)) and np.abs(f64(pre) - want_pre).max() < 1e-5
+    plain = T.DenseExpander(L)
+    assert plain(torch.as_tensor(emb, dtype=torch.float32).cuda()).shape == (B, L, d)
+    # Decoder: the reference's attention_weights keys (values None: the fused kernel never materialises (B,H,L,L))
+    dec = T.Decoder(2, d, 4, 128, 50, rate=0.1)
+    tok = rng.randint(1, 50, size=(B, L))
+    y, aw = dec(tok, got_x, True, None, None)
+    assert y.shape == (B, L, d) and sorted(aw) == ["decoder_layer1_block1", "decoder_layer1_block2", "decoder_layer2_block1", "decoder_layer2_block2"]
+    y2, _ = dec(tok, got_x, True, None, None)
+    assert float((y - y2).abs().max()) > 1e-3                       # training dropout: new masks per call
+    y3, _ = dec(tok, got_x, False, None, None); y4, _ = dec(tok, got_x, False, None, None)
+    assert torch.equal(y3, y4)
 
 
 @pytest.mark.parametrize("extra,keys", [("do_reconstruction=False", ["class_acc", "class_loss", "total_loss"]),
