@@ -132,6 +132,31 @@ int skf_gemm_ln_residual_supported(int M, int N, int K, int precision);
 int skf_gemm_ln_residual_f32(int M, int N, int K, const float* A, int lda, const float* W, int ldw, const float* bias,
                              const float* x, const float* gamma, const float* beta, float* z, float* out, float* stats,
                              float rate, unsigned site, const void* step_state, int precision, skf_stream_t stream);
+/* The feed-forward block of a layer in ONE launch per direction: the reference's `point_wise_feed_forward_network`
+ * (builders/layers/transformer.py:194-198: Dense(dff, relu) -> Dense(d_model)) together with the `layernorm(out + dropout(ffn(out)))`
+ * that wraps it in EncoderLayer.call (:221-224) / DecoderLayer.call (:270-272), and the tape gradient of the two Dense layers:
+ *   forward:   h = relu(x[M,d] . W1[d,dff] + b1);  y = h . W2[dff,d] + b2;  z = x + dropout(y, rate, site);
+ *              out = (z - mean) * rstd * gamma + beta;  stats[row] = (mean, rstd);  relu_bits_out = sign bits of h
+ *   backward:  dh = (dy[M,d] . W2^T) o relu'(h)  (from the sign bits);  dx (+)= dh . W1^T
+ * with the split arithmetic of skf_gemm_f32 (SKF_PREC_BF16X6 / BF16X3), the dropout mask of skf_layernorm_residual_fwd and its
+ * LayerNorm arithmetic; h / dh are written in full (the weight gradients read them), never read back.  The weights are read from
+ * PRE-SPLIT images in the kernel's MFMA operand order: skf_ffn_weight_images builds n of them in one launch (image k from
+ * W1[k] [d][dff] pitch ld1[k], W2[k] [dff][d] pitch ld2[k]; transpose[k] = 0: the forward's image, 1: the backward's;
+ * skf_ffn_image_bytes each, 16-byte aligned) - rebuild them whenever the weights change (once per optimizer step).  Exists for
+ * d = 128, dff = 512 in the split modes (skf_ffn_fused_supported; anything else is an error - use the separate calls).
+ * row_blocks (backward, optional): the 16-row block list of skf_row_blocks_build - dead blocks have dy == 0: their dh rows are
+ * stored as zeros, their dx rows left alone (accumulate) or zeroed. */
+int skf_ffn_fused_supported(int M, int d, int dff, int precision);
+size_t skf_ffn_image_bytes(int d, int dff, int precision);
+size_t skf_ffn_relu_bits_bytes(int M, int d, int dff, int precision);
+int skf_ffn_weight_images(int n, const float* const* W1, const int* ld1, const float* const* W2, const int* ld2,
+                          const int* transpose, void* const* images, int d, int dff, int precision, skf_stream_t stream);
+int skf_ffn_fused_fwd_f32(int M, int d, int dff, const float* x, const void* image, const float* b1, const float* b2,
+                          float* h, void* relu_bits_out, const float* gamma, const float* beta, float* z, float* out,
+                          float* stats, float rate, unsigned site, const void* step_state, int precision, skf_stream_t stream);
+int skf_ffn_fused_bwd_f32(int M, int d, int dff, const float* dy, const void* image_t, const void* relu_bits_in,
+                          float* dh, float* dx, int accumulate, const int* row_blocks, int row_block_rows,
+                          int precision, skf_stream_t stream);
 int skf_gemm_wgrad_partial_rows(int M, int N, int K, const float* A, int lda, const float* B, int ldb, int splits,
                                 int with_bias_grad, float* slab, size_t slab_bytes, int* splits_used_host, int precision,
                                 const int* row_blocks, int row_block_rows, skf_stream_t stream);

@@ -1,0 +1,601 @@
+// The feed-forward block of a transformer layer in ONE launch per direction (d_model = 128, dff = 512):
+//   forward  (builders/layers/transformer.py:194-198 point_wise_feed_forward_network, :221-224 / :270-272 the layer's
+//             `layernorm(out + dropout(ffn(out)))`):  h = relu(x.W1 + b1);  y = h.W2 + b2;  z = x + dropout(y);  out = LayerNorm(z)
+//   backward (its tape gradient):  dh = (dy.W2^T) o relu'(h);  dx (+)= dh.W1^T
+// with the arithmetic of skf_gemm_wsx.hip: every fp32 operand split EXACTLY into P bf16 pieces, the P(P+1)/2 largest piece products
+// summed in fp32 on the bf16 matrix cores.  The three (forward) / two (backward) launches it replaces each paid a launch, a weight
+// prologue, a first-tile latency and a drain for ~100 rows of work per CU, and the hidden tensor made a 52 MB round trip between them.
+//
+// Both directions are the same chain  Y = (f(A.B1)).B2  with A [M][128], B1 [128][512], B2 [512][128]:
+//   * A persistent workgroup (512 threads = 8 waves, two per SIMD, one workgroup per CU) owns a contiguous range of 16-row tiles and
+//     walks it in sub-groups of up to four tiles (64 rows).  The A rows of a sub-group are split once into P bf16 planes in LDS.
+//   * The weights cannot be stationary: B1 and B2 as bf16 planes are 786 KB, a CU has 512 KB of registers and 160 KB of LDS.  They
+//     stream from the L2 in PRE-SPLIT, FRAGMENT-ORDERED images (skf_ffn_weight_images: one kernel per step for all layers) - a wave's
+//     twelve MFMA B operands of a stage are 12 KB of contiguous memory, each a coalesced 1 KB wave load with no arithmetic behind it
+//     (the weight-stationary kernels spend 32 strided loads + ~350 VALU per wave and launch on the same job), requested one stage ahead.
+//   * The hidden dimension goes by in four blocks of 128: stage 1 = hidden block b of all row tiles of the sub-group (wave w owns 16
+//     hidden columns: 24 MFMAs per row tile), written to global memory as fp32 (the weight gradient reads it), its sign bits as wave
+//     ballots, and as P bf16 planes into one of two LDS buffers; one barrier; stage 2 = Y += Hblock.B2[block rows] (wave w owns 16
+//     of the 128 output columns; accumulators of all row tiles stay in registers across the four blocks).  The hidden tensor is
+//     never read back.
+//   * Epilogue: Y through LDS so that a half-wave owns a whole 128-column row: residual + dropout + LayerNorm exactly as
+//     ln_fwd_v4_kernel (skf_rowops.hip) computes them (forward), or the accumulation into dx with 16-byte accesses (backward).
+// LDS rows are 256 bytes (128 bf16) with the 16-byte chunks XOR-swizzled by the row index: every ds_read_b128 service group of a
+// fragment read (lanes {0-3,12-15,20-27}, ...) then touches 16 different bank quads, and the 2-byte hidden-plane stores of the four
+// lane groups g (rows 4g + r, same columns) land in different banks too - no padding, so that X planes + two hidden buffers fit.
+#include "skf_common.h"
+#include "skf_ffn_fused.h"
+#include <string>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int FD = 128;               // model width
+constexpr int FF = 512;               // hidden width
+constexpr int HB = 128;               // hidden units per block
+constexpr int NBLK = FF / HB;
+constexpr int TR = 16;                // rows per tile
+constexpr int MAXRT = 4;              // row tiles per sub-group
+constexpr int ROWS = TR * MAXRT;
+constexpr int RPITCH = 256;           // bytes per plane row
+constexpr int PLANE = ROWS * RPITCH;  // bytes per plane
+constexpr int NKS = 4;                // 32-deep MFMA steps per 128-deep contraction
+constexpr int YPITCH = FD + 4;        // floats per row of the epilogue tile
+constexpr unsigned OOB = 0x7ffffff0u;
+
+// SKF_FFN_ABLATE (diagnostics builds, wrong results): bit 0 no MFMA (one VALU op keeps the operands live), 1 fragment reads only
+// once per sub-group, 2 no hidden-tensor / sign-bit stores, 3 no hidden-plane stores, 4 no stage-1 epilogue at all
+#ifndef SKF_FFN_ABLATE
+#define SKF_FFN_ABLATE 0
+#endif
+__device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
+#if SKF_FFN_ABLATE & 1
+  c[0] += __builtin_bit_cast(float, (a[0] ^ b[0]) & 0x3fffffu);
+  return c;
+#else
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+#endif
+}
+
+// descriptor over rows [row0, M) of a row-major fp32 matrix (byte counts are 32-bit: the launcher checks M * ld * 4 < 2^31)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ffn_rows_rsrc(const float* base, int ld, int M, int row0) {
+  const int rows_left = M - row0 > 0 ? M - row0 : 0;
+  const unsigned rem = rows_left > 0 ? (unsigned)rows_left * (unsigned)ld * 4u : 0u;
+  const unsigned off = rows_left > 0 ? (unsigned)row0 * (unsigned)ld * 4u : 0u;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(base) + off), 0, rem, 0x00020000);
+}
+
+size_t image_bytes(int pieces) { return (size_t)2 * pieces * (FD * FF * 2); }
+
+// ---------------------------------------------------------------- weight images
+// image 1: fragment (cb < 32, s < 4, q < P)   = pieces q of B1[32s + 8g + e][16cb + i], lane = 16g + i, e < 8   (16 bytes per lane)
+// image 2: fragment (cb < 8, s < 16, q < P)   = pieces q of B2[32s + 8g + e][16cb + i]
+// transpose = 0: B1 = W1 [128][512], B2 = W2 [512][128] (forward); 1: B1 = W2^T, B2 = W1^T (input gradient)
+struct FfnImageDesc { const float* W1; const float* W2; char* img; int ld1, ld2, transpose, pad; };
+struct FfnImageBatch { FfnImageDesc d[16]; };
+
+template <int P>
+__global__ __launch_bounds__(256) void ffn_image_kernel(FfnImageBatch batch) {
+  const FfnImageDesc& d = batch.d[blockIdx.y];
+  const SkfSplitSel sel = skf_split_sel();
+  const int t = blockIdx.x * 256 + threadIdx.x;         // < 16384: image (t >> 13), fragment lane
+  const int which = t >> 13, f = (t >> 6) & 127, lane = t & 63, i = lane & 15, g = lane >> 4;
+  const int cb = which == 0 ? f / NKS : f / 16, s = which == 0 ? f % NKS : f % 16;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = 32 * s + 8 * g + e, n = 16 * cb + i;
+    float x;
+    if (which == 0) x = d.transpose ? d.W2[(size_t)n * d.ld2 + k] : d.W1[(size_t)k * d.ld1 + n];
+    else x = d.transpose ? d.W1[(size_t)n * d.ld1 + k] : d.W2[(size_t)k * d.ld2 + n];
+    v[e] = x;
+  }
+  u32x4 pc[P];
+#pragma unroll
+  for (int dd = 0; dd < 4; ++dd) {
+    unsigned o[P];
+    skf_split2<P>(v[2 * dd], v[2 * dd + 1], o, sel);
+#pragma unroll
+    for (int q = 0; q < P; ++q) pc[q][dd] = o[q];
+  }
+  char* base = d.img + (size_t)which * P * (FD * FF * 2) + (size_t)f * P * 1024 + lane * 16;
+#pragma unroll
+  for (int q = 0; q < P; ++q) *reinterpret_cast<u32x4*>(base + q * 1024) = pc[q];
+}
+
+// ---------------------------------------------------------------- the block
+template <int P>
+__device__ __forceinline__ void load_frags(u32x4 (&w)[NKS][P], const char* src) {
+#pragma unroll
+  for (int s = 0; s < NKS; ++s)
+#pragma unroll
+    for (int q = 0; q < P; ++q) w[s][q] = *reinterpret_cast<const u32x4*>(src + (s * P + q) * 1024);
+}
+
+// A 16-row x 16-column x 128-deep product goes by in two halves of two 32-deep steps.  The fragments of a half are requested while
+// the previous half multiplies (an LDS read issued straight in front of its MFMA costs its whole latency: the first version of
+// this kernel ran at the pace of its ds_read_b128s), so they live in two named sets.  Within a half: the small piece products
+// first, its a0.b0 products last (two accumulator chains).
+template <int P> struct FfnFrags { u32x4 f[2][2][P]; };   // [half][step of the half][piece]
+template <int P>
+__device__ __forceinline__ void load_half(const char* rows, const unsigned (&a_off)[NKS], u32x4 (&f)[2][P], int half, bool first = false) {
+#if SKF_FFN_ABLATE & 2
+  if (!first) return;
+#endif
+#pragma unroll
+  for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+    for (int q = 0; q < P; ++q) f[sl][q] = *reinterpret_cast<const u32x4*>(rows + q * PLANE + a_off[2 * half + sl]);
+}
+template <int P>
+__device__ __forceinline__ void half_products(const u32x4 (&w)[NKS][P], const u32x4 (&f)[2][P], int half, f32x4& acc0, f32x4& acc1, int& c) {
+#pragma unroll
+  for (int sl = 0; sl < 2; ++sl) {
+    const int s = 2 * half + sl;
+#pragma unroll
+    for (int d = 1; d < P; ++d)
+#pragma unroll
+      for (int qa = 0; qa <= d; ++qa) {
+        if (c & 1) acc1 = mfma_bf16(w[s][d - qa], f[sl][qa], acc1);
+        else acc0 = mfma_bf16(w[s][d - qa], f[sl][qa], acc0);
+        ++c;
+      }
+  }
+#pragma unroll
+  for (int sl = 0; sl < 2; ++sl) {
+    if (c & 1) acc1 = mfma_bf16(w[2 * half + sl][0], f[sl][0], acc1);
+    else acc0 = mfma_bf16(w[2 * half + sl][0], f[sl][0], acc0);
+    ++c;
+  }
+}
+
+// SKF_FFN_STAMPS (diagnostics builds): s_memtime stamps of wave 0 / wave 7 of every 32nd workgroup (tools/ffn_timeline.py)
+#ifndef SKF_FFN_STAMPS
+#define SKF_FFN_STAMPS 0
+#endif
+#if SKF_FFN_STAMPS
+__device__ long long g_ffn_stamps[16 * 64];
+#define FFN_STAMP() do { if (dbg && dbi < 62) dbg[dbi++] = clock64(); } while (0)
+#else
+#define FFN_STAMP() do { } while (0)
+#endif
+
+// sum over the 32 lanes that share a row of the epilogue (lanes 0-31 / 32-63): a DPP all-reduce inside each 16-lane row, then
+// one exchange with the neighbouring row (five __shfl_xor steps are five dependent ds_bpermute round trips)
+__device__ __forceinline__ float ffn_half_wave_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));   // row_mirror
+  return v + __shfl_xor(v, 16, 64);      // the neighbouring row: one ds_bpermute
+}
+
+// MODE 0 forward, 1 backward
+template <int P, int MODE>
+__global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnFusedParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_f[];
+  char* Xp = smem_f;                     // [P][ROWS][256]
+  char* Hp = smem_f + P * PLANE;         // [2][P][ROWS][256]
+  // epilogue tile [ROWS][YPITCH]: hidden buffer 0 (last read in the third block's second stage) where it fits, else its own region
+  float* Yt = reinterpret_cast<float*>(P * PLANE >= ROWS * YPITCH * 4 ? Hp : Hp + 2 * P * PLANE);
+  float* B1s = reinterpret_cast<float*>(Hp + 2 * P * PLANE + (P * PLANE >= ROWS * YPITCH * 4 ? 0 : ROWS * YPITCH * 4));   // first bias [FF]
+
+  const SkfSplitSel sel = skf_split_sel();
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, g = lane >> 4;
+#if SKF_FFN_STAMPS
+  long long* dbg = (lane == 0 && (wave == 0 || wave == 7) && (blockIdx.x % 32) == 0 && blockIdx.x / 32 < 8) ? g_ffn_stamps + ((blockIdx.x / 32) * 2 + (wave == 7)) * 64 : nullptr;
+  int dbi = 0;
+#endif
+  FFN_STAMP();
+  const int ntiles = (p.M + TR - 1) / TR;
+  typedef const __attribute__((address_space(4))) int* const_i32p;
+  const const_i32p blk = (const_i32p)p.row_blocks;
+  const int nlive = blk ? blk[0] : ntiles;
+  auto phys = [&](int pos) -> int { return pos < nlive ? (blk ? blk[2 + pos] : pos) : ntiles; };
+
+  // this workgroup's positions [pos_begin, pos_begin + count)
+  const int G = gridDim.x, wg = blockIdx.x;
+  const int base = nlive / G, rem = nlive % G;
+  const int pos_begin = wg * base + (wg < rem ? wg : rem), count = base + (wg < rem ? 1 : 0);
+  const int nsub = (count + MAXRT - 1) / MAXRT;
+
+  // per-lane constants
+  unsigned a_off[NKS];                   // fragment read: row i, 16-byte chunk (4s + g) ^ i
+#pragma unroll
+  for (int s = 0; s < NKS; ++s) a_off[s] = (unsigned)(i * RPITCH + (((4 * s + g) ^ i) << 4));
+  // The products are formed TRANSPOSED (weight fragment as the MFMA's first operand): lane (i, g) then holds four CONSECUTIVE
+  // columns 16 wave + 4g + r of ONE row i, so a tile's hidden values leave as one 16-byte global store and one 8-byte LDS store
+  // per plane (row-major C fragments took four 4-byte global stores and twelve 2-byte LDS stores per tile: 14 of the 70 us)
+  const unsigned hw_off = (unsigned)(i * RPITCH + (((2 * wave + (g >> 1)) ^ i) << 4) + 8 * (g & 1));   // hidden plane store
+  const unsigned hc_voff = (unsigned)(i * FF + 16 * wave + 4 * g) * 4u;                                 // hidden tensor store
+  const int st_row = tid >> 5, st_c = tid & 31;            // staging: thread -> (row of the tile, float4 of the row)
+  const unsigned st_off = (unsigned)(st_row * RPITCH + (((st_c >> 1) ^ st_row) << 4) + (st_c & 1) * 8);
+  const unsigned st_voff = (unsigned)(st_row * p.lda + 4 * st_c) * 4u;
+  if (MODE == 0 && tid < FF / 4) *reinterpret_cast<f32x4*>(B1s + 4 * tid) = *reinterpret_cast<const f32x4*>(p.bias1 + 4 * tid);   // (read behind the staging barrier)
+  const float* bias1_p = B1s + 16 * wave + 4 * g;
+  // (s_setprio 1 for the second-dispatched half, which loses the issue arbitration on its SIMD to the older wave and makes waves
+  //  0-3 wait 2-4 k cycles at every block barrier, only swaps the roles: measured with stamps, zero-sum)
+  const f32x4 bias2_r = MODE == 0 ? *reinterpret_cast<const f32x4*>(p.bias2 + 16 * wave + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // epilogue constants: a half-wave owns a row (32 lanes x 4 columns)
+  const int e_half = lane >> 5, e_sub = lane & 31;     // row 2 wave + e_half = tid >> 5 = st_row, float4 e_sub = st_c: the staging map
+  float inv_keep = 1.f;
+  uint32_t thresh = 0u, sk = 0u;
+  f32x4 gm = (f32x4){0.f, 0.f, 0.f, 0.f}, bt = gm;
+  if constexpr (MODE == 0) {
+    if (p.rate > 0.f) {
+      typedef const __attribute__((address_space(4))) uint32_t* const_u32p;
+      const uint32_t key = *(const_u32p)&reinterpret_cast<const SkfStepState*>(p.state)->drop_key;
+      sk = skf_site_key(key, p.site);
+      thresh = skf_drop_thresh(p.rate);
+      inv_keep = 1.0f / (1.0f - p.rate);
+    }
+    gm = *reinterpret_cast<const f32x4*>(p.gamma + 4 * e_sub);
+    bt = *reinterpret_cast<const f32x4*>(p.beta + 4 * e_sub);
+  }
+
+  const char* img1_w = p.img1 + (size_t)wave * (NKS * P * 1024) + lane * 16;            // + b * 8 * NKS * P * 1024
+  const char* img2_w = p.img2 + (size_t)wave * (16 * P * 1024) + lane * 16;             // + b * NKS * P * 1024
+  u32x4 w1[NKS][P], w2[NKS][P];
+  if (nsub > 0) load_frags<P>(w1, img1_w);
+
+  // A rows of a sub-group: thread -> float4 st_c of row st_row of every tile.  Requested one sub-group ahead (the first one here,
+  // the next one under the current one's last hidden block).  In the forward they are also the residual of the epilogue, whose
+  // (row, float4) -> thread map is the same: re-requested there (L2) rather than held in 16 registers across the blocks.
+  f32x4 xn[MAXRT];
+  int tn[MAXRT];
+  auto sub_tiles = [&](int pos0, int sub_i, int (&t)[MAXRT]) -> int {     // even split of what is left -> tile ids, count
+    const int left = count - (pos0 - pos_begin);
+    const int n = sub_i < nsub ? (left + (nsub - sub_i) - 1) / (nsub - sub_i) : 0;
+#pragma unroll
+    for (int rt = 0; rt < MAXRT; ++rt) t[rt] = rt < n ? phys(pos0 + rt) : ntiles;
+    return n;
+  };
+  auto request_rows = [&](const int (&t)[MAXRT], f32x4 (&x)[MAXRT]) {
+#pragma unroll
+    for (int rt = 0; rt < MAXRT; ++rt) {
+      const __amdgpu_buffer_rsrc_t r = ffn_rows_rsrc(p.A, p.lda, p.M, t[rt] * TR);
+      x[rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, st_voff, 0, 0));
+    }
+  };
+  int pos = pos_begin;
+  int nrt_next = sub_tiles(pos, 0, tn);
+  request_rows(tn, xn);
+  for (int sub = 0; sub < nsub; ++sub) {
+    const int nrt = nrt_next;
+    int tl[MAXRT];
+#pragma unroll
+    for (int rt = 0; rt < MAXRT; ++rt) tl[rt] = tn[rt];
+    pos += nrt;
+
+    // One code path for 1..4 tiles: the tile bodies are scheduling regions of their own anyway (see the sched_barriers), absent tiles
+    // are skipped by wave-uniform branches.  (Four instantiations over the tile count behind a switch made the register allocator
+    // spill 231 registers around the sub-group; each alone needs 238 and spills nothing.)
+    {
+    constexpr int NRT = MAXRT;
+    constexpr int TILE = TR * RPITCH;
+    // ---- stage the A rows: registers -> P planes in LDS
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) {
+      unsigned lo[P], hi[P];
+      skf_split2<P>(xn[rt][0], xn[rt][1], lo, sel);
+      skf_split2<P>(xn[rt][2], xn[rt][3], hi, sel);
+#pragma unroll
+      for (int q = 0; q < P; ++q) *reinterpret_cast<u32x2*>(Xp + q * PLANE + rt * TILE + st_off) = (u32x2){lo[q], hi[q]};
+    }
+    FFN_STAMP();   // rows staged
+    __syncthreads();
+    FFN_STAMP();   // behind the staging barrier
+
+    f32x4 y[NRT];
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) y[rt] = bias2_r;
+    FfnFrags<P> fr;
+#if SKF_FFN_ABLATE & 2
+    load_half<P>(Xp, a_off, fr.f[0], 0, true); load_half<P>(Xp, a_off, fr.f[1], 1, true);
+#endif
+
+#pragma unroll 1
+    for (int b = 0; b < NBLK; ++b) {
+      char* Hb = Hp + (b & 1) * (P * PLANE);
+      const f32x4 b1 = MODE == 0 ? *reinterpret_cast<const f32x4*>(bias1_p + HB * b) : (f32x4){0.f, 0.f, 0.f, 0.f};   // (LDS)
+      if (b == NBLK - 1) {                      // the next sub-group's rows (all four descriptors: absent tiles read as zeros)
+        nrt_next = sub_tiles(pos, sub + 1, tn);
+        request_rows(tn, xn);
+      }
+      // the stage-1 epilogue of a tile: activation / mask, sign bits, the hidden rows to global memory and, split, to the LDS planes
+      auto hidden_out = [&](int rt, const f32x4& acc0, const f32x4& acc1) {
+#if SKF_FFN_ABLATE & 16
+        if (p.M >= 0) { if (acc0[0] + acc1[0] == 1.2345f) Hb[0] = 1; return; }
+#endif
+        f32x4 h = acc0 + acc1;
+        const int tile = tl[rt];
+        if constexpr (MODE == 0) {
+          unsigned long long wbits = 0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            h[r] = __builtin_amdgcn_fmed3f(h[r], 0.f, __builtin_inff());
+            const unsigned long long bm = __ballot(h[r] > 0.f);
+            if (lane == r) wbits = bm;
+          }
+          const bool wr = p.bits_out != nullptr;
+          const size_t woff = wr ? (((size_t)tile * NBLK + b) * 8 + wave) * 4 * 8 : 0;
+          const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+              reinterpret_cast<char*>(wr ? (void*)p.bits_out : (void*)p.H) + woff, 0, wr ? 32 : 0, 0x00020000);
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, wbits), rb, (unsigned)lane * 8u, 0, 0);
+        } else {
+          typedef const __attribute__((address_space(4))) unsigned long long* const_u64p;
+          const const_u64p wp = (const_u64p)(p.bits_in + (((size_t)tile * NBLK + b) * 8 + wave) * 4);
+          f32x4 hm;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const unsigned long long m = wp[r];
+            float v;
+            asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(v) : "v"(h[r]), "s"(m));
+            hm[r] = v;
+          }
+          h = hm;
+        }
+#if SKF_FFN_ABLATE & 4
+        const __amdgpu_buffer_rsrc_t rh = ffn_rows_rsrc(p.H, FF, 0, tile * TR);
+#else
+        const __amdgpu_buffer_rsrc_t rh = ffn_rows_rsrc(p.H, FF, p.M, tile * TR);
+#endif
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), rh, hc_voff, b * (HB * 4), 0);
+        unsigned p01[P], p23[P];
+        skf_split2<P>(h[0], h[1], p01, sel);
+        skf_split2<P>(h[2], h[3], p23, sel);
+        char* hrow = Hb + rt * TILE;
+#if SKF_FFN_ABLATE & 8
+        if (p.M < 0)
+#endif
+#pragma unroll
+        for (int q = 0; q < P; ++q) *reinterpret_cast<u32x2*>(hrow + q * PLANE + hw_off) = (u32x2){p01[q], p23[q]};
+      };
+      // ---- stage 1: hidden block b of every row tile; the epilogue of tile t - 1 sits between the halves of tile t
+      load_half<P>(Xp, a_off, fr.f[0], 0);
+      f32x4 pacc0 = b1, pacc1 = b1;
+#pragma unroll
+      for (int t = 0; t < NRT; ++t) {
+        if (t < nrt) {
+          load_half<P>(Xp + t * TILE, a_off, fr.f[1], 1);
+          f32x4 acc0 = b1, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+          int c = 0;
+          half_products<P>(w1, fr.f[0], 0, acc0, acc1, c);
+          if (t == 0) {
+            // the second stage's operands: behind the block's first products, so that the wait in front of those (vmcnt(0) at a loop
+            // head) covers only the first-stage operands requested a whole stage ago, not these
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags<P>(w2, img2_w + (size_t)b * (NKS * P * 1024));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (t > 0) hidden_out(t - 1, pacc0, pacc1);
+          if (t + 1 < NRT) load_half<P>(Xp + (t + 1) * TILE, a_off, fr.f[0], 0);
+          half_products<P>(w1, fr.f[1], 1, acc0, acc1, c);
+          pacc0 = acc0; pacc1 = acc1;
+          __builtin_amdgcn_sched_barrier(0);      // (no fragment reads hoisted across tiles)
+        }
+      }
+      // the last tile's epilogue (nrt - 1 is wave-uniform: a short chain of uniform branches instead of a dynamic register index)
+#pragma unroll
+      for (int t = 0; t < NRT; ++t)
+        if (t == nrt - 1) hidden_out(t, pacc0, pacc1);
+      // the next first-stage operands (block 0 again behind the last block: the next sub-group starts with them)
+      load_frags<P>(w1, img1_w + (size_t)((b + 1) & (NBLK - 1)) * (8 * NKS * P * 1024));
+      FFN_STAMP();   // stage 1 issued
+      __syncthreads();
+      FFN_STAMP();   // behind the block barrier
+      // ---- stage 2: Y += Hblock . B2[block rows]
+      load_half<P>(Hb, a_off, fr.f[0], 0);
+#pragma unroll
+      for (int t = 0; t < NRT; ++t) {
+        if (t < nrt) {
+          load_half<P>(Hb + t * TILE, a_off, fr.f[1], 1);
+          int c = 0;
+          f32x4 ya = (f32x4){0.f, 0.f, 0.f, 0.f}, yb = ya;      // this block's two chains; one persistent accumulator per tile
+          half_products<P>(w2, fr.f[0], 0, ya, yb, c);
+          if (t + 1 < NRT) load_half<P>(Hb + (t + 1) * TILE, a_off, fr.f[0], 0);
+          half_products<P>(w2, fr.f[1], 1, ya, yb, c);
+          y[t] += ya + yb;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      FFN_STAMP();   // stage 2 issued
+    }
+
+    // ---- epilogue: Y through LDS, a half-wave per row
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) *reinterpret_cast<f32x4*>(Yt + (rt * TR + i) * YPITCH + 16 * wave + 4 * g) = y[rt];
+    f32x4 xres[NRT];
+    if constexpr (MODE == 0) {
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt) {
+        const __amdgpu_buffer_rsrc_t r = ffn_rows_rsrc(p.A, p.lda, p.M, tl[rt] * TR);
+        xres[rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, st_voff, 0, 0));
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) {
+      const int rloc = rt * TR + 2 * wave + e_half;
+      const int grow = tl[rt] * TR + 2 * wave + e_half;
+      const bool ok = grow < p.M;
+      const size_t off = (size_t)(ok ? grow : 0) * FD + 4 * e_sub;
+      const f32x4 yv = *reinterpret_cast<const f32x4*>(Yt + rloc * YPITCH + 4 * e_sub);
+      if constexpr (MODE == 0) {
+        const f32x4 xv = xres[rt];             // the residual IS the input row this thread staged
+        f32x4 z;
+        float sum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float yy = yv[e];
+          if (p.rate > 0.f) yy *= skf_keep(sk, (uint32_t)off + e, thresh) ? inv_keep : 0.f;
+          z[e] = xv[e] + yy;
+          sum += z[e];
+        }
+        const float mean = ffn_half_wave_sum(sum) * (1.0f / FD);
+        float sq = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float c = z[e] - mean; sq += c * c; }
+        const float rstd = rsqrtf(ffn_half_wave_sum(sq) * (1.0f / FD) + 1e-6f);
+        if (ok) {
+          *reinterpret_cast<f32x4*>(p.C + off) = z;
+          *reinterpret_cast<f32x4*>(p.out + off) = (z - mean) * rstd * gm + bt;
+          if (e_sub == 0) { p.stats[2 * (size_t)grow] = mean; p.stats[2 * (size_t)grow + 1] = rstd; }
+        }
+      } else {
+        if (ok) {
+          f32x4 v = yv;
+          if (p.accumulate) v += *reinterpret_cast<const f32x4*>(p.C + off);
+          *reinterpret_cast<f32x4*>(p.C + off) = v;
+        }
+      }
+    }
+    FFN_STAMP();   // epilogue done
+    }
+    // (the next sub-group's staging writes Xp, which nobody reads behind the last block's barrier; its first stage writes Hp
+    //  buffer 0 = Yt behind the staging barrier, which every wave reaches after its epilogue reads)
+  }
+
+  // rows of dead tiles: dh = 0 (the weight gradient's 32-row blocks may contain a dead 16-row tile); dx is left alone when
+  // accumulating and zero otherwise
+  if (MODE == 1 && blk) {
+    const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int dpos = nlive + wg; dpos < ntiles; dpos += G) {
+      const int tile = blk[2 + dpos];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int e = tid + v * 512, row = tile * TR + e / (FF / 4), c4 = (e % (FF / 4)) * 4;
+        if (row < p.M) *reinterpret_cast<f32x4*>(p.H + (size_t)row * FF + c4) = zero;
+      }
+      if (!p.accumulate) {
+        const int row = tile * TR + (tid >> 5);
+        if (row < p.M) *reinterpret_cast<f32x4*>(p.C + (size_t)row * FD + 4 * (tid & 31)) = zero;
+      }
+    }
+  }
+}
+
+int n_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+template <int P, int MODE>
+int launch_ffn(const FfnFusedParams& p, hipStream_t st) {
+  const int ntiles = skf_cdiv(p.M, TR);
+  int grid = n_cus();
+  if (grid > ntiles) grid = ntiles;
+  const size_t smem = (size_t)3 * P * PLANE + (P * PLANE >= ROWS * YPITCH * 4 ? 0 : ROWS * YPITCH * 4) + FF * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fused_kernel<P, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_done = true;
+  }
+  static const std::string tag = std::string(MODE == 0 ? "ffn_fused_fwd" : "ffn_fused_bwd") + "<d128,dff512,bf16x" + std::to_string(P * (P + 1) / 2) + ">";
+  const double live = skf_prof_list_fraction(p.row_blocks);
+  const double flops = 2.0 * 2.0 * p.M * FD * FF;
+  const double bytes = 4.0 * ((double)p.M * FD * (MODE == 0 ? 4 : 3) + (double)p.M * FF) + 2.0 * image_bytes(P) / 2;
+  SkfProfScope ps(st, tag.c_str(), flops, bytes);
+  ps.done(flops * live, bytes * live);
+  hipLaunchKernelGGL((ffn_fused_kernel<P, MODE>), dim3(grid), dim3(512), smem, st, p);
+  SKF_LAUNCH_CHECK();
+  return SKF_OK;
+}
+
+}  // namespace
+
+int skf_ffn_fused_launch(const FfnFusedParams& p, int pieces, int direction, hipStream_t st) {
+  if (pieces == 2) return direction == 0 ? launch_ffn<2, 0>(p, st) : launch_ffn<2, 1>(p, st);
+  return direction == 0 ? launch_ffn<3, 0>(p, st) : launch_ffn<3, 1>(p, st);
+}
+
+#if SKF_FFN_STAMPS
+extern "C" int skf_ffn_debug_stamps(long long* out_host) {   // diagnostics builds only
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_ffn_stamps), sizeof(long long) * 16 * 64) == hipSuccess ? 0 : 1;
+}
+#endif
+// ---------------------------------------------------------------- C ABI
+extern "C" int skf_ffn_fused_supported(int M, int d, int dff, int precision) {
+  return (precision == SKF_PREC_BF16X6 || precision == SKF_PREC_BF16X3) && d == FD && dff == FF && M >= 1 && (double)M * FF * 4 < 2147483648.0;
+}
+extern "C" size_t skf_ffn_image_bytes(int d, int dff, int precision) {
+  if (!skf_ffn_fused_supported(1, d, dff, precision)) return 0;
+  return image_bytes(precision == SKF_PREC_BF16X3 ? 2 : 3);
+}
+extern "C" size_t skf_ffn_relu_bits_bytes(int M, int d, int dff, int precision) {
+  if (!skf_ffn_fused_supported(M, d, dff, precision)) return 0;
+  return (size_t)skf_cdiv(M, TR) * NBLK * 8 * 4 * sizeof(unsigned long long);
+}
+
+extern "C" int skf_ffn_weight_images(int n, const float* const* W1, const int* ld1, const float* const* W2, const int* ld2,
+                                     const int* transpose, void* const* images, int d, int dff, int precision, skf_stream_t stream) {
+  SKF_CHECK_ARG(skf_ffn_fused_supported(1, d, dff, precision), "skf_ffn_weight_images: d = 128, dff = 512 in a split-arithmetic mode only");
+  SKF_CHECK_ARG(n >= 0 && (n == 0 || (W1 && ld1 && W2 && ld2 && transpose && images)), "null argument");
+  const int P = precision == SKF_PREC_BF16X3 ? 2 : 3;
+  for (int b0 = 0; b0 < n; b0 += 16) {
+    FfnImageBatch batch{};
+    const int nb = n - b0 < 16 ? n - b0 : 16;
+    for (int j = 0; j < nb; ++j) {
+      SKF_CHECK_ARG(W1[b0 + j] && W2[b0 + j] && images[b0 + j] && ld1[b0 + j] >= dff && ld2[b0 + j] >= d, "bad weight operand");
+      SKF_CHECK_ARG(((uintptr_t)images[b0 + j] & 15) == 0, "images must be 16-byte aligned");
+      batch.d[j] = FfnImageDesc{W1[b0 + j], W2[b0 + j], (char*)images[b0 + j], ld1[b0 + j], ld2[b0 + j], transpose[b0 + j], 0};
+    }
+    if (P == 2) hipLaunchKernelGGL(ffn_image_kernel<2>, dim3(64, nb), dim3(256), 0, (hipStream_t)stream, batch);
+    else hipLaunchKernelGGL(ffn_image_kernel<3>, dim3(64, nb), dim3(256), 0, (hipStream_t)stream, batch);
+    SKF_LAUNCH_CHECK();
+  }
+  return SKF_OK;
+}
+
+static int ffn_common_checks(int M, int d, int dff, int precision, const void* a, const void* img, const void* hid, const void* c) {
+  SKF_CHECK_ARG(skf_ffn_fused_supported(M, d, dff, precision), "fused feed-forward block: d = 128, dff = 512 in a split-arithmetic mode only (skf_ffn_fused_supported)");
+  SKF_CHECK_ARG(a && img && hid && c, "null operand");
+  SKF_CHECK_ARG((((uintptr_t)a | (uintptr_t)img | (uintptr_t)hid | (uintptr_t)c) & 15) == 0, "operands must be 16-byte aligned");
+  return SKF_OK;
+}
+
+extern "C" int skf_ffn_fused_fwd_f32(int M, int d, int dff, const float* x, const void* image, const float* b1, const float* b2,
+                                     float* h, void* relu_bits_out, const float* gamma, const float* beta, float* z, float* out,
+                                     float* stats, float rate, unsigned site, const void* step_state, int precision, skf_stream_t stream) {
+  const int rc = ffn_common_checks(M, d, dff, precision, x, image, h, z);
+  if (rc != SKF_OK) return rc;
+  SKF_CHECK_ARG(gamma && beta && out && stats && b1 && b2, "null bias / LayerNorm operand");
+  SKF_CHECK_ARG(rate >= 0.f && rate < 1.f && (rate == 0.f || step_state), "dropout needs 0 <= rate < 1 and the step state");
+  SKF_CHECK_ARG((((uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0 && (((uintptr_t)stats | (uintptr_t)relu_bits_out) & 7) == 0, "operands must be 16-byte aligned");
+  const int P = precision == SKF_PREC_BF16X3 ? 2 : 3;
+  FfnFusedParams p{};
+  p.A = x; p.lda = d; p.M = M;
+  p.img1 = (const char*)image; p.img2 = (const char*)image + image_bytes(P) / 2;
+  p.bias1 = b1; p.bias2 = b2; p.H = h; p.bits_out = (unsigned long long*)relu_bits_out;
+  p.C = z; p.res = x; p.gamma = gamma; p.beta = beta; p.out = out; p.stats = stats;
+  p.rate = rate; p.site = site; p.state = step_state;
+  return skf_ffn_fused_launch(p, P, 0, (hipStream_t)stream);
+}
+
+extern "C" int skf_ffn_fused_bwd_f32(int M, int d, int dff, const float* dy, const void* image_t, const void* relu_bits_in,
+                                     float* dh, float* dx, int accumulate, const int* row_blocks, int row_block_rows,
+                                     int precision, skf_stream_t stream) {
+  const int rc = ffn_common_checks(M, d, dff, precision, dy, image_t, dh, dx);
+  if (rc != SKF_OK) return rc;
+  SKF_CHECK_ARG(relu_bits_in && ((uintptr_t)relu_bits_in & 7) == 0, "the backward needs the sign bits the forward wrote");
+  SKF_CHECK_ARG(!row_blocks || row_block_rows == TR, "row-block lists of this kernel have 16-row blocks");
+  const int P = precision == SKF_PREC_BF16X3 ? 2 : 3;
+  FfnFusedParams p{};
+  p.A = dy; p.lda = d; p.M = M;
+  p.img1 = (const char*)image_t; p.img2 = (const char*)image_t + image_bytes(P) / 2;
+  p.H = dh; p.bits_in = (const unsigned long long*)relu_bits_in;
+  p.C = dx; p.accumulate = accumulate; p.row_blocks = row_blocks;
+  return skf_ffn_fused_launch(p, P, 1, (hipStream_t)stream);
+}

@@ -237,6 +237,57 @@ def gemm_ln_residual(a, w, bias, x, gamma, beta, rate=0.0, site=0, state=None, p
     return out, z, stats
 
 
+def ffn_fused_supported(M, d, dff, precision=None):
+    return bool(_lib.load().skf_ffn_fused_supported(M, d, dff, _prec(precision)))
+
+
+def ffn_weight_images(pairs, transpose, precision=None):
+    """pairs: [(W1 [d, dff], W2 [dff, d]), ...] -> one uint8 tensor per pair holding the pre-split operand image
+    (transpose=False: the forward's, True: the input gradient's); all pairs in ONE launch (skf_ffn_weight_images)."""
+    n = len(pairs)
+    d, dff = pairs[0][0].shape
+    nbytes = _lib.load().skf_ffn_image_bytes(d, dff, _prec(precision))
+    if not nbytes:
+        raise _lib.SkfError("no fused feed-forward path for d=%d dff=%d" % (d, dff))
+    imgs = [torch.empty(nbytes, dtype=torch.uint8, device=pairs[0][0].device) for _ in range(n)]
+    PA = C.c_void_p * n
+    IA = C.c_int * n
+    for w1, w2 in pairs:
+        _f32(w1, "W1"); _f32(w2, "W2")
+    _lib.call("skf_ffn_weight_images", n, PA(*[w1.data_ptr() for w1, _ in pairs]), IA(*[w1.stride(0) for w1, _ in pairs]),
+              PA(*[w2.data_ptr() for _, w2 in pairs]), IA(*[w2.stride(0) for _, w2 in pairs]), IA(*([int(bool(transpose))] * n)),
+              PA(*[im.data_ptr() for im in imgs]), d, dff, _prec(precision), _stream())
+    return imgs
+
+
+def ffn_fused_fwd(x, image, b1, b2, gamma, beta, dff, rate=0.0, site=0, state=None, precision=None):
+    """One launch: h = relu(x.W1 + b1), z = x + dropout(h.W2 + b2), out = LayerNorm(z) -> out, z, stats, h, sign bits."""
+    _f32(x, "x")
+    M, d = x.shape
+    h = torch.empty(M, dff, dtype=torch.float32, device=x.device)
+    nb = _lib.load().skf_ffn_relu_bits_bytes(M, d, dff, _prec(precision))
+    bits = torch.zeros(max(nb // 8, 1), dtype=torch.int64, device=x.device)
+    z = torch.empty_like(x)
+    out = torch.empty_like(x)
+    stats = torch.empty(M, 2, dtype=torch.float32, device=x.device)
+    _lib.call("skf_ffn_fused_fwd_f32", M, d, dff, _p(x), _p(image), _p(b1), _p(b2), _p(h), _p(bits), _p(gamma), _p(beta),
+              _p(z), _p(out), _p(stats), rate, site, _p(state), _prec(precision), _stream())
+    return out, z, stats, h, bits
+
+
+def ffn_fused_bwd(dy, image_t, bits, dff, dx=None, row_blocks=None, precision=None):
+    """One launch: dh = (dy.W2^T) o relu'(h), dx (+)= dh.W1^T -> dh, dx (accumulated into `dx` when given)."""
+    _f32(dy, "dy")
+    M, d = dy.shape
+    dh = torch.empty(M, dff, dtype=torch.float32, device=dy.device)
+    acc = dx is not None
+    if dx is None:
+        dx = torch.empty_like(dy)
+    _lib.call("skf_ffn_fused_bwd_f32", M, d, dff, _p(dy), _p(image_t), _p(bits), _p(dh), _p(dx), int(acc), _p(row_blocks),
+              16 if row_blocks is not None else 0, _prec(precision), _stream())
+    return dh, dx
+
+
 def layernorm_residual_bwd(dout, z, stats, gamma, rate=0.0, site=0, state=None):
     d = dout.shape[-1]
     rows = dout.numel() // d

@@ -793,6 +793,98 @@ def test_gemm_ln_residual_refuses_other_shapes(ops):
         ops.gemm_ln_residual(a, w, v, a, v, v, precision=6)
 
 
+# ------------------------------------------------------------------ feed-forward block in one launch per direction
+@pytest.mark.parametrize("rows,rate,prec", [(25600, 0.1, 6), (1031, 0.1, 6), (25472, 0.0, 6), (7, 0.1, 6), (4000, 0.1, 3)])
+def test_ffn_fused_forward(ops, rows, rate, prec):
+    """h = relu(x.W1 + b1), z = x + dropout(h.W2 + b2), out = LayerNorm(z) in one launch (builders/layers/transformer.py:194-198,
+    221-224) against the oracle, and against the three launches it replaces."""
+    d, dff = 128, 512
+    rng = np.random.RandomState(rows)
+    x = rng.randn(rows, d)
+    x[rows // 2] = 100.0 + 1e-3 * rng.randn(d)
+    w1, b1 = rng.randn(d, dff) / np.sqrt(d), 0.1 * rng.randn(dff)
+    w2, b2 = rng.randn(dff, d) / np.sqrt(dff), 0.1 * rng.randn(d)
+    gamma, beta = 1 + 0.1 * rng.randn(d), 0.1 * rng.randn(d)
+    st = ops.new_step_state("cuda", iterations=3)
+    ops.step_prologue(st, seed=5)
+    keep = np.ones((rows, d), bool)
+    if rate > 0:
+        keep = ops.dropout_keep_mask(ops.read_step_state(st)["drop_key"], 9, rate, rows * d).reshape(rows, d)
+    h = np.maximum(x @ w1 + b1, 0)
+    z = x + oracle.dropout_fwd(h @ w2 + b2, keep, rate)
+    want, _ = oracle.layernorm_fwd(z, gamma, beta)
+    X, W1, B1, W2, B2, G, Be = _dev(x), _dev(w1), _dev(b1), _dev(w2), _dev(b2), _dev(gamma), _dev(beta)
+    img, = ops.ffn_weight_images([(W1, W2)], transpose=False, precision=prec)
+    out, zz, stats, hh, bits = ops.ffn_fused_fwd(X, img, B1, B2, G, Be, dff, rate=rate, site=9, state=st, precision=prec)
+    tol = RTOL if prec == 6 else 2e-4
+    _close(hh, h, rtol=tol, name="fused h")
+    _close(zz, z, rtol=tol, name="fused z")
+    _close(out, want, rtol=max(tol, 2e-5), name="fused ln out")
+    _close(stats[:, 0], z.mean(-1), rtol=max(tol, 2e-5), name="fused mean")
+    _close(stats[:, 1], 1.0 / np.sqrt(z.var(-1) + 1e-6), rtol=max(tol, 2e-5), name="fused rstd")
+    # sign bits: word [tile][block][wave][r], bit 16g + i <-> h[16 tile + i][128 block + 16 wave + 4g + r] > 0
+    nt = (rows + 15) // 16
+    hp = np.zeros((nt * 16, dff)); hp[:rows] = hh.cpu().numpy(); hp[rows:] = np.maximum(b1, 0)   # rows behind M: x reads as 0
+    lanes = (hp.reshape(nt, 16, 4, 8, 4, 4) > 0)                      # [tile][i][block][wave][g][r]
+    lanes = lanes.transpose(0, 2, 3, 5, 4, 1).reshape(nt, 4, 8, 4, 64)  # [tile][block][wave][r][lane = 16g + i]
+    words = (lanes.astype(np.uint64) << np.arange(64, dtype=np.uint64)).sum(-1, dtype=np.uint64)
+    got_words = bits.cpu().numpy().view(np.uint64)[:words.size].reshape(words.shape)
+    assert np.array_equal(got_words, words), "sign bits differ from the stored hidden tensor"
+    if rows > 2048 and prec == 6:
+        h2 = ops.gemm(X, W1, bias=B1, act=1, precision=prec)
+        y2 = ops.gemm(h2, W2, bias=B2, precision=prec)
+        out2, z2, stats2 = ops.layernorm_residual_fwd(X, y2, G, Be, rate=rate, site=9, state=st)
+        assert (hh - h2).abs().max().item() <= 2e-6 * max(1.0, h2.abs().max().item())
+        assert (zz - z2).abs().max().item() <= 2e-6 * max(1.0, z2.abs().max().item())
+        assert (out - out2).abs().max().item() <= 2e-5 * max(1.0, out2.abs().max().item())
+
+
+@pytest.mark.parametrize("rows,listed,acc", [(25472, True, True), (25600, False, True), (1031, False, False), (3184, True, False), (7, False, True)])
+def test_ffn_fused_backward(ops, rows, listed, acc):
+    """dh = (dy.W2^T) o relu'(h), dx (+)= dh.W1^T in one launch against float64, with and without the live-row-block list of the
+    decoder-side backward (dead rows: dy == 0 -> dh rows stored as zeros, dx rows left alone / zeroed)."""
+    d, dff = 128, 512
+    rng = np.random.RandomState(rows + 1)
+    x = rng.randn(rows, d)
+    w1, b1 = rng.randn(d, dff) / np.sqrt(d), 0.1 * rng.randn(dff)
+    w2, b2 = rng.randn(dff, d) / np.sqrt(dff), 0.1 * rng.randn(d)
+    dy = rng.randn(rows, d)
+    dx0 = rng.randn(rows, d)
+    blocks = None
+    if listed:
+        Ld = 199
+        B = rows // Ld
+        assert B * Ld == rows
+        live = rng.randint(0, Ld + 1, size=B).astype(np.int32)
+        live[0] = 0; live[-1] = Ld
+        for b in range(B):
+            dy[b * Ld + live[b]:(b + 1) * Ld] = 0.0
+        blocks = ops.row_blocks(_dev(live, torch.int32), Ld, 16)
+    X, W1, B1, W2, B2 = _dev(x), _dev(w1), _dev(b1), _dev(w2), _dev(b2)
+    g = _dev(np.ones(d)); be = _dev(np.zeros(d))
+    img, = ops.ffn_weight_images([(W1, W2)], transpose=False)
+    _, _, _, hh, bits = ops.ffn_fused_fwd(X, img, B1, B2, g, be, dff)
+    imgt, = ops.ffn_weight_images([(W1, W2)], transpose=True)
+    hmask = hh.cpu().numpy().astype(np.float64) > 0
+    dh = (dy @ w2.T) * hmask
+    dx = dh @ w1.T + (dx0 if acc else 0.0)
+    DX = _dev(dx0) if acc else None
+    gdh, gdx = ops.ffn_fused_bwd(_dev(dy), imgt, bits, dff, dx=DX, row_blocks=blocks)
+    _close(gdh, dh, name="fused dh")
+    _close(gdx, dx, name="fused dx")
+    if rows > 2048:
+        dh2 = ops.gemm(_dev(dy), W2, a_kcontig=True, b_kcontig=True, relu_src=hh)
+        assert (gdh - dh2).abs().max().item() <= 2e-6 * max(1.0, dh2.abs().max().item())
+
+
+def test_ffn_fused_refuses_other_shapes(ops):
+    lib = ops._lib.load()
+    assert lib.skf_ffn_fused_supported(25600, 128, 512, 6) == 1
+    assert lib.skf_ffn_fused_supported(25600, 128, 512, 0) == 0
+    assert lib.skf_ffn_fused_supported(25600, 256, 1024, 6) == 0
+    assert lib.skf_ffn_image_bytes(128, 512, 6) == 786432 and lib.skf_ffn_image_bytes(256, 1024, 6) == 0
+
+
 # ------------------------------------------------------------------ loss heads
 @pytest.mark.parametrize("V", [1004, 52, 10004])
 def test_recon_softmax_ce(ops, V):
