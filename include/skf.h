@@ -496,6 +496,9 @@ void skf_model_destroy(SkfModel* m);
  * runs the layer-by-layer path (one launch per operator, the form the oracle tests pinned first) instead of the one launch
  * per position of skf_decode_fused.hip - same tokens, kept as the cross-check of the fused kernel. */
 #define SKF_MODEL_DECODE_LAYERWISE 1u
+/* SKF_MODEL_FFN_LAUNCHES: the feed-forward blocks of the step run as separate Dense / LayerNorm launches instead of the one launch
+ * per direction of skf_ffn_fused_fwd_f32 / _bwd_f32 (same arithmetic, the sums in a different order): cross-check and A/B. */
+#define SKF_MODEL_FFN_LAUNCHES 2u
 int skf_model_set_flags(SkfModel* m, uint32_t flags);
 /* params/grads/adam_m/adam_v: skf_model_param_floats floats each; pos: (max_pos, d_model) table
  * (builders/utils.py:17-32, computed by the host in float64 like the reference);

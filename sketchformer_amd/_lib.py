@@ -32,6 +32,7 @@ class SkfError(RuntimeError):
 
 ATTN_TWO_PASS = 0x100                                 # SKF_ATTN_TWO_PASS
 MODEL_DECODE_LAYERWISE = 1                            # SKF_MODEL_DECODE_LAYERWISE
+MODEL_FFN_LAUNCHES = 2                                # SKF_MODEL_FFN_LAUNCHES: feed-forward blocks as separate launches
 
 
 class SkfConfig(C.Structure):

@@ -239,6 +239,17 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnFusedParams p) {
     bt = *reinterpret_cast<const f32x4*>(p.beta + 4 * e_sub);
   }
 
+  // ONE descriptor per tensor for the whole launch, the tile in the VGPR offset (rows behind M fall outside and are dropped / read
+  // as zeros): a descriptor per (tile, block) was ~20 SALU instructions per tile and kept the kernel spilling SGPRs into VGPR lanes
+#if SKF_FFN_ABLATE & 4
+  const __amdgpu_buffer_rsrc_t r_H = __builtin_amdgcn_make_buffer_rsrc(p.H, 0, 0, 0x00020000);
+#else
+  const __amdgpu_buffer_rsrc_t r_H = __builtin_amdgcn_make_buffer_rsrc(p.H, 0, p.M * (FF * 4), 0x00020000);
+#endif
+  const __amdgpu_buffer_rsrc_t r_A = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, p.M * p.lda * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_bits = __builtin_amdgcn_make_buffer_rsrc(MODE == 0 && p.bits_out ? (void*)p.bits_out : (void*)p.H, 0,
+                                                                          MODE == 0 && p.bits_out ? ntiles * (NBLK * 8 * 32) : 0, 0x00020000);
+  const unsigned bits_voff = lane < 4 ? (unsigned)lane * 8u : OOB;
   const char* img1_w = p.img1 + (size_t)wave * (NKS * P * 1024) + lane * 16;            // + b * 8 * NKS * P * 1024
   const char* img2_w = p.img2 + (size_t)wave * (16 * P * 1024) + lane * 16;             // + b * NKS * P * 1024
   u32x4 w1[NKS][P], w2[NKS][P];
@@ -258,10 +269,8 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnFusedParams p) {
   };
   auto request_rows = [&](const int (&t)[MAXRT], f32x4 (&x)[MAXRT]) {
 #pragma unroll
-    for (int rt = 0; rt < MAXRT; ++rt) {
-      const __amdgpu_buffer_rsrc_t r = ffn_rows_rsrc(p.A, p.lda, p.M, t[rt] * TR);
-      x[rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, st_voff, 0, 0));
-    }
+    for (int rt = 0; rt < MAXRT; ++rt)
+      x[rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_A, t[rt] < ntiles ? st_voff + (unsigned)t[rt] * (unsigned)(TR * p.lda * 4) : OOB, 0, 0));
   };
   int pos = pos_begin;
   int nrt_next = sub_tiles(pos, 0, tn);
@@ -316,18 +325,18 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnFusedParams p) {
         f32x4 h = acc0 + acc1;
         const int tile = tl[rt];
         if constexpr (MODE == 0) {
-          unsigned long long wbits = 0;
+          // sign bits: word r = ballot(h[r] > 0) goes to lane r with v_writelane (a compare-and-select per word and half cost
+          // 16 VALU per tile), lanes 0-3 store (the others sit outside the descriptor)
+          unsigned wlo = 0u, whi = 0u;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            h[r] = __builtin_amdgcn_fmed3f(h[r], 0.f, __builtin_inff());
-            const unsigned long long bm = __ballot(h[r] > 0.f);
-            if (lane == r) wbits = bm;
-          }
-          const bool wr = p.bits_out != nullptr;
-          const size_t woff = wr ? (((size_t)tile * NBLK + b) * 8 + wave) * 4 * 8 : 0;
-          const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
-              reinterpret_cast<char*>(wr ? (void*)p.bits_out : (void*)p.H) + woff, 0, wr ? 32 : 0, 0x00020000);
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, wbits), rb, (unsigned)lane * 8u, 0, 0);
+          for (int r = 0; r < 4; ++r) h[r] = __builtin_amdgcn_fmed3f(h[r], 0.f, __builtin_inff());
+          const unsigned long long m0 = __ballot(h[0] > 0.f), m1 = __ballot(h[1] > 0.f), m2 = __ballot(h[2] > 0.f), m3 = __ballot(h[3] > 0.f);
+          // (s_nop 1: a VALU-written SGPR needs two wait states before v_writelane reads it - the compiler inserts them for its own
+          //  v_writelane, it cannot see into inline assembly; without them a few words per launch came out wrong)
+#define FFN_WRITELANE(M, L) asm("s_nop 1\n\tv_writelane_b32 %0, %2, " #L "\n\tv_writelane_b32 %1, %3, " #L : "+v"(wlo), "+v"(whi) : "s"((unsigned)(M)), "s"((unsigned)((M) >> 32)))
+          FFN_WRITELANE(m0, 0); FFN_WRITELANE(m1, 1); FFN_WRITELANE(m2, 2); FFN_WRITELANE(m3, 3);
+#undef FFN_WRITELANE
+          __builtin_amdgcn_raw_buffer_store_b64((u32x2){wlo, whi}, r_bits, bits_voff, ((tile * NBLK + b) * 8 + wave) * 32, 0);
         } else {
           typedef const __attribute__((address_space(4))) unsigned long long* const_u64p;
           const const_u64p wp = (const_u64p)(p.bits_in + (((size_t)tile * NBLK + b) * 8 + wave) * 4);
@@ -341,12 +350,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnFusedParams p) {
           }
           h = hm;
         }
-#if SKF_FFN_ABLATE & 4
-        const __amdgpu_buffer_rsrc_t rh = ffn_rows_rsrc(p.H, FF, 0, tile * TR);
-#else
-        const __amdgpu_buffer_rsrc_t rh = ffn_rows_rsrc(p.H, FF, p.M, tile * TR);
-#endif
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), rh, hc_voff, b * (HB * 4), 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), r_H, hc_voff + (unsigned)tile * (TR * FF * 4), b * (HB * 4), 0);
         unsigned p01[P], p23[P];
         skf_split2<P>(h[0], h[1], p01, sel);
         skf_split2<P>(h[2], h[3], p23, sel);
@@ -414,10 +418,8 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnFusedParams p) {
     f32x4 xres[NRT];
     if constexpr (MODE == 0) {
 #pragma unroll
-      for (int rt = 0; rt < NRT; ++rt) {
-        const __amdgpu_buffer_rsrc_t r = ffn_rows_rsrc(p.A, p.lda, p.M, tl[rt] * TR);
-        xres[rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, st_voff, 0, 0));
-      }
+      for (int rt = 0; rt < NRT; ++rt)
+        xres[rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_A, tl[rt] < ntiles ? st_voff + (unsigned)tl[rt] * (unsigned)(TR * p.lda * 4) : OOB, 0, 0));
     }
     __syncthreads();
 #pragma unroll

@@ -290,8 +290,8 @@ struct Bump {
   size_t take(size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; }
 };
 
-struct EncAct { size_t x_in, qkv, o, z1, st1, astats, x1, h, z2, st2, x2, hbits; };
-struct DecAct { size_t x_in, qkv, o1, z1, st1, astats1, out1, q2, kv2, o2, astats2, z2, st2, out2, h, z3, st3, out3, hbits; };
+struct EncAct { size_t x_in, qkv, o, z1, st1, astats, x1, h, z2, st2, x2, hbits, img[2]; };   // img: pre-split ffn weight images (forward, backward)
+struct DecAct { size_t x_in, qkv, o1, z1, st1, astats1, out1, q2, kv2, o2, astats2, z2, st2, out2, h, z3, st3, out3, hbits, img[2]; };
 
 struct Plan {
   size_t bytes = 0;
@@ -337,7 +337,9 @@ Plan build_plan(const SkfConfig& c) {
     a.x_in = b.take(Me * d * f); a.qkv = b.take(Me * 3 * d * f); a.o = b.take(Me * d * f); a.z1 = b.take(Me * d * f);
     a.st1 = b.take(Me * 2 * f); a.astats = b.take(B * H * L * 2 * f); a.x1 = b.take(Me * d * f);
     a.h = b.take(Me * F * f); a.z2 = b.take(Me * d * f); a.st2 = b.take(Me * 2 * f);
-    a.hbits = b.take(skf_gemm_relu_bits_bytes((int)Me, (int)F, (int)d, c.gemm_precision));      // 0 bytes: no sign-bit path for this shape
+    a.hbits = b.take(std::max(skf_gemm_relu_bits_bytes((int)Me, (int)F, (int)d, c.gemm_precision),        // 0 bytes: no sign-bit path for this shape
+                              skf_ffn_relu_bits_bytes((int)Me, (int)d, (int)F, c.gemm_precision)));
+    a.img[0] = b.take(skf_ffn_image_bytes((int)d, (int)F, c.gemm_precision)); a.img[1] = b.take(skf_ffn_image_bytes((int)d, (int)F, c.gemm_precision));
     a.x2 = 0;
     P.enc.push_back(a);
   }
@@ -356,7 +358,9 @@ Plan build_plan(const SkfConfig& c) {
     a.q2 = b.take(Md * d * f); a.kv2 = b.take(Me * 2 * d * f); a.o2 = b.take(Md * d * f);   // kv2 = pre (Me,E) . Wkv (E,2d)
     a.astats2 = b.take(B * H * Ld * 2 * f); a.z2 = b.take(Md * d * f); a.st2 = b.take(Md * 2 * f);
     a.out2 = b.take(Md * d * f); a.h = b.take(Md * F * f); a.z3 = b.take(Md * d * f); a.st3 = b.take(Md * 2 * f);
-    a.hbits = b.take(skf_gemm_relu_bits_bytes((int)Md, (int)F, (int)d, c.gemm_precision));
+    a.hbits = b.take(std::max(skf_gemm_relu_bits_bytes((int)Md, (int)F, (int)d, c.gemm_precision),
+                              skf_ffn_relu_bits_bytes((int)Md, (int)d, (int)F, c.gemm_precision)));
+    a.img[0] = b.take(skf_ffn_image_bytes((int)d, (int)F, c.gemm_precision)); a.img[1] = b.take(skf_ffn_image_bytes((int)d, (int)F, c.gemm_precision));
     a.out3 = 0;
     P.dec.push_back(a);
   }
@@ -422,6 +426,7 @@ struct SkfModel {
   SkfConfig cfg;
   uint32_t flags = 0;                // skf_model_set_flags
   bool no_ln_fuse = false, no_relu_bits = false;   // a fused entry answered SKF_EUNSUPPORTED once: this model takes the general pair
+  bool ffn_fused = false;            // the feed-forward blocks run as one launch per direction (skf_ffn_fused.hip); set per forward
   Layout lay;
   Plan plan;
   Plan16 p16;                        // bf16 path (cfg.act_dtype == SKF_ACT_BF16): its own workspace plan
@@ -513,6 +518,7 @@ int dense_ln_fwd(SkfModel* M, const DenseP& w, const float* a, int rows, const f
 // sign-bit buffer of an ffn hidden tensor (rows x dff from d inputs), or null when the shape has no such path / SKF_NO_RELU_BITS=1
 void* hbits_of(SkfModel* M, size_t off, int rows) {
   static const bool bits_off = skf_knob("SKF_NO_RELU_BITS") && skf_knob("SKF_NO_RELU_BITS")[0] == '1';
+  if (M->ffn_fused) return M->at<char>(off);      // (the fused block always writes / reads its own sign-bit words)
   if (bits_off || M->no_relu_bits || !skf_gemm_relu_bits_bytes(rows, M->cfg.dff, M->cfg.d_model, M->cfg.gemm_precision)) return nullptr;
   return M->at<char>(off);
 }
@@ -748,6 +754,44 @@ int classify_fwd(SkfModel* M, bool training, hipStream_t s) {
   return dense_fwd(M, L.cls, fc, c.batch, M->at<float>(P.cls_logits), 0, s);
 }
 
+// The feed-forward block as one launch per direction (skf_ffn_fused.hip) where that kernel exists (d_model 128, dff 512, split
+// arithmetic) unless SKF_MODEL_FFN_LAUNCHES asks for the separate launches.  Its pre-split weight images are rebuilt from the fp32
+// masters at the start of every forward (one or two launches for all layers: whoever changed the weights - the optimizer, a
+// checkpoint restore, a test - did not have to tell the library).
+bool ffn_fused_on(const SkfModel* M) {
+  const SkfConfig& c = M->cfg;
+  static const bool off = skf_knob("SKF_NO_FFN_FUSE") && skf_knob("SKF_NO_FFN_FUSE")[0] == '1';   // (measurement builds only)
+  return !off && !(M->flags & SKF_MODEL_FFN_LAUNCHES) && skf_ffn_fused_supported(c.batch * c.seq_len, c.d_model, c.dff, c.gemm_precision) &&
+         skf_ffn_image_bytes(c.d_model, c.dff, c.gemm_precision) > 0;
+}
+int build_ffn_images(SkfModel* M, bool with_backward, bool encoder_only, hipStream_t s) {
+  const SkfConfig& c = M->cfg;
+  const Layout& L = M->lay;
+  const Plan& P = M->plan;
+  std::vector<const float*> w1, w2; std::vector<int> ld1, ld2, tr; std::vector<void*> img;
+  auto add = [&](const DenseP& f1, const DenseP& f2, const size_t (&im)[2]) {
+    for (int t = 0; t < (with_backward ? 2 : 1); ++t) {
+      w1.push_back(M->P(f1.w)); ld1.push_back(f1.ld); w2.push_back(M->P(f2.w)); ld2.push_back(f2.ld); tr.push_back(t); img.push_back(M->at<char>(im[t]));
+    }
+  };
+  for (int i = 0; i < c.num_layers; ++i) add(L.enc[i].f1, L.enc[i].f2, P.enc[i].img);
+  if (!encoder_only && do_recon(c))
+    for (int i = 0; i < c.num_layers; ++i) add(L.dec[i].f1, L.dec[i].f2, P.dec[i].img);
+  return skf_ffn_weight_images((int)w1.size(), w1.data(), ld1.data(), w2.data(), ld2.data(), tr.data(), img.data(), c.d_model, c.dff,
+                               c.gemm_precision, s);
+}
+// out = LayerNorm(x + dropout(ffn(x))): one launch, or Dense(relu) + Dense + residual-LayerNorm
+int ffn_ln_fwd(SkfModel* M, const DenseP& f1, const DenseP& f2, const LnP& ln, const float* x, int rows, float* h, void* bits,
+               const void* image, float* z, float* out, float* stats, float rate, unsigned site, hipStream_t s) {
+  const int d = M->cfg.d_model;
+  if (M->ffn_fused)
+    return skf_ffn_fused_fwd_f32(rows, d, M->cfg.dff, x, image, M->P(f1.b), M->P(f2.b), h, bits, M->P(ln.g), M->P(ln.b), z, out, stats,
+                                 rate, site, M->state, M->cfg.gemm_precision, s);
+  SKF_TRY(dense_fwd_relu_bits(M, f1, x, rows, h, bits, s));
+  SKF_TRY(dense_fwd(M, f2, h, rows, z, 0, s));
+  return skf_layernorm_residual_fwd(x, z, M->P(ln.g), M->P(ln.b), out, stats, rows, d, rate, site, M->state, s);
+}
+
 int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s, bool encoder_only = false) {
   const SkfConfig& c = M->cfg;
   const Layout& L = M->lay;
@@ -762,6 +806,8 @@ int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s, bool 
 
   const float* inpf = M->at<float>(P.inp);      // continuous mode: (B, L, 5) stroke-5 rows
   const float* tarf = M->at<float>(P.tar);
+  M->ffn_fused = ffn_fused_on(M);
+  if (M->ffn_fused) SKF_TRY(build_ffn_images(M, training && with_loss, encoder_only, s));
   if (c.continuous) {
     SKF_TRY(skf_padding_mask_continuous(inpf, Le, B, Le, emask, s));
     SKF_TRY(skf_padding_mask_continuous(tarf, Le, B, Ld, dmask, s));
@@ -787,10 +833,8 @@ int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s, bool 
                               M->at<float>(a.o), d, M->at<float>(a.astats), M->cfg.gemm_precision, s));
     SKF_TRY(dense_ln_fwd(M, w.mha.o, M->at<float>(a.o), Me, x, M->at<float>(a.z1), w.ln1, M->at<float>(a.x1), M->at<float>(a.st1), rate,
                          site_enc(i, 0), s));
-    SKF_TRY(dense_fwd_relu_bits(M, w.f1, M->at<float>(a.x1), Me, M->at<float>(a.h), hbits_of(M, a.hbits, Me), s));
-    SKF_TRY(dense_fwd(M, w.f2, M->at<float>(a.h), Me, M->at<float>(a.z2), 0, s));
-    SKF_TRY(skf_layernorm_residual_fwd(M->at<float>(a.x1), M->at<float>(a.z2), M->P(w.ln2.g), M->P(w.ln2.b),
-                                       M->at<float>(a.x2), M->at<float>(a.st2), Me, d, rate, site_enc(i, 1), M->state, s));
+    SKF_TRY(ffn_ln_fwd(M, w.f1, w.f2, w.ln2, M->at<float>(a.x1), Me, M->at<float>(a.h), hbits_of(M, a.hbits, Me), M->at<char>(a.img[0]),
+                       M->at<float>(a.z2), M->at<float>(a.x2), M->at<float>(a.st2), rate, site_enc(i, 1), s));
   }
   float* enc_out = M->at<float>(P.enc[N - 1].x2);
   // ---------------- bottleneck + classifier + expander (models/sketchformer.py:149-160,183-199,170-176)
@@ -856,10 +900,8 @@ int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s, bool 
                               M->at<float>(a.o2), d, M->at<float>(a.astats2), M->cfg.gemm_precision, s));
     SKF_TRY(dense_ln_fwd(M, w.mha2.o, M->at<float>(a.o2), Md, M->at<float>(a.out1), M->at<float>(a.z2), w.ln2, M->at<float>(a.out2),
                          M->at<float>(a.st2), rate, site_dec(N, i, 1), s));
-    SKF_TRY(dense_fwd_relu_bits(M, w.f1, M->at<float>(a.out2), Md, M->at<float>(a.h), hbits_of(M, a.hbits, Md), s));
-    SKF_TRY(dense_fwd(M, w.f2, M->at<float>(a.h), Md, M->at<float>(a.z3), 0, s));
-    SKF_TRY(skf_layernorm_residual_fwd(M->at<float>(a.out2), M->at<float>(a.z3), M->P(w.ln3.g), M->P(w.ln3.b),
-                                       M->at<float>(a.out3), M->at<float>(a.st3), Md, d, rate, site_dec(N, i, 2), M->state, s));
+    SKF_TRY(ffn_ln_fwd(M, w.f1, w.f2, w.ln3, M->at<float>(a.out2), Md, M->at<float>(a.h), hbits_of(M, a.hbits, Md), M->at<char>(a.img[0]),
+                       M->at<float>(a.z3), M->at<float>(a.out3), M->at<float>(a.st3), rate, site_dec(N, i, 2), s));
   }
   SKF_TRY(dense_fwd(M, L.out, M->at<float>(P.dec[N - 1].out3), Md, M->at<float>(P.logits), 0, s));
   }
@@ -895,7 +937,16 @@ int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s, bool 
 }
 
 int ffn_bwd(SkfModel* M, const DenseP& f1, const DenseP& f2, const float* x_in, const float* h, const float* dy,
-            float* dh, float* dx_acc, int rows, hipStream_t s, const void* hbits) {
+            float* dh, float* dx_acc, int rows, hipStream_t s, const void* hbits, const void* image_t) {
+  if (M->ffn_fused) {       // both input gradients in one launch; the weight gradients read dy / h and x / dh as before
+    SKF_TRY(dense_wgrad(M, f2, h, f2.in, dy, f2.out, rows, s));
+    SKF_TRY(before_write(M, dh, s));
+    SKF_TRY(before_write(M, dx_acc, s));
+    const int* blocks = (M->live16 && rows == M->live_rows) ? M->live16 : nullptr;
+    SKF_TRY(skf_ffn_fused_bwd_f32(rows, M->cfg.d_model, M->cfg.dff, dy, image_t, hbits, dh, dx_acc, 1, blocks, blocks ? 16 : 0,
+                                  M->cfg.gemm_precision, s));
+    return dense_wgrad(M, f1, x_in, f1.in, dh, f1.out, rows, s);
+  }
   SKF_TRY(dense_wgrad(M, f2, h, f2.in, dy, f2.out, rows, s));
   SKF_TRY(dense_dgrad(M, f2, dy, f2.out, rows, dh, f2.in, 0, h, f2.in, s, hbits));
   SKF_TRY(dense_wgrad(M, f1, x_in, f1.in, dh, f1.out, rows, s));
@@ -1002,7 +1053,7 @@ int run_backward(SkfModel* M, hipStream_t s) {
     float* dqkv = M->at<float>(gs.dqkv); float* dkv2 = M->at<float>(gs.dkv2); float* dq2 = M->at<float>(gs.dq2);
     // out3 = LN3(out2 + drop(ffn(out2)))
     SKF_TRY(ln_bwd(M, w.ln3, G, M->at<float>(a.z3), M->at<float>(a.st3), G2, dy3, Md, rate, site_dec(N, i, 2), s));
-    SKF_TRY(ffn_bwd(M, w.f1, w.f2, M->at<float>(a.out2), M->at<float>(a.h), dy3, M->at<float>(gs.dh), G2, Md, s, hbits_of(M, a.hbits, Md)));
+    SKF_TRY(ffn_bwd(M, w.f1, w.f2, M->at<float>(a.out2), M->at<float>(a.h), dy3, M->at<float>(gs.dh), G2, Md, s, hbits_of(M, a.hbits, Md), M->at<char>(a.img[1])));
     // out2 = LN2(out1 + drop(mha2(pre, pre, out1)))
     SKF_TRY(ln_bwd(M, w.ln2, G2, M->at<float>(a.z2), M->at<float>(a.st2), G, dy2, Md, rate, site_dec(N, i, 1), s));
     SKF_TRY(dense_wgrad(M, w.mha2.o, M->at<float>(a.o2), d, dy2, d, Md, s));
@@ -1112,7 +1163,7 @@ int run_backward(SkfModel* M, hipStream_t s) {
     float* dy2 = M->at<float>(gs.dy[0]); float* dy1 = M->at<float>(gs.dy[1]);
     float* dqkv = M->at<float>(gs.dqkv);
     SKF_TRY(ln_bwd(M, w.ln2, G, M->at<float>(a.z2), M->at<float>(a.st2), G2, dy2, Me, rate, site_enc(i, 1), s));
-    SKF_TRY(ffn_bwd(M, w.f1, w.f2, M->at<float>(a.x1), M->at<float>(a.h), dy2, M->at<float>(gs.dh), G2, Me, s, hbits_of(M, a.hbits, Me)));
+    SKF_TRY(ffn_bwd(M, w.f1, w.f2, M->at<float>(a.x1), M->at<float>(a.h), dy2, M->at<float>(gs.dh), G2, Me, s, hbits_of(M, a.hbits, Me), M->at<char>(a.img[1])));
     // last layer of the backward: nothing is left on the main stream to hide a whole layer's weight gradients behind
     // (only the embedding gradient follows), so they go out per sublayer - the step's tail before Adam is one wgrad, not four
     static const bool early_tail = !skf_knob("SKF_NO_EARLY_TAIL");
@@ -1390,7 +1441,7 @@ extern "C" size_t skf_config_size(void) { return sizeof(SkfConfig); }
 
 extern "C" int skf_model_set_flags(SkfModel* M, uint32_t flags) {
   SKF_CHECK_ARG(M, "null model");
-  SKF_CHECK_ARG((flags & ~SKF_MODEL_DECODE_LAYERWISE) == 0, "unknown flag bits");
+  SKF_CHECK_ARG((flags & ~(SKF_MODEL_DECODE_LAYERWISE | SKF_MODEL_FFN_LAUNCHES)) == 0, "unknown flag bits");
   M->flags = flags;
   return SKF_OK;
 }
