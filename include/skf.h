@@ -157,6 +157,18 @@ int skf_ffn_fused_fwd_f32(int M, int d, int dff, const float* x, const void* ima
 int skf_ffn_fused_bwd_f32(int M, int d, int dff, const float* dy, const void* image_t, const void* relu_bits_in,
                           float* dh, float* dx, int accumulate, const int* row_blocks, int row_block_rows,
                           int precision, skf_stream_t stream);
+/* The backward launch starting one step earlier, at the gradient `dout` of the LayerNorm that closes the block
+ * (out = LayerNorm(z), z = x + dropout(ffn(x))): dz = LayerNorm'(dout) from (z, stats, gamma) with the arithmetic of
+ * skf_layernorm_residual_bwd, dy = dropout'(dz) (written: the second Dense's weight gradient reads it), dh as above, and
+ * dx = dz + dh . W1^T (the residual path added in registers; dx is written, not accumulated).  dgamma / dbeta leave as
+ * skf_ffn_fused_ln_partials(M) partial row pairs [n][2][d] in ln_partials - sum them with skf_splitk_reduce(ln_partials, n, 1, 2 * d,
+ * ...) or ride them in a skf_splitk_reduce_batch descriptor like the LayerNorm launch's partials.  Dead row blocks (row_blocks):
+ * dout == 0 there; their dy, dh and dx rows are stored as zeros. */
+int skf_ffn_fused_ln_partials(int M);
+int skf_ffn_fused_bwd_ln_f32(int M, int d, int dff, const float* dout, const float* z, const float* stats, const float* gamma,
+                             float rate, unsigned site, const void* step_state, const void* image_t, const void* relu_bits_in,
+                             float* dy, float* dh, float* dx, float* ln_partials, size_t ln_partials_bytes,
+                             const int* row_blocks, int row_block_rows, int precision, skf_stream_t stream);
 int skf_gemm_wgrad_partial_rows(int M, int N, int K, const float* A, int lda, const float* B, int ldb, int splits,
                                 int with_bias_grad, float* slab, size_t slab_bytes, int* splits_used_host, int precision,
                                 const int* row_blocks, int row_block_rows, skf_stream_t stream);

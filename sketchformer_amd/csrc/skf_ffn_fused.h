@@ -17,6 +17,10 @@ struct FfnFusedParams {
   const float* gamma; const float* beta; float* out; float* stats;   // forward: LayerNorm(z)
   float rate; unsigned site; const void* state;                     // forward: dropout of y (SkfStepState*)
   const int* row_blocks;               // 16-row block list (skf_row_blocks_build) or null
+  // backward with the LayerNorm-backward prologue (ln_dout != null): A is not read; gamma / rate / site / state are the LayerNorm's
+  const float* ln_dout; const float* ln_z; const float* ln_stats;   // gradient of the LayerNorm output, z = x + dropout(y), (mean, rstd)
+  float* ln_dy;                        // dy = dropout'(LayerNorm'(dout)) [M][128] (the second Dense's weight gradient reads it)
+  float* ln_part;                      // [gridDim.x][2][128] partial column sums (dgamma, dbeta)
 };
 
 // pieces = 3 (six products) or 2 (three products); direction 0 forward, 1 backward

@@ -173,9 +173,13 @@ __device__ __forceinline__ float ffn_half_wave_sum(float v) {
   return v + __shfl_xor(v, 16, 64);      // the neighbouring row: one ds_bpermute
 }
 
-// MODE 0 forward, 1 backward
-template <int P, int MODE>
+// MODE 0 forward, 1 backward.  LNB (backward only): the launch starts at the gradient of the LayerNorm OUTPUT - the rows it stages are
+// dy = dropout'(dz), dz = LayerNorm'(dout) (skf_rowops.hip ln_bwd_v4_kernel, same arithmetic), formed on the way to LDS; dy goes
+// to global memory for the weight gradient, dz stays in registers and closes the block as dx = dz + dh.W1^T, the column sums of
+// dout o xhat and dout (dgamma, dbeta) leave as one partial row pair per workgroup.
+template <int P, int MODE, bool LNB = false>
 __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnFusedParams p) {
+  static_assert(!LNB || MODE == 1, "LayerNorm-backward prologue: backward only");
   extern __shared__ __attribute__((aligned(16))) char smem_f[];
   char* Xp = smem_f;                     // [P][ROWS][256]
   char* Hp = smem_f + P * PLANE;         // [2][P][ROWS][256]
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnFusedParams p) {
   float inv_keep = 1.f;
   uint32_t thresh = 0u, sk = 0u;
   f32x4 gm = (f32x4){0.f, 0.f, 0.f, 0.f}, bt = gm;
-  if constexpr (MODE == 0) {
+  if constexpr (MODE == 0 || LNB) {
     if (p.rate > 0.f) {
       typedef const __attribute__((address_space(4))) uint32_t* const_u32p;
       const uint32_t key = *(const_u32p)&reinterpret_cast<const SkfStepState*>(p.state)->drop_key;
@@ -236,8 +240,9 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnFusedParams p) {
       inv_keep = 1.0f / (1.0f - p.rate);
     }
     gm = *reinterpret_cast<const f32x4*>(p.gamma + 4 * e_sub);
-    bt = *reinterpret_cast<const f32x4*>(p.beta + 4 * e_sub);
+    if constexpr (MODE == 0) bt = *reinterpret_cast<const f32x4*>(p.beta + 4 * e_sub);
   }
+  f32x4 ln_dg = (f32x4){0.f, 0.f, 0.f, 0.f}, ln_db = ln_dg;     // LNB: this thread's columns of dgamma / dbeta over its rows
 
   // ONE descriptor per tensor for the whole launch, the tile in the VGPR offset (rows behind M fall outside and are dropped / read
   // as zeros): a descriptor per (tile, block) was ~20 SALU instructions per tile and kept the kernel spilling SGPRs into VGPR lanes
@@ -246,7 +251,10 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnFusedParams p) {
 #else
   const __amdgpu_buffer_rsrc_t r_H = __builtin_amdgcn_make_buffer_rsrc(p.H, 0, p.M * (FF * 4), 0x00020000);
 #endif
-  const __amdgpu_buffer_rsrc_t r_A = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, p.M * p.lda * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_A = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(LNB ? p.ln_dout : p.A), 0, p.M * p.lda * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_Z = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(LNB ? p.ln_z : p.A), 0, LNB ? p.M * (FD * 4) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_S = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(LNB ? p.ln_stats : p.A), 0, LNB ? p.M * 8 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_DY = __builtin_amdgcn_make_buffer_rsrc(LNB ? p.ln_dy : p.H, 0, LNB ? p.M * (FD * 4) : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_bits = __builtin_amdgcn_make_buffer_rsrc(MODE == 0 && p.bits_out ? (void*)p.bits_out : (void*)p.H, 0,
                                                                           MODE == 0 && p.bits_out ? ntiles * (NBLK * 8 * 32) : 0, 0x00020000);
   const unsigned bits_voff = lane < 4 ? (unsigned)lane * 8u : OOB;
@@ -259,6 +267,8 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnFusedParams p) {
   // the next one under the current one's last hidden block).  In the forward they are also the residual of the epilogue, whose
   // (row, float4) -> thread map is the same: re-requested there (L2) rather than held in 16 registers across the blocks.
   f32x4 xn[MAXRT];
+  f32x4 zn[LNB ? MAXRT : 1];       // LNB: the z rows and (mean, rstd) of the same rows
+  u32x2 sn[LNB ? MAXRT : 1];
   int tn[MAXRT];
   auto sub_tiles = [&](int pos0, int sub_i, int (&t)[MAXRT]) -> int {     // even split of what is left -> tile ids, count
     const int left = count - (pos0 - pos_begin);
@@ -269,8 +279,14 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnFusedParams p) {
   };
   auto request_rows = [&](const int (&t)[MAXRT], f32x4 (&x)[MAXRT]) {
 #pragma unroll
-    for (int rt = 0; rt < MAXRT; ++rt)
-      x[rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_A, t[rt] < ntiles ? st_voff + (unsigned)t[rt] * (unsigned)(TR * p.lda * 4) : OOB, 0, 0));
+    for (int rt = 0; rt < MAXRT; ++rt) {
+      const unsigned voff = t[rt] < ntiles ? st_voff + (unsigned)t[rt] * (unsigned)(TR * p.lda * 4) : OOB;
+      x[rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_A, voff, 0, 0));
+      if constexpr (LNB) {
+        zn[rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_Z, voff, 0, 0));
+        sn[rt] = __builtin_amdgcn_raw_buffer_load_b64(r_S, t[rt] < ntiles ? (unsigned)(t[rt] * TR + st_row) * 8u : OOB, 0, 0);
+      }
+    }
   };
   int pos = pos_begin;
   int nrt_next = sub_tiles(pos, 0, tn);
@@ -289,8 +305,31 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnFusedParams p) {
     constexpr int NRT = MAXRT;
     constexpr int TILE = TR * RPITCH;
     // ---- stage the A rows: registers -> P planes in LDS
+    f32x4 dzr[LNB ? NRT : 1];
 #pragma unroll
     for (int rt = 0; rt < NRT; ++rt) {
+      if constexpr (LNB) {
+        // LayerNorm backward of this thread's float4 of row (tile rt, st_row); rows outside the matrix / absent tiles read as zeros
+        const f32x4 dv = xn[rt], zv = zn[rt];
+        // (whole-vector cast: __builtin_bit_cast on ONE element of an ext_vector yields element 0 with this compiler)
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        const f32x2_t ms = __builtin_bit_cast(f32x2_t, sn[rt]);
+        const float mean = ms[0], rstd = ms[1];
+        const f32x4 xh = (zv - mean) * rstd, gg = dv * gm;
+        ln_dg += dv * xh; ln_db += dv;
+        const float s1 = ffn_half_wave_sum((gg[0] + gg[1]) + (gg[2] + gg[3])) * (1.0f / FD);
+        const float s2 = ffn_half_wave_sum((gg[0] * xh[0] + gg[1] * xh[1]) + (gg[2] * xh[2] + gg[3] * xh[3])) * (1.0f / FD);
+        const f32x4 gz = rstd * (gg - s1 - xh * s2);
+        dzr[rt] = gz;
+        f32x4 gy = gz;
+        const unsigned voff = tl[rt] < ntiles ? st_voff + (unsigned)tl[rt] * (unsigned)(TR * FD * 4) : OOB;
+        if (p.rate > 0.f) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) gy[e] = gz[e] * (skf_keep(sk, (voff >> 2) + e, thresh) ? inv_keep : 0.f);
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, gy), r_DY, voff, 0, 0);
+        xn[rt] = gy;
+      }
       unsigned lo[P], hi[P];
       skf_split2<P>(xn[rt][0], xn[rt][1], lo, sel);
       skf_split2<P>(xn[rt][2], xn[rt][3], hi, sel);
@@ -453,7 +492,8 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnFusedParams p) {
       } else {
         if (ok) {
           f32x4 v = yv;
-          if (p.accumulate) v += *reinterpret_cast<const f32x4*>(p.C + off);
+          if constexpr (LNB) v += dzr[rt];
+          else if (p.accumulate) v += *reinterpret_cast<const f32x4*>(p.C + off);
           *reinterpret_cast<f32x4*>(p.C + off) = v;
         }
       }
@@ -475,10 +515,32 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnFusedParams p) {
         const int e = tid + v * 512, row = tile * TR + e / (FF / 4), c4 = (e % (FF / 4)) * 4;
         if (row < p.M) *reinterpret_cast<f32x4*>(p.H + (size_t)row * FF + c4) = zero;
       }
-      if (!p.accumulate) {
+      if (LNB || !p.accumulate) {
         const int row = tile * TR + (tid >> 5);
-        if (row < p.M) *reinterpret_cast<f32x4*>(p.C + (size_t)row * FD + 4 * (tid & 31)) = zero;
+        if (row < p.M) {
+          *reinterpret_cast<f32x4*>(p.C + (size_t)row * FD + 4 * (tid & 31)) = zero;
+          if constexpr (LNB) *reinterpret_cast<f32x4*>(p.ln_dy + (size_t)row * FD + 4 * (tid & 31)) = zero;
+        }
       }
+    }
+  }
+  if constexpr (LNB) {
+    // dgamma / dbeta partials of this workgroup: the two rows of a wave, then the eight waves through LDS -> part[wg][2][FD]
+    // (every workgroup writes its pair, also one without tiles: the batched reduction reads gridDim.x of them)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { ln_dg[e] += __shfl_xor(ln_dg[e], 32, 64); ln_db[e] += __shfl_xor(ln_db[e], 32, 64); }
+    float* red = reinterpret_cast<float*>(smem_f);       // [8 waves][2][FD]
+    __syncthreads();
+    if (lane < 32) {
+      *reinterpret_cast<f32x4*>(red + (wave * 2 + 0) * FD + 4 * lane) = ln_dg;
+      *reinterpret_cast<f32x4*>(red + (wave * 2 + 1) * FD + 4 * lane) = ln_db;
+    }
+    __syncthreads();
+    if (tid < 2 * FD) {
+      float t = red[tid];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) t += red[k * 2 * FD + tid];
+      p.ln_part[(size_t)wg * 2 * FD + tid] = t;
     }
   }
 }
@@ -494,24 +556,28 @@ int n_cus() {
   return n;
 }
 
-template <int P, int MODE>
+int ffn_grid(int M) {
+  const int ntiles = skf_cdiv(M, TR);
+  const int g = n_cus();
+  return g > ntiles ? ntiles : g;
+}
+
+template <int P, int MODE, bool LNB = false>
 int launch_ffn(const FfnFusedParams& p, hipStream_t st) {
-  const int ntiles = skf_cdiv(p.M, TR);
-  int grid = n_cus();
-  if (grid > ntiles) grid = ntiles;
+  const int grid = ffn_grid(p.M);
   const size_t smem = (size_t)3 * P * PLANE + (P * PLANE >= ROWS * YPITCH * 4 ? 0 : ROWS * YPITCH * 4) + FF * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fused_kernel<P, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fused_kernel<P, MODE, LNB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_done = true;
   }
-  static const std::string tag = std::string(MODE == 0 ? "ffn_fused_fwd" : "ffn_fused_bwd") + "<d128,dff512,bf16x" + std::to_string(P * (P + 1) / 2) + ">";
+  static const std::string tag = std::string(MODE == 0 ? "ffn_fused_fwd" : LNB ? "ffn_fused_bwd_ln" : "ffn_fused_bwd") + "<d128,dff512,bf16x" + std::to_string(P * (P + 1) / 2) + ">";
   const double live = skf_prof_list_fraction(p.row_blocks);
   const double flops = 2.0 * 2.0 * p.M * FD * FF;
   const double bytes = 4.0 * ((double)p.M * FD * (MODE == 0 ? 4 : 3) + (double)p.M * FF) + 2.0 * image_bytes(P) / 2;
   SkfProfScope ps(st, tag.c_str(), flops, bytes);
   ps.done(flops * live, bytes * live);
-  hipLaunchKernelGGL((ffn_fused_kernel<P, MODE>), dim3(grid), dim3(512), smem, st, p);
+  hipLaunchKernelGGL((ffn_fused_kernel<P, MODE, LNB>), dim3(grid), dim3(512), smem, st, p);
   SKF_LAUNCH_CHECK();
   return SKF_OK;
 }
@@ -519,6 +585,7 @@ int launch_ffn(const FfnFusedParams& p, hipStream_t st) {
 }  // namespace
 
 int skf_ffn_fused_launch(const FfnFusedParams& p, int pieces, int direction, hipStream_t st) {
+  if (direction == 1 && p.ln_dout) return pieces == 2 ? launch_ffn<2, 1, true>(p, st) : launch_ffn<3, 1, true>(p, st);
   if (pieces == 2) return direction == 0 ? launch_ffn<2, 0>(p, st) : launch_ffn<2, 1>(p, st);
   return direction == 0 ? launch_ffn<3, 0>(p, st) : launch_ffn<3, 1>(p, st);
 }
@@ -599,5 +666,30 @@ extern "C" int skf_ffn_fused_bwd_f32(int M, int d, int dff, const float* dy, con
   p.img1 = (const char*)image_t; p.img2 = (const char*)image_t + image_bytes(P) / 2;
   p.H = dh; p.bits_in = (const unsigned long long*)relu_bits_in;
   p.C = dx; p.accumulate = accumulate; p.row_blocks = row_blocks;
+  return skf_ffn_fused_launch(p, P, 1, (hipStream_t)stream);
+}
+
+extern "C" int skf_ffn_fused_ln_partials(int M) { return ffn_grid(M); }
+
+extern "C" int skf_ffn_fused_bwd_ln_f32(int M, int d, int dff, const float* dout, const float* z, const float* stats, const float* gamma,
+                                        float rate, unsigned site, const void* step_state, const void* image_t, const void* relu_bits_in,
+                                        float* dy, float* dh, float* dx, float* ln_partials, size_t ln_partials_bytes,
+                                        const int* row_blocks, int row_block_rows, int precision, skf_stream_t stream) {
+  const int rc = ffn_common_checks(M, d, dff, precision, dout, image_t, dh, dx);
+  if (rc != SKF_OK) return rc;
+  SKF_CHECK_ARG(z && stats && gamma && dy && ln_partials, "null LayerNorm operand");
+  SKF_CHECK_ARG((((uintptr_t)z | (uintptr_t)gamma | (uintptr_t)dy | (uintptr_t)ln_partials) & 15) == 0 && ((uintptr_t)stats & 7) == 0, "operands must be 16-byte aligned");
+  SKF_CHECK_ARG(relu_bits_in && ((uintptr_t)relu_bits_in & 7) == 0, "the backward needs the sign bits the forward wrote");
+  SKF_CHECK_ARG(rate >= 0.f && rate < 1.f && (rate == 0.f || step_state), "dropout needs 0 <= rate < 1 and the step state");
+  SKF_CHECK_ARG(!row_blocks || row_block_rows == TR, "row-block lists of this kernel have 16-row blocks");
+  SKF_CHECK_ARG(ln_partials_bytes >= (size_t)ffn_grid(M) * 2 * FD * sizeof(float), "partial buffer too small (skf_ffn_fused_ln_partials(M) x 2 x d floats)");
+  const int P = precision == SKF_PREC_BF16X3 ? 2 : 3;
+  FfnFusedParams p{};
+  p.A = dout; p.lda = d; p.M = M;
+  p.img1 = (const char*)image_t; p.img2 = (const char*)image_t + image_bytes(P) / 2;
+  p.H = dh; p.bits_in = (const unsigned long long*)relu_bits_in;
+  p.C = dx; p.accumulate = 0; p.row_blocks = row_blocks;
+  p.gamma = gamma; p.rate = rate; p.site = site; p.state = step_state;
+  p.ln_dout = dout; p.ln_z = z; p.ln_stats = stats; p.ln_dy = dy; p.ln_part = ln_partials;
   return skf_ffn_fused_launch(p, P, 1, (hipStream_t)stream);
 }

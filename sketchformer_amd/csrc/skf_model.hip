@@ -954,6 +954,24 @@ int ffn_bwd(SkfModel* M, const DenseP& f1, const DenseP& f2, const float* x_in, 
   return SKF_OK;
 }
 
+// `splits` partial row pairs [splits][2][d] of a LayerNorm's (dgamma, dbeta) -> one descriptor of the batched split-K reduction
+int ln_partials_desc(SkfModel* M, const LnP& ln, const float* part, int splits) {
+  const int d = M->cfg.d_model;
+  SkfReduceDesc r;
+  r.slab = part; r.C = M->G(ln.g); r.bias_grad = nullptr; r.splits = splits; r.M = 1; r.N = 2 * d;
+  r.ldc = 2 * d; r.block_begin = M->reduce_blocks; r.pad = 0;
+  if (!M->descs_uploaded) M->descs.push_back(r);
+  else {
+    const SkfReduceDesc& o = M->descs[M->desc_cursor];
+    SKF_CHECK_ARG(o.slab == r.slab && o.C == r.C && o.splits == r.splits && o.block_begin == r.block_begin, "reduction sequence changed between steps");
+  }
+  M->reduce_blocks += skf_splitk_reduce_blocks(1, 2 * d);
+  M->desc_cursor += 1;
+  M->ln_cursor += 1;
+  M->side_used = true;
+  return SKF_OK;
+}
+
 int ln_bwd(SkfModel* M, const LnP& ln, const float* dout, const float* z, const float* st, float* dz, float* dy,
            int rows, float rate, unsigned site, hipStream_t s) {
   const Plan& P = M->plan;
@@ -973,19 +991,34 @@ int ln_bwd(SkfModel* M, const LnP& ln, const float* dout, const float* z, const 
   const size_t bytes = skf_layernorm_bwd_workspace_bytes(rows, d);
   SKF_TRY(skf_layernorm_residual_bwd_rows(dout, z, st, M->P(ln.g), dz, dy, nullptr, nullptr, rows, d, rate, site, M->state, part,
                                           bytes, ll, rps, s));
-  SkfReduceDesc r;
-  r.slab = part; r.C = M->G(ln.g); r.bias_grad = nullptr; r.splits = (int)(bytes / (8 * (size_t)d)); r.M = 1; r.N = 2 * d;
-  r.ldc = 2 * d; r.block_begin = M->reduce_blocks; r.pad = 0;
-  if (!M->descs_uploaded) M->descs.push_back(r);
-  else {
-    const SkfReduceDesc& o = M->descs[M->desc_cursor];
-    SKF_CHECK_ARG(o.slab == r.slab && o.C == r.C && o.splits == r.splits && o.block_begin == r.block_begin, "reduction sequence changed between steps");
+  return ln_partials_desc(M, ln, part, (int)(bytes / (8 * (size_t)d)));
+}
+
+// Both input gradients of a feed-forward block AND the backward of the LayerNorm that closes it in one launch
+// (skf_ffn_fused_bwd_ln_f32), where that kernel exists and its dgamma / dbeta partials can ride in the batched reduction;
+// otherwise the LayerNorm launch followed by ffn_bwd.  dout: gradient of the LayerNorm output; dx = dz + d(ffn input) is WRITTEN.
+int ffn_ln_bwd(SkfModel* M, const LnP& ln, const DenseP& f1, const DenseP& f2, const float* dout, const float* z, const float* st,
+               const float* x_in, const float* h, float* dy, float* dh, float* dx, int rows, float rate, unsigned site, hipStream_t s,
+               const void* hbits, const void* image_t) {
+  const Plan& P = M->plan;
+  const int d = M->cfg.d_model;
+  static const bool ln_off = skf_knob("SKF_NO_FFN_LN_BWD") && skf_knob("SKF_NO_FFN_LN_BWD")[0] == '1';   // (measurement builds only)
+  const size_t pbytes = (size_t)skf_ffn_fused_ln_partials(rows) * 2 * d * sizeof(float);
+  if (ln_off || !M->ffn_fused || !M->side || ln.b != ln.g + (size_t)d || pbytes > P.ln_part_stride) {
+    SKF_TRY(ln_bwd(M, ln, dout, z, st, dx, dy, rows, rate, site, s));
+    return ffn_bwd(M, f1, f2, x_in, h, dy, dh, dx, rows, s, hbits, image_t);
   }
-  M->reduce_blocks += skf_splitk_reduce_blocks(1, 2 * d);
-  M->desc_cursor += 1;
-  M->ln_cursor += 1;
-  M->side_used = true;
-  return SKF_OK;
+  SKF_CHECK_ARG(M->ln_cursor < 5 * (size_t)M->cfg.num_layers && M->desc_cursor < P.n_wgrads, "LayerNorm partial arena exhausted");
+  float* part = M->at<float>(P.ln_part + M->ln_cursor * P.ln_part_stride);
+  SKF_TRY(before_write(M, dy, s));
+  SKF_TRY(before_write(M, dh, s));
+  SKF_TRY(before_write(M, dx, s));
+  const int* blocks = (M->live16 && rows == M->live_rows) ? M->live16 : nullptr;
+  SKF_TRY(skf_ffn_fused_bwd_ln_f32(rows, d, M->cfg.dff, dout, z, st, M->P(ln.g), rate, site, M->state, image_t, hbits, dy, dh, dx, part,
+                                   pbytes, blocks, blocks ? 16 : 0, M->cfg.gemm_precision, s));
+  SKF_TRY(ln_partials_desc(M, ln, part, skf_ffn_fused_ln_partials(rows)));
+  SKF_TRY(dense_wgrad(M, f2, h, f2.in, dy, f2.out, rows, s));
+  return dense_wgrad(M, f1, x_in, f1.in, dh, f1.out, rows, s);
 }
 
 // Row-block lists of the decoder-side backward (token mode, split arithmetic only: the fp32-MFMA kernels ignore them)
@@ -1052,8 +1085,8 @@ int run_backward(SkfModel* M, hipStream_t s) {
     float* dy3 = M->at<float>(gs.dy[0]); float* dy2 = M->at<float>(gs.dy[1]); float* dy1 = M->at<float>(gs.dy[2]);
     float* dqkv = M->at<float>(gs.dqkv); float* dkv2 = M->at<float>(gs.dkv2); float* dq2 = M->at<float>(gs.dq2);
     // out3 = LN3(out2 + drop(ffn(out2)))
-    SKF_TRY(ln_bwd(M, w.ln3, G, M->at<float>(a.z3), M->at<float>(a.st3), G2, dy3, Md, rate, site_dec(N, i, 2), s));
-    SKF_TRY(ffn_bwd(M, w.f1, w.f2, M->at<float>(a.out2), M->at<float>(a.h), dy3, M->at<float>(gs.dh), G2, Md, s, hbits_of(M, a.hbits, Md), M->at<char>(a.img[1])));
+    SKF_TRY(ffn_ln_bwd(M, w.ln3, w.f1, w.f2, G, M->at<float>(a.z3), M->at<float>(a.st3), M->at<float>(a.out2), M->at<float>(a.h), dy3,
+                       M->at<float>(gs.dh), G2, Md, rate, site_dec(N, i, 2), s, hbits_of(M, a.hbits, Md), M->at<char>(a.img[1])));
     // out2 = LN2(out1 + drop(mha2(pre, pre, out1)))
     SKF_TRY(ln_bwd(M, w.ln2, G2, M->at<float>(a.z2), M->at<float>(a.st2), G, dy2, Md, rate, site_dec(N, i, 1), s));
     SKF_TRY(dense_wgrad(M, w.mha2.o, M->at<float>(a.o2), d, dy2, d, Md, s));
@@ -1162,8 +1195,8 @@ int run_backward(SkfModel* M, hipStream_t s) {
     const Plan::GradSet& gs = P.gs[layer_no & 1];
     float* dy2 = M->at<float>(gs.dy[0]); float* dy1 = M->at<float>(gs.dy[1]);
     float* dqkv = M->at<float>(gs.dqkv);
-    SKF_TRY(ln_bwd(M, w.ln2, G, M->at<float>(a.z2), M->at<float>(a.st2), G2, dy2, Me, rate, site_enc(i, 1), s));
-    SKF_TRY(ffn_bwd(M, w.f1, w.f2, M->at<float>(a.x1), M->at<float>(a.h), dy2, M->at<float>(gs.dh), G2, Me, s, hbits_of(M, a.hbits, Me), M->at<char>(a.img[1])));
+    SKF_TRY(ffn_ln_bwd(M, w.ln2, w.f1, w.f2, G, M->at<float>(a.z2), M->at<float>(a.st2), M->at<float>(a.x1), M->at<float>(a.h), dy2,
+                       M->at<float>(gs.dh), G2, Me, rate, site_enc(i, 1), s, hbits_of(M, a.hbits, Me), M->at<char>(a.img[1])));
     // last layer of the backward: nothing is left on the main stream to hide a whole layer's weight gradients behind
     // (only the embedding gradient follows), so they go out per sublayer - the step's tail before Adam is one wgrad, not four
     static const bool early_tail = !skf_knob("SKF_NO_EARLY_TAIL");

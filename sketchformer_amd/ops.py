@@ -288,6 +288,22 @@ def ffn_fused_bwd(dy, image_t, bits, dff, dx=None, row_blocks=None, precision=No
     return dh, dx
 
 
+def ffn_fused_bwd_ln(dout, z, stats, gamma, image_t, bits, dff, rate=0.0, site=0, state=None, row_blocks=None, precision=None):
+    """One launch from the gradient of the closing LayerNorm's output: -> dy, dh, dx (= dz + dh.W1^T), dgamma, dbeta."""
+    _f32(dout, "dout")
+    M, d = dout.shape
+    lib = _lib.load()
+    n = lib.skf_ffn_fused_ln_partials(M)
+    part = torch.empty(n, 2, d, dtype=torch.float32, device=dout.device)
+    dy, dx = torch.empty_like(dout), torch.empty_like(dout)
+    dh = torch.empty(M, dff, dtype=torch.float32, device=dout.device)
+    _lib.call("skf_ffn_fused_bwd_ln_f32", M, d, dff, _p(dout), _p(z), _p(stats), _p(gamma), rate, site, _p(state), _p(image_t), _p(bits),
+              _p(dy), _p(dh), _p(dx), _p(part), part.numel() * 4, _p(row_blocks), 16 if row_blocks is not None else 0, _prec(precision),
+              _stream())
+    g = part.sum(0)
+    return dy, dh, dx, g[0], g[1]
+
+
 def layernorm_residual_bwd(dout, z, stats, gamma, rate=0.0, site=0, state=None):
     d = dout.shape[-1]
     rows = dout.numel() // d

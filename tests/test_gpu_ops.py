@@ -877,6 +877,52 @@ def test_ffn_fused_backward(ops, rows, listed, acc):
         assert (gdh - dh2).abs().max().item() <= 2e-6 * max(1.0, dh2.abs().max().item())
 
 
+@pytest.mark.parametrize("rows,listed,rate", [(25472, True, 0.1), (25600, False, 0.1), (1031, False, 0.0), (3184, True, 0.0), (7, False, 0.1)])
+def test_ffn_fused_backward_from_layernorm_gradient(ops, rows, listed, rate):
+    """The backward launch with the LayerNorm-backward prologue: dz = LN'(dout), dy = dropout'(dz), dh, dx = dz + dh.W1^T, dgamma, dbeta
+    against the oracle / float64, and against the LayerNorm launch + plain fused launch it replaces."""
+    d, dff = 128, 512
+    rng = np.random.RandomState(rows + 2)
+    x = rng.randn(rows, d)
+    w1, b1 = rng.randn(d, dff) / np.sqrt(d), 0.1 * rng.randn(dff)
+    w2, b2 = rng.randn(dff, d) / np.sqrt(dff), 0.1 * rng.randn(d)
+    gamma, beta = 1 + 0.1 * rng.randn(d), 0.1 * rng.randn(d)
+    dout = rng.randn(rows, d)
+    blocks = None
+    if listed:
+        Ld = 199
+        B = rows // Ld
+        live = rng.randint(0, Ld + 1, size=B).astype(np.int32)
+        live[0] = 0; live[-1] = Ld
+        for b in range(B):
+            dout[b * Ld + live[b]:(b + 1) * Ld] = 0.0
+        blocks = ops.row_blocks(_dev(live, torch.int32), Ld, 16)
+    st = ops.new_step_state("cuda", iterations=3)
+    ops.step_prologue(st, seed=5)
+    X, W1, B1, W2, B2, G, Be = _dev(x), _dev(w1), _dev(b1), _dev(w2), _dev(b2), _dev(gamma), _dev(beta)
+    img, = ops.ffn_weight_images([(W1, W2)], transpose=False)
+    imgt, = ops.ffn_weight_images([(W1, W2)], transpose=True)
+    out, zz, stats, hh, bits = ops.ffn_fused_fwd(X, img, B1, B2, G, Be, dff, rate=rate, site=9, state=st)
+    keep = np.ones((rows, d), bool)
+    if rate > 0:
+        keep = ops.dropout_keep_mask(ops.read_step_state(st)["drop_key"], 9, rate, rows * d).reshape(rows, d)
+    z64 = zz.cpu().numpy().astype(np.float64)
+    _, cache = oracle.layernorm_fwd(z64, gamma, beta)
+    dz, dg, db = oracle.layernorm_bwd(dout, cache)
+    dy = dz * keep / (1.0 - rate)
+    dh = (dy @ w2.T) * (hh.cpu().numpy() > 0)
+    dx = dz + dh @ w1.T
+    gdy, gdh, gdx, gdg, gdb = ops.ffn_fused_bwd_ln(_dev(dout), zz, stats, G, imgt, bits, dff, rate=rate, site=9, state=st, row_blocks=blocks)
+    _close(gdy, dy, rtol=5e-5, name="dy")
+    _close(gdh, dh, rtol=5e-5, name="dh")
+    _close(gdx, dx, rtol=5e-5, name="dx")
+    _close(gdg, dg, rtol=5e-5, name="dgamma")
+    _close(gdb, db, rtol=5e-5, name="dbeta")
+    if rows > 2048 and not listed:
+        rdz, rdy, _, _ = ops.layernorm_residual_bwd(_dev(dout), zz, stats, G, rate=rate, site=9, state=st)
+        assert (gdy - rdy).abs().max().item() <= 2e-6 * max(1.0, rdy.abs().max().item())
+
+
 def test_ffn_fused_refuses_other_shapes(ops):
     lib = ops._lib.load()
     assert lib.skf_ffn_fused_supported(25600, 128, 512, 6) == 1
