@@ -457,6 +457,7 @@ struct SkfModel {
   bool lists_built = false;             // this step's lists are in P.live16 / P.live32 (issued, not necessarily complete)
   std::map<const void*, SideEvent> pending_writers;    // buffers a side-stream dgrad still writes
   std::vector<QueuedWgrad> wq;                         // wgrads of the current layer, not yet issued
+  std::vector<QueuedWgrad> wq_held;                    // the PREVIOUS layer's group, held back until the next layer's first kernel is queued (hold_wgrads)
   bool side_used = false;
   std::vector<SkfReduceDesc> descs;     // one per wgrad of the step, in launch order
   bool descs_uploaded = false;
@@ -544,11 +545,13 @@ int dense_wgrad_on(SkfModel* M, const DenseP& w, const float* x, int ldx, const 
                       M->G(w.b), 0, M->at<char>(M->plan.gemm_ws), M->plan.gemm_ws_bytes, M->cfg.gemm_precision, s);
 }
 int issue_wgrads(SkfModel* M, hipStream_t s);
+int issue_held_wgrads(SkfModel* M, hipStream_t s);
 // Main-stream kernels that overwrite `buf` must first wait for the side-stream wgrad that still reads it
 // (a wgrad that is still queued is issued first; with the alternating gradient-buffer sets this is the rare case).
 int before_write(SkfModel* M, const void* buf, hipStream_t s) {
-  for (const auto& q : M->wq)
-    if (q.dy == buf || q.x == buf) { SKF_TRY(issue_wgrads(M, s)); break; }
+  for (const auto* qs : {&M->wq_held, &M->wq})
+    for (const auto& q : *qs)
+      if (q.dy == buf || q.x == buf) { SKF_TRY(issue_wgrads(M, s)); break; }
   auto it = M->pending_readers.find(buf);
   if (it == M->pending_readers.end()) return SKF_OK;
   if (it->second.seq > M->side_waited || M->no_wait_dedupe) {
@@ -568,8 +571,9 @@ int dense_wgrad(SkfModel* M, const DenseP& w, const float* x, int ldx, const flo
 }
 // Main-stream kernels that read `buf` first wait for the side-stream dgrad that writes it.
 int before_read(SkfModel* M, const void* buf, hipStream_t s) {
-  for (const auto& q : M->wq)
-    if (q.kind == 1 && q.dx == buf) { SKF_TRY(issue_wgrads(M, s)); break; }
+  for (const auto* qs : {&M->wq_held, &M->wq})
+    for (const auto& q : *qs)
+      if (q.kind == 1 && q.dx == buf) { SKF_TRY(issue_wgrads(M, s)); break; }
   auto it = M->pending_writers.find(buf);
   if (it == M->pending_writers.end()) return SKF_OK;
   if (it->second.seq > M->side_waited || M->no_wait_dedupe) {
@@ -581,7 +585,34 @@ int before_read(SkfModel* M, const void* buf, hipStream_t s) {
 }
 // Issue the queued wgrads on the side stream: ONE ready event (everything queued on `s` so far is complete before they
 // start) and ONE done event for the whole group; they are serialized among themselves and joined before the optimizer.
+// The fused feed-forward backward is the FIRST kernel of a layer's backward, and its workgroups (147 KB of LDS, two waves per SIMD)
+// cannot share a CU with a weight-gradient workgroup (66 KB, 272 registers): issued together - the previous layer's group on the side
+// stream, the block on the main stream - they ran one after the other (134 + 136 us where 45 + 100 were expected, per layer).  So a
+// layer's group is HELD at the end of the layer and goes out right behind the next layer's first launch: it then runs beside the
+// LayerNorm / projection / attention kernels of that layer, which share CUs with it well.
+int issue_held_wgrads(SkfModel* M, hipStream_t s) {
+  if (M->wq_held.empty()) return SKF_OK;
+  std::vector<SkfModel::QueuedWgrad> cur;
+  cur.swap(M->wq);
+  M->wq.swap(M->wq_held);
+  const int rc = issue_wgrads(M, s);
+  M->wq.swap(cur);
+  return rc;
+}
+int hold_wgrads(SkfModel* M, hipStream_t s) {
+  if (!M->wq_held.empty()) SKF_TRY(issue_wgrads(M, s));       // (never two groups held)
+  M->wq_held.swap(M->wq);
+  return SKF_OK;
+}
 int issue_wgrads(SkfModel* M, hipStream_t s) {
+  if (!M->wq_held.empty()) {                                   // the held group first, as a group of its own
+    std::vector<SkfModel::QueuedWgrad> cur;
+    cur.swap(M->wq);
+    M->wq.swap(M->wq_held);
+    const int rc = issue_wgrads(M, s);
+    M->wq.swap(cur);
+    if (rc != SKF_OK) return rc;
+  }
   if (M->wq.empty()) return SKF_OK;
   std::vector<SkfModel::QueuedWgrad> group;
   group.swap(M->wq);
@@ -656,8 +687,8 @@ int issue_wgrads(SkfModel* M, hipStream_t s) {
 }
 // Reduce the split-K partials of the wgrads issued since the last flush (one batched launch on the side stream) and
 // mark gradient bucket `bucket` complete.  final = the main stream waits for the side stream (before the optimizer).
-int flush_wgrads(SkfModel* M, hipStream_t s, int bucket, bool final) {
-  SKF_TRY(issue_wgrads(M, s));
+int flush_wgrads(SkfModel* M, hipStream_t s, int bucket, bool final, bool issue_queued = true) {
+  if (issue_queued) SKF_TRY(issue_wgrads(M, s));      // (false: reduce what has been issued; queued / held groups stay where they are)
   const size_t begin = M->phase_desc_begin, end = M->desc_cursor;
   hipStream_t ready_on = s;
   if (M->side && M->side_used && end > begin) {
@@ -945,6 +976,7 @@ int ffn_bwd(SkfModel* M, const DenseP& f1, const DenseP& f2, const float* x_in, 
     const int* blocks = (M->live16 && rows == M->live_rows) ? M->live16 : nullptr;
     SKF_TRY(skf_ffn_fused_bwd_f32(rows, M->cfg.d_model, M->cfg.dff, dy, image_t, hbits, dh, dx_acc, 1, blocks, blocks ? 16 : 0,
                                   M->cfg.gemm_precision, s));
+    SKF_TRY(issue_held_wgrads(M, s));
     return dense_wgrad(M, f1, x_in, f1.in, dh, f1.out, rows, s);
   }
   SKF_TRY(dense_wgrad(M, f2, h, f2.in, dy, f2.out, rows, s));
@@ -1017,6 +1049,7 @@ int ffn_ln_bwd(SkfModel* M, const LnP& ln, const DenseP& f1, const DenseP& f2, c
   SKF_TRY(skf_ffn_fused_bwd_ln_f32(rows, d, M->cfg.dff, dout, z, st, M->P(ln.g), rate, site, M->state, image_t, hbits, dy, dh, dx, part,
                                    pbytes, blocks, blocks ? 16 : 0, M->cfg.gemm_precision, s));
   SKF_TRY(ln_partials_desc(M, ln, part, skf_ffn_fused_ln_partials(rows)));
+  SKF_TRY(issue_held_wgrads(M, s));      // the previous layer's weight gradients: behind this launch (see hold_wgrads)
   SKF_TRY(dense_wgrad(M, f2, h, f2.in, dy, f2.out, rows, s));
   return dense_wgrad(M, f1, x_in, f1.in, dh, f1.out, rows, s);
 }
@@ -1057,7 +1090,7 @@ int run_backward(SkfModel* M, hipStream_t s) {
   float* dO = M->at<float>(P.do_);
   float* dpre = M->at<float>(P.dpre);
   float* demb = M->at<float>(P.demb);
-  M->wq.clear();
+  M->wq.clear(); M->wq_held.clear();
   int layer_no = 0;     // running layer counter: picks the gradient-buffer set
 
   const bool bott = has_bott(c), cls = has_cls(c), recon = do_recon(c);
@@ -1118,7 +1151,10 @@ int run_backward(SkfModel* M, hipStream_t s) {
     SKF_TRY(dense_wgrad(M, w.mha1.qkv, M->at<float>(a.x_in), d, dqkv, 3 * d, Md, s));
     SKF_TRY(dense_dgrad(M, w.mha1.qkv, dqkv, 3 * d, Md, G2, d, 1, nullptr, 0, s));
     float* t = G; G = G2; G2 = t;
-    SKF_TRY(issue_wgrads(M, s));          // the 8 weight gradients of this layer: one event pair
+    // the 8 weight gradients of this layer: one event pair - held until the next layer's fused feed-forward launch is queued
+    static const bool hold_off = skf_knob("SKF_NO_WGRAD_HOLD") && skf_knob("SKF_NO_WGRAD_HOLD")[0] == '1';   // (measurement builds only)
+    if (M->ffn_fused && i > 0 && !hold_off) SKF_TRY(hold_wgrads(M, s));
+    else SKF_TRY(issue_wgrads(M, s));
   }
   M->live16 = M->live32 = nullptr; M->live_rows = 0;
   // decoder embedding
@@ -1215,11 +1251,15 @@ int run_backward(SkfModel* M, hipStream_t s) {
     // to the side stream and the kernel itself then run under that GEMM and the embedding gradient instead of behind them
     if (i == 0 && early_tail) SKF_TRY(issue_wgrads(M, s));
     SKF_TRY(dense_dgrad(M, w.mha.qkv, dqkv, 3 * d, Me, G, d, 1, nullptr, 0, s));
-    SKF_TRY(issue_wgrads(M, s));
+    static const bool hold_off_e = skf_knob("SKF_NO_WGRAD_HOLD") && skf_knob("SKF_NO_WGRAD_HOLD")[0] == '1';
+    if (M->ffn_fused && i > 0 && !hold_off_e) SKF_TRY(hold_wgrads(M, s));
+    else SKF_TRY(issue_wgrads(M, s));
     // half-way through the encoder: the slabs and LayerNorm partials finished so far are reduced on the side stream now, under the
     // remaining layers - the final reduction, which the optimizer waits for on the main stream, shrinks to the last layers' share
+    // (with a held group: only what is already on the side stream - issuing the held group here would put it beside the next layer's
+    //  fused feed-forward launch again)
     static const bool mid_flush = !(skf_knob("SKF_MID_FLUSH") && skf_knob("SKF_MID_FLUSH")[0] == '0');
-    if (mid_flush && M->side && N >= 2 && i == N / 2) SKF_TRY(flush_wgrads(M, s, -1, false));
+    if (mid_flush && M->side && N >= 2 && i == N / 2) SKF_TRY(flush_wgrads(M, s, -1, false, M->wq_held.empty()));
   }
   if (c.continuous) {
     SKF_TRY(skf_embed_continuous_bwd(M->at<float>(P.inp), Le, B, Le, G, d, M->G(L.enc_embd.w), M->G(L.enc_embd.b), rate,
