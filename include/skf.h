@@ -169,6 +169,24 @@ int skf_ffn_fused_bwd_ln_f32(int M, int d, int dff, const float* dout, const flo
                              float rate, unsigned site, const void* step_state, const void* image_t, const void* relu_bits_in,
                              float* dy, float* dh, float* dx, float* ln_partials, size_t ln_partials_bytes,
                              const int* row_blocks, int row_block_rows, int precision, skf_stream_t stream);
+/* Pre-split operand images in general: image j of B_j [K][N] (K % 32 == 0, N % 16 == 0; transpose[j] = 0: B[k][n] = src[k * ld + n],
+ * 1: B[k][n] = src[n * ld + k]), skf_dense_image_bytes(K, N, precision) bytes each, all in one launch per 40 images. */
+size_t skf_dense_image_bytes(int K, int N, int precision);
+int skf_dense_weight_images(int n, const float* const* src, const int* ld, const int* transpose, const int* K, const int* N,
+                            void* const* images, int precision, skf_stream_t stream);
+/* The backward of `out = LayerNorm(x + dropout(Dense(a)))` - the MultiHeadAttention output projection with the residual LayerNorm
+ * behind it (builders/layers/transformer.py:186, 216-224, 258-268) - from the gradient of `out` to the gradient of `a` in ONE launch:
+ *   dz = LayerNorm'(dout) (written: the residual path's gradient), dy = dropout'(dz) (written: the Dense's weight gradient reads it),
+ *   da = dy[M,d] . W^T   (image_t = the transposed image of W [d][d]: skf_dense_weight_images(.., transpose = 1, K = d, N = d))
+ * with the arithmetic of skf_layernorm_residual_bwd followed by skf_gemm_f32; dgamma / dbeta as skf_layernorm_bwd_dgrad_partials(M)
+ * partial row pairs [n][2][d] (see skf_ffn_fused_bwd_ln_f32).  Exists for d = 128 in the split modes.  row_blocks: 16-row blocks,
+ * dead blocks have dout == 0 and get zero rows in dz, dy and da. */
+int skf_layernorm_bwd_dgrad_supported(int M, int d, int precision);
+int skf_layernorm_bwd_dgrad_partials(int M);
+int skf_layernorm_bwd_dgrad_f32(int M, int d, const float* dout, const float* z, const float* stats, const float* gamma,
+                                float rate, unsigned site, const void* step_state, const void* image_t, float* dz, float* dy,
+                                float* da, float* ln_partials, size_t ln_partials_bytes, const int* row_blocks,
+                                int row_block_rows, int precision, skf_stream_t stream);
 int skf_gemm_wgrad_partial_rows(int M, int N, int K, const float* A, int lda, const float* B, int ldb, int splits,
                                 int with_bias_grad, float* slab, size_t slab_bytes, int* splits_used_host, int precision,
                                 const int* row_blocks, int row_block_rows, skf_stream_t stream);

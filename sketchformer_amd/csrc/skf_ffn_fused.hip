@@ -26,6 +26,7 @@
 #include "skf_common.h"
 #include "skf_ffn_fused.h"
 #include <string>
+#include <vector>
 
 namespace {
 
@@ -71,27 +72,30 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t ffn_rows_rsrc(const float* bas
 size_t image_bytes(int pieces) { return (size_t)2 * pieces * (FD * FF * 2); }
 
 // ---------------------------------------------------------------- weight images
-// image 1: fragment (cb < 32, s < 4, q < P)   = pieces q of B1[32s + 8g + e][16cb + i], lane = 16g + i, e < 8   (16 bytes per lane)
-// image 2: fragment (cb < 8, s < 16, q < P)   = pieces q of B2[32s + 8g + e][16cb + i]
-// transpose = 0: B1 = W1 [128][512], B2 = W2 [512][128] (forward); 1: B1 = W2^T, B2 = W1^T (input gradient)
-struct FfnImageDesc { const float* W1; const float* W2; char* img; int ld1, ld2, transpose, pad; };
-struct FfnImageBatch { FfnImageDesc d[16]; };
+// Image of an MFMA B operand B [K][N] (K % 32 == 0, N % 16 == 0): fragment (cb < N / 16, s < K / 32, q < P) = pieces q of
+// B[32s + 8g + e][16cb + i], lane = 16g + i, e < 8 (16 bytes per lane, 1 KB per fragment), fragments ordered [cb][s][q].
+// transpose = 0: B[k][n] = src[k * ld + n]; 1: B[k][n] = src[n * ld + k].
+// The feed-forward pair: image 1 = B1 [128][512] followed by image 2 = B2 [512][128]; forward B1 = W1, B2 = W2; input gradient
+// B1 = W2^T, B2 = W1^T.
+struct DenseImageDesc { const float* src; char* img; int ld, transpose, K, N, block_begin, pad; };
+constexpr int kImageBatch = 40;
+struct DenseImageBatch { DenseImageDesc d[kImageBatch]; int n; };
 
 template <int P>
-__global__ __launch_bounds__(256) void ffn_image_kernel(FfnImageBatch batch) {
-  const FfnImageDesc& d = batch.d[blockIdx.y];
+__global__ __launch_bounds__(256) void dense_image_kernel(DenseImageBatch batch) {
+  int j = 0;
+  while (j + 1 < batch.n && (int)blockIdx.x >= batch.d[j + 1].block_begin) ++j;       // (wave-uniform, <= 40 steps)
+  const DenseImageDesc d = batch.d[j];
   const SkfSplitSel sel = skf_split_sel();
-  const int t = blockIdx.x * 256 + threadIdx.x;         // < 16384: image (t >> 13), fragment lane
-  const int which = t >> 13, f = (t >> 6) & 127, lane = t & 63, i = lane & 15, g = lane >> 4;
-  const int cb = which == 0 ? f / NKS : f / 16, s = which == 0 ? f % NKS : f % 16;
+  const int t = ((int)blockIdx.x - d.block_begin) * 256 + threadIdx.x;
+  const int nks = d.K / 32, f = t >> 6, lane = t & 63, i = lane & 15, g = lane >> 4;
+  if (f >= (d.N / 16) * nks) return;
+  const int cb = f / nks, s = f % nks;
   float v[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int k = 32 * s + 8 * g + e, n = 16 * cb + i;
-    float x;
-    if (which == 0) x = d.transpose ? d.W2[(size_t)n * d.ld2 + k] : d.W1[(size_t)k * d.ld1 + n];
-    else x = d.transpose ? d.W1[(size_t)n * d.ld1 + k] : d.W2[(size_t)k * d.ld2 + n];
-    v[e] = x;
+    v[e] = d.transpose ? d.src[(size_t)n * d.ld + k] : d.src[(size_t)k * d.ld + n];
   }
   u32x4 pc[P];
 #pragma unroll
@@ -101,9 +105,26 @@ __global__ __launch_bounds__(256) void ffn_image_kernel(FfnImageBatch batch) {
 #pragma unroll
     for (int q = 0; q < P; ++q) pc[q][dd] = o[q];
   }
-  char* base = d.img + (size_t)which * P * (FD * FF * 2) + (size_t)f * P * 1024 + lane * 16;
+  char* base = d.img + (size_t)f * P * 1024 + lane * 16;
 #pragma unroll
   for (int q = 0; q < P; ++q) *reinterpret_cast<u32x4*>(base + q * 1024) = pc[q];
+}
+
+int launch_images(const DenseImageDesc* descs, int n, int P, hipStream_t st) {
+  for (int b0 = 0; b0 < n; b0 += kImageBatch) {
+    DenseImageBatch batch{};
+    batch.n = n - b0 < kImageBatch ? n - b0 : kImageBatch;
+    int blocks = 0;
+    for (int j = 0; j < batch.n; ++j) {
+      batch.d[j] = descs[b0 + j];
+      batch.d[j].block_begin = blocks;
+      blocks += skf_cdiv((batch.d[j].N / 16) * (batch.d[j].K / 32) * 64, 256);
+    }
+    if (P == 2) hipLaunchKernelGGL(dense_image_kernel<2>, dim3(blocks), dim3(256), 0, st, batch);
+    else hipLaunchKernelGGL(dense_image_kernel<3>, dim3(blocks), dim3(256), 0, st, batch);
+    SKF_LAUNCH_CHECK();
+  }
+  return SKF_OK;
 }
 
 // ---------------------------------------------------------------- the block
@@ -545,6 +566,171 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnFusedParams p) {
   }
 }
 
+// ---------------------------------------------------------------- LayerNorm backward + the input gradient of the Dense in front of it
+// The attention sublayers' counterpart of the LNB prologue above: out = LayerNorm(x + dropout(Dense(a))) (the MultiHeadAttention
+// output projection, builders/layers/transformer.py:186, 221-224).  One launch forms dz = LayerNorm'(dout) (written: the residual
+// path), dy = dropout'(dz) (written: the weight gradient reads it) and da = dy . W^T (K = N = 128: a wave keeps its 16 columns of
+// the pre-split W^T image in registers for the whole launch) - it replaces the LayerNorm-backward launch and a weight-stationary
+// GEMM launch that each moved the same rows (12 + 12 launches per step at cfg 2).
+struct LnDgradParams {
+  const float* dout; const float* z; const float* stats; const float* gamma;
+  float* dz; float* dy; float* C;
+  const char* img;
+  float* part;
+  int M; float rate; unsigned site; const void* state;
+  const int* row_blocks;
+};
+
+template <int P>
+__global__ __launch_bounds__(512, 2) void ln_bwd_dgrad_kernel(LnDgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_f[];
+  char* Xp = smem_f;                     // [P][ROWS][256]
+  constexpr int TILE = TR * RPITCH;
+  const SkfSplitSel sel = skf_split_sel();
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, g = lane >> 4;
+  const int ntiles = (p.M + TR - 1) / TR;
+  typedef const __attribute__((address_space(4))) int* const_i32p;
+  const const_i32p blk = (const_i32p)p.row_blocks;
+  const int nlive = blk ? blk[0] : ntiles;
+  auto phys = [&](int pos) -> int { return pos < nlive ? (blk ? blk[2 + pos] : pos) : ntiles; };
+  const int G = gridDim.x, wg = blockIdx.x;
+  const int base = nlive / G, rem = nlive % G;
+  const int pos_begin = wg * base + (wg < rem ? wg : rem), count = base + (wg < rem ? 1 : 0);
+  const int nsub = (count + MAXRT - 1) / MAXRT;
+
+  unsigned a_off[NKS];
+#pragma unroll
+  for (int s = 0; s < NKS; ++s) a_off[s] = (unsigned)(i * RPITCH + (((4 * s + g) ^ i) << 4));
+  const unsigned c_voff = (unsigned)(i * FD + 16 * wave + 4 * g) * 4u;          // transposed products: row i, columns 16 wave + 4g ..
+  const int st_row = tid >> 5, st_c = tid & 31;
+  const unsigned st_off = (unsigned)(st_row * RPITCH + (((st_c >> 1) ^ st_row) << 4) + (st_c & 1) * 8);
+  const unsigned st_voff = (unsigned)(st_row * FD + 4 * st_c) * 4u;
+  float inv_keep = 1.f;
+  uint32_t thresh = 0u, sk = 0u;
+  if (p.rate > 0.f) {
+    typedef const __attribute__((address_space(4))) uint32_t* const_u32p;
+    const uint32_t key = *(const_u32p)&reinterpret_cast<const SkfStepState*>(p.state)->drop_key;
+    sk = skf_site_key(key, p.site);
+    thresh = skf_drop_thresh(p.rate);
+    inv_keep = 1.0f / (1.0f - p.rate);
+  }
+  const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gamma + 4 * st_c);
+  f32x4 ln_dg = (f32x4){0.f, 0.f, 0.f, 0.f}, ln_db = ln_dg;
+  const unsigned row_bytes = (unsigned)p.M * (FD * 4);
+  const __amdgpu_buffer_rsrc_t r_D = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dout), 0, row_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_Z = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.z), 0, row_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_S = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.stats), 0, (unsigned)p.M * 8u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_DZ = __builtin_amdgcn_make_buffer_rsrc(p.dz, 0, row_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_DY = __builtin_amdgcn_make_buffer_rsrc(p.dy, 0, row_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_C = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, row_bytes, 0x00020000);
+
+  u32x4 w[NKS][P];
+  if (nsub > 0) load_frags<P>(w, p.img + (size_t)wave * (NKS * P * 1024) + lane * 16);
+
+  f32x4 xn[MAXRT], zn[MAXRT];
+  u32x2 sn[MAXRT];
+  int tn[MAXRT];
+  auto sub_tiles = [&](int pos0, int sub_i, int (&t)[MAXRT]) -> int {
+    const int left = count - (pos0 - pos_begin);
+    const int n = sub_i < nsub ? (left + (nsub - sub_i) - 1) / (nsub - sub_i) : 0;
+#pragma unroll
+    for (int rt = 0; rt < MAXRT; ++rt) t[rt] = rt < n ? phys(pos0 + rt) : ntiles;
+    return n;
+  };
+  auto request_rows = [&]() {
+#pragma unroll
+    for (int rt = 0; rt < MAXRT; ++rt) {
+      const unsigned voff = tn[rt] < ntiles ? st_voff + (unsigned)tn[rt] * (unsigned)(TR * FD * 4) : OOB;
+      xn[rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_D, voff, 0, 0));
+      zn[rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_Z, voff, 0, 0));
+      sn[rt] = __builtin_amdgcn_raw_buffer_load_b64(r_S, tn[rt] < ntiles ? (unsigned)(tn[rt] * TR + st_row) * 8u : OOB, 0, 0);
+    }
+  };
+  int pos = pos_begin;
+  int nrt_next = sub_tiles(pos, 0, tn);
+  request_rows();
+  for (int sub = 0; sub < nsub; ++sub) {
+    const int nrt = nrt_next;
+    int tl[MAXRT];
+#pragma unroll
+    for (int rt = 0; rt < MAXRT; ++rt) tl[rt] = tn[rt];
+    pos += nrt;
+    // ---- LayerNorm backward of this thread's float4 of row (tile rt, st_row) (ln_bwd_v4_kernel's arithmetic) on the way to LDS
+#pragma unroll
+    for (int rt = 0; rt < MAXRT; ++rt) {
+      typedef float f32x2_t __attribute__((ext_vector_type(2)));
+      const f32x2_t ms = __builtin_bit_cast(f32x2_t, sn[rt]);
+      const f32x4 dv = xn[rt], zv = zn[rt];
+      const f32x4 xh = (zv - ms[0]) * ms[1], gg = dv * gm;
+      ln_dg += dv * xh; ln_db += dv;
+      const float s1 = ffn_half_wave_sum((gg[0] + gg[1]) + (gg[2] + gg[3])) * (1.0f / FD);
+      const float s2 = ffn_half_wave_sum((gg[0] * xh[0] + gg[1] * xh[1]) + (gg[2] * xh[2] + gg[3] * xh[3])) * (1.0f / FD);
+      const f32x4 gz = ms[1] * (gg - s1 - xh * s2);
+      f32x4 gy = gz;
+      const unsigned voff = tl[rt] < ntiles ? st_voff + (unsigned)tl[rt] * (unsigned)(TR * FD * 4) : OOB;
+      if (p.rate > 0.f) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gy[e] = gz[e] * (skf_keep(sk, (voff >> 2) + e, thresh) ? inv_keep : 0.f);
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, gz), r_DZ, voff, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, gy), r_DY, voff, 0, 0);
+      unsigned lo[P], hi[P];
+      skf_split2<P>(gy[0], gy[1], lo, sel);
+      skf_split2<P>(gy[2], gy[3], hi, sel);
+#pragma unroll
+      for (int q = 0; q < P; ++q) *reinterpret_cast<u32x2*>(Xp + q * PLANE + rt * TILE + st_off) = (u32x2){lo[q], hi[q]};
+    }
+    nrt_next = sub_tiles(pos, sub + 1, tn);       // the next sub-group's rows fly under the products
+    request_rows();
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < MAXRT; ++t) {
+      if (t < nrt) {
+        FfnFrags<P> fr;
+        load_half<P>(Xp + t * TILE, a_off, fr.f[0], 0);
+        load_half<P>(Xp + t * TILE, a_off, fr.f[1], 1);
+        f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+        int c = 0;
+        half_products<P>(w, fr.f[0], 0, acc0, acc1, c);
+        half_products<P>(w, fr.f[1], 1, acc0, acc1, c);
+        const f32x4 r = acc0 + acc1;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r), r_C, c_voff + (unsigned)tl[t] * (TR * FD * 4), 0, 0);
+      }
+    }
+    __syncthreads();                            // the planes are overwritten by the next sub-group's staging
+  }
+  if (blk) {                                    // rows of dead tiles: dout == 0 there -> dz = dy = da = 0
+    const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int dpos = nlive + wg; dpos < ntiles; dpos += G) {
+      const int row = blk[2 + dpos] * TR + st_row;
+      if (row < p.M) {
+        const size_t off = (size_t)row * FD + 4 * st_c;
+        *reinterpret_cast<f32x4*>(p.dz + off) = zero;
+        *reinterpret_cast<f32x4*>(p.dy + off) = zero;
+        *reinterpret_cast<f32x4*>(p.C + off) = zero;
+      }
+    }
+  }
+  // dgamma / dbeta partials -> part[wg][2][FD]
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { ln_dg[e] += __shfl_xor(ln_dg[e], 32, 64); ln_db[e] += __shfl_xor(ln_db[e], 32, 64); }
+  float* red = reinterpret_cast<float*>(smem_f);
+  __syncthreads();
+  if (lane < 32) {
+    *reinterpret_cast<f32x4*>(red + (wave * 2 + 0) * FD + 4 * lane) = ln_dg;
+    *reinterpret_cast<f32x4*>(red + (wave * 2 + 1) * FD + 4 * lane) = ln_db;
+  }
+  __syncthreads();
+  if (tid < 2 * FD) {
+    float t = red[tid];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += red[k * 2 * FD + tid];
+    p.part[(size_t)wg * 2 * FD + tid] = t;
+  }
+}
+
 int n_cus() {
   static int n = 0;
   if (!n) {
@@ -608,24 +794,44 @@ extern "C" size_t skf_ffn_relu_bits_bytes(int M, int d, int dff, int precision) 
   return (size_t)skf_cdiv(M, TR) * NBLK * 8 * 4 * sizeof(unsigned long long);
 }
 
+extern "C" size_t skf_dense_image_bytes(int K, int N, int precision) {
+  if ((precision != SKF_PREC_BF16X6 && precision != SKF_PREC_BF16X3) || K <= 0 || N <= 0 || (K & 31) || (N & 15)) return 0;
+  return (size_t)(precision == SKF_PREC_BF16X3 ? 2 : 3) * K * N * 2;
+}
+
+extern "C" int skf_dense_weight_images(int n, const float* const* src, const int* ld, const int* transpose, const int* K, const int* N,
+                                       void* const* images, int precision, skf_stream_t stream) {
+  SKF_CHECK_ARG(precision == SKF_PREC_BF16X6 || precision == SKF_PREC_BF16X3, "pre-split images exist in the split-arithmetic modes only");
+  SKF_CHECK_ARG(n >= 0 && (n == 0 || (src && ld && transpose && K && N && images)), "null argument");
+  std::vector<DenseImageDesc> descs((size_t)n);
+  for (int j = 0; j < n; ++j) {
+    SKF_CHECK_ARG(src[j] && images[j] && ((uintptr_t)images[j] & 15) == 0, "null / unaligned operand");
+    SKF_CHECK_ARG(K[j] > 0 && N[j] > 0 && (K[j] & 31) == 0 && (N[j] & 15) == 0 && ld[j] >= (transpose[j] ? K[j] : N[j]), "K % 32, N % 16, pitch");
+    descs[j] = DenseImageDesc{src[j], (char*)images[j], ld[j], transpose[j] ? 1 : 0, K[j], N[j], 0, 0};
+  }
+  return launch_images(descs.data(), n, precision == SKF_PREC_BF16X3 ? 2 : 3, (hipStream_t)stream);
+}
+
 extern "C" int skf_ffn_weight_images(int n, const float* const* W1, const int* ld1, const float* const* W2, const int* ld2,
                                      const int* transpose, void* const* images, int d, int dff, int precision, skf_stream_t stream) {
   SKF_CHECK_ARG(skf_ffn_fused_supported(1, d, dff, precision), "skf_ffn_weight_images: d = 128, dff = 512 in a split-arithmetic mode only");
   SKF_CHECK_ARG(n >= 0 && (n == 0 || (W1 && ld1 && W2 && ld2 && transpose && images)), "null argument");
   const int P = precision == SKF_PREC_BF16X3 ? 2 : 3;
-  for (int b0 = 0; b0 < n; b0 += 16) {
-    FfnImageBatch batch{};
-    const int nb = n - b0 < 16 ? n - b0 : 16;
-    for (int j = 0; j < nb; ++j) {
-      SKF_CHECK_ARG(W1[b0 + j] && W2[b0 + j] && images[b0 + j] && ld1[b0 + j] >= dff && ld2[b0 + j] >= d, "bad weight operand");
-      SKF_CHECK_ARG(((uintptr_t)images[b0 + j] & 15) == 0, "images must be 16-byte aligned");
-      batch.d[j] = FfnImageDesc{W1[b0 + j], W2[b0 + j], (char*)images[b0 + j], ld1[b0 + j], ld2[b0 + j], transpose[b0 + j], 0};
+  std::vector<DenseImageDesc> descs;
+  for (int j = 0; j < n; ++j) {
+    SKF_CHECK_ARG(W1[j] && W2[j] && images[j] && ld1[j] >= dff && ld2[j] >= d, "bad weight operand");
+    SKF_CHECK_ARG(((uintptr_t)images[j] & 15) == 0, "images must be 16-byte aligned");
+    char* img = (char*)images[j];
+    // forward: B1 = W1 [d][dff], B2 = W2 [dff][d]; input gradient: B1 = W2^T, B2 = W1^T
+    if (!transpose[j]) {
+      descs.push_back(DenseImageDesc{W1[j], img, ld1[j], 0, d, dff, 0, 0});
+      descs.push_back(DenseImageDesc{W2[j], img + image_bytes(P) / 2, ld2[j], 0, dff, d, 0, 0});
+    } else {
+      descs.push_back(DenseImageDesc{W2[j], img, ld2[j], 1, d, dff, 0, 0});
+      descs.push_back(DenseImageDesc{W1[j], img + image_bytes(P) / 2, ld1[j], 1, dff, d, 0, 0});
     }
-    if (P == 2) hipLaunchKernelGGL(ffn_image_kernel<2>, dim3(64, nb), dim3(256), 0, (hipStream_t)stream, batch);
-    else hipLaunchKernelGGL(ffn_image_kernel<3>, dim3(64, nb), dim3(256), 0, (hipStream_t)stream, batch);
-    SKF_LAUNCH_CHECK();
   }
-  return SKF_OK;
+  return launch_images(descs.data(), (int)descs.size(), P, (hipStream_t)stream);
 }
 
 static int ffn_common_checks(int M, int d, int dff, int precision, const void* a, const void* img, const void* hid, const void* c) {
@@ -692,4 +898,37 @@ extern "C" int skf_ffn_fused_bwd_ln_f32(int M, int d, int dff, const float* dout
   p.gamma = gamma; p.rate = rate; p.site = site; p.state = step_state;
   p.ln_dout = dout; p.ln_z = z; p.ln_stats = stats; p.ln_dy = dy; p.ln_part = ln_partials;
   return skf_ffn_fused_launch(p, P, 1, (hipStream_t)stream);
+}
+
+extern "C" int skf_layernorm_bwd_dgrad_supported(int M, int d, int precision) {
+  return (precision == SKF_PREC_BF16X6 || precision == SKF_PREC_BF16X3) && d == FD && M >= 1 && (double)M * FD * 4 < 2147483648.0;
+}
+extern "C" int skf_layernorm_bwd_dgrad_partials(int M) { return ffn_grid(M); }
+
+extern "C" int skf_layernorm_bwd_dgrad_f32(int M, int d, const float* dout, const float* z, const float* stats, const float* gamma,
+                                           float rate, unsigned site, const void* step_state, const void* image_t, float* dz, float* dy,
+                                           float* da, float* ln_partials, size_t ln_partials_bytes, const int* row_blocks,
+                                           int row_block_rows, int precision, skf_stream_t stream) {
+  SKF_CHECK_ARG(skf_layernorm_bwd_dgrad_supported(M, d, precision), "LayerNorm backward + input gradient: d = 128 in a split-arithmetic mode only");
+  SKF_CHECK_ARG(dout && z && stats && gamma && image_t && dz && dy && da && ln_partials, "null operand");
+  SKF_CHECK_ARG((((uintptr_t)dout | (uintptr_t)z | (uintptr_t)gamma | (uintptr_t)image_t | (uintptr_t)dz | (uintptr_t)dy | (uintptr_t)da |
+                  (uintptr_t)ln_partials) & 15) == 0 && ((uintptr_t)stats & 7) == 0, "operands must be 16-byte aligned");
+  SKF_CHECK_ARG(rate >= 0.f && rate < 1.f && (rate == 0.f || step_state), "dropout needs 0 <= rate < 1 and the step state");
+  SKF_CHECK_ARG(!row_blocks || row_block_rows == TR, "row-block lists of this kernel have 16-row blocks");
+  SKF_CHECK_ARG(ln_partials_bytes >= (size_t)ffn_grid(M) * 2 * FD * sizeof(float), "partial buffer too small (skf_layernorm_bwd_dgrad_partials(M) x 2 x d floats)");
+  const int P = precision == SKF_PREC_BF16X3 ? 2 : 3;
+  LnDgradParams p{};
+  p.dout = dout; p.z = z; p.stats = stats; p.gamma = gamma; p.dz = dz; p.dy = dy; p.C = da; p.img = (const char*)image_t;
+  p.part = ln_partials; p.M = M; p.rate = rate; p.site = site; p.state = step_state; p.row_blocks = row_blocks;
+  const int grid = ffn_grid(M);
+  const size_t smem = (size_t)P * PLANE;
+  hipStream_t st = (hipStream_t)stream;
+  static const std::string tag2 = "ln_bwd_dgrad<d128,bf16x3>", tag3 = "ln_bwd_dgrad<d128,bf16x6>";
+  const double live = skf_prof_list_fraction(row_blocks);
+  SkfProfScope ps(st, (P == 2 ? tag2 : tag3).c_str(), 2.0 * M * FD * FD, 4.0 * 5.0 * M * FD);
+  ps.done(2.0 * M * FD * FD * live, 4.0 * 5.0 * M * FD * live);
+  if (P == 2) hipLaunchKernelGGL(ln_bwd_dgrad_kernel<2>, dim3(grid), dim3(512), smem, st, p);
+  else hipLaunchKernelGGL(ln_bwd_dgrad_kernel<3>, dim3(grid), dim3(512), smem, st, p);
+  SKF_LAUNCH_CHECK();
+  return SKF_OK;
 }

@@ -290,8 +290,8 @@ struct Bump {
   size_t take(size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; }
 };
 
-struct EncAct { size_t x_in, qkv, o, z1, st1, astats, x1, h, z2, st2, x2, hbits, img[2]; };   // img: pre-split ffn weight images (forward, backward)
-struct DecAct { size_t x_in, qkv, o1, z1, st1, astats1, out1, q2, kv2, o2, astats2, z2, st2, out2, h, z3, st3, out3, hbits, img[2]; };
+struct EncAct { size_t x_in, qkv, o, z1, st1, astats, x1, h, z2, st2, x2, hbits, img[2], img_o; };   // img: pre-split ffn weight images (forward, backward); img_o: Wo^T
+struct DecAct { size_t x_in, qkv, o1, z1, st1, astats1, out1, q2, kv2, o2, astats2, z2, st2, out2, h, z3, st3, out3, hbits, img[2], img_o1, img_o2; };
 
 struct Plan {
   size_t bytes = 0;
@@ -340,6 +340,7 @@ Plan build_plan(const SkfConfig& c) {
     a.hbits = b.take(std::max(skf_gemm_relu_bits_bytes((int)Me, (int)F, (int)d, c.gemm_precision),        // 0 bytes: no sign-bit path for this shape
                               skf_ffn_relu_bits_bytes((int)Me, (int)d, (int)F, c.gemm_precision)));
     a.img[0] = b.take(skf_ffn_image_bytes((int)d, (int)F, c.gemm_precision)); a.img[1] = b.take(skf_ffn_image_bytes((int)d, (int)F, c.gemm_precision));
+    a.img_o = b.take(skf_dense_image_bytes((int)d, (int)d, c.gemm_precision));
     a.x2 = 0;
     P.enc.push_back(a);
   }
@@ -361,6 +362,7 @@ Plan build_plan(const SkfConfig& c) {
     a.hbits = b.take(std::max(skf_gemm_relu_bits_bytes((int)Md, (int)F, (int)d, c.gemm_precision),
                               skf_ffn_relu_bits_bytes((int)Md, (int)d, (int)F, c.gemm_precision)));
     a.img[0] = b.take(skf_ffn_image_bytes((int)d, (int)F, c.gemm_precision)); a.img[1] = b.take(skf_ffn_image_bytes((int)d, (int)F, c.gemm_precision));
+    a.img_o1 = b.take(skf_dense_image_bytes((int)d, (int)d, c.gemm_precision)); a.img_o2 = b.take(skf_dense_image_bytes((int)d, (int)d, c.gemm_precision));
     a.out3 = 0;
     P.dec.push_back(a);
   }
@@ -799,17 +801,27 @@ int build_ffn_images(SkfModel* M, bool with_backward, bool encoder_only, hipStre
   const SkfConfig& c = M->cfg;
   const Layout& L = M->lay;
   const Plan& P = M->plan;
-  std::vector<const float*> w1, w2; std::vector<int> ld1, ld2, tr; std::vector<void*> img;
-  auto add = [&](const DenseP& f1, const DenseP& f2, const size_t (&im)[2]) {
-    for (int t = 0; t < (with_backward ? 2 : 1); ++t) {
-      w1.push_back(M->P(f1.w)); ld1.push_back(f1.ld); w2.push_back(M->P(f2.w)); ld2.push_back(f2.ld); tr.push_back(t); img.push_back(M->at<char>(im[t]));
-    }
+  const int d = c.d_model, F = c.dff;
+  const size_t half = skf_ffn_image_bytes(d, F, c.gemm_precision) / 2;
+  std::vector<const float*> src; std::vector<int> ld, tr, K, N; std::vector<void*> img;
+  auto one = [&](const DenseP& w, int t, int k, int n, char* im) {
+    src.push_back(M->P(w.w)); ld.push_back(w.ld); tr.push_back(t); K.push_back(k); N.push_back(n); img.push_back(im);
   };
-  for (int i = 0; i < c.num_layers; ++i) add(L.enc[i].f1, L.enc[i].f2, P.enc[i].img);
-  if (!encoder_only && do_recon(c))
-    for (int i = 0; i < c.num_layers; ++i) add(L.dec[i].f1, L.dec[i].f2, P.dec[i].img);
-  return skf_ffn_weight_images((int)w1.size(), w1.data(), ld1.data(), w2.data(), ld2.data(), tr.data(), img.data(), c.d_model, c.dff,
-                               c.gemm_precision, s);
+  auto ffn = [&](const DenseP& f1, const DenseP& f2, const size_t (&im)[2]) {
+    one(f1, 0, d, F, M->at<char>(im[0])); one(f2, 0, F, d, M->at<char>(im[0]) + half);                  // forward: B1 = W1, B2 = W2
+    if (with_backward) { one(f2, 1, d, F, M->at<char>(im[1])); one(f1, 1, F, d, M->at<char>(im[1]) + half); }   // backward: B1 = W2^T, B2 = W1^T
+  };
+  const bool dec = !encoder_only && do_recon(c);
+  for (int i = 0; i < c.num_layers; ++i) {
+    ffn(L.enc[i].f1, L.enc[i].f2, P.enc[i].img);
+    if (with_backward) one(L.enc[i].mha.o, 1, d, d, M->at<char>(P.enc[i].img_o));
+  }
+  if (dec)
+    for (int i = 0; i < c.num_layers; ++i) {
+      ffn(L.dec[i].f1, L.dec[i].f2, P.dec[i].img);
+      if (with_backward) { one(L.dec[i].mha1.o, 1, d, d, M->at<char>(P.dec[i].img_o1)); one(L.dec[i].mha2.o, 1, d, d, M->at<char>(P.dec[i].img_o2)); }
+    }
+  return skf_dense_weight_images((int)src.size(), src.data(), ld.data(), tr.data(), K.data(), N.data(), img.data(), c.gemm_precision, s);
 }
 // out = LayerNorm(x + dropout(ffn(x))): one launch, or Dense(relu) + Dense + residual-LayerNorm
 int ffn_ln_fwd(SkfModel* M, const DenseP& f1, const DenseP& f2, const LnP& ln, const float* x, int rows, float* h, void* bits,
@@ -1054,6 +1066,32 @@ int ffn_ln_bwd(SkfModel* M, const LnP& ln, const DenseP& f1, const DenseP& f2, c
   return dense_wgrad(M, f1, x_in, f1.in, dh, f1.out, rows, s);
 }
 
+// The backward of an attention sublayer's tail, out = LayerNorm(x + dropout(o_proj(a))): LayerNorm backward + the projection's
+// input gradient in one launch (skf_layernorm_bwd_dgrad_f32) where it exists, else the two launches.  The weight gradient is queued.
+int ln_oproj_bwd(SkfModel* M, const LnP& ln, const DenseP& o, const float* dout, const float* z, const float* st, const float* a_in,
+                 float* dz, float* dy, float* da, int rows, float rate, unsigned site, hipStream_t s, const void* image_t) {
+  const Plan& P = M->plan;
+  const int d = M->cfg.d_model;
+  static const bool off = skf_knob("SKF_NO_LN_DGRAD") && skf_knob("SKF_NO_LN_DGRAD")[0] == '1';   // (measurement builds only)
+  const size_t pbytes = (size_t)skf_layernorm_bwd_dgrad_partials(rows) * 2 * d * sizeof(float);
+  if (off || !M->ffn_fused || !M->side || ln.b != ln.g + (size_t)d || pbytes > P.ln_part_stride || o.in != d || o.out != d ||
+      !skf_layernorm_bwd_dgrad_supported(rows, d, M->cfg.gemm_precision)) {
+    SKF_TRY(ln_bwd(M, ln, dout, z, st, dz, dy, rows, rate, site, s));
+    SKF_TRY(dense_wgrad(M, o, a_in, d, dy, d, rows, s));
+    return dense_dgrad(M, o, dy, d, rows, da, d, 0, nullptr, 0, s);
+  }
+  SKF_CHECK_ARG(M->ln_cursor < 5 * (size_t)M->cfg.num_layers && M->desc_cursor < P.n_wgrads, "LayerNorm partial arena exhausted");
+  float* part = M->at<float>(P.ln_part + M->ln_cursor * P.ln_part_stride);
+  SKF_TRY(before_write(M, dz, s));
+  SKF_TRY(before_write(M, dy, s));
+  SKF_TRY(before_write(M, da, s));
+  const int* blocks = (M->live16 && rows == M->live_rows) ? M->live16 : nullptr;
+  SKF_TRY(skf_layernorm_bwd_dgrad_f32(rows, d, dout, z, st, M->P(ln.g), rate, site, M->state, image_t, dz, dy, da, part, pbytes, blocks,
+                                      blocks ? 16 : 0, M->cfg.gemm_precision, s));
+  SKF_TRY(ln_partials_desc(M, ln, part, skf_layernorm_bwd_dgrad_partials(rows)));
+  return dense_wgrad(M, o, a_in, d, dy, d, rows, s);
+}
+
 // Row-block lists of the decoder-side backward (token mode, split arithmetic only: the fp32-MFMA kernels ignore them)
 int build_row_lists(SkfModel* M, hipStream_t s) {
   const SkfConfig& c = M->cfg;
@@ -1121,9 +1159,8 @@ int run_backward(SkfModel* M, hipStream_t s) {
     SKF_TRY(ffn_ln_bwd(M, w.ln3, w.f1, w.f2, G, M->at<float>(a.z3), M->at<float>(a.st3), M->at<float>(a.out2), M->at<float>(a.h), dy3,
                        M->at<float>(gs.dh), G2, Md, rate, site_dec(N, i, 2), s, hbits_of(M, a.hbits, Md), M->at<char>(a.img[1])));
     // out2 = LN2(out1 + drop(mha2(pre, pre, out1)))
-    SKF_TRY(ln_bwd(M, w.ln2, G2, M->at<float>(a.z2), M->at<float>(a.st2), G, dy2, Md, rate, site_dec(N, i, 1), s));
-    SKF_TRY(dense_wgrad(M, w.mha2.o, M->at<float>(a.o2), d, dy2, d, Md, s));
-    SKF_TRY(dense_dgrad(M, w.mha2.o, dy2, d, Md, dO, d, 0, nullptr, 0, s));
+    SKF_TRY(ln_oproj_bwd(M, w.ln2, w.mha2.o, G2, M->at<float>(a.z2), M->at<float>(a.st2), M->at<float>(a.o2), G, dy2, dO, Md, rate,
+                         site_dec(N, i, 1), s, M->at<char>(a.img_o2)));
     const float* kv2 = M->at<float>(a.kv2);
     SKF_TRY(before_write(M, dq2, s));
     SKF_TRY(before_write(M, dkv2, s));
@@ -1140,9 +1177,8 @@ int run_backward(SkfModel* M, hipStream_t s) {
       SKF_TRY(dense_dgrad(M, w.mha2.kv, dkv2, 2 * d, Me, dpre, L.E, i != N - 1, nullptr, 0, s));
     } else SKF_TRY(dense_dgrad_deferred(M, w.mha2.kv, dkv2, 2 * d, Me, dpre, L.E, i != N - 1, s));
     // out1 = LN1(x + drop(mha1(x,x,x)))
-    SKF_TRY(ln_bwd(M, w.ln1, G, M->at<float>(a.z1), M->at<float>(a.st1), G2, dy1, Md, rate, site_dec(N, i, 0), s));
-    SKF_TRY(dense_wgrad(M, w.mha1.o, M->at<float>(a.o1), d, dy1, d, Md, s));
-    SKF_TRY(dense_dgrad(M, w.mha1.o, dy1, d, Md, dO, d, 0, nullptr, 0, s));
+    SKF_TRY(ln_oproj_bwd(M, w.ln1, w.mha1.o, G, M->at<float>(a.z1), M->at<float>(a.st1), M->at<float>(a.o1), G2, dy1, dO, Md, rate,
+                         site_dec(N, i, 0), s, M->at<char>(a.img_o1)));
     const float* qkv = M->at<float>(a.qkv);
     SKF_TRY(before_write(M, dqkv, s));
     SKF_TRY(skf_attention_bwd_rows(qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, M->at<float>(a.o1), d, dO, d,
@@ -1237,9 +1273,8 @@ int run_backward(SkfModel* M, hipStream_t s) {
     // (only the embedding gradient follows), so they go out per sublayer - the step's tail before Adam is one wgrad, not four
     static const bool early_tail = !skf_knob("SKF_NO_EARLY_TAIL");
     if (i == 0 && early_tail) SKF_TRY(issue_wgrads(M, s));
-    SKF_TRY(ln_bwd(M, w.ln1, G2, M->at<float>(a.z1), M->at<float>(a.st1), G, dy1, Me, rate, site_enc(i, 0), s));
-    SKF_TRY(dense_wgrad(M, w.mha.o, M->at<float>(a.o), d, dy1, d, Me, s));
-    SKF_TRY(dense_dgrad(M, w.mha.o, dy1, d, Me, dO, d, 0, nullptr, 0, s));
+    SKF_TRY(ln_oproj_bwd(M, w.ln1, w.mha.o, G2, M->at<float>(a.z1), M->at<float>(a.st1), M->at<float>(a.o), G, dy1, dO, Me, rate,
+                         site_enc(i, 0), s, M->at<char>(a.img_o)));
     if (i == 0 && early_tail) SKF_TRY(issue_wgrads(M, s));
     const float* qkv = M->at<float>(a.qkv);
     SKF_TRY(before_write(M, dqkv, s));

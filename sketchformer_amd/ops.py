@@ -304,6 +304,33 @@ def ffn_fused_bwd_ln(dout, z, stats, gamma, image_t, bits, dff, rate=0.0, site=0
     return dy, dh, dx, g[0], g[1]
 
 
+def dense_weight_image(w, transpose, precision=None):
+    """Pre-split MFMA operand image of B = w [K, N] (transpose=False) or w^T (w is [N, K]) - skf_dense_weight_images."""
+    _f32(w, "w")
+    K, N = (w.shape[1], w.shape[0]) if transpose else (w.shape[0], w.shape[1])
+    nbytes = _lib.load().skf_dense_image_bytes(K, N, _prec(precision))
+    if not nbytes:
+        raise _lib.SkfError("no operand image for K=%d N=%d" % (K, N))
+    img = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    PA, IA = C.c_void_p * 1, C.c_int * 1
+    _lib.call("skf_dense_weight_images", 1, PA(w.data_ptr()), IA(w.stride(0)), IA(int(bool(transpose))), IA(K), IA(N), PA(img.data_ptr()),
+              _prec(precision), _stream())
+    return img
+
+
+def layernorm_bwd_dgrad(dout, z, stats, gamma, image_t, rate=0.0, site=0, state=None, row_blocks=None, precision=None):
+    """One launch: dz = LayerNorm'(dout), dy = dropout'(dz), da = dy . W^T -> dz, dy, da, dgamma, dbeta (skf_layernorm_bwd_dgrad_f32)."""
+    _f32(dout, "dout")
+    M, d = dout.shape
+    n = _lib.load().skf_layernorm_bwd_dgrad_partials(M)
+    part = torch.empty(n, 2, d, dtype=torch.float32, device=dout.device)
+    dz, dy, da = torch.empty_like(dout), torch.empty_like(dout), torch.empty_like(dout)
+    _lib.call("skf_layernorm_bwd_dgrad_f32", M, d, _p(dout), _p(z), _p(stats), _p(gamma), rate, site, _p(state), _p(image_t), _p(dz), _p(dy),
+              _p(da), _p(part), part.numel() * 4, _p(row_blocks), 16 if row_blocks is not None else 0, _prec(precision), _stream())
+    g = part.sum(0)
+    return dz, dy, da, g[0], g[1]
+
+
 def layernorm_residual_bwd(dout, z, stats, gamma, rate=0.0, site=0, state=None):
     d = dout.shape[-1]
     rows = dout.numel() // d

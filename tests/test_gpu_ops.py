@@ -923,6 +923,51 @@ def test_ffn_fused_backward_from_layernorm_gradient(ops, rows, listed, rate):
         assert (gdy - rdy).abs().max().item() <= 2e-6 * max(1.0, rdy.abs().max().item())
 
 
+@pytest.mark.parametrize("rows,listed,rate", [(25472, True, 0.1), (25600, False, 0.1), (1031, False, 0.0), (3184, True, 0.0), (7, False, 0.1)])
+def test_layernorm_bwd_dgrad_one_launch(ops, rows, listed, rate):
+    """dz = LayerNorm'(dout), dy = dropout'(dz), da = dy . W^T in one launch (the attention output projection's backward,
+    builders/layers/transformer.py:186, 221-224) against the oracle, and against the two launches it replaces."""
+    d = 128
+    rng = np.random.RandomState(rows + 3)
+    z = rng.randn(rows, d) * 1.5 + 0.3
+    w = rng.randn(d, d) / np.sqrt(d)
+    gamma, beta = 1 + 0.1 * rng.randn(d), 0.1 * rng.randn(d)
+    dout = rng.randn(rows, d)
+    blocks = None
+    if listed:
+        Ld = 199
+        B = rows // Ld
+        live = rng.randint(0, Ld + 1, size=B).astype(np.int32)
+        live[0] = 0; live[-1] = Ld
+        for b in range(B):
+            dout[b * Ld + live[b]:(b + 1) * Ld] = 0.0
+        blocks = ops.row_blocks(_dev(live, torch.int32), Ld, 16)
+    st = ops.new_step_state("cuda", iterations=3)
+    ops.step_prologue(st, seed=5)
+    keep = np.ones((rows, d), bool)
+    if rate > 0:
+        keep = ops.dropout_keep_mask(ops.read_step_state(st)["drop_key"], 6, rate, rows * d).reshape(rows, d)
+    Z, W, G = _dev(z), _dev(w), _dev(gamma)
+    z32 = Z.cpu().numpy().astype(np.float64)
+    _, cache = oracle.layernorm_fwd(z32, gamma, beta)
+    stats = _dev(np.stack([z32.mean(-1), 1.0 / np.sqrt(z32.var(-1) + 1e-6)], -1))
+    dz, dg, db = oracle.layernorm_bwd(dout, cache)
+    dy = dz * keep / (1.0 - rate)
+    da = dy @ w.T
+    img = ops.dense_weight_image(W, transpose=True)
+    gdz, gdy, gda, gdg, gdb = ops.layernorm_bwd_dgrad(_dev(dout), Z, stats, G, img, rate=rate, site=6, state=st, row_blocks=blocks)
+    _close(gdz, dz, rtol=5e-5, name="dz")
+    _close(gdy, dy, rtol=5e-5, name="dy")
+    _close(gda, da, rtol=5e-5, name="da")
+    _close(gdg, dg, rtol=5e-5, name="dgamma")
+    _close(gdb, db, rtol=5e-5, name="dbeta")
+    if rows > 2048 and not listed:
+        rdz, rdy, _, _ = ops.layernorm_residual_bwd(_dev(dout), Z, stats, G, rate=rate, site=6, state=st)
+        rda = ops.gemm(rdy, W, a_kcontig=True, b_kcontig=True)
+        assert (gdy - rdy).abs().max().item() <= 2e-6 * max(1.0, rdy.abs().max().item())
+        assert (gda - rda).abs().max().item() <= 4e-6 * max(1.0, rda.abs().max().item())
+
+
 def test_ffn_fused_refuses_other_shapes(ops):
     lib = ops._lib.load()
     assert lib.skf_ffn_fused_supported(25600, 128, 512, 6) == 1
