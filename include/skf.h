@@ -157,6 +157,14 @@ int skf_ffn_fused_fwd_f32(int M, int d, int dff, const float* x, const void* ima
 int skf_ffn_fused_bwd_f32(int M, int d, int dff, const float* dy, const void* image_t, const void* relu_bits_in,
                           float* dh, float* dx, int accumulate, const int* row_blocks, int row_block_rows,
                           int precision, skf_stream_t stream);
+/* The forward launch going one step further: proj_out[M, proj_n] = out . Wp + proj_bias for the Dense that consumes the block's
+ * LayerNorm output - the NEXT layer's fused q|k|v projection (builders/layers/transformer.py:154-158, 216-217; proj_n = 384) or a
+ * query projection (128) - with proj_image = skf_dense_weight_images(Wp [d][proj_n], transpose = 0).  Same arithmetic as
+ * skf_gemm_f32 on `out`; everything else as skf_ffn_fused_fwd_f32. */
+int skf_ffn_fused_fwd_proj_f32(int M, int d, int dff, const float* x, const void* image, const float* b1, const float* b2,
+                               float* h, void* relu_bits_out, const float* gamma, const float* beta, float* z, float* out,
+                               float* stats, float rate, unsigned site, const void* step_state, const void* proj_image,
+                               const float* proj_bias, int proj_n, float* proj_out, int precision, skf_stream_t stream);
 /* The backward launch starting one step earlier, at the gradient `dout` of the LayerNorm that closes the block
  * (out = LayerNorm(z), z = x + dropout(ffn(x))): dz = LayerNorm'(dout) from (z, stats, gamma) with the arithmetic of
  * skf_layernorm_residual_bwd, dy = dropout'(dz) (written: the second Dense's weight gradient reads it), dh as above, and

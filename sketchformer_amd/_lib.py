@@ -103,6 +103,7 @@ SIGNATURES = {
     "skf_layernorm_bwd_dgrad_supported": (_I, [_I, _I, _I]),
     "skf_layernorm_bwd_dgrad_partials": (_I, [_I]),
     "skf_layernorm_bwd_dgrad_f32": (_I, [_I, _I, _P, _P, _P, _P, _F, _U, _P, _P, _P, _P, _P, _P, _Z, _P, _I, _I, _P]),
+    "skf_ffn_fused_fwd_proj_f32": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _U, _P, _P, _P, _I, _P, _I, _P]),
     "skf_target_live_len": (_I, [_P, _I, _I, _I, _P, _P]),
     "skf_row_blocks_bytes": (_Z, [_I, _I]),
     "skf_row_blocks_build": (_I, [_P, _I, _I, _I, _P, _P]),

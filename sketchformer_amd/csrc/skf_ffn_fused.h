@@ -17,6 +17,8 @@ struct FfnFusedParams {
   const float* gamma; const float* beta; float* out; float* stats;   // forward: LayerNorm(z)
   float rate; unsigned site; const void* state;                     // forward: dropout of y (SkfStepState*)
   const int* row_blocks;               // 16-row block list (skf_row_blocks_build) or null
+  // forward with a chained projection (img3 != null): out2[M][n2] = out . B3 + bias3, B3 [128][n2] as a pre-split image, n2 in {128, 256, 384}
+  const char* img3; const float* bias3; float* out2; int n2;
   // backward with the LayerNorm-backward prologue (ln_dout != null): A is not read; gamma / rate / site / state are the LayerNorm's
   const float* ln_dout; const float* ln_z; const float* ln_stats;   // gradient of the LayerNorm output, z = x + dropout(y), (mean, rstd)
   float* ln_dy;                        // dy = dropout'(LayerNorm'(dout)) [M][128] (the second Dense's weight gradient reads it)

@@ -48,7 +48,8 @@ constexpr int YPITCH = FD + 4;        // floats per row of the epilogue tile
 constexpr unsigned OOB = 0x7ffffff0u;
 
 // SKF_FFN_ABLATE (diagnostics builds, wrong results): bit 0 no MFMA (one VALU op keeps the operands live), 1 fragment reads only
-// once per sub-group, 2 no hidden-tensor / sign-bit stores, 3 no hidden-plane stores, 4 no stage-1 epilogue at all
+// once per sub-group, 2 no hidden-tensor / sign-bit stores, 3 no hidden-plane stores, 4 no stage-1 epilogue at all, 5 weight
+// fragments loaded once per launch, 6 no block barriers
 #ifndef SKF_FFN_ABLATE
 #define SKF_FFN_ABLATE 0
 #endif
@@ -128,12 +129,18 @@ int launch_images(const DenseImageDesc* descs, int n, int P, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------- the block
+// a wave's NKS * P operand fragments (12 KB of contiguous image): buffer loads - one descriptor per image, the lane's 16 bytes in the
+// VGPR offset, everything else wave-uniform in the scalar offset.  (As global loads from per-lane 64-bit addresses the twelve
+// addresses of a rarely used image were spilled one by one: scratch reload + vmcnt(0) + load, twelve dependent round trips.)
 template <int P>
-__device__ __forceinline__ void load_frags(u32x4 (&w)[NKS][P], const char* src) {
+__device__ __forceinline__ void load_frags(u32x4 (&w)[NKS][P], __amdgpu_buffer_rsrc_t img, unsigned lane16, int soff, bool first = false) {
+#if SKF_FFN_ABLATE & 32
+  if (!first) return;
+#endif
 #pragma unroll
   for (int s = 0; s < NKS; ++s)
 #pragma unroll
-    for (int q = 0; q < P; ++q) w[s][q] = *reinterpret_cast<const u32x4*>(src + (s * P + q) * 1024);
+    for (int q = 0; q < P; ++q) w[s][q] = __builtin_amdgcn_raw_buffer_load_b128(img, lane16, soff + (s * P + q) * 1024, 0);
 }
 
 // A 16-row x 16-column x 128-deep product goes by in two halves of two 32-deep steps.  The fragments of a half are requested while
@@ -198,9 +205,13 @@ __device__ __forceinline__ float ffn_half_wave_sum(float v) {
 // dy = dropout'(dz), dz = LayerNorm'(dout) (skf_rowops.hip ln_bwd_v4_kernel, same arithmetic), formed on the way to LDS; dy goes
 // to global memory for the weight gradient, dz stays in registers and closes the block as dx = dz + dh.W1^T, the column sums of
 // dout o xhat and dout (dgamma, dbeta) leave as one partial row pair per workgroup.
-template <int P, int MODE, bool LNB = false>
+// POST (forward only): the launch goes on to the Dense that consumes its LayerNorm output (the next layer's q|k|v projection,
+// builders/layers/transformer.py:154-158: K = 128, N = 128 or 384) - the rows are split again on their way out, one more set of
+// first-stage products per 128 output columns, stored from the transposed fragments like the hidden tensor.
+template <int P, int MODE, bool LNB = false, bool POST = false>
 __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnFusedParams p) {
   static_assert(!LNB || MODE == 1, "LayerNorm-backward prologue: backward only");
+  static_assert(!POST || MODE == 0, "chained projection: forward only");
   extern __shared__ __attribute__((aligned(16))) char smem_f[];
   char* Xp = smem_f;                     // [P][ROWS][256]
   char* Hp = smem_f + P * PLANE;         // [2][P][ROWS][256]
@@ -242,6 +253,9 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnFusedParams p) {
   const unsigned st_off = (unsigned)(st_row * RPITCH + (((st_c >> 1) ^ st_row) << 4) + (st_c & 1) * 8);
   const unsigned st_voff = (unsigned)(st_row * p.lda + 4 * st_c) * 4u;
   if (MODE == 0 && tid < FF / 4) *reinterpret_cast<f32x4*>(B1s + 4 * tid) = *reinterpret_cast<const f32x4*>(p.bias1 + 4 * tid);   // (read behind the staging barrier)
+  float* B3s = B1s + FF;                 // POST: the chained projection's bias [n2 <= 384] (a global load in front of each block's
+                                         // first product was a cold miss per block: the chained launch took 34 us for 24 us of projection)
+  if (POST && tid >= 128 && tid - 128 < p.n2 / 4) *reinterpret_cast<f32x4*>(B3s + 4 * (tid - 128)) = *reinterpret_cast<const f32x4*>(p.bias3 + 4 * (tid - 128));
   const float* bias1_p = B1s + 16 * wave + 4 * g;
   // (s_setprio 1 for the second-dispatched half, which loses the issue arbitration on its SIMD to the older wave and makes waves
   //  0-3 wait 2-4 k cycles at every block barrier, only swaps the roles: measured with stamps, zero-sum)
@@ -279,10 +293,18 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnFusedParams p) {
   const __amdgpu_buffer_rsrc_t r_bits = __builtin_amdgcn_make_buffer_rsrc(MODE == 0 && p.bits_out ? (void*)p.bits_out : (void*)p.H, 0,
                                                                           MODE == 0 && p.bits_out ? ntiles * (NBLK * 8 * 32) : 0, 0x00020000);
   const unsigned bits_voff = lane < 4 ? (unsigned)lane * 8u : OOB;
-  const char* img1_w = p.img1 + (size_t)wave * (NKS * P * 1024) + lane * 16;            // + b * 8 * NKS * P * 1024
-  const char* img2_w = p.img2 + (size_t)wave * (16 * P * 1024) + lane * 16;             // + b * NKS * P * 1024
+  const __amdgpu_buffer_rsrc_t r_O2 = __builtin_amdgcn_make_buffer_rsrc(POST ? (void*)p.out2 : (void*)p.H, 0, POST ? p.M * p.n2 * 4 : 0, 0x00020000);
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const __amdgpu_buffer_rsrc_t r_img1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.img1), 0, P * (FD * FF * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_img2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.img2), 0, P * (FD * FF * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_img3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(POST ? p.img3 : p.img1), 0, POST ? P * FD * 2 * p.n2 : 0, 0x00020000);
+  const int img1_w = wave * (NKS * P * 1024);            // + b * 8 * NKS * P * 1024
+  const int img2_w = wave * (16 * P * 1024);             // + b * NKS * P * 1024
   u32x4 w1[NKS][P], w2[NKS][P];
-  if (nsub > 0) load_frags<P>(w1, img1_w);
+  if (nsub > 0) load_frags<P>(w1, r_img1, lane16, img1_w, true);
+#if SKF_FFN_ABLATE & 32
+  load_frags<P>(w2, r_img2, lane16, img2_w, true);
+#endif
 
   // A rows of a sub-group: thread -> float4 st_c of row st_row of every tile.  Requested one sub-group ahead (the first one here,
   // the next one under the current one's last hidden block).  In the forward they are also the residual of the epilogue, whose
@@ -435,7 +457,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnFusedParams p) {
             // the second stage's operands: behind the block's first products, so that the wait in front of those (vmcnt(0) at a loop
             // head) covers only the first-stage operands requested a whole stage ago, not these
             __builtin_amdgcn_sched_barrier(0);
-            load_frags<P>(w2, img2_w + (size_t)b * (NKS * P * 1024));
+            load_frags<P>(w2, r_img2, lane16, img2_w + b * (NKS * P * 1024));
             __builtin_amdgcn_sched_barrier(0);
           }
           if (t > 0) hidden_out(t - 1, pacc0, pacc1);
@@ -450,9 +472,11 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnFusedParams p) {
       for (int t = 0; t < NRT; ++t)
         if (t == nrt - 1) hidden_out(t, pacc0, pacc1);
       // the next first-stage operands (block 0 again behind the last block: the next sub-group starts with them)
-      load_frags<P>(w1, img1_w + (size_t)((b + 1) & (NBLK - 1)) * (8 * NKS * P * 1024));
+      load_frags<P>(w1, r_img1, lane16, img1_w + ((b + 1) & (NBLK - 1)) * (8 * NKS * P * 1024));
       FFN_STAMP();   // stage 1 issued
+#if !(SKF_FFN_ABLATE & 64)
       __syncthreads();
+#endif
       FFN_STAMP();   // behind the block barrier
       // ---- stage 2: Y += Hblock . B2[block rows]
       load_half<P>(Hb, a_off, fr.f[0], 0);
@@ -473,6 +497,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnFusedParams p) {
     }
 
     // ---- epilogue: Y through LDS, a half-wave per row
+    if constexpr (POST) load_frags<P>(w2, r_img3, lane16, wave * (NKS * P * 1024));   // the chained projection's first operands
 #pragma unroll
     for (int rt = 0; rt < NRT; ++rt) *reinterpret_cast<f32x4*>(Yt + (rt * TR + i) * YPITCH + 16 * wave + 4 * g) = y[rt];
     f32x4 xres[NRT];
@@ -510,6 +535,16 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnFusedParams p) {
           *reinterpret_cast<f32x4*>(p.out + off) = (z - mean) * rstd * gm + bt;
           if (e_sub == 0) { p.stats[2 * (size_t)grow] = mean; p.stats[2 * (size_t)grow + 1] = rstd; }
         }
+        if constexpr (POST) {
+          // the LayerNorm output as the next product's A rows: same (row, float4) -> thread map as the staging, so the planes go
+          // where the staging put them (Xp: last read in the last block's first stage, two barriers ago)
+          const f32x4 o = (z - mean) * rstd * gm + bt;
+          unsigned lo[P], hi[P];
+          skf_split2<P>(o[0], o[1], lo, sel);
+          skf_split2<P>(o[2], o[3], hi, sel);
+#pragma unroll
+          for (int q = 0; q < P; ++q) *reinterpret_cast<u32x2*>(Xp + q * PLANE + rt * TILE + st_off) = (u32x2){lo[q], hi[q]};
+        }
       } else {
         if (ok) {
           f32x4 v = yv;
@@ -518,6 +553,47 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnFusedParams p) {
           *reinterpret_cast<f32x4*>(p.C + off) = v;
         }
       }
+    }
+    if constexpr (POST) {
+      // ---- the chained projection: out2[rows][nb * 128 + 16 wave + 4g ..] = out . B3 + bias3, 128 output columns at a time.
+      // Operand registers: w2 for even blocks (free since the last hidden block), w1 for odd ones (it holds the next sub-group's
+      // first operands: re-requested behind the last block).
+      const int nb2 = p.n2 >> 7;
+      const int img3_w = wave * (NKS * P * 1024);           // + nb * 8 * NKS * P * 1024
+      const unsigned o_voff = (unsigned)(i * p.n2 + 16 * wave + 4 * g) * 4u;
+      auto post_block = [&](const u32x4 (&w)[NKS][P], int nb) {
+        const f32x4 b3 = *reinterpret_cast<const f32x4*>(B3s + nb * 128 + 16 * wave + 4 * g);
+        load_half<P>(Xp, a_off, fr.f[0], 0);
+#pragma unroll
+        for (int t = 0; t < NRT; ++t) {
+          if (t < nrt) {
+            load_half<P>(Xp + t * TILE, a_off, fr.f[1], 1);
+            f32x4 acc0 = b3, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+            int c = 0;
+            half_products<P>(w, fr.f[0], 0, acc0, acc1, c);
+            if (t + 1 < NRT) load_half<P>(Xp + (t + 1) * TILE, a_off, fr.f[0], 0);
+            half_products<P>(w, fr.f[1], 1, acc0, acc1, c);
+            const f32x4 r = acc0 + acc1;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r), r_O2, o_voff + (unsigned)tl[t] * (unsigned)(TR * 4) * (unsigned)p.n2, nb * 512, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      };
+      FFN_STAMP();   // (POST) row epilogue done
+      __syncthreads();                                   // the planes of `out` are complete
+      FFN_STAMP();   // (POST) behind the planes barrier
+      if (nb2 > 1) load_frags<P>(w1, r_img3, lane16, img3_w + 1 * (8 * NKS * P * 1024));
+      post_block(w2, 0);
+      FFN_STAMP();   // (POST) block 0
+      if (nb2 > 1) {
+        if (nb2 > 2) load_frags<P>(w2, r_img3, lane16, img3_w + 2 * (8 * NKS * P * 1024));
+        post_block(w1, 1);
+        FFN_STAMP();   // (POST) block 1
+        if (nb2 > 2) post_block(w2, 2);
+        FFN_STAMP();   // (POST) block 2
+        load_frags<P>(w1, r_img1, lane16, img1_w);        // the next sub-group's first operands again
+      }
+      __syncthreads();                                   // the next sub-group's staging overwrites the planes
     }
     FFN_STAMP();   // epilogue done
     }
@@ -627,7 +703,7 @@ __global__ __launch_bounds__(512, 2) void ln_bwd_dgrad_kernel(LnDgradParams p) {
   const __amdgpu_buffer_rsrc_t r_C = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, row_bytes, 0x00020000);
 
   u32x4 w[NKS][P];
-  if (nsub > 0) load_frags<P>(w, p.img + (size_t)wave * (NKS * P * 1024) + lane * 16);
+  if (nsub > 0) load_frags<P>(w, __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.img), 0, P * FD * FD * 2, 0x00020000), (unsigned)lane * 16u, wave * (NKS * P * 1024));
 
   f32x4 xn[MAXRT], zn[MAXRT];
   u32x2 sn[MAXRT];
@@ -748,22 +824,22 @@ int ffn_grid(int M) {
   return g > ntiles ? ntiles : g;
 }
 
-template <int P, int MODE, bool LNB = false>
+template <int P, int MODE, bool LNB = false, bool POST = false>
 int launch_ffn(const FfnFusedParams& p, hipStream_t st) {
   const int grid = ffn_grid(p.M);
-  const size_t smem = (size_t)3 * P * PLANE + (P * PLANE >= ROWS * YPITCH * 4 ? 0 : ROWS * YPITCH * 4) + FF * sizeof(float);
+  const size_t smem = (size_t)3 * P * PLANE + (P * PLANE >= ROWS * YPITCH * 4 ? 0 : ROWS * YPITCH * 4) + (FF + 384) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fused_kernel<P, MODE, LNB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fused_kernel<P, MODE, LNB, POST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_done = true;
   }
-  static const std::string tag = std::string(MODE == 0 ? "ffn_fused_fwd" : LNB ? "ffn_fused_bwd_ln" : "ffn_fused_bwd") + "<d128,dff512,bf16x" + std::to_string(P * (P + 1) / 2) + ">";
+  static const std::string tag = std::string(MODE == 0 ? (POST ? "ffn_fused_fwd_proj" : "ffn_fused_fwd") : LNB ? "ffn_fused_bwd_ln" : "ffn_fused_bwd") + "<d128,dff512,bf16x" + std::to_string(P * (P + 1) / 2) + ">";
   const double live = skf_prof_list_fraction(p.row_blocks);
-  const double flops = 2.0 * 2.0 * p.M * FD * FF;
-  const double bytes = 4.0 * ((double)p.M * FD * (MODE == 0 ? 4 : 3) + (double)p.M * FF) + 2.0 * image_bytes(P) / 2;
+  const double flops = 2.0 * 2.0 * p.M * FD * FF + (POST ? 2.0 * p.M * FD * p.n2 : 0.0);
+  const double bytes = 4.0 * ((double)p.M * FD * (MODE == 0 ? 4 : 3) + (double)p.M * FF + (POST ? (double)p.M * p.n2 : 0.0)) + 2.0 * image_bytes(P) / 2;
   SkfProfScope ps(st, tag.c_str(), flops, bytes);
   ps.done(flops * live, bytes * live);
-  hipLaunchKernelGGL((ffn_fused_kernel<P, MODE, LNB>), dim3(grid), dim3(512), smem, st, p);
+  hipLaunchKernelGGL((ffn_fused_kernel<P, MODE, LNB, POST>), dim3(grid), dim3(512), smem, st, p);
   SKF_LAUNCH_CHECK();
   return SKF_OK;
 }
@@ -772,6 +848,7 @@ int launch_ffn(const FfnFusedParams& p, hipStream_t st) {
 
 int skf_ffn_fused_launch(const FfnFusedParams& p, int pieces, int direction, hipStream_t st) {
   if (direction == 1 && p.ln_dout) return pieces == 2 ? launch_ffn<2, 1, true>(p, st) : launch_ffn<3, 1, true>(p, st);
+  if (direction == 0 && p.img3) return pieces == 2 ? launch_ffn<2, 0, false, true>(p, st) : launch_ffn<3, 0, false, true>(p, st);
   if (pieces == 2) return direction == 0 ? launch_ffn<2, 0>(p, st) : launch_ffn<2, 1>(p, st);
   return direction == 0 ? launch_ffn<3, 0>(p, st) : launch_ffn<3, 1>(p, st);
 }
@@ -931,4 +1008,26 @@ extern "C" int skf_layernorm_bwd_dgrad_f32(int M, int d, const float* dout, cons
   else hipLaunchKernelGGL(ln_bwd_dgrad_kernel<3>, dim3(grid), dim3(512), smem, st, p);
   SKF_LAUNCH_CHECK();
   return SKF_OK;
+}
+
+extern "C" int skf_ffn_fused_fwd_proj_f32(int M, int d, int dff, const float* x, const void* image, const float* b1, const float* b2,
+                                          float* h, void* relu_bits_out, const float* gamma, const float* beta, float* z, float* out,
+                                          float* stats, float rate, unsigned site, const void* step_state, const void* proj_image,
+                                          const float* proj_bias, int proj_n, float* proj_out, int precision, skf_stream_t stream) {
+  const int rc = ffn_common_checks(M, d, dff, precision, x, image, h, z);
+  if (rc != SKF_OK) return rc;
+  SKF_CHECK_ARG(gamma && beta && out && stats && b1 && b2, "null bias / LayerNorm operand");
+  SKF_CHECK_ARG(rate >= 0.f && rate < 1.f && (rate == 0.f || step_state), "dropout needs 0 <= rate < 1 and the step state");
+  SKF_CHECK_ARG((((uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0 && (((uintptr_t)stats | (uintptr_t)relu_bits_out) & 7) == 0, "operands must be 16-byte aligned");
+  SKF_CHECK_ARG(proj_image && proj_bias && proj_out && (proj_n == 128 || proj_n == 256 || proj_n == 384), "chained projection: N in {128, 256, 384} with its image, bias and output");
+  SKF_CHECK_ARG((((uintptr_t)proj_image | (uintptr_t)proj_bias | (uintptr_t)proj_out) & 15) == 0 && (double)M * proj_n * 4 < 2147483648.0, "chained projection operands");
+  const int P = precision == SKF_PREC_BF16X3 ? 2 : 3;
+  FfnFusedParams p{};
+  p.A = x; p.lda = d; p.M = M;
+  p.img1 = (const char*)image; p.img2 = (const char*)image + image_bytes(P) / 2;
+  p.bias1 = b1; p.bias2 = b2; p.H = h; p.bits_out = (unsigned long long*)relu_bits_out;
+  p.C = z; p.res = x; p.gamma = gamma; p.beta = beta; p.out = out; p.stats = stats;
+  p.rate = rate; p.site = site; p.state = step_state;
+  p.img3 = (const char*)proj_image; p.bias3 = proj_bias; p.out2 = proj_out; p.n2 = proj_n;
+  return skf_ffn_fused_launch(p, P, 0, (hipStream_t)stream);
 }

@@ -290,8 +290,8 @@ struct Bump {
   size_t take(size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; }
 };
 
-struct EncAct { size_t x_in, qkv, o, z1, st1, astats, x1, h, z2, st2, x2, hbits, img[2], img_o; };   // img: pre-split ffn weight images (forward, backward); img_o: Wo^T
-struct DecAct { size_t x_in, qkv, o1, z1, st1, astats1, out1, q2, kv2, o2, astats2, z2, st2, out2, h, z3, st3, out3, hbits, img[2], img_o1, img_o2; };
+struct EncAct { size_t x_in, qkv, o, z1, st1, astats, x1, h, z2, st2, x2, hbits, img[2], img_o, img_qkv; };   // img: pre-split ffn weight images (forward, backward); img_o: Wo^T; img_qkv: this layer's Wqkv (read by the PREVIOUS layer's feed-forward launch)
+struct DecAct { size_t x_in, qkv, o1, z1, st1, astats1, out1, q2, kv2, o2, astats2, z2, st2, out2, h, z3, st3, out3, hbits, img[2], img_o1, img_o2, img_qkv; };
 
 struct Plan {
   size_t bytes = 0;
@@ -341,6 +341,7 @@ Plan build_plan(const SkfConfig& c) {
                               skf_ffn_relu_bits_bytes((int)Me, (int)d, (int)F, c.gemm_precision)));
     a.img[0] = b.take(skf_ffn_image_bytes((int)d, (int)F, c.gemm_precision)); a.img[1] = b.take(skf_ffn_image_bytes((int)d, (int)F, c.gemm_precision));
     a.img_o = b.take(skf_dense_image_bytes((int)d, (int)d, c.gemm_precision));
+    a.img_qkv = b.take(skf_dense_image_bytes((int)d, 3 * (int)d, c.gemm_precision));
     a.x2 = 0;
     P.enc.push_back(a);
   }
@@ -363,6 +364,7 @@ Plan build_plan(const SkfConfig& c) {
                               skf_ffn_relu_bits_bytes((int)Md, (int)d, (int)F, c.gemm_precision)));
     a.img[0] = b.take(skf_ffn_image_bytes((int)d, (int)F, c.gemm_precision)); a.img[1] = b.take(skf_ffn_image_bytes((int)d, (int)F, c.gemm_precision));
     a.img_o1 = b.take(skf_dense_image_bytes((int)d, (int)d, c.gemm_precision)); a.img_o2 = b.take(skf_dense_image_bytes((int)d, (int)d, c.gemm_precision));
+    a.img_qkv = b.take(skf_dense_image_bytes((int)d, 3 * (int)d, c.gemm_precision));
     a.out3 = 0;
     P.dec.push_back(a);
   }
@@ -814,19 +816,31 @@ int build_ffn_images(SkfModel* M, bool with_backward, bool encoder_only, hipStre
   const bool dec = !encoder_only && do_recon(c);
   for (int i = 0; i < c.num_layers; ++i) {
     ffn(L.enc[i].f1, L.enc[i].f2, P.enc[i].img);
+    if (i > 0) one(L.enc[i].mha.qkv, 0, d, 3 * d, M->at<char>(P.enc[i].img_qkv));
     if (with_backward) one(L.enc[i].mha.o, 1, d, d, M->at<char>(P.enc[i].img_o));
   }
   if (dec)
     for (int i = 0; i < c.num_layers; ++i) {
       ffn(L.dec[i].f1, L.dec[i].f2, P.dec[i].img);
+      if (i > 0) one(L.dec[i].mha1.qkv, 0, d, 3 * d, M->at<char>(P.dec[i].img_qkv));
       if (with_backward) { one(L.dec[i].mha1.o, 1, d, d, M->at<char>(P.dec[i].img_o1)); one(L.dec[i].mha2.o, 1, d, d, M->at<char>(P.dec[i].img_o2)); }
     }
   return skf_dense_weight_images((int)src.size(), src.data(), ld.data(), tr.data(), K.data(), N.data(), img.data(), c.gemm_precision, s);
 }
 // out = LayerNorm(x + dropout(ffn(x))): one launch, or Dense(relu) + Dense + residual-LayerNorm
+// next / next_image / next_out: the Dense that consumes `out` (the next layer's q|k|v projection), taken into the same launch when
+// the fused kernel runs (*next_done = true), else left to the caller
 int ffn_ln_fwd(SkfModel* M, const DenseP& f1, const DenseP& f2, const LnP& ln, const float* x, int rows, float* h, void* bits,
-               const void* image, float* z, float* out, float* stats, float rate, unsigned site, hipStream_t s) {
+               const void* image, float* z, float* out, float* stats, float rate, unsigned site, hipStream_t s,
+               const DenseP* next = nullptr, const void* next_image = nullptr, float* next_out = nullptr, bool* next_done = nullptr) {
   const int d = M->cfg.d_model;
+  static const bool chain_off = skf_knob("SKF_NO_FFN_CHAIN") && skf_knob("SKF_NO_FFN_CHAIN")[0] == '1';   // (measurement builds only)
+  if (next_done) *next_done = false;
+  if (M->ffn_fused && next && !chain_off && next->in == d && (next->out == 128 || next->out == 256 || next->out == 384) && next->ld == next->out) {
+    if (next_done) *next_done = true;
+    return skf_ffn_fused_fwd_proj_f32(rows, d, M->cfg.dff, x, image, M->P(f1.b), M->P(f2.b), h, bits, M->P(ln.g), M->P(ln.b), z, out, stats,
+                                      rate, site, M->state, next_image, M->P(next->b), next->out, next_out, M->cfg.gemm_precision, s);
+  }
   if (M->ffn_fused)
     return skf_ffn_fused_fwd_f32(rows, d, M->cfg.dff, x, image, M->P(f1.b), M->P(f2.b), h, bits, M->P(ln.g), M->P(ln.b), z, out, stats,
                                  rate, site, M->state, M->cfg.gemm_precision, s);
@@ -866,18 +880,22 @@ int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s, bool 
   else
     SKF_TRY(skf_embed_fwd(inp, Le, B, Le, M->P(L.enc_emb), c.vocab_size, d, M->pos, M->at<float>(P.enc[0].x_in), rate,
                           site_enc_embed(), M->state, s));
+  bool enc_qkv_done = false;
   for (int i = 0; i < N; ++i) {
     const EncLayerP& w = L.enc[i];
     const EncAct& a = P.enc[i];
     float* x = M->at<float>(a.x_in);
     float* qkv = M->at<float>(a.qkv);
-    SKF_TRY(dense_fwd(M, w.mha.qkv, x, Me, qkv, 0, s));
+    if (!enc_qkv_done) SKF_TRY(dense_fwd(M, w.mha.qkv, x, Me, qkv, 0, s));     // (else: the previous layer's feed-forward launch wrote it)
     SKF_TRY(skf_attention_fwd(qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, emask, Le, 0, B, H, Le, Le, dh,
                               M->at<float>(a.o), d, M->at<float>(a.astats), M->cfg.gemm_precision, s));
     SKF_TRY(dense_ln_fwd(M, w.mha.o, M->at<float>(a.o), Me, x, M->at<float>(a.z1), w.ln1, M->at<float>(a.x1), M->at<float>(a.st1), rate,
                          site_enc(i, 0), s));
+    const bool has_next = i + 1 < N;
     SKF_TRY(ffn_ln_fwd(M, w.f1, w.f2, w.ln2, M->at<float>(a.x1), Me, M->at<float>(a.h), hbits_of(M, a.hbits, Me), M->at<char>(a.img[0]),
-                       M->at<float>(a.z2), M->at<float>(a.x2), M->at<float>(a.st2), rate, site_enc(i, 1), s));
+                       M->at<float>(a.z2), M->at<float>(a.x2), M->at<float>(a.st2), rate, site_enc(i, 1), s,
+                       has_next ? &L.enc[i + 1].mha.qkv : nullptr, has_next ? M->at<char>(P.enc[i + 1].img_qkv) : nullptr,
+                       has_next ? M->at<float>(P.enc[i + 1].qkv) : nullptr, &enc_qkv_done));
   }
   float* enc_out = M->at<float>(P.enc[N - 1].x2);
   // ---------------- bottleneck + classifier + expander (models/sketchformer.py:149-160,183-199,170-176)
@@ -925,12 +943,13 @@ int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s, bool 
     for (int i = 0; i < N; ++i) SKF_TRY(dense_fwd(M, L.dec[i].mha2.kv, pre, Me, M->at<float>(P.dec[i].kv2), 0, M->side));
     SKF_HIP(hipEventRecord(kv_done, M->side));
   }
+  bool dec_qkv_done = false;
   for (int i = 0; i < N; ++i) {
     const DecLayerP& w = L.dec[i];
     const DecAct& a = P.dec[i];
     float* x = M->at<float>(a.x_in);
     float* qkv = M->at<float>(a.qkv);
-    SKF_TRY(dense_fwd(M, w.mha1.qkv, x, Md, qkv, 0, s));
+    if (!dec_qkv_done) SKF_TRY(dense_fwd(M, w.mha1.qkv, x, Md, qkv, 0, s));
     SKF_TRY(skf_attention_fwd(qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, dmask, Ld, 1, B, H, Ld, Ld, dh,
                               M->at<float>(a.o1), d, M->at<float>(a.astats1), M->cfg.gemm_precision, s));
     SKF_TRY(dense_ln_fwd(M, w.mha1.o, M->at<float>(a.o1), Md, x, M->at<float>(a.z1), w.ln1, M->at<float>(a.out1), M->at<float>(a.st1),
@@ -943,8 +962,11 @@ int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s, bool 
                               M->at<float>(a.o2), d, M->at<float>(a.astats2), M->cfg.gemm_precision, s));
     SKF_TRY(dense_ln_fwd(M, w.mha2.o, M->at<float>(a.o2), Md, M->at<float>(a.out1), M->at<float>(a.z2), w.ln2, M->at<float>(a.out2),
                          M->at<float>(a.st2), rate, site_dec(N, i, 1), s));
+    const bool has_next = i + 1 < N;
     SKF_TRY(ffn_ln_fwd(M, w.f1, w.f2, w.ln3, M->at<float>(a.out2), Md, M->at<float>(a.h), hbits_of(M, a.hbits, Md), M->at<char>(a.img[0]),
-                       M->at<float>(a.z3), M->at<float>(a.out3), M->at<float>(a.st3), rate, site_dec(N, i, 2), s));
+                       M->at<float>(a.z3), M->at<float>(a.out3), M->at<float>(a.st3), rate, site_dec(N, i, 2), s,
+                       has_next ? &L.dec[i + 1].mha1.qkv : nullptr, has_next ? M->at<char>(P.dec[i + 1].img_qkv) : nullptr,
+                       has_next ? M->at<float>(P.dec[i + 1].qkv) : nullptr, &dec_qkv_done));
   }
   SKF_TRY(dense_fwd(M, L.out, M->at<float>(P.dec[N - 1].out3), Md, M->at<float>(P.logits), 0, s));
   }

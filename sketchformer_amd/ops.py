@@ -260,8 +260,9 @@ def ffn_weight_images(pairs, transpose, precision=None):
     return imgs
 
 
-def ffn_fused_fwd(x, image, b1, b2, gamma, beta, dff, rate=0.0, site=0, state=None, precision=None):
-    """One launch: h = relu(x.W1 + b1), z = x + dropout(h.W2 + b2), out = LayerNorm(z) -> out, z, stats, h, sign bits."""
+def ffn_fused_fwd(x, image, b1, b2, gamma, beta, dff, rate=0.0, site=0, state=None, precision=None, proj=None):
+    """One launch: h = relu(x.W1 + b1), z = x + dropout(h.W2 + b2), out = LayerNorm(z) -> out, z, stats, h, sign bits.
+    proj = (image of Wp [d, n], bias [n]): also out . Wp + bias in the same launch -> (..., proj_out)."""
     _f32(x, "x")
     M, d = x.shape
     h = torch.empty(M, dff, dtype=torch.float32, device=x.device)
@@ -270,6 +271,12 @@ def ffn_fused_fwd(x, image, b1, b2, gamma, beta, dff, rate=0.0, site=0, state=No
     z = torch.empty_like(x)
     out = torch.empty_like(x)
     stats = torch.empty(M, 2, dtype=torch.float32, device=x.device)
+    if proj is not None:
+        pimg, pbias = proj
+        po = torch.empty(M, pbias.numel(), dtype=torch.float32, device=x.device)
+        _lib.call("skf_ffn_fused_fwd_proj_f32", M, d, dff, _p(x), _p(image), _p(b1), _p(b2), _p(h), _p(bits), _p(gamma), _p(beta),
+                  _p(z), _p(out), _p(stats), rate, site, _p(state), _p(pimg), _p(pbias), pbias.numel(), _p(po), _prec(precision), _stream())
+        return out, z, stats, h, bits, po
     _lib.call("skf_ffn_fused_fwd_f32", M, d, dff, _p(x), _p(image), _p(b1), _p(b2), _p(h), _p(bits), _p(gamma), _p(beta),
               _p(z), _p(out), _p(stats), rate, site, _p(state), _prec(precision), _stream())
     return out, z, stats, h, bits

@@ -968,6 +968,36 @@ def test_layernorm_bwd_dgrad_one_launch(ops, rows, listed, rate):
         assert (gda - rda).abs().max().item() <= 4e-6 * max(1.0, rda.abs().max().item())
 
 
+@pytest.mark.parametrize("rows,n2", [(25600, 384), (25472, 128), (1031, 384), (7, 128)])
+def test_ffn_fused_forward_with_chained_projection(ops, rows, n2):
+    """The forward launch going on to the next layer's q|k|v (N = 384) / query (N = 128) projection of its LayerNorm output."""
+    d, dff = 128, 512
+    rng = np.random.RandomState(rows + n2)
+    x = rng.randn(rows, d)
+    w1, b1 = rng.randn(d, dff) / np.sqrt(d), 0.1 * rng.randn(dff)
+    w2, b2 = rng.randn(dff, d) / np.sqrt(dff), 0.1 * rng.randn(d)
+    wp, bp = rng.randn(d, n2) / np.sqrt(d), 0.1 * rng.randn(n2)
+    gamma, beta = 1 + 0.1 * rng.randn(d), 0.1 * rng.randn(d)
+    st = ops.new_step_state("cuda", iterations=3)
+    ops.step_prologue(st, seed=5)
+    keep = ops.dropout_keep_mask(ops.read_step_state(st)["drop_key"], 9, 0.1, rows * d).reshape(rows, d)
+    h = np.maximum(x @ w1 + b1, 0)
+    z = x + oracle.dropout_fwd(h @ w2 + b2, keep, 0.1)
+    want, _ = oracle.layernorm_fwd(z, gamma, beta)
+    X, W1, B1, W2, B2, G, Be, WP, BP = _dev(x), _dev(w1), _dev(b1), _dev(w2), _dev(b2), _dev(gamma), _dev(beta), _dev(wp), _dev(bp)
+    img, = ops.ffn_weight_images([(W1, W2)], transpose=False)
+    pimg = ops.dense_weight_image(WP, transpose=False)
+    out, zz, stats, hh, bits, po = ops.ffn_fused_fwd(X, img, B1, B2, G, Be, dff, rate=0.1, site=9, state=st, proj=(pimg, BP))
+    _close(zz, z, name="z")
+    _close(out, want, name="ln out")
+    _close(po, want @ wp + bp, rtol=3e-5, name="chained projection")
+    out1, z1, _, _, _ = ops.ffn_fused_fwd(X, img, B1, B2, G, Be, dff, rate=0.1, site=9, state=st)
+    assert torch.equal(out, out1) and torch.equal(zz, z1), "the chained launch changes the block's own outputs"
+    if rows > 2048:
+        ref = ops.gemm(out, WP, bias=BP)
+        assert (po - ref).abs().max().item() <= 4e-6 * max(1.0, ref.abs().max().item())
+
+
 def test_ffn_fused_refuses_other_shapes(ops):
     lib = ops._lib.load()
     assert lib.skf_ffn_fused_supported(25600, 128, 512, 6) == 1

@@ -35,6 +35,17 @@ def main():
     hb = ops.relu_bits(M, F, d, dev)
     y = torch.empty(M, d, device=dev)
 
+    wp, bp = r(d, 384) / 11, r(384)
+    pimg = ops.dense_weight_image(wp, transpose=False)
+    po = torch.empty(M, 384, device=dev)
+
+    def fused_fwd_proj():
+        _lib.call("skf_ffn_fused_fwd_proj_f32", M, d, F, p(x), p(img), p(b1), p(b2), p(h), p(bits), p(g), p(be), p(z), p(out), p(stats),
+                  rate, 7, p(st), p(pimg), p(bp), 384, p(po), 6, s())
+
+    def qkv_gemm():
+        ops.gemm(out, wp, bias=bp, out=po)
+
     def unfused_fwd():
         ops.gemm(x, w1, bias=b1, act=1, out=h, relu_bits_out=hb)
         ops.gemm(h, w2, bias=b2, out=y)
@@ -53,7 +64,7 @@ def main():
         ops.ffn_weight_images([(w1, w2)] * 8, transpose=False)
 
     fl = 4.0 * M * d * F
-    for name, fn in (("fused fwd", fused_fwd), ("3 launches fwd", unfused_fwd), ("fused bwd", fused_bwd), ("2 launches bwd", unfused_bwd),
+    for name, fn in (("fused fwd", fused_fwd), ("fused fwd + qkv", fused_fwd_proj), ("qkv gemm alone", qkv_gemm), ("3 launches fwd", unfused_fwd), ("fused bwd", fused_bwd), ("2 launches bwd", unfused_bwd),
                      ("8 image pairs", images)):
         med, mn = timeit(fn, iters=50)
         print("%-16s med %7.1f us  min %7.1f us  %6.1f TF fp32-equivalent" % (name, med, mn, fl / med / 1e6), flush=True)

@@ -18,8 +18,12 @@ r = lambda *s: torch.randn(*s, device=dev)  # noqa: E731
 x, w1, b1, w2, b2, g, be = r(M, d), r(d, F) / 11, r(F), r(F, d) / 22, r(d), r(d), r(d)
 img, = ops.ffn_weight_images([(w1, w2)], transpose=False)
 imgt, = ops.ffn_weight_images([(w1, w2)], transpose=True)
+proj = None
+if mode == "proj":
+    wp, bp = r(d, 384) / 11, r(384)
+    proj = (ops.dense_weight_image(wp, transpose=False), bp)
 for _ in range(3):
-    out, z, stats, h, bits = ops.ffn_fused_fwd(x, img, b1, b2, g, be, F)
+    out, z, stats, h, bits = ops.ffn_fused_fwd(x, img, b1, b2, g, be, F, proj=proj)[:5]
     if mode == "bwd":
         ops.ffn_fused_bwd(r(M, d), imgt, bits, F, dx=r(M, d))
 torch.cuda.synchronize()
@@ -27,7 +31,7 @@ lib = C.CDLL(_lib.LIB_PATH)
 buf = (C.c_longlong * (16 * 64))()
 assert lib.skf_ffn_debug_stamps(buf) == 0
 a = np.frombuffer(buf, dtype=np.int64).reshape(16, 64)
-names = ["staged", "barrier"] + sum([["s1.%d" % b, "bar.%d" % b, "s2.%d" % b] for b in range(4)], []) + ["epilogue"]
+names = ["staged", "barrier"] + sum([["s1.%d" % b, "bar.%d" % b, "s2.%d" % b] for b in range(4)], []) + (["rowepi", "bar", "post0", "post1", "post2", "end"] if mode == "proj" else ["epilogue"])
 for w in range(16):
     t = a[w]
     n = int((t != 0).sum())
