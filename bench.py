@@ -175,6 +175,12 @@ def _kernel_prefix(tag):
     m = re.match(r"gemm_ws(x?)<K(\d+),CW(\d+)", tag)
     if m:   # kernel template is <K, columns per lane = CW/16, ...>
         return "gemm_ws%s_kernel<%s, %d," % (m.group(1), m.group(2), int(m.group(3)) // 16)
+    m = re.match(r"ffn_fused<d128,dff512,bf16x(\d)>", tag)
+    if m:   # ffn_fused_kernel<P, MODE, LNB, POST>: the family = every variant of one piece count
+        return "ffn_fused_kernel<%d," % (3 if m.group(1) == "6" else 2)
+    m = re.match(r"ln_bwd_dgrad<d128,bf16x(\d)>", tag)
+    if m:
+        return "ln_bwd_dgrad_kernel<%d>" % (3 if m.group(1) == "6" else 2)
     table = {"wgrad<64x64>": "wgrad_kernel", "wgrad<64x64,bf16x6>": "wgrad_x_kernel<3", "wgrad<64x64,bf16x3>": "wgrad_x_kernel<2",
              "attn_bwd<dh16>": "attn_bwd_kernel<16", "attn_fwd<dh16>": "attn_fwd_kernel<16", "attn_bwd<dh32>": "attn_bwd_kernel<32",
              "attn_fwd<dh32>": "attn_fwd_kernel<32", "ln_fwd": "ln_fwd", "ln_bwd": "ln_bwd", "gemm_bf16_nt": "gemm_bf16_nt_kernel",
@@ -386,6 +392,13 @@ def sub_record(engine, synthetic, name, B, steps, warmup, seed=0, traffic=True):
         key = "full_length" if full else "padded"
         rec[key] = {"ms_per_step": 1e3 * e / steps, "value": B * w["L"] * steps / e,
                     "pad_fraction": float((xs[..., 4] == 1).mean() if w["cont"] else (xs == 0).mean())}
+    if not w["cont"] and w["L"] != 200:
+        # SURVEY 8(d) draws the lengths from N(80, 35^2) whatever the sequence length: 83 % padding at L = 512.  The same distribution
+        # stretched with the sequence length (58 % padding, like the L = 200 batches) beside it.
+        xs, ys = synthetic.token_batch(B, w["L"], w["V"], CN, seed=seed, length_scale=w["L"] / 200.0)
+        e = timed(eng, torch.from_numpy(xs).cuda(), torch.from_numpy(ys).cuda(), steps, warmup)
+        rec["scaled_lengths"] = {"ms_per_step": 1e3 * e / steps, "value": B * w["L"] * steps / e, "pad_fraction": float((xs == 0).mean()),
+                                 "what": "lengths ~ N(80, 35^2) x L / 200"}
     assert np.isfinite(eng.step_metrics()["total_loss"])
     P = eng.n_floats
     del eng
@@ -499,6 +512,9 @@ def compact_line(out):
                 s["full_length_ms"] = _r(rec["full_length"].get("ms_per_step"), 4)
             if isinstance(rec.get("padded"), dict):
                 s["pad_fraction"] = _r(rec["padded"].get("pad_fraction"), 3)
+            if isinstance(rec.get("scaled_lengths"), dict):
+                s["scaled_lengths_ms"] = _r(rec["scaled_lengths"].get("ms_per_step"), 4)
+                s["scaled_pad_fraction"] = _r(rec["scaled_lengths"].get("pad_fraction"), 3)
             if "error" in rec:
                 s["error"] = str(rec["error"])[:80]
             line[leg] = s
@@ -633,9 +649,20 @@ def main():
         del eng0
         out["fp32_mfma_mode"] = {"ms_per_step": 1e3 * e1 / args.steps, "value": B * L * args.steps / e1,
                                  "step_mfma_frac": f_step / (e1 / args.steps) / (PEAK_F32_MFMA_TFLOPS * 1e12)}
+    if extras and not args.graph and not args.full_length:
+        # the same step replayed from hipGraphs (one stream: graph nodes of different streams did not overlap, so the weight gradients
+        # lose their side stream) - reported beside the eager headline, which is the default because it is faster
+        try:
+            engg = engine.TrainEngine(engine.make_config(use_graph=True, **cfg_kwargs), init_seed=0)
+            e1 = timed(engg, x, y, args.steps, 5)
+            del engg
+            out["hip_graph_mode"] = {"ms_per_step": 1e3 * e1 / args.steps, "value": B * L * args.steps / e1,
+                                     "step_mfma_frac": f_step / (e1 / args.steps) / (peak * 1e12)}
+        except Exception as exc:      # noqa: BLE001
+            out["hip_graph_mode"] = {"error": str(exc)[:80]}
     del eng
     torch.cuda.empty_cache()
-    _progress("full-length / fp32-MFMA legs done")
+    _progress("full-length / fp32-MFMA / hipGraph legs done")
     if rank == 0 and not args.no_profile:
         rows, _ = kernel_profile(engine, cfg_kwargs, x, y)
         rows.sort(key=lambda r: -r["ms"])

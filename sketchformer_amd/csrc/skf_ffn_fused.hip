@@ -833,7 +833,11 @@ int launch_ffn(const FfnFusedParams& p, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fused_kernel<P, MODE, LNB, POST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_done = true;
   }
-  static const std::string tag = std::string(MODE == 0 ? (POST ? "ffn_fused_fwd_proj" : "ffn_fused_fwd") : LNB ? "ffn_fused_bwd_ln" : "ffn_fused_bwd") + "<d128,dff512,bf16x" + std::to_string(P * (P + 1) / 2) + ">";
+  // one profiler line for the family (the kernel template's forward / backward / LayerNorm-prologue / chained-projection variants,
+  // like the epilogue kinds of gemm_wsx); SKF_PROF_FINE=1 (measurement builds): one line per variant
+  static const bool fine = skf_knob("SKF_PROF_FINE") && skf_knob("SKF_PROF_FINE")[0] == '1';
+  static const std::string tag = std::string("ffn_fused") + (!fine ? "" : MODE == 0 ? (POST ? "_fwd_proj" : "_fwd") : LNB ? "_bwd_ln" : "_bwd") +
+                                 "<d128,dff512,bf16x" + std::to_string(P * (P + 1) / 2) + ">";
   const double live = skf_prof_list_fraction(p.row_blocks);
   const double flops = 2.0 * 2.0 * p.M * FD * FF + (POST ? 2.0 * p.M * FD * p.n2 : 0.0);
   const double bytes = 4.0 * ((double)p.M * FD * (MODE == 0 ? 4 : 3) + (double)p.M * FF + (POST ? (double)p.M * p.n2 : 0.0)) + 2.0 * image_bytes(P) / 2;
