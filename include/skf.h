@@ -165,6 +165,22 @@ int skf_ffn_fused_fwd_proj_f32(int M, int d, int dff, const float* x, const void
                                float* h, void* relu_bits_out, const float* gamma, const float* beta, float* z, float* out,
                                float* stats, float rate, unsigned site, const void* step_state, const void* proj_image,
                                const float* proj_bias, int proj_n, float* proj_out, int precision, skf_stream_t stream);
+/* The forward launch in its general form: the feed-forward block with an optional LEADING stage and an optional CHAINED projection.
+ * Leading stage (pre_image != NULL): the launch starts at the attention output a (= x [M, d]):
+ *   pre_z = pre_residual + dropout(a . Wo + pre_bias, rate, pre_site);  pre_out = LayerNorm(pre_z; pre_gamma, pre_beta);  pre_stats = (mean, rstd)
+ * - the MultiHeadAttention output projection with its residual LayerNorm (builders/layers/transformer.py:186, 216-224 / 262-268), i.e.
+ * skf_gemm_ln_residual_f32 - and pre_out is the block's input and residual (pre_image = skf_dense_weight_images(Wo [d][d], transpose 0)).
+ * Chained projection (proj_image != NULL): as skf_ffn_fused_fwd_proj_f32.  struct_size = sizeof(SkfFfnBlockFwd). */
+typedef struct SkfFfnBlockFwd {
+  uint32_t struct_size; int32_t M, d, dff, precision;
+  const float* x; const void* image; const float* b1; const float* b2; float* h; void* relu_bits_out;
+  const float* gamma; const float* beta; float* z; float* out; float* stats;
+  float rate; uint32_t site; const void* step_state;
+  const void* pre_image; const float* pre_bias; const float* pre_residual; const float* pre_gamma; const float* pre_beta;
+  float* pre_z; float* pre_out; float* pre_stats; uint32_t pre_site; int32_t proj_n;
+  const void* proj_image; const float* proj_bias; float* proj_out;
+} SkfFfnBlockFwd;
+int skf_ffn_block_fwd_f32(const SkfFfnBlockFwd* block, skf_stream_t stream);
 /* The backward launch starting one step earlier, at the gradient `dout` of the LayerNorm that closes the block
  * (out = LayerNorm(z), z = x + dropout(ffn(x))): dz = LayerNorm'(dout) from (z, stats, gamma) with the arithmetic of
  * skf_layernorm_residual_bwd, dy = dropout'(dz) (written: the second Dense's weight gradient reads it), dh as above, and

@@ -62,6 +62,17 @@ class SkfConfig(C.Structure):
             self.struct_size = C.sizeof(SkfConfig)
 
 
+class SkfFfnBlockFwd(C.Structure):
+    """include/skf.h: struct SkfFfnBlockFwd, field for field (skf_ffn_block_fwd_f32)."""
+    _fields_ = [("struct_size", C.c_uint32), ("M", C.c_int32), ("d", C.c_int32), ("dff", C.c_int32), ("precision", C.c_int32),
+                ("x", C.c_void_p), ("image", C.c_void_p), ("b1", C.c_void_p), ("b2", C.c_void_p), ("h", C.c_void_p), ("relu_bits_out", C.c_void_p),
+                ("gamma", C.c_void_p), ("beta", C.c_void_p), ("z", C.c_void_p), ("out", C.c_void_p), ("stats", C.c_void_p),
+                ("rate", C.c_float), ("site", C.c_uint32), ("step_state", C.c_void_p),
+                ("pre_image", C.c_void_p), ("pre_bias", C.c_void_p), ("pre_residual", C.c_void_p), ("pre_gamma", C.c_void_p), ("pre_beta", C.c_void_p),
+                ("pre_z", C.c_void_p), ("pre_out", C.c_void_p), ("pre_stats", C.c_void_p), ("pre_site", C.c_uint32), ("proj_n", C.c_int32),
+                ("proj_image", C.c_void_p), ("proj_bias", C.c_void_p), ("proj_out", C.c_void_p)]
+
+
 class SkfParamEntry(C.Structure):
     _fields_ = [("name", C.c_char * 96), ("offset", C.c_int64), ("rows", C.c_int32), ("cols", C.c_int32),
                 ("row_stride", C.c_int32)]
@@ -104,6 +115,7 @@ SIGNATURES = {
     "skf_layernorm_bwd_dgrad_partials": (_I, [_I]),
     "skf_layernorm_bwd_dgrad_f32": (_I, [_I, _I, _P, _P, _P, _P, _F, _U, _P, _P, _P, _P, _P, _P, _Z, _P, _I, _I, _P]),
     "skf_ffn_fused_fwd_proj_f32": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _U, _P, _P, _P, _I, _P, _I, _P]),
+    "skf_ffn_block_fwd_f32": (_I, [C.POINTER(SkfFfnBlockFwd), _P]),
     "skf_target_live_len": (_I, [_P, _I, _I, _I, _P, _P]),
     "skf_row_blocks_bytes": (_Z, [_I, _I]),
     "skf_row_blocks_build": (_I, [_P, _I, _I, _I, _P, _P]),

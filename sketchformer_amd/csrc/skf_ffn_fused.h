@@ -17,6 +17,9 @@ struct FfnFusedParams {
   const float* gamma; const float* beta; float* out; float* stats;   // forward: LayerNorm(z)
   float rate; unsigned site; const void* state;                     // forward: dropout of y (SkfStepState*)
   const int* row_blocks;               // 16-row block list (skf_row_blocks_build) or null
+  // forward starting at the attention output (pre_img != null): A = a [M][128]; x1 = LayerNorm(pre_res + dropout(a . Bp + pre_bias)) is the block's input
+  const char* pre_img; const float* pre_bias; const float* pre_res; const float* pre_gamma; const float* pre_beta; unsigned pre_site;
+  float* pre_z; float* pre_out; float* pre_stats;
   // forward with a chained projection (img3 != null): out2[M][n2] = out . B3 + bias3, B3 [128][n2] as a pre-split image, n2 in {128, 256, 384}
   const char* img3; const float* bias3; float* out2; int n2;
   // backward with the LayerNorm-backward prologue (ln_dout != null): A is not read; gamma / rate / site / state are the LayerNorm's

@@ -208,10 +208,14 @@ __device__ __forceinline__ float ffn_half_wave_sum(float v) {
 // POST (forward only): the launch goes on to the Dense that consumes its LayerNorm output (the next layer's q|k|v projection,
 // builders/layers/transformer.py:154-158: K = 128, N = 128 or 384) - the rows are split again on their way out, one more set of
 // first-stage products per 128 output columns, stored from the transposed fragments like the hidden tensor.
-template <int P, int MODE, bool LNB = false, bool POST = false>
+// PRE (forward only): the launch STARTS one sublayer earlier, at the attention output a: x1 = LayerNorm(x + dropout(a . Wo + bo)) - the
+// MultiHeadAttention output projection with its residual LayerNorm (builders/layers/transformer.py:186, 216-224) - is formed by one
+// product stage (K = N = 128) and a row epilogue in front of the feed-forward block, whose input and residual it is.
+template <int P, int MODE, bool LNB = false, bool POST = false, bool PRE = false>
 __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnFusedParams p) {
   static_assert(!LNB || MODE == 1, "LayerNorm-backward prologue: backward only");
   static_assert(!POST || MODE == 0, "chained projection: forward only");
+  static_assert(!PRE || MODE == 0, "leading projection + LayerNorm: forward only");
   extern __shared__ __attribute__((aligned(16))) char smem_f[];
   char* Xp = smem_f;                     // [P][ROWS][256]
   char* Hp = smem_f + P * PLANE;         // [2][P][ROWS][256]
@@ -256,6 +260,12 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnFusedParams p) {
   float* B3s = B1s + FF;                 // POST: the chained projection's bias [n2 <= 384] (a global load in front of each block's
                                          // first product was a cold miss per block: the chained launch took 34 us for 24 us of projection)
   if (POST && tid >= 128 && tid - 128 < p.n2 / 4) *reinterpret_cast<f32x4*>(B3s + 4 * (tid - 128)) = *reinterpret_cast<const f32x4*>(p.bias3 + 4 * (tid - 128));
+  float* PREs = B3s + 384;               // PRE: [bias 128][gamma 128][beta 128] of the leading projection / LayerNorm
+  if (PRE && tid >= 256 && tid < 256 + 96) {
+    const int j = tid - 256, which = j >> 5, c4 = (j & 31) * 4;
+    const float* src = which == 0 ? p.pre_bias : which == 1 ? p.pre_gamma : p.pre_beta;
+    *reinterpret_cast<f32x4*>(PREs + which * FD + c4) = *reinterpret_cast<const f32x4*>(src + c4);
+  }
   const float* bias1_p = B1s + 16 * wave + 4 * g;
   // (s_setprio 1 for the second-dispatched half, which loses the issue arbitration on its SIMD to the older wave and makes waves
   //  0-3 wait 2-4 k cycles at every block barrier, only swaps the roles: measured with stamps, zero-sum)
@@ -294,6 +304,16 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnFusedParams p) {
                                                                           MODE == 0 && p.bits_out ? ntiles * (NBLK * 8 * 32) : 0, 0x00020000);
   const unsigned bits_voff = lane < 4 ? (unsigned)lane * 8u : OOB;
   const __amdgpu_buffer_rsrc_t r_O2 = __builtin_amdgcn_make_buffer_rsrc(POST ? (void*)p.out2 : (void*)p.H, 0, POST ? p.M * p.n2 * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_R = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(PRE ? p.pre_out : p.A), 0, p.M * (PRE ? FD : p.lda) * 4, 0x00020000);   // residual rows of the main epilogue
+  const __amdgpu_buffer_rsrc_t r_PR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(PRE ? p.pre_res : p.A), 0, PRE ? p.M * (FD * 4) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_imgp = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(PRE ? p.pre_img : p.img1), 0, PRE ? P * FD * FD * 2 : 0, 0x00020000);
+  uint32_t sk_pre = 0u;
+  if constexpr (PRE) {
+    if (p.rate > 0.f) {
+      typedef const __attribute__((address_space(4))) uint32_t* const_u32p;
+      sk_pre = skf_site_key(*(const_u32p)&reinterpret_cast<const SkfStepState*>(p.state)->drop_key, p.pre_site);
+    }
+  }
   const unsigned lane16 = (unsigned)lane * 16u;
   const __amdgpu_buffer_rsrc_t r_img1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.img1), 0, P * (FD * FF * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t r_img2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.img2), 0, P * (FD * FF * 2), 0x00020000);
@@ -382,11 +402,79 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnFusedParams p) {
     FFN_STAMP();   // rows staged
     __syncthreads();
     FFN_STAMP();   // behind the staging barrier
+    FfnFrags<P> fr;
+    // z = residual + dropout(y), out = LayerNorm(z) for this thread's float4 of row (tile rt, 2 wave + e_half), exactly as
+    // ln_fwd_v4_kernel; optionally the planes of `out` for the next product stage (same thread map as the staging)
+    auto ln_row = [&](int rt, const f32x4& yv, const f32x4& xv, uint32_t skey, const f32x4& gmv, const f32x4& btv, float* zp, float* op,
+                      float* sp, bool planes) {
+      const int grow = tl[rt] * TR + 2 * wave + e_half;
+      const bool ok = grow < p.M;
+      const size_t off = (size_t)(ok ? grow : 0) * FD + 4 * e_sub;
+      f32x4 z;
+      float sum = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float yy = yv[e];
+        if (p.rate > 0.f) yy *= skf_keep(skey, (uint32_t)off + e, thresh) ? inv_keep : 0.f;
+        z[e] = xv[e] + yy;
+        sum += z[e];
+      }
+      const float mean = ffn_half_wave_sum(sum) * (1.0f / FD);
+      float sq = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float c = z[e] - mean; sq += c * c; }
+      const float rstd = rsqrtf(ffn_half_wave_sum(sq) * (1.0f / FD) + 1e-6f);
+      const f32x4 o = (z - mean) * rstd * gmv + btv;
+      if (ok) {
+        *reinterpret_cast<f32x4*>(zp + off) = z;
+        *reinterpret_cast<f32x4*>(op + off) = o;
+        if (e_sub == 0) { sp[2 * (size_t)grow] = mean; sp[2 * (size_t)grow + 1] = rstd; }
+      }
+      if (planes) {
+        unsigned lo[P], hi[P];
+        skf_split2<P>(o[0], o[1], lo, sel);
+        skf_split2<P>(o[2], o[3], hi, sel);
+#pragma unroll
+        for (int q = 0; q < P; ++q) *reinterpret_cast<u32x2*>(Xp + q * PLANE + rt * TILE + st_off) = (u32x2){lo[q], hi[q]};
+      }
+    };
+    if constexpr (PRE) {
+      // ---- the leading projection: y = a . Wo + bo for the staged rows (wave w: 16 of the 128 columns; operands in w2, free until
+      // the first hidden block requests its second-stage operands), through the Y tile, then the row epilogue -> z1, x1, statistics
+      // and the planes of x1 where the staged rows were
+      load_frags<P>(w2, r_imgp, lane16, wave * (NKS * P * 1024));
+      f32x4 xres[NRT];
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt)
+        xres[rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_PR, tl[rt] < ntiles ? st_voff + (unsigned)tl[rt] * (unsigned)(TR * FD * 4) : OOB, 0, 0));
+      const f32x4 bp = *reinterpret_cast<const f32x4*>(PREs + 16 * wave + 4 * g);
+      load_half<P>(Xp, a_off, fr.f[0], 0);
+#pragma unroll
+      for (int t = 0; t < NRT; ++t) {
+        if (t < nrt) {
+          load_half<P>(Xp + t * TILE, a_off, fr.f[1], 1);
+          f32x4 acc0 = bp, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+          int c = 0;
+          half_products<P>(w2, fr.f[0], 0, acc0, acc1, c);
+          if (t + 1 < NRT) load_half<P>(Xp + (t + 1) * TILE, a_off, fr.f[0], 0);
+          half_products<P>(w2, fr.f[1], 1, acc0, acc1, c);
+          *reinterpret_cast<f32x4*>(Yt + (t * TR + i) * YPITCH + 16 * wave + 4 * g) = acc0 + acc1;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __syncthreads();
+      const f32x4 gmp = *reinterpret_cast<const f32x4*>(PREs + FD + 4 * e_sub), btp = *reinterpret_cast<const f32x4*>(PREs + 2 * FD + 4 * e_sub);
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt) {
+        const f32x4 yv = *reinterpret_cast<const f32x4*>(Yt + (rt * TR + 2 * wave + e_half) * YPITCH + 4 * e_sub);
+        ln_row(rt, yv, xres[rt], sk_pre, gmp, btp, p.pre_z, p.pre_out, p.pre_stats, true);
+      }
+      __syncthreads();               // the planes of x1 are complete (and the Y tile free for the first hidden block)
+    }
 
     f32x4 y[NRT];
 #pragma unroll
     for (int rt = 0; rt < NRT; ++rt) y[rt] = bias2_r;
-    FfnFrags<P> fr;
 #if SKF_FFN_ABLATE & 2
     load_half<P>(Xp, a_off, fr.f[0], 0, true); load_half<P>(Xp, a_off, fr.f[1], 1, true);
 #endif
@@ -504,7 +592,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnFusedParams p) {
     if constexpr (MODE == 0) {
 #pragma unroll
       for (int rt = 0; rt < NRT; ++rt)
-        xres[rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_A, tl[rt] < ntiles ? st_voff + (unsigned)tl[rt] * (unsigned)(TR * p.lda * 4) : OOB, 0, 0));
+        xres[rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_R, tl[rt] < ntiles ? st_voff + (unsigned)tl[rt] * (unsigned)(TR * (PRE ? FD : p.lda) * 4) : OOB, 0, 0));
     }
     __syncthreads();
 #pragma unroll
@@ -515,36 +603,8 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnFusedParams p) {
       const size_t off = (size_t)(ok ? grow : 0) * FD + 4 * e_sub;
       const f32x4 yv = *reinterpret_cast<const f32x4*>(Yt + rloc * YPITCH + 4 * e_sub);
       if constexpr (MODE == 0) {
-        const f32x4 xv = xres[rt];             // the residual IS the input row this thread staged
-        f32x4 z;
-        float sum = 0.f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float yy = yv[e];
-          if (p.rate > 0.f) yy *= skf_keep(sk, (uint32_t)off + e, thresh) ? inv_keep : 0.f;
-          z[e] = xv[e] + yy;
-          sum += z[e];
-        }
-        const float mean = ffn_half_wave_sum(sum) * (1.0f / FD);
-        float sq = 0.f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { const float c = z[e] - mean; sq += c * c; }
-        const float rstd = rsqrtf(ffn_half_wave_sum(sq) * (1.0f / FD) + 1e-6f);
-        if (ok) {
-          *reinterpret_cast<f32x4*>(p.C + off) = z;
-          *reinterpret_cast<f32x4*>(p.out + off) = (z - mean) * rstd * gm + bt;
-          if (e_sub == 0) { p.stats[2 * (size_t)grow] = mean; p.stats[2 * (size_t)grow + 1] = rstd; }
-        }
-        if constexpr (POST) {
-          // the LayerNorm output as the next product's A rows: same (row, float4) -> thread map as the staging, so the planes go
-          // where the staging put them (Xp: last read in the last block's first stage, two barriers ago)
-          const f32x4 o = (z - mean) * rstd * gm + bt;
-          unsigned lo[P], hi[P];
-          skf_split2<P>(o[0], o[1], lo, sel);
-          skf_split2<P>(o[2], o[3], hi, sel);
-#pragma unroll
-          for (int q = 0; q < P; ++q) *reinterpret_cast<u32x2*>(Xp + q * PLANE + rt * TILE + st_off) = (u32x2){lo[q], hi[q]};
-        }
+        // (the residual is the block's input row: the row this thread staged, or with PRE the x1 row it wrote above)
+        ln_row(rt, yv, xres[rt], sk, gm, bt, p.C, p.out, p.stats, POST);
       } else {
         if (ok) {
           f32x4 v = yv;
@@ -824,26 +884,26 @@ int ffn_grid(int M) {
   return g > ntiles ? ntiles : g;
 }
 
-template <int P, int MODE, bool LNB = false, bool POST = false>
+template <int P, int MODE, bool LNB = false, bool POST = false, bool PRE = false>
 int launch_ffn(const FfnFusedParams& p, hipStream_t st) {
   const int grid = ffn_grid(p.M);
-  const size_t smem = (size_t)3 * P * PLANE + (P * PLANE >= ROWS * YPITCH * 4 ? 0 : ROWS * YPITCH * 4) + (FF + 384) * sizeof(float);
+  const size_t smem = (size_t)3 * P * PLANE + (P * PLANE >= ROWS * YPITCH * 4 ? 0 : ROWS * YPITCH * 4) + (FF + 384 + 3 * FD) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fused_kernel<P, MODE, LNB, POST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fused_kernel<P, MODE, LNB, POST, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_done = true;
   }
   // one profiler line for the family (the kernel template's forward / backward / LayerNorm-prologue / chained-projection variants,
   // like the epilogue kinds of gemm_wsx); SKF_PROF_FINE=1 (measurement builds): one line per variant
   static const bool fine = skf_knob("SKF_PROF_FINE") && skf_knob("SKF_PROF_FINE")[0] == '1';
-  static const std::string tag = std::string("ffn_fused") + (!fine ? "" : MODE == 0 ? (POST ? "_fwd_proj" : "_fwd") : LNB ? "_bwd_ln" : "_bwd") +
+  static const std::string tag = std::string("ffn_fused") + (!fine ? "" : MODE == 0 ? (PRE ? (POST ? "_fwd_pre_proj" : "_fwd_pre") : POST ? "_fwd_proj" : "_fwd") : LNB ? "_bwd_ln" : "_bwd") +
                                  "<d128,dff512,bf16x" + std::to_string(P * (P + 1) / 2) + ">";
   const double live = skf_prof_list_fraction(p.row_blocks);
-  const double flops = 2.0 * 2.0 * p.M * FD * FF + (POST ? 2.0 * p.M * FD * p.n2 : 0.0);
-  const double bytes = 4.0 * ((double)p.M * FD * (MODE == 0 ? 4 : 3) + (double)p.M * FF + (POST ? (double)p.M * p.n2 : 0.0)) + 2.0 * image_bytes(P) / 2;
+  const double flops = 2.0 * 2.0 * p.M * FD * FF + (POST ? 2.0 * p.M * FD * p.n2 : 0.0) + (PRE ? 2.0 * p.M * FD * FD : 0.0);
+  const double bytes = 4.0 * ((double)p.M * FD * (MODE == 0 ? 4 : 3) + (double)p.M * FF + (POST ? (double)p.M * p.n2 : 0.0) + (PRE ? 4.0 * p.M * FD : 0.0)) + 2.0 * image_bytes(P) / 2;
   SkfProfScope ps(st, tag.c_str(), flops, bytes);
   ps.done(flops * live, bytes * live);
-  hipLaunchKernelGGL((ffn_fused_kernel<P, MODE, LNB, POST>), dim3(grid), dim3(512), smem, st, p);
+  hipLaunchKernelGGL((ffn_fused_kernel<P, MODE, LNB, POST, PRE>), dim3(grid), dim3(512), smem, st, p);
   SKF_LAUNCH_CHECK();
   return SKF_OK;
 }
@@ -852,6 +912,8 @@ int launch_ffn(const FfnFusedParams& p, hipStream_t st) {
 
 int skf_ffn_fused_launch(const FfnFusedParams& p, int pieces, int direction, hipStream_t st) {
   if (direction == 1 && p.ln_dout) return pieces == 2 ? launch_ffn<2, 1, true>(p, st) : launch_ffn<3, 1, true>(p, st);
+  if (direction == 0 && p.pre_img && p.img3) return pieces == 2 ? launch_ffn<2, 0, false, true, true>(p, st) : launch_ffn<3, 0, false, true, true>(p, st);
+  if (direction == 0 && p.pre_img) return pieces == 2 ? launch_ffn<2, 0, false, false, true>(p, st) : launch_ffn<3, 0, false, false, true>(p, st);
   if (direction == 0 && p.img3) return pieces == 2 ? launch_ffn<2, 0, false, true>(p, st) : launch_ffn<3, 0, false, true>(p, st);
   if (pieces == 2) return direction == 0 ? launch_ffn<2, 0>(p, st) : launch_ffn<2, 1>(p, st);
   return direction == 0 ? launch_ffn<3, 0>(p, st) : launch_ffn<3, 1>(p, st);
@@ -1033,5 +1095,35 @@ extern "C" int skf_ffn_fused_fwd_proj_f32(int M, int d, int dff, const float* x,
   p.C = z; p.res = x; p.gamma = gamma; p.beta = beta; p.out = out; p.stats = stats;
   p.rate = rate; p.site = site; p.state = step_state;
   p.img3 = (const char*)proj_image; p.bias3 = proj_bias; p.out2 = proj_out; p.n2 = proj_n;
+  return skf_ffn_fused_launch(p, P, 0, (hipStream_t)stream);
+}
+
+extern "C" int skf_ffn_block_fwd_f32(const SkfFfnBlockFwd* b, skf_stream_t stream) {
+  SKF_CHECK_ARG(b && b->struct_size == sizeof(SkfFfnBlockFwd), "SkfFfnBlockFwd.struct_size does not match this library's include/skf.h");
+  const int rc = ffn_common_checks(b->M, b->d, b->dff, b->precision, b->x, b->image, b->h, b->z);
+  if (rc != SKF_OK) return rc;
+  SKF_CHECK_ARG(b->gamma && b->beta && b->out && b->stats && b->b1 && b->b2, "null bias / LayerNorm operand");
+  SKF_CHECK_ARG(b->rate >= 0.f && b->rate < 1.f && (b->rate == 0.f || b->step_state), "dropout needs 0 <= rate < 1 and the step state");
+  SKF_CHECK_ARG((((uintptr_t)b->out | (uintptr_t)b->gamma | (uintptr_t)b->beta | (uintptr_t)b->b1 | (uintptr_t)b->b2) & 15) == 0 &&
+                (((uintptr_t)b->stats | (uintptr_t)b->relu_bits_out) & 7) == 0, "operands must be 16-byte aligned");
+  const int P = b->precision == SKF_PREC_BF16X3 ? 2 : 3;
+  FfnFusedParams p{};
+  p.A = b->x; p.lda = b->d; p.M = b->M;
+  p.img1 = (const char*)b->image; p.img2 = (const char*)b->image + image_bytes(P) / 2;
+  p.bias1 = b->b1; p.bias2 = b->b2; p.H = b->h; p.bits_out = (unsigned long long*)b->relu_bits_out;
+  p.C = b->z; p.res = b->x; p.gamma = b->gamma; p.beta = b->beta; p.out = b->out; p.stats = b->stats;
+  p.rate = b->rate; p.site = b->site; p.state = b->step_state;
+  if (b->pre_image) {
+    SKF_CHECK_ARG(b->pre_bias && b->pre_residual && b->pre_gamma && b->pre_beta && b->pre_z && b->pre_out && b->pre_stats, "leading projection: null operand");
+    SKF_CHECK_ARG((((uintptr_t)b->pre_image | (uintptr_t)b->pre_bias | (uintptr_t)b->pre_residual | (uintptr_t)b->pre_gamma | (uintptr_t)b->pre_beta |
+                    (uintptr_t)b->pre_z | (uintptr_t)b->pre_out) & 15) == 0 && ((uintptr_t)b->pre_stats & 7) == 0, "leading projection: alignment");
+    p.pre_img = (const char*)b->pre_image; p.pre_bias = b->pre_bias; p.pre_res = b->pre_residual; p.pre_gamma = b->pre_gamma;
+    p.pre_beta = b->pre_beta; p.pre_site = b->pre_site; p.pre_z = b->pre_z; p.pre_out = b->pre_out; p.pre_stats = b->pre_stats;
+  }
+  if (b->proj_image) {
+    SKF_CHECK_ARG(b->proj_bias && b->proj_out && (b->proj_n == 128 || b->proj_n == 256 || b->proj_n == 384), "chained projection: N in {128, 256, 384} with its image, bias and output");
+    SKF_CHECK_ARG((((uintptr_t)b->proj_image | (uintptr_t)b->proj_bias | (uintptr_t)b->proj_out) & 15) == 0 && (double)b->M * b->proj_n * 4 < 2147483648.0, "chained projection operands");
+    p.img3 = (const char*)b->proj_image; p.bias3 = b->proj_bias; p.out2 = b->proj_out; p.n2 = b->proj_n;
+  }
   return skf_ffn_fused_launch(p, P, 0, (hipStream_t)stream);
 }

@@ -290,8 +290,8 @@ struct Bump {
   size_t take(size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; }
 };
 
-struct EncAct { size_t x_in, qkv, o, z1, st1, astats, x1, h, z2, st2, x2, hbits, img[2], img_o, img_qkv; };   // img: pre-split ffn weight images (forward, backward); img_o: Wo^T; img_qkv: this layer's Wqkv (read by the PREVIOUS layer's feed-forward launch)
-struct DecAct { size_t x_in, qkv, o1, z1, st1, astats1, out1, q2, kv2, o2, astats2, z2, st2, out2, h, z3, st3, out3, hbits, img[2], img_o1, img_o2, img_qkv; };
+struct EncAct { size_t x_in, qkv, o, z1, st1, astats, x1, h, z2, st2, x2, hbits, img[2], img_o, img_qkv, img_of; };   // img: pre-split ffn weight images (forward, backward); img_o: Wo^T; img_qkv: this layer's Wqkv (read by the PREVIOUS layer's feed-forward launch)
+struct DecAct { size_t x_in, qkv, o1, z1, st1, astats1, out1, q2, kv2, o2, astats2, z2, st2, out2, h, z3, st3, out3, hbits, img[2], img_o1, img_o2, img_qkv, img_o2f; };
 
 struct Plan {
   size_t bytes = 0;
@@ -342,6 +342,7 @@ Plan build_plan(const SkfConfig& c) {
     a.img[0] = b.take(skf_ffn_image_bytes((int)d, (int)F, c.gemm_precision)); a.img[1] = b.take(skf_ffn_image_bytes((int)d, (int)F, c.gemm_precision));
     a.img_o = b.take(skf_dense_image_bytes((int)d, (int)d, c.gemm_precision));
     a.img_qkv = b.take(skf_dense_image_bytes((int)d, 3 * (int)d, c.gemm_precision));
+    a.img_of = b.take(skf_dense_image_bytes((int)d, (int)d, c.gemm_precision));
     a.x2 = 0;
     P.enc.push_back(a);
   }
@@ -365,6 +366,7 @@ Plan build_plan(const SkfConfig& c) {
     a.img[0] = b.take(skf_ffn_image_bytes((int)d, (int)F, c.gemm_precision)); a.img[1] = b.take(skf_ffn_image_bytes((int)d, (int)F, c.gemm_precision));
     a.img_o1 = b.take(skf_dense_image_bytes((int)d, (int)d, c.gemm_precision)); a.img_o2 = b.take(skf_dense_image_bytes((int)d, (int)d, c.gemm_precision));
     a.img_qkv = b.take(skf_dense_image_bytes((int)d, 3 * (int)d, c.gemm_precision));
+    a.img_o2f = b.take(skf_dense_image_bytes((int)d, (int)d, c.gemm_precision));
     a.out3 = 0;
     P.dec.push_back(a);
   }
@@ -817,12 +819,14 @@ int build_ffn_images(SkfModel* M, bool with_backward, bool encoder_only, hipStre
   for (int i = 0; i < c.num_layers; ++i) {
     ffn(L.enc[i].f1, L.enc[i].f2, P.enc[i].img);
     if (i > 0) one(L.enc[i].mha.qkv, 0, d, 3 * d, M->at<char>(P.enc[i].img_qkv));
+    one(L.enc[i].mha.o, 0, d, d, M->at<char>(P.enc[i].img_of));
     if (with_backward) one(L.enc[i].mha.o, 1, d, d, M->at<char>(P.enc[i].img_o));
   }
   if (dec)
     for (int i = 0; i < c.num_layers; ++i) {
       ffn(L.dec[i].f1, L.dec[i].f2, P.dec[i].img);
       if (i > 0) one(L.dec[i].mha1.qkv, 0, d, 3 * d, M->at<char>(P.dec[i].img_qkv));
+      one(L.dec[i].mha2.o, 0, d, d, M->at<char>(P.dec[i].img_o2f));
       if (with_backward) { one(L.dec[i].mha1.o, 1, d, d, M->at<char>(P.dec[i].img_o1)); one(L.dec[i].mha2.o, 1, d, d, M->at<char>(P.dec[i].img_o2)); }
     }
   return skf_dense_weight_images((int)src.size(), src.data(), ld.data(), tr.data(), K.data(), N.data(), img.data(), c.gemm_precision, s);
@@ -847,6 +851,32 @@ int ffn_ln_fwd(SkfModel* M, const DenseP& f1, const DenseP& f2, const LnP& ln, c
   SKF_TRY(dense_fwd_relu_bits(M, f1, x, rows, h, bits, s));
   SKF_TRY(dense_fwd(M, f2, h, rows, z, 0, s));
   return skf_layernorm_residual_fwd(x, z, M->P(ln.g), M->P(ln.b), out, stats, rows, d, rate, site, M->state, s);
+}
+
+// The tail of a layer behind its last attention: x1 = LayerNorm(x + dropout(o_proj(a))), out = LayerNorm(x1 + dropout(ffn(x1))) and,
+// when there is one, the next layer's q|k|v projection - ONE launch (skf_ffn_block_fwd_f32) where the fused kernel runs, else the
+// output-projection launch followed by ffn_ln_fwd.
+int attn_tail_ffn_fwd(SkfModel* M, const DenseP& o, const LnP& ln_a, const float* a, const float* x, float* z1, float* x1, float* st1,
+                      unsigned site_a, const void* o_image, const DenseP& f1, const DenseP& f2, const LnP& ln, float* h, void* bits,
+                      const void* image, float* z, float* out, float* stats, unsigned site, int rows, float rate, hipStream_t s,
+                      const DenseP* next, const void* next_image, float* next_out, bool* next_done) {
+  const int d = M->cfg.d_model;
+  static const bool pre_off = skf_knob("SKF_NO_FFN_PRE") && skf_knob("SKF_NO_FFN_PRE")[0] == '1';   // (measurement builds only)
+  static const bool chain_off = skf_knob("SKF_NO_FFN_CHAIN") && skf_knob("SKF_NO_FFN_CHAIN")[0] == '1';
+  if (!M->ffn_fused || pre_off || o.in != d || o.out != d || ln_a.b != ln_a.g + (size_t)d) {
+    SKF_TRY(dense_ln_fwd(M, o, a, rows, x, z1, ln_a, x1, st1, rate, site_a, s));
+    return ffn_ln_fwd(M, f1, f2, ln, x1, rows, h, bits, image, z, out, stats, rate, site, s, next, next_image, next_out, next_done);
+  }
+  SkfFfnBlockFwd b{};
+  b.struct_size = sizeof(SkfFfnBlockFwd); b.M = rows; b.d = d; b.dff = M->cfg.dff; b.precision = M->cfg.gemm_precision;
+  b.x = a; b.image = image; b.b1 = M->P(f1.b); b.b2 = M->P(f2.b); b.h = h; b.relu_bits_out = bits;
+  b.gamma = M->P(ln.g); b.beta = M->P(ln.b); b.z = z; b.out = out; b.stats = stats; b.rate = rate; b.site = site; b.step_state = M->state;
+  b.pre_image = o_image; b.pre_bias = M->P(o.b); b.pre_residual = x; b.pre_gamma = M->P(ln_a.g); b.pre_beta = M->P(ln_a.b);
+  b.pre_z = z1; b.pre_out = x1; b.pre_stats = st1; b.pre_site = site_a;
+  const bool chain = next && !chain_off && next->in == d && (next->out == 128 || next->out == 256 || next->out == 384) && next->ld == next->out;
+  if (chain) { b.proj_image = next_image; b.proj_bias = M->P(next->b); b.proj_out = next_out; b.proj_n = next->out; }
+  if (next_done) *next_done = chain;
+  return skf_ffn_block_fwd_f32(&b, s);
 }
 
 int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s, bool encoder_only = false) {
@@ -889,13 +919,12 @@ int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s, bool 
     if (!enc_qkv_done) SKF_TRY(dense_fwd(M, w.mha.qkv, x, Me, qkv, 0, s));     // (else: the previous layer's feed-forward launch wrote it)
     SKF_TRY(skf_attention_fwd(qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, emask, Le, 0, B, H, Le, Le, dh,
                               M->at<float>(a.o), d, M->at<float>(a.astats), M->cfg.gemm_precision, s));
-    SKF_TRY(dense_ln_fwd(M, w.mha.o, M->at<float>(a.o), Me, x, M->at<float>(a.z1), w.ln1, M->at<float>(a.x1), M->at<float>(a.st1), rate,
-                         site_enc(i, 0), s));
     const bool has_next = i + 1 < N;
-    SKF_TRY(ffn_ln_fwd(M, w.f1, w.f2, w.ln2, M->at<float>(a.x1), Me, M->at<float>(a.h), hbits_of(M, a.hbits, Me), M->at<char>(a.img[0]),
-                       M->at<float>(a.z2), M->at<float>(a.x2), M->at<float>(a.st2), rate, site_enc(i, 1), s,
-                       has_next ? &L.enc[i + 1].mha.qkv : nullptr, has_next ? M->at<char>(P.enc[i + 1].img_qkv) : nullptr,
-                       has_next ? M->at<float>(P.enc[i + 1].qkv) : nullptr, &enc_qkv_done));
+    SKF_TRY(attn_tail_ffn_fwd(M, w.mha.o, w.ln1, M->at<float>(a.o), x, M->at<float>(a.z1), M->at<float>(a.x1), M->at<float>(a.st1),
+                              site_enc(i, 0), M->at<char>(a.img_of), w.f1, w.f2, w.ln2, M->at<float>(a.h), hbits_of(M, a.hbits, Me),
+                              M->at<char>(a.img[0]), M->at<float>(a.z2), M->at<float>(a.x2), M->at<float>(a.st2), site_enc(i, 1), Me, rate, s,
+                              has_next ? &L.enc[i + 1].mha.qkv : nullptr, has_next ? M->at<char>(P.enc[i + 1].img_qkv) : nullptr,
+                              has_next ? M->at<float>(P.enc[i + 1].qkv) : nullptr, &enc_qkv_done));
   }
   float* enc_out = M->at<float>(P.enc[N - 1].x2);
   // ---------------- bottleneck + classifier + expander (models/sketchformer.py:149-160,183-199,170-176)
@@ -960,13 +989,13 @@ int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s, bool 
     else if (i == 0) SKF_HIP(hipStreamWaitEvent(s, kv_done, 0));
     SKF_TRY(skf_attention_fwd(M->at<float>(a.q2), d, kv2, 2 * d, kv2 + d, 2 * d, cross_mask, Le, 0, B, H, Ld, Le, dh,
                               M->at<float>(a.o2), d, M->at<float>(a.astats2), M->cfg.gemm_precision, s));
-    SKF_TRY(dense_ln_fwd(M, w.mha2.o, M->at<float>(a.o2), Md, M->at<float>(a.out1), M->at<float>(a.z2), w.ln2, M->at<float>(a.out2),
-                         M->at<float>(a.st2), rate, site_dec(N, i, 1), s));
     const bool has_next = i + 1 < N;
-    SKF_TRY(ffn_ln_fwd(M, w.f1, w.f2, w.ln3, M->at<float>(a.out2), Md, M->at<float>(a.h), hbits_of(M, a.hbits, Md), M->at<char>(a.img[0]),
-                       M->at<float>(a.z3), M->at<float>(a.out3), M->at<float>(a.st3), rate, site_dec(N, i, 2), s,
-                       has_next ? &L.dec[i + 1].mha1.qkv : nullptr, has_next ? M->at<char>(P.dec[i + 1].img_qkv) : nullptr,
-                       has_next ? M->at<float>(P.dec[i + 1].qkv) : nullptr, &dec_qkv_done));
+    SKF_TRY(attn_tail_ffn_fwd(M, w.mha2.o, w.ln2, M->at<float>(a.o2), M->at<float>(a.out1), M->at<float>(a.z2), M->at<float>(a.out2),
+                              M->at<float>(a.st2), site_dec(N, i, 1), M->at<char>(a.img_o2f), w.f1, w.f2, w.ln3, M->at<float>(a.h),
+                              hbits_of(M, a.hbits, Md), M->at<char>(a.img[0]), M->at<float>(a.z3), M->at<float>(a.out3), M->at<float>(a.st3),
+                              site_dec(N, i, 2), Md, rate, s, has_next ? &L.dec[i + 1].mha1.qkv : nullptr,
+                              has_next ? M->at<char>(P.dec[i + 1].img_qkv) : nullptr, has_next ? M->at<float>(P.dec[i + 1].qkv) : nullptr,
+                              &dec_qkv_done));
   }
   SKF_TRY(dense_fwd(M, L.out, M->at<float>(P.dec[N - 1].out3), Md, M->at<float>(P.logits), 0, s));
   }

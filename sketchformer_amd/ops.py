@@ -282,6 +282,31 @@ def ffn_fused_fwd(x, image, b1, b2, gamma, beta, dff, rate=0.0, site=0, state=No
     return out, z, stats, h, bits
 
 
+def ffn_block_fwd(a, residual, pre, image, b1, b2, gamma, beta, dff, rate=0.0, pre_site=0, site=0, state=None, precision=None, proj=None):
+    """The forward launch in its general form (skf_ffn_block_fwd_f32): pre = (image of Wo, bias, gamma1, beta1): the launch starts at the
+    attention output `a` and forms z1 = residual + dropout(a.Wo + bo), x1 = LayerNorm(z1) in front of the feed-forward block
+    -> dict(z1, x1, stats1, h, bits, z, out, stats[, proj_out])."""
+    _f32(a, "a")
+    M, d = a.shape
+    dev = a.device
+    e = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)  # noqa: E731
+    r = {"h": e(M, dff), "z": e(M, d), "out": e(M, d), "stats": e(M, 2), "z1": e(M, d), "x1": e(M, d), "stats1": e(M, 2)}
+    nb = _lib.load().skf_ffn_relu_bits_bytes(M, d, dff, _prec(precision))
+    r["bits"] = torch.zeros(max(nb // 8, 1), dtype=torch.int64, device=dev)
+    pimg, pbias, pg, pb = pre
+    P = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    blk = _lib.SkfFfnBlockFwd(struct_size=C.sizeof(_lib.SkfFfnBlockFwd), M=M, d=d, dff=dff, precision=_prec(precision), x=P(a), image=P(image),
+                              b1=P(b1), b2=P(b2), h=P(r["h"]), relu_bits_out=P(r["bits"]), gamma=P(gamma), beta=P(beta), z=P(r["z"]),
+                              out=P(r["out"]), stats=P(r["stats"]), rate=rate, site=site, step_state=P(state), pre_image=P(pimg),
+                              pre_bias=P(pbias), pre_residual=P(residual), pre_gamma=P(pg), pre_beta=P(pb), pre_z=P(r["z1"]), pre_out=P(r["x1"]),
+                              pre_stats=P(r["stats1"]), pre_site=pre_site)
+    if proj is not None:
+        r["proj_out"] = e(M, proj[1].numel())
+        blk.proj_image, blk.proj_bias, blk.proj_out, blk.proj_n = P(proj[0]), P(proj[1]), P(r["proj_out"]), proj[1].numel()
+    _lib.call("skf_ffn_block_fwd_f32", C.byref(blk), _stream())
+    return r
+
+
 def ffn_fused_bwd(dy, image_t, bits, dff, dx=None, row_blocks=None, precision=None):
     """One launch: dh = (dy.W2^T) o relu'(h), dx (+)= dh.W1^T -> dh, dx (accumulated into `dx` when given)."""
     _f32(dy, "dy")

@@ -998,6 +998,52 @@ def test_ffn_fused_forward_with_chained_projection(ops, rows, n2):
         assert (po - ref).abs().max().item() <= 4e-6 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("rows,n2,rate", [(25600, 384, 0.1), (25472, 0, 0.1), (1031, 384, 0.0), (7, 0, 0.1)])
+def test_ffn_block_forward_from_attention_output(ops, rows, n2, rate):
+    """The forward launch starting at the attention output: x1 = LayerNorm(x + dropout(a.Wo + bo)) (builders/layers/transformer.py:186,
+    216-224), the feed-forward block on x1, optionally the next q|k|v projection - against the oracle and the launches it replaces."""
+    d, dff = 128, 512
+    rng = np.random.RandomState(rows + n2 + 5)
+    a, x = rng.randn(rows, d), rng.randn(rows, d)
+    wo, bo = rng.randn(d, d) / np.sqrt(d), 0.1 * rng.randn(d)
+    w1, b1 = rng.randn(d, dff) / np.sqrt(d), 0.1 * rng.randn(dff)
+    w2, b2 = rng.randn(dff, d) / np.sqrt(dff), 0.1 * rng.randn(d)
+    g1, be1, g2, be2 = 1 + 0.1 * rng.randn(d), 0.1 * rng.randn(d), 1 + 0.1 * rng.randn(d), 0.1 * rng.randn(d)
+    st = ops.new_step_state("cuda", iterations=3)
+    ops.step_prologue(st, seed=5)
+    key = ops.read_step_state(st)["drop_key"]
+    k1 = k2 = np.ones((rows, d), bool)
+    if rate > 0:
+        k1 = ops.dropout_keep_mask(key, 4, rate, rows * d).reshape(rows, d)
+        k2 = ops.dropout_keep_mask(key, 9, rate, rows * d).reshape(rows, d)
+    z1 = x + oracle.dropout_fwd(a @ wo + bo, k1, rate)
+    x1, _ = oracle.layernorm_fwd(z1, g1, be1)
+    h = np.maximum(x1 @ w1 + b1, 0)
+    z2 = x1 + oracle.dropout_fwd(h @ w2 + b2, k2, rate)
+    x2, _ = oracle.layernorm_fwd(z2, g2, be2)
+    A, X, WO, BO, W1, B1, W2, B2 = (_dev(v) for v in (a, x, wo, bo, w1, b1, w2, b2))
+    G1, BE1, G2, BE2 = (_dev(v) for v in (g1, be1, g2, be2))
+    img, = ops.ffn_weight_images([(W1, W2)], transpose=False)
+    pimg = ops.dense_weight_image(WO, transpose=False)
+    proj = None
+    if n2:
+        wp, bp = rng.randn(d, n2) / np.sqrt(d), 0.1 * rng.randn(n2)
+        proj = (ops.dense_weight_image(_dev(wp), transpose=False), _dev(bp))
+    r = ops.ffn_block_fwd(A, X, (pimg, BO, G1, BE1), img, B1, B2, G2, BE2, dff, rate=rate, pre_site=4, site=9, state=st, proj=proj)
+    _close(r["z1"], z1, name="z1")
+    _close(r["x1"], x1, name="x1")
+    _close(r["stats1"][:, 0], z1.mean(-1), name="mean1")
+    _close(r["h"], h, rtol=4e-5, name="h")
+    _close(r["z"], z2, rtol=4e-5, name="z2")
+    _close(r["out"], x2, rtol=4e-5, name="x2")
+    if n2:
+        _close(r["proj_out"], x2 @ wp + bp, rtol=6e-5, name="chained projection")
+    if rows > 2048:
+        o1, zz1, _ = ops.gemm_ln_residual(A, WO, BO, X, G1, BE1, rate=rate, site=4, state=st, precision=6)
+        assert (r["z1"] - zz1).abs().max().item() <= 2e-6 * max(1.0, zz1.abs().max().item())
+        assert (r["x1"] - o1).abs().max().item() <= 2e-5 * max(1.0, o1.abs().max().item())
+
+
 def test_ffn_fused_refuses_other_shapes(ops):
     lib = ops._lib.load()
     assert lib.skf_ffn_fused_supported(25600, 128, 512, 6) == 1
