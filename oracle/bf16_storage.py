@@ -117,17 +117,24 @@ def attn_fwd16(q, k, v, mask, H, KB=64):
     o = acc / l_run
     ohi = rbf(o)
     olo = rbf(o - ohi)
-    return _merge(ohi), (qh, kh, vh, mask, m_run, 1.0 / l_run, ohi, olo, H)
+    return _merge(ohi), (qh, kh, vh, mask, m_run, 1.0 / l_run, ohi, olo, H, o)
+
+
+# Sensitivity experiments of tools/bf16_delta_sensitivity.py (None = the product's arithmetic): a callable
+# (delta, dp, do, ohi, olo, o_exact) -> (delta, dp) that replaces / perturbs the two terms whose difference forms dS.
+DELTA_HOOK = None
 
 
 def attn_bwd16(dout, cache):
-    qh, kh, vh, mask, m, rinv, ohi, olo, H = cache
+    qh, kh, vh, mask, m, rinv, ohi, olo, H, o_exact = cache
     do = _heads(dout, H)
     dh = qh.shape[-1]
     delta = (do * (ohi + olo)).sum(-1, keepdims=True)
     s = _scores2(qh, kh, mask)
     p = np.exp2(s - m) * rinv
     dp = do @ np.swapaxes(vh, -1, -2)
+    if DELTA_HOOK is not None:
+        delta, dp = DELTA_HOOK(delta, dp, do, ohi, olo, o_exact)
     ds = rbf(p * (dp - delta))                              # dS and P are bf16 operands of the gradient products
     scale = 1.0 / np.sqrt(dh)
     dq = rbf((ds @ kh) * scale)

@@ -135,7 +135,9 @@ def test_bf16_losses_and_all_gradients(name, B, rate):
     # cfg-5 dimensions (8 layers, L = 512) median 3.6e-3, 22 tensors at or above 1.5e-2 - query / key projections
     # of the upper attention layers (up to 6.7e-2), the bottleneck scorer and the expander - are sums that cancel to ~1e-5 of their
     # terms (dS = P o (dP - delta); column sums over every position), where the fp32 accumulation order of the device against
-    # float64 here is amplified: the one thing this restatement does not model.  Bars: small model every tensor < 2.5e-2 and
+    # float64 here is amplified: the one thing this restatement does not model.  (Round 4, tools/bf16_delta_sensitivity.py, CPU only,
+    # profiles/r04_cfg5_delta_sensitivity.txt: relative noise of 2^-24 - one fp32 rounding - on dP and delta alone moves tensors of this model by
+    # up to 2.3e-2 ... 3.8e-2; the unrounded O instead of value + residual moves the worst by 2.6e-2.)  Bars: small model every tensor < 2.5e-2 and
     # median < 5e-3; cfg-5 dimensions median < 5e-3, worst < 1e-1, at least 90 % of the tensors below 1.5e-2.
     above = {k: round(float(v), 4) for k, v in rel16.items() if v >= 1.5e-2}
     print("[bf16 %s] %d of %d tensors at or above 1.5e-2: %s" % (name, len(above), len(rel16), above))
