@@ -81,18 +81,24 @@ def test_bf16_forward_logits_and_argmax(name, B, blind):
     assert agree_safe == 1.0 and agree > 0.9
 
 
-@pytest.mark.parametrize("name,B,rate", [("small", 6, 0.0), ("small", 6, 0.1), ("cfg5", 2, 0.0)])
-def test_bf16_losses_and_all_gradients(name, B, rate):
+# lengths: "bench" = the N(80, 35^2) lengths of SURVEY 8(d) as bench.py draws them (83 % padding at L = 512), "full" = every row n = L
+@pytest.mark.parametrize("name,B,rate,lengths", [("small", 6, 0.0, "bench"), ("small", 6, 0.1, "bench"), ("cfg5", 2, 0.0, "bench"),
+                                                 ("cfg5", 8, 0.0, "bench"), ("cfg5", 8, 0.0, "full")])
+def test_bf16_losses_and_all_gradients(name, B, rate, lengths):
     kw = SMALL if name == "small" else CFG5
     eng, ocfg = _build(kw, B, rate=rate)
-    x, y = synthetic.token_batch(B, ocfg.seq_len, ocfg.vocab_size, ocfg.n_classes, seed=3)
-    x[1, ocfg.seq_len // 4:] = 0
+    x, y = synthetic.token_batch(B, ocfg.seq_len, ocfg.vocab_size, ocfg.n_classes, seed=3, full=lengths == "full")
+    if lengths != "full":
+        x[1, ocfg.seq_len // 4:] = 0
     P = {k: v.astype(np.float64) for k, v in eng.state_dict_numpy().items()}
     eng.forward_backward(x, None, y)
     torch.cuda.synchronize()
     drops = _drops(eng, ocfg, B) if rate > 0 else None
     n_units = B * (2 * ocfg.seq_len - 1) * ocfg.dff * ocfg.num_layers
-    with device_relu_branches(eng, ocfg, B, kink=5e-2, max_flips=n_units // 20) as chk:
+    # the float64 oracle follows the device's ReLU branch only for units whose own pre-activation lies within the bf16 noise of zero:
+    # 2^-7 of the largest pre-activation in the two-layer model; 2^-5 at the cfg-5 depth (measured round 4: a unit of decoder layer 5
+    # differs at |pre| = 2.4e-2 - sixteen layers of 2^-9 roundings - and 2^-7 fails there)
+    with device_relu_branches(eng, ocfg, B, kink=2.0 ** -7 if name == "small" else 2.0 ** -5, max_flips=n_units // 20) as chk:
         losses, out, G = oracle.loss_and_grads(P, ocfg, x, x, y, drops)
     m = eng.step_metrics()
     for k in ("recon_loss", "class_loss", "total_loss"):
@@ -106,7 +112,8 @@ def test_bf16_losses_and_all_gradients(name, B, rate):
           "units followed the device's branch" % (name, rate, {k: round(m[k], 4) for k in ("recon_loss", "class_loss")},
                                                   {k: round(float(losses[k]), 4) for k in ("recon_loss", "class_loss")}, worst[0],
                                                   worst[1], np.median(list(rel.values())), len(rel), chk.flips, n_units))
-    assert worst[0] < 6e-2, worst
+    # (cfg-5 dimensions, B = 8, bench lengths: 7.6e-2 on encoder/layer7/mha/wq measured - see the note at the tight check below)
+    assert worst[0] < (1e-1 if (name, B, lengths) == ("cfg5", 8, "bench") else 6e-2), worst
     assert np.median(list(rel.values())) < 1.5e-2
     assert np.isfinite(eng.grads.cpu().numpy()).all()
     # ---- the tight check: the same step restated with bf16 rounding at the product's storage points (oracle/bf16_storage.py:
@@ -139,12 +146,20 @@ def test_bf16_losses_and_all_gradients(name, B, rate):
     # profiles/r04_cfg5_delta_sensitivity.txt: relative noise of 2^-24 - one fp32 rounding - on dP and delta alone moves tensors of this model by
     # up to 2.3e-2 ... 3.8e-2; the unrounded O instead of value + residual moves the worst by 2.6e-2.)  Bars: small model every tensor < 2.5e-2 and
     # median < 5e-3; cfg-5 dimensions median < 5e-3, worst < 1e-1, at least 90 % of the tensors below 1.5e-2.
+    # Round 4, B = 8 (profiles/r04_cfg5_parity_B8.txt): with the bench's lengths worst 9.4e-2 (encoder/layer7/mha/wq), 20 of 323 tensors at or above
+    # 1.5e-2, median 2.5e-3; the SAME model and batch size with full-length rows: worst 3.8e-2 (bottleneck/W_attn), 9 tensors, median 1.1e-3.  The
+    # outliers are the query / key projections of the upper ENCODER layers, growing with depth (layer 3: 1.5e-2 ... layer 7: 9.4e-2), and the
+    # bottleneck scorer: with 83 % of the rows PAD the encoder states of most positions are nearly identical (same token, same visible keys), so
+    # dS = P o (dP - delta) and the pooling softmax gradient are differences of nearly equal terms there - the padding structure, not the batch
+    # size, sets the amplification.  Full-length bars: worst < 5e-2, at most 4 % of the tensors at or above 1.5e-2.
     above = {k: round(float(v), 4) for k, v in rel16.items() if v >= 1.5e-2}
     print("[bf16 %s] %d of %d tensors at or above 1.5e-2: %s" % (name, len(above), len(rel16), above))
     if not SKF_LOOSE:
         assert np.median(list(rel16.values())) < 5e-3
         if name == "small":
             assert worst16[0] < 2.5e-2, worst16
+        elif lengths == "full":
+            assert worst16[0] < 5e-2 and len(above) <= len(rel16) // 25, (worst16, len(above), len(rel16))
         else:
             assert worst16[0] < 1e-1 and len(above) <= len(rel16) // 10, (worst16, len(above), len(rel16))
     assert st["relu_overrides"] <= st["relu_units"] // 200
