@@ -38,6 +38,8 @@ extern "C" int skf_device_info(char* name_host, size_t name_len, int* n_devices_
 }
 
 // ------------------------------------------------------------------ launch profiler
+int skf_stage_inputs_launch(const void* inp, void* dinp, const void* tar, void* dtar, size_t row, size_t src_row, size_t copy, int batch,
+                            const void* labels, void* dlabels, hipStream_t st);   // skf_rowops.hip
 namespace {
 struct ProfRec { const char* tag; double flops, bytes, flops_done, bytes_done; hipEvent_t e0, e1; };
 bool g_prof_on = false;
@@ -1558,6 +1560,13 @@ int stage_inputs(SkfModel* M, const void* inp, const void* tar, int tar_ld, cons
   SKF_CHECK_ARG(inp && tar, "null input");
   const size_t row = c.continuous ? (size_t)c.seq_len * 5 * sizeof(float) : (size_t)c.seq_len * 8;     // bytes per sample
   const size_t src_row = c.continuous ? (size_t)tar_ld * 5 * sizeof(float) : (size_t)tar_ld * 8;
+  // one launch for the three copies (skf_rowops.hip); operands that are not 4-byte aligned take the copy engine below
+  static const bool stage_off = skf_knob("SKF_NO_STAGE_KERNEL") && skf_knob("SKF_NO_STAGE_KERNEL")[0] == '1';   // (measurement builds only)
+  if (!stage_off) {
+    const int rc = skf_stage_inputs_launch(inp, M->at<char>(P.inp), tar, M->at<char>(P.tar), row, src_row, row < src_row ? row : src_row, c.batch,
+                                           labels, M->at<char>(P.labels), s);
+    if (rc != SKF_EUNSUPPORTED) return rc;
+  }
   SKF_HIP(hipMemcpyAsync(M->at<char>(P.inp), inp, row * c.batch, hipMemcpyDeviceToDevice, s));
   if (tar_ld == c.seq_len) {
     SKF_HIP(hipMemcpyAsync(M->at<char>(P.tar), tar, row * c.batch, hipMemcpyDeviceToDevice, s));

@@ -1157,6 +1157,32 @@ extern "C" int skf_padding_mask(const long long* tokens, int tok_ld, int B, int 
   return SKF_OK;
 }
 
+// The three input copies of a step (inputs, targets with their own pitch, labels or zeros) as ONE launch instead of three
+// copy-engine kernels (6 us each, back to back at the head of every step); 4-byte words, internal to the library (skf_model.hip).
+__global__ void stage_inputs_kernel(const unsigned* __restrict__ inp, unsigned* __restrict__ dinp, const unsigned* __restrict__ tar,
+                                    unsigned* __restrict__ dtar, int row_w, int src_row_w, int copy_w, int batch,
+                                    const unsigned* __restrict__ labels, unsigned* __restrict__ dlabels) {
+  const int n_inp = row_w * batch, n_tar = copy_w * batch, n_lab = 2 * batch;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_inp + n_tar + n_lab; e += gridDim.x * blockDim.x) {
+    if (e < n_inp) dinp[e] = inp[e];
+    else if (e < n_inp + n_tar) { const int t = e - n_inp, b = t / copy_w, w = t % copy_w; dtar[(size_t)b * row_w + w] = tar[(size_t)b * src_row_w + w]; }
+    else { const int t = e - n_inp - n_tar; dlabels[t] = labels ? labels[t] : 0u; }
+  }
+}
+// row / src_row / copy in bytes (multiples of 4); returns SKF_EUNSUPPORTED when an operand is not 4-byte aligned (caller copies)
+int skf_stage_inputs_launch(const void* inp, void* dinp, const void* tar, void* dtar, size_t row, size_t src_row, size_t copy, int batch,
+                            const void* labels, void* dlabels, hipStream_t st) {
+  if (((uintptr_t)inp | (uintptr_t)dinp | (uintptr_t)tar | (uintptr_t)dtar | (uintptr_t)labels | (uintptr_t)dlabels | row | src_row | copy) & 3)
+    return SKF_EUNSUPPORTED;
+  if ((double)(row + copy) * batch / 4 + 2.0 * batch >= 2147483648.0) return SKF_EUNSUPPORTED;
+  const int total = (int)((row + copy) / 4) * batch + 2 * batch;
+  int grid = skf_cdiv(total, 256); if (grid > 512) grid = 512;
+  hipLaunchKernelGGL(stage_inputs_kernel, dim3(grid), dim3(256), 0, st, (const unsigned*)inp, (unsigned*)dinp, (const unsigned*)tar,
+                     (unsigned*)dtar, (int)(row / 4), (int)(src_row / 4), (int)(copy / 4), batch, (const unsigned*)labels, (unsigned*)dlabels);
+  SKF_LAUNCH_CHECK();
+  return SKF_OK;
+}
+
 extern "C" int skf_embed_bwd(const long long* tokens, int tok_ld, int B, int L, const float* dx, int vocab, int d,
                              float* dtable, float rate, unsigned site, const void* step_state, skf_stream_t stream) {
   SKF_CHECK_ARG(tokens && dx && dtable, "null operand");
