@@ -79,13 +79,13 @@ size_t image_bytes(int pieces) { return (size_t)2 * pieces * (FD * FF * 2); }
 // The feed-forward pair: image 1 = B1 [128][512] followed by image 2 = B2 [512][128]; forward B1 = W1, B2 = W2; input gradient
 // B1 = W2^T, B2 = W1^T.
 struct DenseImageDesc { const float* src; char* img; int ld, transpose, K, N, block_begin, pad; };
-constexpr int kImageBatch = 40;
+constexpr int kImageBatch = 64;   // (64 descriptors of 40 bytes: 2.5 KB of kernel arguments; the 58 images of a cfg-2 train step are one launch)
 struct DenseImageBatch { DenseImageDesc d[kImageBatch]; int n; };
 
 template <int P>
 __global__ __launch_bounds__(256) void dense_image_kernel(DenseImageBatch batch) {
   int j = 0;
-  while (j + 1 < batch.n && (int)blockIdx.x >= batch.d[j + 1].block_begin) ++j;       // (wave-uniform, <= 40 steps)
+  while (j + 1 < batch.n && (int)blockIdx.x >= batch.d[j + 1].block_begin) ++j;       // (wave-uniform, <= 64 steps)
   const DenseImageDesc d = batch.d[j];
   const SkfSplitSel sel = skf_split_sel();
   const int t = ((int)blockIdx.x - d.block_begin) * 256 + threadIdx.x;
