@@ -537,6 +537,27 @@ def test_host_batches_are_staged_before_the_step_reads_them():
     assert torch.equal(eng.params, ref.params)
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_benchmarked_step_is_run_to_run_deterministic(use_graph):
+    """Two engines from one seed take the same 40 batches at the benchmarked size (cfg 2, B = 128, dropout 0.1): parameters and both Adam
+    moments bit-equal afterwards.  The eager step runs weight gradients, deferred input gradients and the sorts on a side stream; a missing
+    cross-stream dependency shows up here as a difference (tools/soak_determinism.py is the long form: 1000 steps,
+    profiles/r04_soak_determinism.txt).  Eager and graph replay are not bit-equal to EACH OTHER: the replayed step has no side stream and
+    takes the single-stream launch forms."""
+    from sketchformer_amd import engine
+    B = 128
+    engs = [engine.TrainEngine(engine.make_config(batch=B, dropout_rate=0.1, use_graph=use_graph, seed=7), init_seed=3) for _ in range(2)]
+    batches = [synthetic.token_batch(B, 200, 1004, 345, seed=100 + i) for i in range(4)]
+    for step in range(40):
+        x, y = batches[step % 4]
+        for e in engs:
+            e.train_step(x, y)
+    torch.cuda.synchronize()
+    a, b = engs
+    assert torch.equal(a.params, b.params) and torch.equal(a.adam_m, b.adam_m) and torch.equal(a.adam_v, b.adam_v)
+    assert np.isfinite(a.params.cpu().numpy()).all() and a.iterations == 40
+
+
 def test_sgd_momentum_trajectory_matches_oracle():
     """optimizer='sgd' (models/sketchformer.py:124-126): Keras SGD(schedule, momentum=0.9); the schedule is evaluated on
     the pre-increment step, so the very first update is a no-op here too."""

@@ -1,0 +1,47 @@
+#!/usr/bin/env python
+"""Soak test of the cfg-2 train step (B = 128, dropout 0.1): several engines from the same seed take the same N batches; after every CHECK
+steps the flat parameter buffers and both Adam moments of engines of the SAME mode (eager two-stream / hipGraph replay) must be bit-equal, and
+their hashes are printed so that two processes can be compared.  A cross-stream race in the eager schedule shows up as a difference between two
+eager engines.  Eager and graph replay are each deterministic but not bit-equal to each other: without the side stream the replayed step takes
+the single-stream forms of the LayerNorm backward / weight-gradient launches (different summation order), which is reported, not counted.
+usage (GPU box): python tools/soak_determinism.py [steps=400] [check=50] [modes=eeg: one letter per engine, e = eager, g = graph]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sketchformer_amd import engine, synthetic  # noqa: E402
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+check = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+B = 128
+modes = [m == 'g' for m in (sys.argv[3] if len(sys.argv) > 3 else 'eeg')]
+engs = [engine.TrainEngine(engine.make_config(batch=B, dropout_rate=float(os.environ.get('SOAK_RATE', 0.1)), use_graph=g, seed=7), init_seed=3) for g in modes]
+batches = [synthetic.token_batch(B, 200, 1004, 345, seed=100 + i) for i in range(8)]
+bad = 0
+for step in range(steps):
+    x, y = batches[step % len(batches)]
+    for e in engs:
+        e.train_step(x, y)
+    if (step + 1) % check == 0:
+        torch.cuda.synchronize()
+        ref = engs[0]
+        for k in range(1, len(engs)):
+            e = engs[k]
+            peer = next(j for j in range(len(engs)) if modes[j] == modes[k])        # first engine of the same mode
+            if peer != k:
+                p = engs[peer]
+                if not (torch.equal(p.params, e.params) and torch.equal(p.adam_m, e.adam_m) and torch.equal(p.adam_v, e.adam_v)):
+                    bad += 1
+                    print("step %d: engine %d differs from engine %d of the same mode (max |dparam| %.3e)" % (step + 1, k, peer, (p.params - e.params).abs().max().item()))
+            elif not torch.equal(ref.params, e.params):
+                print("step %d: %s vs eager: max |dparam| %.3e (different launch forms, expected)" % (step + 1, "graph" if modes[k] else "eager", (ref.params - e.params).abs().max().item()))
+        if True:
+            import hashlib
+            print("   hashes:", [hashlib.sha1(e.params.cpu().numpy().tobytes()).hexdigest()[:10] for e in engs])
+        m = ref.step_metrics()
+        print("step %4d  total_loss %.4f  finite %s" % (step + 1, m["total_loss"], bool(np.isfinite(ref.params.cpu().numpy()).all())), flush=True)
+print("soak: %d steps, %d mismatching checks" % (steps, bad))
+sys.exit(1 if bad else 0)
