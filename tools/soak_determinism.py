@@ -18,8 +18,12 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 check = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 B = 128
 modes = [m == 'g' for m in (sys.argv[3] if len(sys.argv) > 3 else 'eeg')]
-engs = [engine.TrainEngine(engine.make_config(batch=B, dropout_rate=float(os.environ.get('SOAK_RATE', 0.1)), use_graph=g, seed=7), init_seed=3) for g in modes]
-batches = [synthetic.token_batch(B, 200, 1004, 345, seed=100 + i) for i in range(8)]
+kw, L, V = {}, 200, 1004
+if os.environ.get("SOAK_BF16") == "1":       # the bf16 path at the cfg-5 dimensions, B = 8
+    B, L = 8, 512
+    kw = dict(seq_len=512, d_model=512, num_heads=8, dff=2048, num_layers=8, vocab_size=1004, n_classes=345, lowerdim=256, act_dtype="bf16")
+engs = [engine.TrainEngine(engine.make_config(batch=B, dropout_rate=float(os.environ.get('SOAK_RATE', 0.1)), use_graph=g, seed=7, **kw), init_seed=3) for g in modes]
+batches = [synthetic.token_batch(B, L, V, 345, seed=100 + i) for i in range(8)]
 bad = 0
 for step in range(steps):
     x, y = batches[step % len(batches)]
