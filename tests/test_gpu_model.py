@@ -537,6 +537,30 @@ def test_host_batches_are_staged_before_the_step_reads_them():
     assert torch.equal(eng.params, ref.params)
 
 
+@pytest.mark.parametrize("B,L,rate", [(3, 37, 0.1), (1, 200, 0.0), (17, 50, 0.1), (5, 16, 0.0)])
+def test_row_owner_launches_agree_with_the_launches_they_replace(B, L, rate):
+    """d = 128, dff = 512 (the shapes the fused feed-forward / LayerNorm launches are built for) at row counts that are no multiple of a
+    16-row tile or a 64-row sub-group: forward + backward with the row-owner launches (default) against the same step with
+    SKF_MODEL_FFN_LAUNCHES (one launch per Dense / LayerNorm, builders/layers/transformer.py:194-224) - losses and every gradient."""
+    from sketchformer_amd import engine, _lib
+    kw = dict(seq_len=L, d_model=128, num_heads=8, dff=512, num_layers=2, vocab_size=1004, n_classes=345, lowerdim=64)
+    x, y = synthetic.token_batch(B, L, 1004, 345, seed=B + L)
+    res = []
+    for flags in (0, _lib.MODEL_FFN_LAUNCHES):
+        eng = engine.TrainEngine(engine.make_config(batch=B, dropout_rate=rate, use_graph=False, seed=5, **kw), init_seed=2)
+        eng.set_flags(flags)
+        eng.forward_backward(x, None, y)
+        torch.cuda.synchronize()
+        res.append((eng.step_metrics(), eng.state_dict_numpy("grads")))
+    (m0, g0), (m1, g1) = res
+    for k in ("recon_loss", "class_loss", "total_loss"):
+        assert abs(m0[k] - m1[k]) <= 2e-6 * max(1.0, abs(m1[k])), (k, m0[k], m1[k])
+    scale = np.median([np.abs(v).max() for v in g1.values()])
+    # (the key-projection bias gradient is analytically zero - softmax is invariant to it - and pure rounding noise in both forms)
+    worst = max((np.abs(g0[k].astype(np.float64) - g1[k]).max() / max(np.abs(g1[k]).max(), 1e-2 * scale), k) for k in g1 if not k.endswith("wk/bias"))
+    assert worst[0] < 2e-5, worst
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_benchmarked_step_is_run_to_run_deterministic(use_graph):
     """Two engines from one seed take the same 40 batches at the benchmarked size (cfg 2, B = 128, dropout 0.1): parameters and both Adam
