@@ -537,28 +537,61 @@ def test_host_batches_are_staged_before_the_step_reads_them():
     assert torch.equal(eng.params, ref.params)
 
 
-@pytest.mark.parametrize("B,L,rate", [(3, 37, 0.1), (1, 200, 0.0), (17, 50, 0.1), (5, 16, 0.0)])
-def test_row_owner_launches_agree_with_the_launches_they_replace(B, L, rate):
-    """d = 128, dff = 512 (the shapes the fused feed-forward / LayerNorm launches are built for) at row counts that are no multiple of a
-    16-row tile or a 64-row sub-group: forward + backward with the row-owner launches (default) against the same step with
-    SKF_MODEL_FFN_LAUNCHES (one launch per Dense / LayerNorm, builders/layers/transformer.py:194-224) - losses and every gradient."""
+def _fb_both_launch_forms(B, L, rate, x, y):
+    """forward + backward with the row-owner launches and with SKF_MODEL_FFN_LAUNCHES -> (metrics, gradients) of both and whether
+    every hidden unit took the same ReLU branch in both (the two forms sum the pre-activations in different orders: a unit within
+    rounding of zero may take either branch and then shifts a column of dW1 - tests/relu_branches.py; seen at 1 unit in ~10^6)."""
     from sketchformer_amd import engine, _lib
     kw = dict(seq_len=L, d_model=128, num_heads=8, dff=512, num_layers=2, vocab_size=1004, n_classes=345, lowerdim=64)
-    x, y = synthetic.token_batch(B, L, 1004, 345, seed=B + L)
-    res = []
+    res, masks = [], []
     for flags in (0, _lib.MODEL_FFN_LAUNCHES):
         eng = engine.TrainEngine(engine.make_config(batch=B, dropout_rate=rate, use_graph=False, seed=5, **kw), init_seed=2)
         eng.set_flags(flags)
         eng.forward_backward(x, None, y)
         torch.cuda.synchronize()
         res.append((eng.step_metrics(), eng.state_dict_numpy("grads")))
-    (m0, g0), (m1, g1) = res
+        masks.append([(eng.buffer("%s/layer%d/ffn_h" % (side, i)) > 0).cpu().numpy() for side in ("encoder", "decoder") for i in range(2)])
+    same_branches = all(np.array_equal(a, b) for a, b in zip(*masks))
+    return res[0], res[1], same_branches
+
+
+@pytest.mark.parametrize("case", ["all PAD", "SOS only", "one empty and one length-1 sample", "full length"])
+def test_row_owner_launches_on_degenerate_batches(case):
+    """The same comparison on batches at the edges of the padding structure (live-row lists with zero or one entry, attention rows that see one
+    key or none, no padding at all): finite everywhere, losses equal, every gradient within 2e-5 of the largest gradient of the step."""
+    B, L = 6, 40
+    x, y = synthetic.token_batch(B, L, 1004, 345, seed=1, full=case == "full length")
+    if case == "all PAD":
+        x[:] = 0
+    elif case == "SOS only":
+        x[:] = 0
+        x[:, 0] = 1002
+    elif case == "one empty and one length-1 sample":
+        x[2] = 0
+        x[4, 1:] = 0
+    (m0, g0), (m1, g1), same = _fb_both_launch_forms(B, L, 0.1, x, y)
+    bar = 2e-5 if same else 5e-3          # a ReLU unit on the kink took different branches in the two forms
+    for k in ("recon_loss", "class_loss", "total_loss"):
+        assert np.isfinite(m0[k]) and abs(m0[k] - m1[k]) <= 2e-6 * max(1.0, abs(m1[k])), (k, m0[k], m1[k])
+    top = max(np.abs(v).max() for v in g1.values())
+    for k in g1:
+        assert np.isfinite(g0[k]).all(), k
+        assert np.abs(g0[k].astype(np.float64) - g1[k]).max() <= bar * top, (k, np.abs(g0[k] - g1[k]).max(), top, same)
+
+
+@pytest.mark.parametrize("B,L,rate", [(3, 37, 0.1), (1, 200, 0.0), (17, 50, 0.1), (5, 16, 0.0)])
+def test_row_owner_launches_agree_with_the_launches_they_replace(B, L, rate):
+    """d = 128, dff = 512 (the shapes the fused feed-forward / LayerNorm launches are built for) at row counts that are no multiple of a
+    16-row tile or a 64-row sub-group: forward + backward with the row-owner launches (default) against the same step with
+    SKF_MODEL_FFN_LAUNCHES (one launch per Dense / LayerNorm, builders/layers/transformer.py:194-224) - losses and every gradient."""
+    x, y = synthetic.token_batch(B, L, 1004, 345, seed=B + L)
+    (m0, g0), (m1, g1), same = _fb_both_launch_forms(B, L, rate, x, y)
     for k in ("recon_loss", "class_loss", "total_loss"):
         assert abs(m0[k] - m1[k]) <= 2e-6 * max(1.0, abs(m1[k])), (k, m0[k], m1[k])
     scale = np.median([np.abs(v).max() for v in g1.values()])
     # (the key-projection bias gradient is analytically zero - softmax is invariant to it - and pure rounding noise in both forms)
     worst = max((np.abs(g0[k].astype(np.float64) - g1[k]).max() / max(np.abs(g1[k]).max(), 1e-2 * scale), k) for k in g1 if not k.endswith("wk/bias"))
-    assert worst[0] < 2e-5, worst
+    assert worst[0] < (2e-5 if same else 5e-2), (worst, same)      # (per tensor: a kink unit shifts one column of dW1 by ~1e-2 of its largest entry)
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
