@@ -537,12 +537,14 @@ def test_host_batches_are_staged_before_the_step_reads_them():
     assert torch.equal(eng.params, ref.params)
 
 
-def _fb_both_launch_forms(B, L, rate, x, y):
+def _fb_both_launch_forms(B, L, rate, x, y, **over):
     """forward + backward with the row-owner launches and with SKF_MODEL_FFN_LAUNCHES -> (metrics, gradients) of both and whether
     every hidden unit took the same ReLU branch in both (the two forms sum the pre-activations in different orders: a unit within
     rounding of zero may take either branch and then shifts a column of dW1 - tests/relu_branches.py; seen at 1 unit in ~10^6)."""
     from sketchformer_amd import engine, _lib
     kw = dict(seq_len=L, d_model=128, num_heads=8, dff=512, num_layers=2, vocab_size=1004, n_classes=345, lowerdim=64)
+    kw.update(over)
+    sides = ("encoder", "decoder") if kw.get("do_reconstruction", True) else ("encoder",)
     res, masks = [], []
     for flags in (0, _lib.MODEL_FFN_LAUNCHES):
         eng = engine.TrainEngine(engine.make_config(batch=B, dropout_rate=rate, use_graph=False, seed=5, **kw), init_seed=2)
@@ -550,7 +552,7 @@ def _fb_both_launch_forms(B, L, rate, x, y):
         eng.forward_backward(x, None, y)
         torch.cuda.synchronize()
         res.append((eng.step_metrics(), eng.state_dict_numpy("grads")))
-        masks.append([(eng.buffer("%s/layer%d/ffn_h" % (side, i)) > 0).cpu().numpy() for side in ("encoder", "decoder") for i in range(2)])
+        masks.append([(eng.buffer("%s/layer%d/ffn_h" % (side, i)) > 0).cpu().numpy() for side in sides for i in range(kw["num_layers"])])
     same_branches = all(np.array_equal(a, b) for a, b in zip(*masks))
     return res[0], res[1], same_branches
 
@@ -574,6 +576,29 @@ def test_row_owner_launches_on_degenerate_batches(case):
     for k in ("recon_loss", "class_loss", "total_loss"):
         assert np.isfinite(m0[k]) and abs(m0[k] - m1[k]) <= 2e-6 * max(1.0, abs(m1[k])), (k, m0[k], m1[k])
     top = max(np.abs(v).max() for v in g1.values())
+    for k in g1:
+        assert np.isfinite(g0[k]).all(), k
+        assert np.abs(g0[k].astype(np.float64) - g1[k]).max() <= bar * top, (k, np.abs(g0[k] - g1[k]).max(), top, same)
+
+
+@pytest.mark.parametrize("over", [dict(blind_decoder_mask=False), dict(do_reconstruction=False), dict(do_classification=False),
+                                  dict(lowerdim=0, do_classification=False), dict(attn_version=2), dict(class_buffer_layers=2), dict(num_layers=1), dict(num_layers=3),
+                                  dict(continuous=True, vocab_size=None), dict(optimizer="SGD"), dict(num_heads=4), dict(num_heads=2)],
+                         ids=lambda o: ",".join("%s=%s" % kv for kv in o.items()))
+def test_row_owner_launches_in_every_model_structure(over):
+    """The structural options of the reference (models/sketchformer.py:63-129: expected-length cross mask, no decoder, no classifier, no
+    bottleneck, SelfAttnV2, class buffers, layer counts, continuous input, head counts) at d = 128 / dff = 512, where the row-owner
+    launches are in use: forward + backward against the same step on the per-Dense launches."""
+    B, L = 5, 33
+    if over.get("continuous"):
+        x, y = synthetic.continuous_batch(B, L, 345, seed=3)
+    else:
+        x, y = synthetic.token_batch(B, L, 1004, 345, seed=3)
+    (m0, g0), (m1, g1), same = _fb_both_launch_forms(B, L, 0.1, x, y, **over)
+    for k in ("recon_loss", "class_loss", "total_loss"):
+        assert np.isfinite(m0[k]) and abs(m0[k] - m1[k]) <= 2e-6 * max(1.0, abs(m1[k])), (k, m0[k], m1[k])
+    top = max(np.abs(v).max() for v in g1.values())
+    bar = 2e-5 if same else 5e-3
     for k in g1:
         assert np.isfinite(g0[k]).all(), k
         assert np.abs(g0[k].astype(np.float64) - g1[k]).max() <= bar * top, (k, np.abs(g0[k] - g1[k]).max(), top, same)
