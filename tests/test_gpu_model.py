@@ -619,6 +619,30 @@ def test_row_owner_launches_agree_with_the_launches_they_replace(B, L, rate):
     assert worst[0] < (2e-5 if same else 5e-2), (worst, same)      # (per tensor: a kink unit shifts one column of dW1 by ~1e-2 of its largest entry)
 
 
+@pytest.mark.parametrize("over", [dict(), dict(blind_decoder_mask=False), dict(do_reconstruction=False), dict(do_classification=False),
+                                  dict(lowerdim=0, do_classification=False), dict(attn_version=2), dict(class_buffer_layers=2),
+                                  dict(num_layers=1), dict(num_layers=3), dict(continuous=True, vocab_size=None), dict(optimizer="SGD")],
+                         ids=lambda o: ",".join("%s=%s" % kv for kv in o.items()) or "default")
+def test_two_stream_step_is_deterministic_in_every_model_structure(over):
+    """The eager step's side-stream schedule (held weight-gradient groups, deferred input gradients, sorts) differs with the model
+    structure: two engines from one seed, 25 train steps each at d = 128 / dff = 512, bit-equal parameters and moments."""
+    from sketchformer_amd import engine
+    B, L = 16, 50
+    kw = dict(seq_len=L, d_model=128, num_heads=8, dff=512, num_layers=2, vocab_size=1004, n_classes=345, lowerdim=64)
+    kw.update(over)
+    engs = [engine.TrainEngine(engine.make_config(batch=B, dropout_rate=0.1, use_graph=False, seed=9, **kw), init_seed=4) for _ in range(2)]
+    mk = (lambda i: synthetic.continuous_batch(B, L, 345, seed=60 + i)) if over.get("continuous") else (lambda i: synthetic.token_batch(B, L, 1004, 345, seed=60 + i))
+    batches = [mk(i) for i in range(5)]
+    for step in range(25):
+        x, y = batches[step % 5]
+        for e in engs:
+            e.train_step(x, y)
+    torch.cuda.synchronize()
+    a, b = engs
+    assert torch.equal(a.params, b.params) and torch.equal(a.adam_m, b.adam_m) and torch.equal(a.adam_v, b.adam_v)
+    assert np.isfinite(a.params.cpu().numpy()).all()
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_benchmarked_step_is_run_to_run_deterministic(use_graph):
     """Two engines from one seed take the same 40 batches at the benchmarked size (cfg 2, B = 128, dropout 0.1): parameters and both Adam
