@@ -537,7 +537,7 @@ def test_host_batches_are_staged_before_the_step_reads_them():
     assert torch.equal(eng.params, ref.params)
 
 
-def _fb_both_launch_forms(B, L, rate, x, y, **over):
+def _fb_both_launch_forms(B, L, rate, x, y, with_graph=False, **over):
     """forward + backward with the row-owner launches and with SKF_MODEL_FFN_LAUNCHES -> (metrics, gradients) of both and whether
     every hidden unit took the same ReLU branch in both (the two forms sum the pre-activations in different orders: a unit within
     rounding of zero may take either branch and then shifts a column of dW1 - tests/relu_branches.py; seen at 1 unit in ~10^6)."""
@@ -546,14 +546,16 @@ def _fb_both_launch_forms(B, L, rate, x, y, **over):
     kw.update(over)
     sides = ("encoder", "decoder") if kw.get("do_reconstruction", True) else ("encoder",)
     res, masks = [], []
-    for flags in (0, _lib.MODEL_FFN_LAUNCHES):
-        eng = engine.TrainEngine(engine.make_config(batch=B, dropout_rate=rate, use_graph=False, seed=5, **kw), init_seed=2)
+    for flags, graph in ((0, False), (_lib.MODEL_FFN_LAUNCHES, False)) + (((0, True),) if with_graph else ()):
+        eng = engine.TrainEngine(engine.make_config(batch=B, dropout_rate=rate, use_graph=graph, seed=5, **kw), init_seed=2)
         eng.set_flags(flags)
         eng.forward_backward(x, None, y)
         torch.cuda.synchronize()
         res.append((eng.step_metrics(), eng.state_dict_numpy("grads")))
         masks.append([(eng.buffer("%s/layer%d/ffn_h" % (side, i)) > 0).cpu().numpy() for side in sides for i in range(kw["num_layers"])])
-    same_branches = all(np.array_equal(a, b) for a, b in zip(*masks))
+    same_branches = all(np.array_equal(m[0], mm) for m in zip(*masks) for mm in m[1:])
+    if with_graph:
+        return res[0], res[1], res[2], same_branches
     return res[0], res[1], same_branches
 
 
@@ -594,14 +596,18 @@ def test_row_owner_launches_in_every_model_structure(over):
         x, y = synthetic.continuous_batch(B, L, 345, seed=3)
     else:
         x, y = synthetic.token_batch(B, L, 1004, 345, seed=3)
-    (m0, g0), (m1, g1), same = _fb_both_launch_forms(B, L, 0.1, x, y, **over)
+    # (third run: the same step captured into a hipGraph and replayed on ONE stream - what a missing cross-stream dependency of the
+    #  eager two-stream schedule would differ from)
+    (m0, g0), (m1, g1), (m2, g2), same = _fb_both_launch_forms(B, L, 0.1, x, y, with_graph=True, **over)
     for k in ("recon_loss", "class_loss", "total_loss"):
         assert np.isfinite(m0[k]) and abs(m0[k] - m1[k]) <= 2e-6 * max(1.0, abs(m1[k])), (k, m0[k], m1[k])
+        assert abs(m0[k] - m2[k]) <= 2e-6 * max(1.0, abs(m2[k])), (k, m0[k], m2[k])
     top = max(np.abs(v).max() for v in g1.values())
     bar = 2e-5 if same else 5e-3
     for k in g1:
         assert np.isfinite(g0[k]).all(), k
         assert np.abs(g0[k].astype(np.float64) - g1[k]).max() <= bar * top, (k, np.abs(g0[k] - g1[k]).max(), top, same)
+        assert np.abs(g0[k].astype(np.float64) - g2[k]).max() <= bar * top, ("graph replay", k, np.abs(g0[k] - g2[k]).max(), top, same)
 
 
 @pytest.mark.parametrize("B,L,rate", [(3, 37, 0.1), (1, 200, 0.0), (17, 50, 0.1), (5, 16, 0.0)])
