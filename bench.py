@@ -212,7 +212,8 @@ def rocprof_views(workload, steps=15, want_trace=True):
     script as a child of rocprofv3 (separate runs: a kernel trace, then one PMC pass per counter, as MI355X_MICROARCH.md
     prescribes): per-kernel average durations under concurrency, and HBM bytes per launch (FETCH_SIZE doubled for the gfx950
     wide-load under-count, x1024)."""
-    out = {"kernels_concurrent": None, "traffic": None, "wall_per_step_us": None}
+    out = {"kernels_concurrent": None, "traffic": None, "wall_per_step_us": None, "traffic_per_step": None}
+    launches = {}
     base = ["--workload", workload, "--no-profile", "--no-cpu-baseline", "--no-extras"]
     tmp = tempfile.mkdtemp(prefix="skf_rocprof_")
     try:
@@ -232,6 +233,7 @@ def rocprof_views(workload, steps=15, want_trace=True):
                 out["kernels_concurrent"] = sorted(({"kernel": k[:90], "launches_per_step": round(v[0] / n, 2), "avg_us": round(v[1] / v[0], 2),
                                                      "per_step_ms": round(v[1] / n / 1e3, 4)} for k, v in agg.items()),
                                                    key=lambda r: -r["per_step_ms"])[:16]
+                launches = {k: v[0] / n for k, v in agg.items()}
                 out["wall_per_step_us"] = (seg[-1][1] - seg[0][0]) / 1e3 / n
                 out["kernels_per_step"] = len(seg) / n
         traffic = {}
@@ -249,6 +251,12 @@ def rocprof_views(workload, steps=15, want_trace=True):
         if traffic:
             out["traffic"] = {k: (v["FETCH_SIZE"][0] / max(v["FETCH_SIZE"][1], 1)) + (v["WRITE_SIZE"][0] / max(v["WRITE_SIZE"][1], 1))
                               for k, v in traffic.items()}
+            # step-level HBM bytes: every kernel of the traced step x its PMC bytes per launch (the figure to hold against the
+            # algorithmic bytes of SURVEY 8(d): step_bytes())
+            hit = [k for k in launches if k in out["traffic"]]
+            if hit:
+                out["traffic_per_step"] = {"bytes": sum(out["traffic"][k] * launches[k] for k in hit),
+                                           "launches_covered": sum(launches[k] for k in hit) / max(sum(launches.values()), 1e-9)}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return out
@@ -358,6 +366,9 @@ def apply_concurrent(roof, views):
             roof["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two child runs of this script (FETCH doubled, x1024)"
     conc = [r for r in (views.get("kernels_concurrent") or []) if r["kernel"].startswith(prefix)]
     if conc:
+        # `frac` must follow from the fields printed beside it: frac = algorithmic_per_launch / avg_launch_us / peak, with
+        # avg_launch_us = this kernel's rocprofv3 kernel-trace average in the real two-stream step; the in-library HIP-event
+        # figures (which serialise the two streams) stay beside them as *_hip_events.
         n = sum(r["launches_per_step"] for r in conc)
         avg = sum(r["avg_us"] * r["launches_per_step"] for r in conc) / n
         scale = roof["avg_launch_us"] / avg
@@ -365,9 +376,18 @@ def apply_concurrent(roof, views):
             if k in roof:
                 roof[k + "_hip_events"] = roof[k]
                 roof[k] = roof[k] * scale
-        roof["avg_launch_us_concurrent"] = avg
+        roof["avg_launch_us_hip_events"] = roof["avg_launch_us"]
+        roof["avg_launch_us"] = avg
         roof["timing"] = ("rocprofv3 --kernel-trace average of this kernel in the un-instrumented two-stream step (child run of this script); "
                           "*_hip_events = the in-library HIP-event figures, which serialise the two streams")
+
+
+def roofline_identity_error(roof):
+    """|frac - algorithmic_per_launch / avg_launch_us / peak| / frac from the fields of a `roofline` object alone (0 when the
+    object is self-consistent; tests/test_bench_line_cpu.py asserts it on canned and on freshly built records)."""
+    unit = 1e12 if roof["unit"] == "TFLOP/s" else 1e9
+    derived = roof["algorithmic_per_launch"] / (roof["avg_launch_us"] * 1e-6) / unit / roof["peak"]
+    return abs(derived - roof["frac"]) / max(abs(roof["frac"]), 1e-30)
 
 
 def kernel_table(rows):
@@ -490,7 +510,7 @@ def compact_line(out):
     if roof:
         line["roofline"] = _pick(roof, ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us", "launches_per_step",
                                         "per_step_ms", "frac_dense_counted", "frac_of_executing_pipe", "algorithmic_per_launch",
-                                        "avg_launch_us_concurrent", "frac_hip_events"))
+                                        "avg_launch_us_hip_events", "frac_hip_events", "traffic_per_step", "algorithmic_bytes_per_step"))
         line["roofline"].setdefault("traffic", None)
         if roof.get("timing"):
             line["roofline"]["timing"] = "rocprofv3 kernel trace" if roof["timing"].startswith("rocprofv3") else "HIP events"
@@ -683,6 +703,12 @@ def main():
             views = rocprof_views(args.workload)
             _progress("rocprofv3 child runs (kernel trace + 2 PMC passes) done")
             apply_concurrent(roof, views)
+            if views.get("traffic_per_step"):
+                # step-level HBM bytes by PMC (sum over the kernels of the traced step of launches x bytes per launch) beside the
+                # algorithmic bytes of the step (every saved activation written once and read once + weights / optimizer)
+                roof["traffic_per_step"] = views["traffic_per_step"]["bytes"]
+                roof["traffic_per_step_launches_covered"] = views["traffic_per_step"]["launches_covered"]
+                roof["algorithmic_bytes_per_step"] = bytes_step
             if views["kernels_concurrent"]:
                 out["kernels_concurrent"] = views["kernels_concurrent"]
                 out["kernels_per_step"] = views.get("kernels_per_step")

@@ -249,6 +249,16 @@ int skf_attention_bwd_rows(const float* Q, int ldq, const float* K, int ldk, con
                            const float* dO, int lddo, const float* stats, const unsigned char* key_mask, int key_mask_ld,
                            int causal, int B, int H, int Lq, int Lk, int dh, float* dQ, int lddq, float* dK, int lddk,
                            float* dV, int lddv, int precision, const int* q_live_len, skf_stream_t stream);
+/* The second return value of scaled_dot_product_attention (builders/utils.py:105: `return output, attention_weights`):
+ * W (B,H,Lq,Lk) = softmax(q.k/sqrt(dh) + mask * -1e9) over the keys, same mask arguments as skf_attention_fwd.  Only the builders
+ * front-end calls it, on request (the train step of the reference drops the weights: models/sketchformer.py:140-145); plain fp32
+ * kernel, any dh <= 128, Lq, Lk <= 1024. */
+int skf_attention_weights(const float* Q, int ldq, const float* K, int ldk, const unsigned char* key_mask, int key_mask_ld,
+                          int causal, int B, int H, int Lq, int Lk, int dh, float* W, skf_stream_t stream);
+/* Row means behind LossManager.add_mean_loss / add_mae_loss / add_mse_loss (builders/losses.py:68-75; tf.keras.losses.MAE / MSE
+ * reduce the LAST axis): out[r] = mean_c a[r][c] (mode 0), mean_c |a - b| (mode 1), mean_c (a - b)^2 (mode 2); a, b (rows, cols)
+ * contiguous. */
+int skf_row_mean(const float* a, const float* b, long rows, int cols, int mode, float* out, skf_stream_t stream);
 
 /* ------------------------------------------------------------------ embedding stage
  * Encoder.call / Decoder.call head, builders/layers/transformer.py:288-296, 325-334:

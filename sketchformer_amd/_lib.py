@@ -127,6 +127,8 @@ SIGNATURES = {
     "skf_attention_bwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I,
                                _P, _I, _P, _I, _P, _I, _I, _P]),
     "skf_attention_bwd_rows": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P]),
+    "skf_attention_weights": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "skf_row_mean": (_I, [_P, _P, C.c_long, _I, _I, _P, _P]),
     "skf_embed_fwd": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _P, _F, _U, _P, _P]),
     "skf_embed_bwd": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _F, _U, _P, _P]),
     "skf_embed_sort_workspace_bytes": (_Z, [_I, _I, _I]),

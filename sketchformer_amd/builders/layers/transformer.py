@@ -22,9 +22,14 @@ class DropoutState(object):
     """Device-side step scalars (skf_step_prologue) for the training-mode dropout of a layer stack: ``advance()`` once per
     training call draws fresh masks (tf.keras.layers.Dropout draws new ones per call), ``site()`` numbers the Dropout layers."""
 
-    def __init__(self, device="cuda", seed=0):
-        self.device, self.seed, self.calls = device, seed, 0
+    _seeds = itertools.count()          # every state object draws from its own stream: two stacks (or two stand-alone layers) must
+                                        # not repeat each other's keep masks (tf.keras.layers.Dropout instances are independent)
+
+    def __init__(self, device="cuda", seed=None):
+        self.device, self.calls = device, 0
+        self.seed = next(DropoutState._seeds) if seed is None else seed
         self.state = None
+        self.in_stack_call = False          # True while the owning stack's call() runs: its layers then share the advanced state
         self._sites = itertools.count()
 
     def site(self):
@@ -73,8 +78,8 @@ class _Droppable(object):
         if self.drop is None:
             self.drop = DropoutState(self._device)
             self._own_drop = True
-        if getattr(self, "_own_drop", False):
-            return self.drop.advance()
+        if getattr(self, "_own_drop", False) or not self.drop.in_stack_call:
+            return self.drop.advance()      # stand-alone layer, or a stack's layer called on its own: fresh masks per call
         return self.drop.state
 
 
@@ -181,9 +186,13 @@ class Encoder(_Stack):
 
     def call(self, x, training, mask):
         st = self._drop_state(training)
-        x = self._embed(x, st)
-        for layer in self.enc_layers:
-            x = layer(x, training, mask)
+        self.drop.in_stack_call = True
+        try:
+            x = self._embed(x, st)
+            for layer in self.enc_layers:
+                x = layer(x, training, mask)
+        finally:
+            self.drop.in_stack_call = False
         return x
 
     __call__ = call
@@ -197,12 +206,16 @@ class Decoder(_Stack):
 
     def call(self, x, enc_output, training, look_ahead_mask, padding_mask):
         st = self._drop_state(training)
-        x = self._embed(x, st)
         attention_weights = {}
-        for i, layer in enumerate(self.dec_layers):
-            x, block1, block2 = layer(x, enc_output, training, look_ahead_mask, padding_mask)
-            attention_weights['decoder_layer{}_block1'.format(i + 1)] = block1
-            attention_weights['decoder_layer{}_block2'.format(i + 1)] = block2
+        self.drop.in_stack_call = True
+        try:
+            x = self._embed(x, st)
+            for i, layer in enumerate(self.dec_layers):
+                x, block1, block2 = layer(x, enc_output, training, look_ahead_mask, padding_mask)
+                attention_weights['decoder_layer{}_block1'.format(i + 1)] = block1
+                attention_weights['decoder_layer{}_block2'.format(i + 1)] = block2
+        finally:
+            self.drop.in_stack_call = False
         return x, attention_weights
 
     __call__ = call

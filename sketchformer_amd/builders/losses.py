@@ -45,6 +45,19 @@ class LossManager(object):
             return scal[3]
         self._add_loss(name, weight, fn)
 
+    # builders/losses.py:68-75.  tf.keras.losses.MAE / MSE reduce the last axis and keep the others; tf.reduce_mean reduces everything.
+    def add_mae_loss(self, name, weight=1.):
+        self._add_loss(name, weight, lambda y_true, y_pred: ops.row_mean(torch.as_tensor(y_pred), y_true, mode=1))
+
+    def add_mean_loss(self, name, weight=1.):
+        def fn(x):
+            x = torch.as_tensor(x).detach().to(torch.float32).contiguous().view(1, -1)
+            return ops.row_mean(x)[0]
+        self._add_loss(name, weight, fn)
+
+    def add_mse_loss(self, name, weight=1.):
+        self._add_loss(name, weight, lambda y_true, y_pred: ops.row_mean(torch.as_tensor(y_pred), y_true, mode=2))
+
     def compute_all_loss(self, rp_dict):
         return {n: self.loss_weights[n] * self.loss_fns[n](*rp_dict[n]) for n in self.loss_names}
 

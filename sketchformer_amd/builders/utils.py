@@ -53,14 +53,24 @@ def _decode_mask(mask, B, Lq, Lk):
     return km, causal
 
 
-def scaled_dot_product_attention(q, k, v, mask):
-    """q,k,v: (B, H, L, depth) as in the reference.  Returns (output (B,H,Lq,depth), None): the attention
-    weights are never materialised (the train step of the reference drops them, models/sketchformer.py:140-145)."""
+# The reference returns (output, attention_weights) from every call (builders/utils.py:105) and its train step drops the weights
+# (models/sketchformer.py:140-145).  The fused kernel never forms them; a caller that wants them asks - per call
+# (``return_weights=True``) or for every call of the front-end (``RETURN_ATTENTION_WEIGHTS = True``) - and gets the (B,H,Lq,Lk)
+# tensor from a second launch (skf_attention_weights).
+RETURN_ATTENTION_WEIGHTS = False
+
+
+def scaled_dot_product_attention(q, k, v, mask, return_weights=None):
+    """q,k,v: (B, H, L, depth) as in the reference.  Returns (output (B,H,Lq,depth), attention_weights (B,H,Lq,Lk) or None):
+    the weights are materialised on request only (see RETURN_ATTENTION_WEIGHTS)."""
     B, H, Lq, dh = q.shape
     Lk = k.shape[2]
     km, causal = _decode_mask(mask, B, Lq, Lk)
 
     def flat(x):
         return x.permute(0, 2, 1, 3).reshape(B, x.shape[2], H * dh).contiguous()
-    o, _ = ops.attention_fwd(flat(q), flat(k), flat(v), H, key_mask=km, causal=causal)
-    return o.view(B, Lq, H, dh).permute(0, 2, 1, 3), None
+    qf, kf = flat(q), flat(k)
+    o, _ = ops.attention_fwd(qf, kf, flat(v), H, key_mask=km, causal=causal)
+    want = RETURN_ATTENTION_WEIGHTS if return_weights is None else return_weights
+    w = ops.attention_weights(qf, kf, H, key_mask=km, causal=causal) if want else None
+    return o.view(B, Lq, H, dh).permute(0, 2, 1, 3), w

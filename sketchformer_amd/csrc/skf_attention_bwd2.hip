@@ -364,12 +364,8 @@ static int bwd2_launch(const AttnParams& p, hipStream_t st) {
   SKF_CHECK_ARG(nkt <= 32 && nqt <= 32, "more than 32 key / query tiles");
   SKF_CHECK_ARG((p.ldq & 3) == 0 && (p.ldk & 3) == 0 && (p.ldv & 3) == 0 && (p.ldo & 3) == 0 && (p.lddo & 3) == 0 && (p.lddq & 3) == 0 &&
                 (p.lddk & 3) == 0 && (p.lddv & 3) == 0, "row strides must be multiples of 4");
-  static bool attr[2] = {false, false};
   const void* kfn = p.causal ? (const void*)attn_bwd2_kernel<NC, true> : (const void*)attn_bwd2_kernel<NC, false>;
-  if (!attr[p.causal ? 1 : 0]) {
-    SKF_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr[p.causal ? 1 : 0] = true;
-  }
+  SKF_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));   // per launch: the attribute is per device
   // (query tiles whose dO rows are all zero are skipped as well; with the live lengths of the train step those are the tiles
   //  behind q_live - without the lengths the figure below only knows the masks)
   const double visited = skf_prof_attention_fraction(p.key_mask, p.key_mask_ld, p.causal, p.B, p.Lq, p.Lk, p.q_live, 16, 16);

@@ -319,12 +319,8 @@ int skf_decode_fused_launch(const SkfDecodeFused& p, hipStream_t st) {
   SkfProfScope ps(st, "decode_position", 0.0, 0.0);
 #define SKF_DF(DHV)                                                                                                  \
   {                                                                                                                  \
-    static bool attr_done = false;                                                                                   \
-    if (!attr_done) {                                                                                                \
-      SKF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_position_kernel<DHV>),                         \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));                          \
-      attr_done = true;                                                                                              \
-    }                                                                                                                \
+    SKF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_position_kernel<DHV>),                           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024)); /* per launch: per-device attribute */ \
     hipLaunchKernelGGL((decode_position_kernel<DHV>), dim3(p.B), dim3(NT), smem, st, p);                             \
   }
   if (dh == 16) SKF_DF(16) else if (dh == 32) SKF_DF(32) else SKF_DF(64)

@@ -867,15 +867,17 @@ __global__ __launch_bounds__(512, 2) void ln_bwd_dgrad_kernel(LnDgradParams p) {
   }
 }
 
+// CU count of the CURRENT device (one process may drive several GPUs; cached per device id, read-mostly: a benign race writes the same value)
 int n_cus() {
-  static int n = 0;
-  if (!n) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-    if (n <= 0) n = 256;
+  static int cache[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!cache[dev]) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cache[dev] = n;
   }
-  return n;
+  return cache[dev];
 }
 
 // One workgroup per CU - minus one: these launches need a whole CU per workgroup (LDS), so a single-workgroup kernel of the side
@@ -892,11 +894,8 @@ template <int P, int MODE, bool LNB = false, bool POST = false, bool PRE = false
 int launch_ffn(const FfnFusedParams& p, hipStream_t st) {
   const int grid = ffn_grid(p.M);
   const size_t smem = (size_t)3 * P * PLANE + (P * PLANE >= ROWS * YPITCH * 4 ? 0 : ROWS * YPITCH * 4) + (FF + 384 + 3 * FD) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fused_kernel<P, MODE, LNB, POST, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_done = true;
-  }
+  // per launch like skf_attention.hip's set_smem: the attribute belongs to the (function, device) pair and its failure must surface here
+  SKF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fused_kernel<P, MODE, LNB, POST, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   // one profiler line for the family (the kernel template's forward / backward / LayerNorm-prologue / chained-projection variants,
   // like the epilogue kinds of gemm_wsx); SKF_PROF_FINE=1 (measurement builds): one line per variant
   static const bool fine = skf_knob("SKF_PROF_FINE") && skf_knob("SKF_PROF_FINE")[0] == '1';

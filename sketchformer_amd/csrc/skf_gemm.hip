@@ -310,11 +310,7 @@ int launch_variant(const GemmParams& p, int a_kc, int b_kc, int splits, hipStrea
   {                                                                                                            \
     constexpr size_t smem = 2 * BK * (TileLD<BM, AK>::value + TileLD<BN, BKC>::value) * sizeof(float);         \
     auto kfn = gemm_kernel<BM, BN, WGM, AK, BKC, SPLITK, VECV>;                                                \
-    static bool attr_done = false;                                                                             \
-    if (!attr_done) {                                                                                          \
-      SKF_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));   \
-      attr_done = true;                                                                                        \
-    }                                                                                                          \
+    SKF_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); /* per launch: per-device attribute */ \
     static const std::string tag = std::string(SPLITK ? "gemm_splitk" : "gemm") + "<" + std::to_string(BM) + "x" + \
         std::to_string(BN) + "," + (AK ? "Ak" : "Am") + (BKC ? "Bk" : "Bn") + (VECV ? "" : ",scalar") + ">";  \
     SkfProfScope ps(st, tag.c_str(), 2.0 * p.M * p.N * p.K,                                                    \

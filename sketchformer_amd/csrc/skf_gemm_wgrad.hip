@@ -402,11 +402,7 @@ int skf_gemm_wgrad_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, i
   if (q.row_block_rows != 32) q.row_blocks = nullptr;       // wgrad_x walks 32-row blocks; the fp32 kernel ignores the list
   q.tiles_m = skf_cdiv(p.M, 64); q.tiles_n = skf_cdiv(p.N, 64);
   const size_t smem = (size_t)(4 * 4096 + 4 * 64) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    SKF_HIP(hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr_done = true;
-  }
+  SKF_HIP(hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));   // per launch: the attribute is per device
   const int prec = p.precision;
   const bool fits32 = (double)p.K * p.lda * 4 < 2147483648.0 && (double)p.K * p.ldb * 4 < 2147483648.0;
   if (prec && fits32) {

@@ -194,6 +194,70 @@ __global__ __launch_bounds__(256) void attn_fwd_any_kernel(AttnParams p, int DH)
   }
 }
 
+// The attention weights themselves, softmax(q.k/sqrt(dh) + mask*-1e9) as a (B, H, Lq, Lk) tensor: what
+// builders/utils.py:105 returns beside the output.  Never used by the train step (models/sketchformer.py:140-145 drops them);
+// materialised only when a caller of the builders front-end asks.  One wave per (sample, head, query), the arithmetic of
+// attn_fwd_any_kernel.
+__global__ __launch_bounds__(256) void attn_weights_any_kernel(AttnParams p, int DH, float* __restrict__ W) {
+  __shared__ float qs[4][kMaxDh];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row_ = blockIdx.x * 4 + wave;
+  const bool active = row_ < p.B * p.H * p.Lq;
+  const int row = active ? row_ : 0;
+  const int q = row % p.Lq, bh = row / p.Lq, h = bh % p.H, b = bh / p.H;
+  const float c2 = 1.44269504088896340736f / sqrtf((float)DH);
+  const float* qp = p.Q + (size_t)(b * p.Lq + q) * p.ldq + h * DH;
+  for (int d = lane; d < DH; d += 64) qs[wave][d] = qp[d];
+  __syncthreads();
+  const unsigned char* km = p.key_mask ? p.key_mask + (size_t)b * p.key_mask_ld : nullptr;
+  float s[kMaxKeysPerLane];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < kMaxKeysPerLane; ++j) {
+    const int key = lane + 64 * j;
+    s[j] = -INFINITY;
+    if (key < p.Lk) {
+      const float* kp = p.K + (size_t)(b * p.Lk + key) * p.ldk + h * DH;
+      float dot = 0.f;
+      for (int d = 0; d < DH; ++d) dot += qs[wave][d] * kp[d];
+      s[j] = masked_score2(dot, c2, km, key, q, p.causal);
+      mx = fmaxf(mx, s[j]);
+    }
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < kMaxKeysPerLane; ++j) {
+    s[j] = lane + 64 * j < p.Lk ? exp2f(s[j] - mx) : 0.f;
+    sum += s[j];
+  }
+  sum = wave_sum(sum);
+  const float rinv = 1.0f / sum;
+  float* wp = W + (size_t)row * p.Lk;
+#pragma unroll
+  for (int j = 0; j < kMaxKeysPerLane; ++j) {
+    const int key = lane + 64 * j;
+    if (active && key < p.Lk) wp[key] = s[j] * rinv;
+  }
+}
+
+// Row reductions behind LossManager.add_mae_loss / add_mse_loss / add_mean_loss (builders/losses.py:68-75): out[r] = mean over the
+// last axis of |a - b| (mode 1), (a - b)^2 (mode 2) or a (mode 0, b ignored).  One wave per row.
+__global__ __launch_bounds__(256) void row_mean_kernel(const float* __restrict__ a, const float* __restrict__ b, long rows, int cols, int mode,
+                                                       float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float acc = 0.f;
+  for (int c = lane; c < cols; c += 64) {
+    const float x = a[row * cols + c];
+    if (mode == 0) acc += x;
+    else { const float d = x - b[row * cols + c]; acc += mode == 1 ? fabsf(d) : d * d; }
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) out[row] = acc / (float)cols;
+}
+
 // dQ: one wave per (sample, head, query).  P from the saved statistics, delta = dO . O, dS = P o (dP - delta)
 __global__ __launch_bounds__(256) void attn_bwd_q_any_kernel(AttnParams p, int DH) {
   __shared__ float qs[4][kMaxDh], dos[4][kMaxDh];
@@ -314,6 +378,29 @@ int skf_attention_bwd_any(const AttnParams& p, int dh, hipStream_t s) {
   SkfProfScope ps(s, "attn_bwd<any>", 8.0 * p.B * p.H * (double)p.Lq * p.Lk * dh, 4.0 * p.B * p.H * dh * (4.0 * p.Lq + 4.0 * p.Lk));
   hipLaunchKernelGGL(attn_bwd_q_any_kernel, dim3(skf_cdiv((long)p.B * p.H * p.Lq, 4)), dim3(256), 0, s, p, dh);
   hipLaunchKernelGGL(attn_bwd_kv_any_kernel, dim3(skf_cdiv((long)p.B * p.H * p.Lk, 4)), dim3(256), 0, s, p, dh);
+  SKF_LAUNCH_CHECK();
+  return SKF_OK;
+}
+
+extern "C" int skf_attention_weights(const float* Q, int ldq, const float* K, int ldk, const unsigned char* key_mask, int key_mask_ld,
+                                     int causal, int B, int H, int Lq, int Lk, int dh, float* W, skf_stream_t stream) {
+  SKF_CHECK_ARG(Q && K && W, "null operand");
+  SKF_CHECK_ARG(B > 0 && H > 0 && Lq > 0 && Lk > 0, "empty problem");
+  SKF_CHECK_ARG(skf_attention_any_supported(dh, Lq, Lk), "head size > 128 or sequence > 1024");
+  SKF_CHECK_ARG(!causal || Lq == Lk, "causal attention needs Lq == Lk");
+  AttnParams p{};
+  p.Q = Q; p.K = K; p.ldq = ldq; p.ldk = ldk; p.key_mask = key_mask; p.key_mask_ld = key_mask_ld; p.causal = causal;
+  p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk;
+  hipLaunchKernelGGL(attn_weights_any_kernel, dim3(skf_cdiv((long)B * H * Lq, 4)), dim3(256), 0, (hipStream_t)stream, p, dh, W);
+  SKF_LAUNCH_CHECK();
+  return SKF_OK;
+}
+
+extern "C" int skf_row_mean(const float* a, const float* b, long rows, int cols, int mode, float* out, skf_stream_t stream) {
+  SKF_CHECK_ARG(a && out && rows > 0 && cols > 0, "null operand / empty problem");
+  SKF_CHECK_ARG(mode >= 0 && mode <= 2, "mode must be 0 (mean), 1 (mean absolute error) or 2 (mean squared error)");
+  SKF_CHECK_ARG(mode == 0 || b, "the error modes need both operands");
+  hipLaunchKernelGGL(row_mean_kernel, dim3(skf_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, a, b, rows, cols, mode, out);
   SKF_LAUNCH_CHECK();
   return SKF_OK;
 }

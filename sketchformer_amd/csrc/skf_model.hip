@@ -1611,6 +1611,16 @@ extern "C" size_t skf_config_size(void) { return sizeof(SkfConfig); }
 extern "C" int skf_model_set_flags(SkfModel* M, uint32_t flags) {
   SKF_CHECK_ARG(M, "null model");
   SKF_CHECK_ARG((flags & ~(SKF_MODEL_DECODE_LAYERWISE | SKF_MODEL_FFN_LAUNCHES)) == 0, "unknown flag bits");
+  // SKF_MODEL_FFN_LAUNCHES changes the launch sequence of the step, hence the split counts of the LayerNorm partials and the
+  // reduction descriptors that were built (and uploaded once) by the first step, and the captured step graphs: drop them like
+  // skf_model_bind does, so that the next step rebuilds its descriptors / re-captures with the new sequence.
+  if ((M->flags ^ flags) & SKF_MODEL_FFN_LAUNCHES) {
+    SKF_HIP(hipDeviceSynchronize());     // steps in flight still read the descriptor table the next step uploads again
+    if (M->g_fb) { (void)hipGraphExecDestroy(M->g_fb); M->g_fb = nullptr; }
+    if (M->g_opt) { (void)hipGraphExecDestroy(M->g_opt); M->g_opt = nullptr; }
+    M->descs.clear(); M->descs_uploaded = false;
+    M->slab_cursor = 0; M->desc_cursor = 0; M->ln_cursor = 0; M->reduce_blocks = 0; M->phase_desc_begin = 0;
+  }
   M->flags = flags;
   return SKF_OK;
 }

@@ -140,6 +140,27 @@ def attention_fwd(q, k, v, num_heads, key_mask=None, causal=False, precision=Non
     return o, stats
 
 
+def attention_weights(q, k, num_heads, key_mask=None, causal=False):
+    """softmax(q.k/sqrt(dh) + mask*-1e9) as the (B,H,Lq,Lk) tensor builders/utils.py:105 returns; q (B,Lq,d), k (B,Lk,d) views."""
+    B, Lq, d = q.shape
+    Lk = k.shape[1]
+    w = torch.empty(B, num_heads, Lq, Lk, dtype=torch.float32, device=q.device)
+    _lib.call("skf_attention_weights", _p(q), q.stride(1), _p(k), k.stride(1), _p(key_mask),
+              key_mask.stride(0) if key_mask is not None else 0, int(causal), B, num_heads, Lq, Lk, d // num_heads, _p(w), _stream())
+    return w
+
+
+def row_mean(a, b=None, mode=0):
+    """mean over the last axis of a (mode 0), |a - b| (1) or (a - b)^2 (2) -> a.shape[:-1]  (skf_row_mean)"""
+    a = torch.as_tensor(a).detach().to(device="cuda", dtype=torch.float32).contiguous()
+    if b is not None:
+        b = torch.as_tensor(b, device=a.device).detach().to(torch.float32).expand_as(a).contiguous()
+    cols = a.shape[-1]
+    out = torch.empty(a.shape[:-1], dtype=torch.float32, device=a.device)
+    _lib.call("skf_row_mean", _p(a), _p(b), a.numel() // cols, cols, int(mode), _p(out), _stream())
+    return out
+
+
 def attention_decode(q, k, v, num_heads, n_keys=None, key_mask=None, key_limit=None, key_limit_all=0, step=None,
                      k_new=None, v_new=None, limit_from_step=False):
     """One query row per (sample, head): q (B,d), k/v (B,Lcap,d) cache views with unit inner stride, the first

@@ -70,3 +70,34 @@ def test_compact_line_survives_pathological_records():
     assert got["rccl_ranks"] == 8 and got["cpu_baseline"]["value"] == 1.0
     rec["value"] = float("nan")
     assert json.loads(bench.compact_line(rec))["value"] is None     # strict JSON: never a bare NaN
+
+
+def test_roofline_frac_follows_from_the_fields_beside_it():
+    """`frac` == algorithmic_per_launch / avg_launch_us / peak, on a canned record re-priced with the
+    concurrent (rocprofv3) average the way main() does, and the HIP-event figures stay beside it under *_hip_events; the
+    compact line keeps the identity and carries the step-level PMC byte total."""
+    name, rec = [(n, r) for n, r in RECORDS if "roofline" in r and r["roofline"].get("algorithmic_per_launch")][-1]
+    roof = dict(rec["roofline"])
+    # undo a round-4 style record (frac priced with avg_launch_us_concurrent) back to the HIP-event state roofline_of() returns
+    if "frac_hip_events" in roof:
+        for k in ("achieved", "frac", "frac_dense_counted", "issued_bf16_tflops", "frac_of_executing_pipe"):
+            if k + "_hip_events" in roof:
+                roof[k] = roof.pop(k + "_hip_events")
+        roof.pop("avg_launch_us_concurrent", None)
+    assert bench.roofline_identity_error(roof) < 2e-3, name
+    prefix = bench._kernel_prefix(roof["kernel"])
+    views = {"traffic": {prefix + " a>": 1.0e8, prefix + " b>": 2.0e8},
+             "kernels_concurrent": [{"kernel": prefix + " a>", "launches_per_step": 4, "avg_us": 0.9 * roof["avg_launch_us"], "per_step_ms": 0.1},
+                                    {"kernel": prefix + " b>", "launches_per_step": 12, "avg_us": 0.95 * roof["avg_launch_us"], "per_step_ms": 0.3},
+                                    {"kernel": "something_else", "launches_per_step": 3, "avg_us": 1.0, "per_step_ms": 0.003}]}
+    hip_avg, hip_frac = roof["avg_launch_us"], roof["frac"]
+    bench.apply_concurrent(roof, views)
+    assert roof["avg_launch_us_hip_events"] == hip_avg and roof["frac_hip_events"] == hip_frac
+    assert roof["avg_launch_us"] == pytest.approx((4 * 0.9 + 12 * 0.95) / 16 * hip_avg)
+    assert bench.roofline_identity_error(roof) < 2e-3 and roof["frac"] > hip_frac
+    assert roof["traffic"] == pytest.approx(1.5e8) and "avg_launch_us_concurrent" not in roof
+    roof["traffic_per_step"], roof["algorithmic_bytes_per_step"] = 9.5e9, 3.2e9
+    line = json.loads(bench.compact_line(dict(rec, roofline=roof)))["roofline"]
+    assert bench.roofline_identity_error(line) < 2e-3
+    assert line["traffic_per_step"] == pytest.approx(9.5e9, rel=1e-4) and line["algorithmic_bytes_per_step"] == pytest.approx(3.2e9, rel=1e-4)
+    assert line["avg_launch_us_hip_events"] == pytest.approx(hip_avg, rel=1e-4)

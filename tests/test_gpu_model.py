@@ -559,6 +559,37 @@ def _fb_both_launch_forms(B, L, rate, x, y, with_graph=False, **over):
     return res[0], res[1], same_branches
 
 
+@pytest.mark.parametrize("graph", [False, True], ids=["eager", "graph"])
+def test_ffn_launch_flag_toggles_after_a_step(graph):
+    """SKF_MODEL_FFN_LAUNCHES is a RUN-TIME switch (include/skf.h): toggling it on a model that has already stepped must rebuild the
+    reduction descriptors (their LayerNorm-partial split counts differ between the two launch forms) and re-capture the step graph
+    - round 4 only ever set it on fresh models, where a toggle failed with 'reduction sequence changed between steps' (eager) or was
+    silently ignored (captured graph)."""
+    from sketchformer_amd import engine, _lib
+    B, L = 5, 33
+    kw = dict(seq_len=L, d_model=128, num_heads=8, dff=512, num_layers=2, vocab_size=1004, n_classes=345, lowerdim=64)
+    x, y = synthetic.token_batch(B, L, 1004, 345, seed=3)
+    mk = lambda: engine.TrainEngine(engine.make_config(batch=B, dropout_rate=0.1, use_graph=graph, seed=5, **kw), init_seed=2)   # noqa: E731
+    grads = {}
+    for flags in (0, _lib.MODEL_FFN_LAUNCHES):                 # fresh models: the two forms as the other tests pin them
+        eng = mk()
+        eng.set_flags(flags)
+        eng.forward_backward(x, None, y)
+        torch.cuda.synchronize()
+        grads[flags] = eng.grads.clone()
+    eng = mk()
+    for flags in (0, _lib.MODEL_FFN_LAUNCHES, 0, _lib.MODEL_FFN_LAUNCHES):
+        eng.set_flags(flags)
+        eng.state[0] = 0                                       # same dropout key as the fresh models' first step
+        eng.forward_backward(x, None, y)
+        torch.cuda.synchronize()
+        assert torch.equal(eng.grads, grads[flags]), flags      # bit-equal to the fresh model of that form: the flag took effect
+    eng.set_flags(0)
+    eng.train_step(x, y)                                       # and the optimizer half still runs after the toggles
+    torch.cuda.synchronize()
+    assert np.isfinite(eng.step_metrics()["total_loss"])
+
+
 @pytest.mark.parametrize("case", ["all PAD", "SOS only", "one empty and one length-1 sample", "full length"])
 def test_row_owner_launches_on_degenerate_batches(case):
     """The same comparison on batches at the edges of the padding structure (live-row lists with zero or one entry, attention rows that see one

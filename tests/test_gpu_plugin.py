@@ -148,6 +148,34 @@ def test_builders_front_ends_against_oracle():
     assert abs(float(lm.compute_loss("recon", tok[:, 1:], torch.as_tensor(logits, dtype=torch.float32).cuda())) - want_l) < 1e-5
     with pytest.raises(AssertionError):
         lm.compute_loss("nope")
+    # the attention weights the reference returns beside the output (builders/utils.py:105): on request, per call or for the module
+    qkv_t = [torch.as_tensor(t, dtype=torch.float32).cuda() for t in (q, k, v)]
+    _, want_w, _ = oracle.sdpa_fwd(q, k, v, oc.astype(np.float64))
+    got2, w2 = builders.utils.scaled_dot_product_attention(*qkv_t, comb_m, return_weights=True)
+    assert torch.equal(got2, got) and w2.shape == (B, H, L - 1, L - 1) and np.abs(w2.cpu().numpy() - want_w).max() < 1e-6
+    _, want_wp, _ = oracle.sdpa_fwd(q, k, v, oe[:, :, :, :L - 1].astype(np.float64))
+    _, w3 = builders.utils.scaled_dot_product_attention(*qkv_t, enc_m[..., :L - 1], return_weights=True)
+    assert np.abs(w3.cpu().numpy() - want_wp).max() < 1e-6
+    _, w4 = builders.utils.scaled_dot_product_attention(*qkv_t, None, return_weights=True)
+    assert np.abs(w4.cpu().numpy() - oracle.sdpa_fwd(q, k, v, None)[1]).max() < 1e-6
+    builders.utils.RETURN_ATTENTION_WEIGHTS = True
+    try:
+        mha = builders.layers.transformer.MultiHeadAttention(64, 4)
+        xx = torch.as_tensor(rng.randn(B, L - 1, 64), dtype=torch.float32).cuda()
+        _, wm = mha(xx, xx, xx, comb_m)
+        assert wm.shape == (B, 4, L - 1, L - 1) and float((wm.sum(-1) - 1).abs().max()) < 1e-5
+        assert float(wm[0, 0, 3, 4:].abs().max()) == 0.0               # look-ahead: no weight on later keys
+    finally:
+        builders.utils.RETURN_ATTENTION_WEIGHTS = False
+    # add_mae_loss / add_mse_loss / add_mean_loss (builders/losses.py:68-75): Keras MAE / MSE reduce the last axis, tf.reduce_mean everything
+    a_, b_ = rng.randn(B, L, 7).astype(np.float32), rng.randn(B, L, 7).astype(np.float32)
+    lm.add_mae_loss("mae", weight=2.0); lm.add_mse_loss("mse"); lm.add_mean_loss("mean", weight=0.25)
+    ta, tb = torch.as_tensor(a_).cuda(), torch.as_tensor(b_).cuda()
+    mae, mse = lm.compute_loss("mae", ta, tb), lm.compute_loss("mse", ta, tb)
+    assert mae.shape == (B, L) and np.abs(mae.cpu().numpy() - 2.0 * np.abs(b_ - a_).mean(-1)).max() < 1e-6
+    assert mse.shape == (B, L) and np.abs(mse.cpu().numpy() - ((b_ - a_) ** 2).mean(-1)).max() < 1e-6
+    assert abs(float(lm.compute_loss("mean", ta)) - 0.25 * a_.mean()) < 1e-6
+    assert lm.loss_names == ["recon", "class", "mae", "mse", "mean"]
     mm = builders.keras_metrics.MetricManager()
     mm.add_mean_metric("m"); mm.add_sparse_categorical_accuracy("a")
     mm.compute("m", 1.0); mm.compute("m", 3.0); mm.compute("a", tok[:, 1:], torch.as_tensor(logits))
@@ -182,6 +210,14 @@ def test_builders_front_ends_against_oracle():
     want_t, _ = oracle.sketchformer_oracle.encoder_layer_fwd(P, "encoder/layer0", x0d, oe.astype(np.float64), 4, 0.1, drops)
     assert np.abs(got_t.cpu().numpy() - want_t).max() < 1e-4
     assert np.abs(got_t.cpu().numpy() - want_x).max() > 1e-2                      # it did drop something
+    # a stack's layer called on its own advances the shared state (fresh masks per call, never a stale or missing state), and two
+    # stacks draw from different streams (independent Dropout layers of the reference)
+    x0t = torch.as_tensor(x0, dtype=torch.float32).cuda()
+    l1, l2 = lay(x0t, True, enc_m), lay(x0t, True, enc_m)
+    assert float((l1 - l2).abs().max()) > 1e-2 and float((l1 - torch.as_tensor(want_x, dtype=torch.float32).cuda()).abs().max()) > 1e-2
+    fresh = builders.layers.transformer.Encoder(1, 64, 4, 128, 50, rate=0.1).enc_layers[0]
+    assert float(fresh(x0t, True, enc_m).abs().max()) > 0                          # before its stack ever ran: dropout is applied, state exists
+    assert fresh.drop.state is not None and fresh.drop.seed != enc.drop.seed
     again = enc(tok, True, enc_m)                                                 # a new call draws new masks
     assert np.abs(again.cpu().numpy() - got_t.cpu().numpy()).max() > 1e-2
     assert np.abs(enc(tok, False, enc_m).cpu().numpy() - want_x).max() < 1e-4     # and inference is unchanged
