@@ -724,6 +724,12 @@ extern "C" int skf_attention_bwd_rows(const float* Q, int ldq, const float* K, i
   // (round 3: with its prologue loads batched the one-pass kernel also wins the causal dh = 16 calls - 4.134 vs 4.149 ms/step padded,
   //  4.777 vs 4.774 full-length at cfg 2 - so head size 16 takes the two-pass kernel only when forced; head size 32 keeps it:
   //  15.9 vs 17.2 ms/step at cfg 3)
+  // round 5: head size 16, sequences up to 208, split modes: skf_attention_bwd3.hip (one workgroup per head stages every operand
+  // once, the dQ items and the dK / dV items of the two-pass scheme run side by side from one queue, per-score arithmetic folded
+  // into operands and accumulator seeds); SKF_ATTN_BWD3=0 (measurement builds) or SKF_ATTN_TWO_PASS keep the older kernels reachable
+  const char* bwd3_env = skf_knob("SKF_ATTN_BWD3");          // (per call: tools/attn_bwd3_ablate.py flips it inside one process)
+  if (skf_attention_bwd3_supported(dh, Lq, Lk) && precision != SKF_PREC_F32 && !bwd2_all && !bwd2_off && !(bwd3_env && bwd3_env[0] == '0'))
+    return skf_attention_bwd3_launch(p, (hipStream_t)stream);
   const bool bwd2_shape = (dh == 16 && bwd2_all) || (dh == 32 && Lk <= 256 && Lq <= 256);
   if (bwd2_shape && precision != SKF_PREC_F32 && !bwd2_off && Lk <= 512 && Lq <= 512)
     return skf_attention_bwd2_launch(p, dh, (hipStream_t)stream);

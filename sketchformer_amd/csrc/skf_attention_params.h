@@ -24,6 +24,10 @@ struct AttnParams {
 // two-pass backward on the bf16 matrix cores with exactly split fp32 operands (head size 16 or 32); returns SKF_OK after launching
 int skf_attention_bwd2_launch(const AttnParams& p, int dh, hipStream_t st);
 
+// round 5, head size 16: the two passes as independent workgroups of one launch (skf_attention_bwd3.hip); returns SKF_OK after launching
+int skf_attention_bwd3_supported(int dh, int Lq, int Lk);
+int skf_attention_bwd3_launch(const AttnParams& p, hipStream_t st);
+
 // any head size <= 128 / sequence <= 1024 (skf_generic.hip): plain fp32 FMA kernels, the same semantics and statistics
 int skf_attention_any_supported(int dh, int Lq, int Lk);
 int skf_attention_fwd_any(const AttnParams& p, int dh, hipStream_t st);
