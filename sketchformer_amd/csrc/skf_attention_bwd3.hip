@@ -142,6 +142,23 @@ __global__ __launch_bounds__(512, 4) void attn_bwd3_kernel(AttnParams p) {
   // head assignment loses more on padded batches (91 vs 71 us) than the offset gains (100 vs 107 us on full-length rows).
   const int bh = p.xcd_remap ? skf_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   const int b = bh / p.H, h = bh % p.H;
+#if SKF_MEASURE     // clock stamps of a few workgroups (tools/attn_bwd3_timeline.py): measurement builds only
+  long long* dbg = (p.dbg && lane == 0 && (blockIdx.x % 131) == 0 && blockIdx.x / 131 < 8) ? p.dbg + ((blockIdx.x / 131) * 8 + wave) * 16 : nullptr;
+  int dbi = 0;
+#define SKF_STAMP3() do { if (dbg && dbi < 16) dbg[dbi++] = wall_clock64(); } while (0)
+#else
+#define SKF_STAMP3() do { } while (0)
+#endif
+#if SKF_MEASURE     // experiment (tools/attn_bwd3_stagger.py): the second workgroup of a CU in the first round starts late
+  if (p.ablate >= 1000 && (int)blockIdx.x < 512) {
+    const unsigned lds_base = __builtin_amdgcn_s_getreg((12 - 1) << 11 | 0 << 6 | 6);      // HW_REG_LDS_ALLOC.LDS_BASE
+    if (lds_base != 0u) {
+      const long long t0 = wall_clock64();
+      while (wall_clock64() - t0 < (long long)(p.ablate / 1000)) __builtin_amdgcn_s_sleep(32);
+    }
+  }
+#endif
+  SKF_STAMP3();      // 0: start
   // query tiles behind the sample's last live row have dO == 0 exactly: nothing for dK / dV, dQ = 0 (skf_attention_bwd_rows)
   const int nqt = p.q_live ? min(nqt_all, (max(p.q_live[b], 0) + 15) >> 4) : nqt_all;
   // ---------------- which key tiles are visited: the key mask first (one byte per thread: Lk <= 208 < 512), so that the rows of a
@@ -156,6 +173,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd3_kernel(AttnParams p) {
     else atomicMax(&ctl[0], tid);
   }
   __syncthreads();
+  SKF_STAMP3();      // 1: key mask known
   const int lastk = ctl[0];
   // skipping fully look-ahead-masked tiles is exact only if key 0 is visible; trailing all-padding key tiles have P == 0 exactly
   // unless some row may see no key at all (see skf_attention.hip)
@@ -190,6 +208,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd3_kernel(AttnParams p) {
       }
     }
   }
+  SKF_STAMP3();      // 2: loads requested
   // live query tiles: the 64 chunks of a wave in pass u are the 16 rows of tile (e >> 6): one ballot, one LDS atomic
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
@@ -197,6 +216,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd3_kernel(AttnParams p) {
     const bool nz = row < p.Lq && (gv[u].x != 0.f || gv[u].y != 0.f || gv[u].z != 0.f || gv[u].w != 0.f);
     if (__ballot(nz) != 0ull && lane == 0 && (e >> 6) < nqt) atomicOr(reinterpret_cast<unsigned*>(&ctl[1]), 1u << (e >> 6));
   }
+  SKF_STAMP3();      // 3: rows arrived (the ballot above waits for dO)
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int e = tid + 512 * u, row = e >> 2, c4 = (e & 3) * 4;
@@ -225,7 +245,9 @@ __global__ __launch_bounds__(512, 4) void attn_bwd3_kernel(AttnParams p) {
       *reinterpret_cast<float4*>(p.dQ + (size_t)(b * p.Lq + row) * p.lddq + h * 16 + c4) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
+  SKF_STAMP3();      // 4: planes written (this wave)
   __syncthreads();
+  SKF_STAMP3();      // 5: planes complete
   const unsigned q_live = (unsigned)ctl[1], k_masked = (unsigned)ctl[3];
 
   // ---------------- the queue.  Items in falling order of cost: key tiles ascend (under the look-ahead mask key tile t is seen by
@@ -324,6 +346,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd3_kernel(AttnParams p) {
     int nx = 0;
     if (lane == 0) nx = atomicAdd(&ctl[2], 1);
     item = __builtin_amdgcn_readfirstlane(nx);
+    SKF_STAMP3();    // 6..: one per item
   }
   // out of items: request the next head's rows (the staging registers are free again) and wait for the other waves to leave the planes
 }
@@ -340,6 +363,9 @@ int skf_attention_bwd3_launch(const AttnParams& p_in, hipStream_t st) {
   const void* kfn = p.causal ? (const void*)attn_bwd3_kernel<true> : (const void*)attn_bwd3_kernel<false>;
   SKF_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
   const int grid = p.B * p.H;
+#if SKF_MEASURE
+  { const char* db = skf_knob("SKF_ATTN_DBG"); p.dbg = db ? (long long*)strtoull(db, nullptr, 0) : nullptr; }
+#endif
   const double visited = skf_prof_attention_fraction(p.key_mask, p.key_mask_ld, p.causal, p.B, p.Lq, p.Lk, p.q_live, 16, 16);
   SkfProfScope ps(st, "attn_bwd<dh16>", 8.0 * p.B * p.H * (double)p.Lq * p.Lk * 16, 4.0 * p.B * p.H * 16 * (4.0 * p.Lq + 4.0 * p.Lk));
   ps.done(8.0 * p.B * p.H * (double)p.Lq * p.Lk * 16 * visited, 4.0 * p.B * p.H * 16 * (4.0 * p.Lq + 4.0 * p.Lk));
