@@ -79,7 +79,22 @@ __device__ __forceinline__ int nt_lds_off(int row, int chunk) {       // byte of
 // byte that is proportional to BM BN / (BM + BN): the large tile doubles it (and halves the L2 -> LDS traffic per flop).
 // EXTRA: relu_src / accumulate / fp32 copy, TANH: act == 2 - separate instantiations keep the plain epilogue lean (unrolled
 // over the 32 pieces of a lane, a runtime tanh branch made it 50 KB of code that every piece jumps across)
-template <bool EXTRA, bool DMA, int BK, bool BIG, bool TANH>
+// PH8 (round 5, BIG only): the K loop as FOUR PHASES per 64-deep step (cdna_hip_programming.md section 5, "the 256^2 8-phase template"; the
+// schedule below is this file's own - the guide's example source is not in the image).  A phase = one quadrant of the wave's 128 x 64
+// block (2 m tiles x 1 n tile x 4 k steps = 8 MFMAs, 256 matrix-pipe cycles) between two raw s_barriers:
+//     [fragment reads of the quadrant | 2 DMA pieces of ONE half-tile, six half-tiles ahead | counted s_waitcnt vmcnt(8)]  s_barrier
+//     [s_waitcnt lgkmcnt(0) | s_setprio 1 | 8 MFMAs | s_setprio 0]                                                        s_barrier
+// The waves of the second wave row run ONE barrier behind the first (an extra s_barrier in front of the loop, its twin behind it): on
+// every SIMD one wave multiplies while the other reads and issues - the role split that s_setprio then arbitrates.  The loads of a
+// K step are never drained: a half-tile (A rows of one m half, or B rows of one n half, of ALL waves: 16 KB = 2 DMA pieces per wave)
+// is requested 6 phases before the phase that first reads it, retired by a counted wait 2 phases before that read (data becomes
+// readable one phase after the wait that retires it: the barrier in between publishes the other waves' pieces), and overwrites a
+// region whose last reader finished >= 2 phases earlier.  Order of the quadrants (0,0) (0,1) (1,1) (1,0) with BOTH n halves of B kept
+// in registers: phase 1 reads A(m half 0) + B(n half 0), phase 2 B(n half 1), phase 3 A(m half 1), phase 4 nothing.
+#ifndef SKF_PH8_ABLATE
+#define SKF_PH8_ABLATE 0      // timing experiments (results wrong): 1 no stagger, 2 no s_setprio, 4 no fragment reads, 8 no DMA, 16 no MFMA
+#endif
+template <bool EXTRA, bool DMA, int BK, bool BIG, bool TANH, bool PH8 = false>
 __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_bf16_nt_kernel(NtParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int WN = BIG ? 4 : 2, MT = BIG ? 4 : 2, NT = 2, NW = 2 * WN;    // waves along n, MFMA tiles per wave, waves
@@ -89,6 +104,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_bf16_nt_kernel(NtPara
   constexpr int NJ = TBA / 1024 / NW;         // DMA pieces per wave and tile
   static_assert(BM == BN, "the staging below assumes equally tall A and B tiles");
   static_assert(DMA || (BK == 64 && !BIG), "the register-staged variant is written for 128 x 128 tiles and 64-deep steps");
+  static_assert(!PH8 || (BIG && DMA && BK == 64), "the phased K loop is written for the 256 x 256 DMA tile");
   // buffer b of the A / B tile images: A at b * TB2, B TBA behind it
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
@@ -188,6 +204,81 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_bf16_nt_kernel(NtPara
                                        (__attribute__((address_space(3))) void*)(la + TBA), 16, 0, 0);
     }
   };
+  const int lrow = lane & 31, lhi = lane >> 5;
+  if constexpr (PH8) {
+    // ---- half-tile DMA.  kind 0 = A rows of m half 0 (of both wave rows), 1 = B rows of n half 0 (of the four wave columns), 2 = B n half 1,
+    // 3 = A m half 1: the order in which a K step first reads them.  A wave moves pieces q = 2 wave + {0,1} of the 16 of a half-tile.
+    const skf_bf16* sp[4][2];
+    int spo[4][2];                                   // byte offset of the piece in its buffer (wave-uniform)
+#pragma unroll
+    for (int kind = 0; kind < 4; ++kind)
+#pragma unroll
+      for (int j2 = 0; j2 < 2; ++j2) {
+        const int q = 2 * wave + j2, is_a = kind == 0 || kind == 3, half = kind >> 1;     // (kind 0: m half 0, 3: m half 1; 1: n half 0, 2: n half 1)
+        const int piece = is_a ? (q < 8 ? 8 * half + q : 16 + 8 * half + (q - 8)) : 8 * (q >> 2) + 4 * half + (q & 3);
+        const int S = 4 * piece + (lane >> 4), hc = (lane & 15) ^ (S & 15), r = 2 * S + (hc >> 3), c = hc & 7;
+        sp[kind][j2] = is_a ? p.A + (size_t)prow(min(m0 + r, p.M - 1)) * p.lda + c * 8 : p.B + (size_t)min(n0 + r, p.N - 1) * p.ldb + c * 8;
+        spo[kind][j2] = (is_a ? 0 : TBA) + piece * 1024;
+      }
+    const int n_stage = 4 * nk;
+    auto stage = [&](int kind, int kts) {            // half-tile `kind` of K step kts -> buffer kts & 1
+#pragma unroll
+      for (int j2 = 0; j2 < 2; ++j2)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sp[kind][j2] + kts * BK),
+                                         (__attribute__((address_space(3))) void*)(smem + (kts & 1) * TB2 + spo[kind][j2]), 16, 0, 0);
+    };
+    // fragment addresses: tile row lrow, chunk 2 ks + lhi -> the XOR-ed slot depends on the lane and on ks only (tile bases are multiples of 32 rows)
+    int fo[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) fo[ks] = nt_lds_off<BK>(lrow, ks * 2 + lhi);
+    const int a_base = wm * (MT * 32) * 128, b_base = TBA + wn * (NT * 32) * 128;     // 128 bytes per tile row
+    skf_bf16x8 af[2][4], bf[2][4];
+    // the first six half-tiles (the loop keeps requesting six ahead); the first K step's A / B halves 0 must have landed
+#pragma unroll
+    for (int s0 = 0; s0 < 6; ++s0)
+      if (s0 < n_stage) stage(s0 & 3, s0 >> 2);
+    if (n_stage > 6) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1 && !(SKF_PH8_ABLATE & 1)) __builtin_amdgcn_s_barrier();       // the second wave row runs one barrier behind
+    for (int kt = 0; kt < nk; ++kt) {
+      const char* At = smem + (kt & 1) * TB2 + a_base;
+      const char* Bt = smem + (kt & 1) * TB2 + b_base;
+#pragma unroll
+      for (int ph = 0; ph < 4; ++ph) {
+        const int mh = ph >> 1, nh = (ph == 1 || ph == 2) ? 1 : 0;
+        if ((ph == 0 || ph == 1) && !((SKF_PH8_ABLATE & 4) && kt > 0)) {
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) bf[nh][ks] = *reinterpret_cast<const skf_bf16x8*>(Bt + nh * 32 * 128 + fo[ks]);
+        }
+        if ((ph == 0 || ph == 2) && !((SKF_PH8_ABLATE & 4) && kt > 0)) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) af[t][ks] = *reinterpret_cast<const skf_bf16x8*>(At + (2 * mh + t) * 32 * 128 + fo[ks]);
+        }
+        const int sn = 4 * kt + ph + 6;               // the half-tile requested in this phase: kind (ph + 2) & 3 of K step kt + 1 (ph < 2) / kt + 2
+        if (sn < n_stage && !(SKF_PH8_ABLATE & 8)) { stage((ph + 2) & 3, kt + (ph < 2 ? 1 : 2)); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(SKF_PH8_ABLATE & 2)) __builtin_amdgcn_s_setprio(1);
+        if (!(SKF_PH8_ABLATE & 16)) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            acc[nh][2 * mh + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[nh][ks], af[t][ks], acc[nh][2 * mh + t], 0, 0, 0);
+        }
+        if (!(SKF_PH8_ABLATE & 2)) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+    if (wm == 0 && !(SKF_PH8_ABLATE & 1)) __builtin_amdgcn_s_barrier();       // (the twin of the extra barrier in front of the loop)
+    __syncthreads();                                  // the tile buffers are dead: the epilogue's images may overwrite them
+  } else {
   if constexpr (DMA) {
     dma(0, 0);
   } else {
@@ -195,7 +286,6 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_bf16_nt_kernel(NtPara
     lstore(0);
   }
   __syncthreads();
-  const int lrow = lane & 31, lhi = lane >> 5;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if constexpr (DMA) { if (kt + 1 < nk) dma(kt + 1, cur ^ 1); }
@@ -217,6 +307,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_bf16_nt_kernel(NtPara
     }
     if constexpr (!DMA) { if (kt + 1 < nk) lstore(cur ^ 1); }
     __syncthreads();
+  }
   }
 
   // ---- epilogue.  acc[a][b][r]: n = n0 + wn*64 + a*32 + (r&3) + 8*(r>>2) + 4*lhi, m = m0 + wm*(MT*32) + b*32 + lrow.
@@ -735,11 +826,20 @@ extern "C" int skf_gemm_bf16_bits(int M, int N, int K, const void* A, int lda, c
     if ((rc = set_smem(gemm_bf16_nt_kernel<EX, DM, 64, BG, TH>, smem))) return rc;                                           \
     hipLaunchKernelGGL((gemm_bf16_nt_kernel<EX, DM, 64, BG, TH>), dim3(p.tiles_m * p.tiles_n), dim3(BG ? 512 : 256), smem, st, p); \
   }
+  // the phased K loop (PH8) for the 256 x 256 tile with at least two 64-deep steps; SKF_BF16_GEMM_PH8=0 (measurement builds): the two-buffer loop
+  static const bool ph8_off = skf_knob("SKF_BF16_GEMM_PH8") && skf_knob("SKF_BF16_GEMM_PH8")[0] == '0';
+  const bool ph8 = big && K >= 128 && !ph8_off;
+#define SKF_NT_GO8(EX)                                                                                                       \
+  {                                                                                                                          \
+    if ((rc = set_smem(gemm_bf16_nt_kernel<EX, true, 64, true, false, true>, smem))) return rc;                              \
+    hipLaunchKernelGGL((gemm_bf16_nt_kernel<EX, true, 64, true, false, true>), dim3(p.tiles_m * p.tiles_n), dim3(512), smem, st, p); \
+  }
 #define SKF_NT_GO2(EX, TH)                                                                                         \
-  { if (big) SKF_NT_GO(EX, true, true, false) else if (dma) SKF_NT_GO(EX, true, false, TH) else SKF_NT_GO(EX, false, false, TH) }
+  { if (ph8) SKF_NT_GO8(EX) else if (big) SKF_NT_GO(EX, true, true, false) else if (dma) SKF_NT_GO(EX, true, false, TH) else SKF_NT_GO(EX, false, false, TH) }
   if (act == 2) { if (extra) SKF_NT_GO2(true, true) else SKF_NT_GO2(false, true) }
   else { if (extra) SKF_NT_GO2(true, false) else SKF_NT_GO2(false, false) }
 #undef SKF_NT_GO2
+#undef SKF_NT_GO8
 #undef SKF_NT_GO
   SKF_LAUNCH_CHECK();
   return SKF_OK;
