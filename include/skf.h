@@ -522,7 +522,8 @@ typedef struct SkfConfig {
   float sched_p0, sched_p1, sched_p2, sched_p3;
   float beta1, beta2, eps;
   uint32_t seed;
-  int32_t use_graph; /* capture the step into hipGraphs and replay them */
+  int32_t use_graph; /* 0: eager launches, weight gradients on a side stream; 1: the step captured into hipGraphs on ONE stream and replayed;
+                      * 2: the two-stream step captured (the side stream is forked / joined inside the capture; the first step runs eagerly) */
   int32_t optimizer; /* 0 = Keras Adam (beta1, beta2, eps above), 1 = Keras SGD with momentum (models/sketchformer.py:120-126) */
   float momentum;
   int32_t class_buffer_layers; /* Dense(lowerdim, relu) + Dropout(class_dropout) layers before classify (models/sketchformer.py:44-45,101-104) */

@@ -448,6 +448,7 @@ struct SkfModel {
   float g_opt_scale = 0.f;
   // weight-gradient GEMMs run on a side stream, off the dgrad critical path
   hipStream_t side = nullptr;
+  hipEvent_t fork_event = nullptr, join_event = nullptr;      // use_graph = 2: the side stream's entry into / exit from the capture
   std::vector<hipEvent_t> events;
   size_t next_event = 0;
   // Side-stream events carry a sequence number (their record order on the in-order side stream): once the main stream has
@@ -1579,17 +1580,32 @@ int stage_inputs(SkfModel* M, const void* inp, const void* tar, int tar_ld, cons
   return SKF_OK;
 }
 
+// use_graph = 1: the step is captured on ONE stream (no side stream exists).  use_graph = 2 (round 5): the two-stream step is captured -
+// the side stream joins the capture through an event recorded on the capturing stream (fork) and is joined back before the capture
+// ends, so the weight-gradient groups / embedding sorts / K|V projections become parallel branches of the graph.  The first call runs
+// eagerly: it builds and uploads the reduction descriptors (a synchronous copy, not capturable) that the captured sequence reuses.
 template <typename F>
 int capture_or_run(SkfModel* M, hipGraphExec_t* exec, hipStream_t s, F body) {
   if (!M->cfg.use_graph) return body();
+  const bool two_stream = M->side != nullptr && exec == &M->g_fb;
+  if (two_stream && !M->descs_uploaded) return body();
   if (!*exec) {
     hipGraph_t graph = nullptr;
     SKF_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     ++g_capturing;
-    int rc = body();
+    int rc = SKF_OK;
+    if (two_stream) {
+      hipEvent_t fork = M->fork_event;
+      if (hipEventRecord(fork, s) != hipSuccess || hipStreamWaitEvent(M->side, fork, 0) != hipSuccess) rc = SKF_EHIP;
+    }
+    if (rc == SKF_OK) rc = body();
+    if (two_stream && rc == SKF_OK) {
+      hipEvent_t join = M->join_event;
+      if (hipEventRecord(join, M->side) != hipSuccess || hipStreamWaitEvent(s, join, 0) != hipSuccess) rc = SKF_EHIP;
+    }
     --g_capturing;
     hipError_t e = hipStreamEndCapture(s, &graph);
-    if (rc != SKF_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (rc != SKF_OK) { if (graph) (void)hipGraphDestroy(graph); if (rc == SKF_EHIP) skf_set_error("two-stream capture: fork / join failed"); return rc; }
     if (e != hipSuccess) { skf_set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return SKF_EHIP; }
     e = hipGraphInstantiate(exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
@@ -1745,8 +1761,13 @@ extern "C" int skf_model_create(const SkfConfig* cfg, SkfModel** out) {
   reg("dec_embed_out", P.dec[0].x_in, B * Ld, d);
   // measured on MI355X: eager launches + a wgrad side stream beat hipGraph replay (graph nodes of different
   // streams do not overlap, 7.50 vs 7.72 ms/step), so the side stream is only used on the eager path
-  if (!cfg->use_graph && !(skf_knob("SKF_NO_SIDE_STREAM") && skf_knob("SKF_NO_SIDE_STREAM")[0] == '1'))
+  // (round 5: use_graph = 2 captures the two-stream step - capture_or_run)
+  if (cfg->use_graph != 1 && !(skf_knob("SKF_NO_SIDE_STREAM") && skf_knob("SKF_NO_SIDE_STREAM")[0] == '1'))
     SKF_HIP(hipStreamCreateWithFlags(&M->side, hipStreamNonBlocking));
+  if (cfg->use_graph == 2 && M->side) {
+    SKF_HIP(hipEventCreateWithFlags(&M->fork_event, hipEventDisableTiming));
+    SKF_HIP(hipEventCreateWithFlags(&M->join_event, hipEventDisableTiming));
+  }
   if (!cfg->use_graph) {     // events cannot be recorded for outside waiters inside a captured graph: one bucket there
     M->n_buckets = do_recon(*cfg) ? 2 : 1;
     for (int i = 0; i < 2; ++i) SKF_HIP(hipEventCreateWithFlags(&M->bucket_ready[i], hipEventDisableTiming));
@@ -1762,6 +1783,8 @@ extern "C" void skf_model_destroy(SkfModel* m) {
   if (m->g_dec) (void)hipGraphExecDestroy(m->g_dec);
   for (hipEvent_t e : m->events) (void)hipEventDestroy(e);
   for (int i = 0; i < 2; ++i) if (m->bucket_ready[i]) (void)hipEventDestroy(m->bucket_ready[i]);
+  if (m->fork_event) (void)hipEventDestroy(m->fork_event);
+  if (m->join_event) (void)hipEventDestroy(m->join_event);
   if (m->side) (void)hipStreamDestroy(m->side);
   delete m;
 }

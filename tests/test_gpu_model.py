@@ -832,3 +832,24 @@ def test_structural_variants_losses_gradients_and_inference(kw, rate):
     else:
         with pytest.raises(Exception):
             eng.greedy_decode(None)
+
+
+def test_two_stream_graph_capture_is_bit_equal_to_the_eager_step():
+    """use_graph = 2 (round 5): the two-stream step captured into one hipGraph - the side stream enters the capture through an event
+    recorded on the capturing stream and is joined back before the capture ends.  Same launches, same launch forms, same order per
+    stream as the eager step: parameters after four Adam steps are bit-equal to the eager engine's (the single-stream capture,
+    use_graph = 1, takes other launch forms and only agrees to rounding)."""
+    from sketchformer_amd import engine
+    B, L = 16, 56
+    kw = dict(batch=B, seq_len=L, d_model=128, num_heads=8, dff=512, num_layers=2, vocab_size=1004, n_classes=345, lowerdim=64,
+              dropout_rate=0.1, seed=7)
+    batches = [synthetic.token_batch(B, L, 1004, 345, seed=60 + i) for i in range(4)]
+    got = {}
+    for mode in (0, 2):
+        eng = engine.TrainEngine(engine.make_config(use_graph=mode, **kw), init_seed=1)
+        for x, y in batches:
+            eng.train_step(x, y)
+        torch.cuda.synchronize()
+        got[mode] = (eng.params.clone(), eng.step_metrics()["total_loss"])
+    assert np.isfinite(got[2][1]) and got[0][1] == got[2][1]
+    assert torch.equal(got[0][0], got[2][0])
