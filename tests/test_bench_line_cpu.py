@@ -78,7 +78,10 @@ def test_roofline_frac_follows_from_the_fields_beside_it():
     compact line keeps the identity and carries the step-level PMC byte total."""
     name, rec = [(n, r) for n, r in RECORDS if "roofline" in r and r["roofline"].get("algorithmic_per_launch")][-1]
     roof = dict(rec["roofline"])
-    # undo a round-4 style record (frac priced with avg_launch_us_concurrent) back to the HIP-event state roofline_of() returns
+    if "avg_launch_us_hip_events" in roof:       # a round-5 record: consistent as stored
+        assert bench.roofline_identity_error(roof) < 2e-3, name
+        roof["avg_launch_us"] = roof.pop("avg_launch_us_hip_events")
+    # undo the re-pricing with the concurrent average back to the HIP-event state roofline_of() returns
     if "frac_hip_events" in roof:
         for k in ("achieved", "frac", "frac_dense_counted", "issued_bf16_tflops", "frac_of_executing_pipe"):
             if k + "_hip_events" in roof:
