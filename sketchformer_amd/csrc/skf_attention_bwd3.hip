@@ -25,10 +25,13 @@
 //     on tiles that hold a masked key or the look-ahead diagonal.  dK is rescaled by ln 2, dQ by 1/sqrt(dh) when stored.
 //   * Every MFMA operand is read from LDS into the registers it is consumed from: both sides of the contractions over d are
 //     16-byte reads of plane rows (lane half selects the plane: [x0|x1] / [x0|x2] against [y0|y0] / [y1|y1] / [y2|y0], two A
-//     reads per tensor and tile pair), the row-contraction operands are windows of one 8-register block ([t2 t1 t0 t0] from four
-//     transposing reads, [y0 y0 y1 y2] from the split) - no v_mov assembling operands; plane pitches are compile-time, so
-//     every LDS address is one of two or three per-lane base registers plus an immediate.
-// 81.6 KB of LDS, <= 128 VGPRs: two workgroups = 16 waves per CU.
+//     reads per tensor and tile pair); the row-contraction operands are {x0,x2}, {x1,x1}, {x0,x0} from SIX transposing reads
+//     against {y0,y1} (used twice from the same registers) and {y2,y0} from the split - an LDS read issues beside the vector
+//     stream, a v_mov assembling an operand does not; plane pitches are compile-time and the dynamic LDS segment starts at 0,
+//     so every LDS address is one of two or three per-lane base registers plus an immediate.
+//   * Rows of tiles nobody visits (padded keys, dead query tiles) are not even requested: on QuickDraw-shaped batches a
+//     launch is a burst of row loads followed by little arithmetic.
+// 81.6 KB of LDS, <= 105 VGPRs: two workgroups = 16 waves per CU.  DESIGN.md section 3e has the measurements and the dropped designs.
 #include <stdlib.h>
 #include "skf_attention_params.h"
 
