@@ -450,6 +450,49 @@ def test_attention_padding_tile_skipping_is_exact(ops, causal):
     assert float(gk[2, 32:].abs().max()) == 0.0 and float(gv[2, 32:].abs().max()) == 0.0     # skipped tiles: exact zeros
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_attention_backward_random_shapes_masks_and_live_lengths(ops, seed):
+    """Round 5 (skf_attention_bwd3.hip serves head size 16 up to 208 positions): random batch / head counts, query and key lengths off the
+    tile grid (1 ... 208), key masks with holes and fully padded samples, look-ahead masks, zero dO rows behind random live lengths with
+    and without the length list - every case against the float64 oracle, and the two calls against each other bit for bit."""
+    rng = np.random.RandomState(1000 + seed)
+    B, H, dh = int(rng.randint(1, 5)), int(rng.choice([1, 2, 4, 8])), 16
+    causal = bool(rng.rand() < 0.4)
+    Lq = int(rng.choice([1, 7, 16, 17, 63, 100, 199, 200, 208, int(rng.randint(1, 209))]))
+    Lk = Lq if causal else int(rng.choice([1, 15, 16, 33, 128, 200, 208, int(rng.randint(1, 209))]))
+    d = H * dh
+    q, k, v, do = rng.randn(B, Lq, d), rng.randn(B, Lk, d), rng.randn(B, Lk, d), rng.randn(B, Lq, d)
+    km = None
+    if rng.rand() < 0.7:
+        lens = rng.randint(0 if rng.rand() < 0.3 else 1, Lk + 1, size=B)           # length 0: a fully padded sample (uniform weights)
+        km = np.arange(Lk)[None, :] >= lens[:, None]
+        if Lk > 8 and rng.rand() < 0.5:
+            a = int(rng.randint(0, Lk - 4))
+            km[0, a:a + int(rng.randint(1, 5))] = True                               # padded keys inside the valid range
+    live = rng.randint(0, Lq + 1, size=B).astype(np.int32) if rng.rand() < 0.6 else None
+    if live is not None:
+        do = do * (np.arange(Lq)[None, :, None] < live[:, None, None])
+    mask = np.zeros((B, 1, Lq, Lk), np.float32)
+    if km is not None:
+        mask = np.maximum(mask, km[:, None, None, :].astype(np.float32))
+    if causal:
+        mask = np.maximum(mask, oracle.create_look_ahead_mask(Lq)[None, None])
+    f32 = np.float32      # (the additive -1e9 only rounds away in fp32: the fully-padded-sample semantics are fp32 semantics)
+    want_o, _, cache = oracle.sdpa_fwd(_split(q, H).astype(f32), _split(k, H).astype(f32), _split(v, H).astype(f32), mask)
+    dq, dk, dv = oracle.sdpa_bwd(_split(do, H).astype(f32), cache)
+    kmd = _dev(km, torch.uint8) if km is not None else None
+    o, stats = ops.attention_fwd(_dev(q), _dev(k), _dev(v), H, key_mask=kmd, causal=causal)
+    _close(o, _merge(want_o), rtol=1e-4, name="fwd")
+    a = ops.attention_bwd(_dev(q), _dev(k), _dev(v), o, _dev(do), stats, H, key_mask=kmd, causal=causal)
+    for g, w, n in zip(a, (dq, dk, dv), ("dQ", "dK", "dV")):
+        _close(g, _merge(w), rtol=3e-4, name=n, floor=0.1)
+    if live is not None:
+        b = ops.attention_bwd(_dev(q), _dev(k), _dev(v), o, _dev(do), stats, H, key_mask=kmd, causal=causal,
+                              q_live_len=torch.as_tensor(live).cuda())
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+
+
 @pytest.fixture
 def ops_two_pass(ops, monkeypatch):
     """`ops` with attention_bwd asking for the two-pass kernel (SKF_ATTN_TWO_PASS in the precision argument)."""
