@@ -94,6 +94,14 @@ __global__ __launch_bounds__(256, MAXT <= 13 ? 4 : 1) void attn_fwd_kernel(AttnP
       dst[c] = row < p.Lq ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
+#if SKF_MEASURE     // clock stamps of a few workgroups (tools/attn_fwd_timeline.py): measurement builds only
+  long long* fdbg = (p.dbg && lane == 0 && (blockIdx.x % 131) == 0 && blockIdx.x / 131 < 8) ? p.dbg + ((blockIdx.x / 131) * 4 + wave) * 16 : nullptr;
+  int fdbi = 0;
+#define SKF_FSTAMP() do { if (fdbg && fdbi < 16) fdbg[fdbi++] = wall_clock64(); } while (0)
+#else
+#define SKF_FSTAMP() do { } while (0)
+#endif
+  SKF_FSTAMP();      // start
   load_q((wave + bh) & 3, qnext);
   // ---- stage K, V^T (zero-filled tail rows) and the key mask.  All global loads of the prologue are issued before the first wait
   // (clamped, always valid addresses; rows past Lk zeroed afterwards): the guarded form - `if (row < Lk) load` inside a 256-element
@@ -147,6 +155,7 @@ __global__ __launch_bounds__(256, MAXT <= 13 ? 4 : 1) void attn_fwd_kernel(AttnP
     for (int o = 32; o > 0; o >>= 1) lv = max(lv, __shfl_xor(lv, o, 64));
     if (lane == 0) last_valid[wave] = lv;
   }
+  SKF_FSTAMP();      // this wave's share of K / V staged
   __syncthreads();
   if (tid < nkt) {
     int f = 0;
@@ -154,6 +163,7 @@ __global__ __launch_bounds__(256, MAXT <= 13 ? 4 : 1) void attn_fwd_kernel(AttnP
     Tf[tid] = f;
   }
   __syncthreads();
+  SKF_FSTAMP();      // staging complete
 
   // Causal tile skipping is exact only when key 0 is visible to every query
   // (then every row max is a real score and masked probabilities are exactly 0).
@@ -277,6 +287,7 @@ __global__ __launch_bounds__(256, MAXT <= 13 ? 4 : 1) void attn_fwd_kernel(AttnP
     }
     __builtin_amdgcn_raw_buffer_store_b64((attn_u32x2){__builtin_bit_cast(unsigned, mx), __builtin_bit_cast(unsigned, rinv)}, st_rsrc,
                                           (qok && g == 0) ? (unsigned)qrow * 8u : 0x7ffffff0u, 0, 0);
+    SKF_FSTAMP();    // one per query tile
   }
 }
 
@@ -646,6 +657,9 @@ extern "C" int skf_attention_fwd(const float* Q, int ldq, const float* K, int ld
   p.Q = Q; p.K = K; p.V = V; p.O = O; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
   p.key_mask = key_mask; p.key_mask_ld = key_mask_ld; p.causal = causal; p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.stats = stats;
   { const char* e = skf_knob("SKF_ATTN_XCD"); p.xcd_remap = !(e && e[0] == '0'); }
+#if SKF_MEASURE
+  { const char* db = skf_knob("SKF_ATTN_DBG"); p.dbg = db ? (long long*)strtoull(db, nullptr, 0) : nullptr; }
+#endif
   int rc = check_common(p, dh);
   if (rc) return rc;
   SKF_CHECK_ARG(Q && K && V && O, "null operand");
