@@ -94,18 +94,19 @@ __device__ __forceinline__ void tile_lstore(const TileRegs& r, char* tile, int t
   for (int j = 0; j < 2; ++j) *reinterpret_cast<uint4*>(tile + ((tid >> 3) + 32 * j) * TP + (tid & 7) * 16) = r.v[j];
 }
 
-// last un-padded key of sample b (or -1) and whether any key is padded, workgroup-wide; `red` = 8 ints of LDS
-__device__ __forceinline__ int last_valid_key(const unsigned char* km, int Lk, int* red, int tid, bool* any_masked) {
-  int lv = -1, nm = 0;
+// last un-padded key of sample b (or -1) and which 64-key blocks hold a padded key (bit min(block, 31)), workgroup-wide; `red` = 8 ints of LDS
+__device__ __forceinline__ int last_valid_key(const unsigned char* km, int Lk, int* red, int tid, unsigned* masked_blocks) {
+  int lv = -1;
+  unsigned nm = 0u;
   for (int key = tid; key < Lk; key += 256) {
     if (!(km && km[key])) lv = key;
-    else nm = 1;
+    else nm |= 1u << min(key >> 6, 31);
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { lv = max(lv, __shfl_xor(lv, o, 64)); nm |= __shfl_xor(nm, o, 64); }
-  if ((tid & 63) == 0) { red[tid >> 6] = lv; red[4 + (tid >> 6)] = nm; }
+  for (int o = 32; o > 0; o >>= 1) { lv = max(lv, __shfl_xor(lv, o, 64)); nm |= (unsigned)__shfl_xor((int)nm, o, 64); }
+  if ((tid & 63) == 0) { red[tid >> 6] = lv; red[4 + (tid >> 6)] = (int)nm; }
   __syncthreads();
-  *any_masked = (red[4] | red[5] | red[6] | red[7]) != 0;
+  *masked_blocks = (unsigned)(red[4] | red[5] | red[6] | red[7]);
   return max(max(red[0], red[1]), max(red[2], red[3]));
 }
 
@@ -131,8 +132,11 @@ __global__ __launch_bounds__(256, 3) void attn_bf16_q_kernel(AP p) {
   const int nqb = (p.Lq + 127) >> 7;
   // XCD-contiguous ids, query block fastest: the blocks of one (b, h) - and the 8 heads of a sample, whose 128-byte slices
   // interleave in every activation row - run on one XCD back to back (K/V re-reads and neighbouring heads hit that L2)
+  // (round 5) the block a workgroup takes is rotated by its (b, h): under the look-ahead mask block nqb-1 visits the most keys, and
+  // with 4 blocks per (b, h) numbered in order every such block went to the same shader engine (see skf_part_major; the part-major
+  // numbering itself costs this kernel 10 % - measured, profiles/r05n_bf16_attn_dispatch.txt)
   const int lid = skf_xcd_remap(blockIdx.x, gridDim.x);
-  const int qb = lid % nqb, bh = lid / nqb, b = bh / p.H, h = bh % p.H;
+  const int bh = lid / nqb, qb = (lid - bh * nqb + bh + (bh >> 3)) % nqb, b = bh / p.H, h = bh % p.H;
   const int q0 = qb * 128 + wave * 32, q = q0 + lq;
   const bool qok = q < p.Lq;
   if constexpr (MODE == 1) {
@@ -186,8 +190,8 @@ __global__ __launch_bounds__(256, 3) void attn_bf16_q_kernel(AP p) {
     if (qok && hi == 0) p.delta[(size_t)bh * p.Lq + q] = dl;
   }
 
-  bool has_pad;
-  const int lastk = last_valid_key(km, p.Lk, red, tid, &has_pad);
+  unsigned masked_blocks;
+  const int lastk = last_valid_key(km, p.Lk, red, tid, &masked_blocks);
   // causal skipping is exact only when key 0 is visible to every query; trailing all-padding blocks contribute exactly 0
   // unless some row may see no key at all (see skf_attention.hip)
   const bool can_skip = p.causal && !(km && km[0]);
@@ -217,7 +221,8 @@ __global__ __launch_bounds__(256, 3) void attn_bf16_q_kernel(AP p) {
     }
     const int k0 = kb * 64;
     // wave-uniform: may this block hold a masked key for this wave's queries?
-    const bool need_mask = has_pad || k0 + 64 > p.Lk || (p.causal && k0 + 63 > q0);
+    // (round 5: per 64-key block, not per sample - on a padded batch every sample has padded keys, but only in its last visited block)
+    const bool need_mask = ((masked_blocks >> min(kb, 31)) & 1u) != 0u || k0 + 64 > p.Lk || (p.causal && k0 + 63 > q0);
     // ---- S^T (two 32-key tiles): lane = query lq, regs = keys (r&3) + 8*(r>>2) + 4*hi
     float s[2][16];
 #pragma unroll
@@ -275,6 +280,7 @@ __global__ __launch_bounds__(256, 3) void attn_bf16_q_kernel(AP p) {
         }
     } else {
       // P^T from the saved statistics, dP^T = V . dO^T, dS^T = P^T o (dP^T - delta)
+      // (a dP accumulator seeded with -delta costs 16 more live registers here: 7 spilled at the 168 this kernel may use - measured, not kept)
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         f32x16 dp = zero16();
@@ -343,7 +349,9 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kv_kernel(AP p) {
   const int lk = lane & 31, hi = lane >> 5;
   const int nkb = (p.Lk + 127) >> 7;
   const int lid = skf_xcd_remap(blockIdx.x, gridDim.x);
-  const int kbk = lid % nkb, bh = lid / nkb, b = bh / p.H, h = bh % p.H;
+  int kbk, bh;
+  skf_part_major(lid, p.B * p.H, nkb, &bh, &kbk);       // key block 0 (never all padding, the most queries under the look-ahead mask) first
+  const int b = bh / p.H, h = bh % p.H;
   const int k0 = kbk * 128 + wave * 32, key = k0 + lk;
   const bool kok = key < p.Lk;
   const int kc = kok ? key : p.Lk - 1;
@@ -364,9 +372,12 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kv_kernel(AP p) {
       vf[ks] = __builtin_bit_cast(skf_bf16x8, vv);
     }
   }
-  bool has_pad;
-  const int lastk = last_valid_key(km, p.Lk, red, tid, &has_pad);
-  (void)has_pad;
+  unsigned masked_blocks;
+  const int lastk = last_valid_key(km, p.Lk, red, tid, &masked_blocks);
+  (void)masked_blocks;
+  // (round 5) does any of this wave's 32 keys carry a mask value?  If not - and no query of the block sits before a key under the
+  // look-ahead mask - the per-score mask arithmetic (two compares, two selects, a min) is skipped: wave-uniform branch
+  const bool wave_masked = __ballot(kadd != 0.f) != 0ull;
   const bool can_skip = p.causal && !(km && km[0]);
   const bool pad_skip = lastk >= 0 && (!p.causal || can_skip);       // same rule as the forward: padded keys have P == 0 exactly
   // query blocks behind the sample's last live row have dO == 0: they contribute nothing to dK / dV
@@ -391,7 +402,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kv_kernel(AP p) {
       }
     };
     auto stats_lstore = [&](int buf) {
-      if (tid < 64) { float* s = St + buf * 192; s[tid] = st_m; s[64 + tid] = st_r; s[128 + tid] = st_d; }
+      if (tid < 64) { float* s = St + buf * 192; s[tid] = st_m; s[64 + tid] = st_r; s[128 + tid] = -st_d; }     // (-delta: the dP accumulator's seed)
     };
     tile_gload(rq, qbase, p.ldq, qb_first * 64, p.Lq, tid);
     tile_gload(rd, dbase, p.lddo, qb_first * 64, p.Lq, tid);
@@ -411,29 +422,44 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kv_kernel(AP p) {
       const int qq0 = qb * 64;
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        // S and dP tiles: lane = key lk, regs = queries qq0 + 32 t + (r&3) + 8*(r>>2) + 4*hi
-        f32x16 sa = zero16(), dp = zero16();
+        // S and dP tiles: lane = key lk, regs = queries qq0 + 32 t + (r&3) + 8*(r>>2) + 4*hi; the dP accumulator starts at -delta of its rows
+        f32x16 sa = zero16(), dp;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const float4 d4 = *reinterpret_cast<const float4*>(st + 128 + t * 32 + 8 * r4 + 4 * hi);
+          dp[4 * r4] = d4.x; dp[4 * r4 + 1] = d4.y; dp[4 * r4 + 2] = d4.z; dp[4 * r4 + 3] = d4.w;
+        }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           sa = mfma32(read_rows(qt, t * 32 + lk, ks, hi), kf[ks], sa);
           dp = mfma32(read_rows(dt_, t * 32 + lk, ks, hi), vf[ks], dp);
         }
         float pr[16], ds[16];
+        const bool need_mask = wave_masked || (p.causal && k0 + 31 > qq0 + t * 32);      // wave-uniform
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
           const int qo = t * 32 + 8 * r4 + 4 * hi;
           const float4 m4 = *reinterpret_cast<const float4*>(st + qo);
           const float4 r4v = *reinterpret_cast<const float4*>(st + 64 + qo);
-          const float4 d4 = *reinterpret_cast<const float4*>(st + 128 + qo);
-          const float mr[4] = {m4.x, m4.y, m4.z, m4.w}, rr[4] = {r4v.x, r4v.y, r4v.z, r4v.w}, dr[4] = {d4.x, d4.y, d4.z, d4.w};
+          const float mr[4] = {m4.x, m4.y, m4.z, m4.w}, rr[4] = {r4v.x, r4v.y, r4v.z, r4v.w};
+          if (need_mask) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int r = 4 * r4 + e, q = qq0 + qo + e;
-            const float mv = p.causal ? fminf(kadd, key > q ? -1e9f : 0.f) : kadd;
-            const float sv = mv < 0.f ? mv : sa[r] * c2;
-            const float pv = __builtin_amdgcn_exp2f(sv - mr[e]) * rr[e];       // rows past Lq: rr == 0
-            pr[r] = pv;
-            ds[r] = pv * (dp[r] - dr[e]);
+            for (int e = 0; e < 4; ++e) {
+              const int r = 4 * r4 + e, q = qq0 + qo + e;
+              const float mv = p.causal ? fminf(kadd, key > q ? -1e9f : 0.f) : kadd;
+              const float sv = mv < 0.f ? mv : sa[r] * c2;
+              const float pv = __builtin_amdgcn_exp2f(sv - mr[e]) * rr[e];       // rows past Lq: rr == 0
+              pr[r] = pv;
+              ds[r] = pv * dp[r];
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int r = 4 * r4 + e;
+              const float pv = __builtin_amdgcn_exp2f(fmaf(sa[r], c2, -mr[e])) * rr[e];
+              pr[r] = pv;
+              ds[r] = pv * dp[r];
+            }
           }
         }
         // dV^T += dO^T . P ; dK^T += Q^T . dS

@@ -80,6 +80,21 @@ __device__ __forceinline__ int skf_xcd_remap(int orig, int nwg) {
   const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
 }
+// Numbering of work items (group g, part w) whose cost depends on the PART with a period that divides the dispatcher's own.
+// Consecutive workgroups of an XCD are handed to its 4 shader engines in turn and a workgroup only ever runs on the 8 CUs of the
+// engine it was handed to, so with 4 parts per group and the part as the fastest index every heavy part (the one live 128-key block
+// of a padded sample, the last query block under the look-ahead mask) queues on the same quarter of the chip and the launch takes
+// as long as if all parts were heavy (measured, bf16 dK/dV pass, B 128 / H 8 / L 512: 8 live keys of 512 223 us against 236 us
+// full-length, 111 us with this numbering; profiles/r05n_bf16_attn_dispatch.txt).  Here: chunks of 32 groups, part-major inside a
+// chunk, so 32 consecutive workgroups carry the same part (part 0 first) and the parts of a group stay close enough in time to
+// share the L2.
+__device__ __forceinline__ void skf_part_major(int lid, int ngroups, int nparts, int* g, int* w) {
+  constexpr int G = 32;
+  const int chunk = lid / (G * nparts), j = lid - chunk * G * nparts;
+  const int gc = min(G, ngroups - chunk * G);
+  *w = j / gc;
+  *g = chunk * G + j - *w * gc;
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
