@@ -249,6 +249,22 @@ int skf_attention_bwd_rows(const float* Q, int ldq, const float* K, int ldk, con
                            const float* dO, int lddo, const float* stats, const unsigned char* key_mask, int key_mask_ld,
                            int causal, int B, int H, int Lq, int Lk, int dh, float* dQ, int lddq, float* dK, int lddk,
                            float* dV, int lddv, int precision, const int* q_live_len, skf_stream_t stream);
+/* Padded batches: a (sample, head) workgroup costs what its sample's length makes it cost, and consecutive workgroups of an XCD are
+ * handed to its four shader engines in turn and never leave them - so the engine that draws the long samples finishes last.
+ * skf_sample_order: order[0..B) = the samples sorted by the number of UNMASKED positions in up to two padding-mask matrices (either may
+ * be NULL), most first, stable.  The *_ordered forms take that list (or NULL = the plain numbering) and deal the sorted (sample, head)
+ * pairs over the 32 engines, heaviest first; used when B * H is a multiple of 32, ignored otherwise and by the kernels other than the
+ * dh = 16 forward / skf_attention_bwd3.  The numbering never changes a result bit.  Measured (B 128, H 8, L 200, 58 % padding): the three
+ * backward calls of a layer 168 -> 143 us, the forward calls 98 -> 90 us (profiles/r05o_attn_order.txt). */
+int skf_sample_order(const unsigned char* mask_a, int lda, int La, const unsigned char* mask_b, int ldb, int Lb, int B, int* order,
+                     skf_stream_t stream);
+int skf_attention_fwd_ordered(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
+                              const unsigned char* key_mask, int key_mask_ld, int causal, int B, int H, int Lq, int Lk, int dh,
+                              float* O, int ldo, float* stats, int precision, const int* sample_order, skf_stream_t stream);
+int skf_attention_bwd_ordered(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* O, int ldo,
+                              const float* dO, int lddo, const float* stats, const unsigned char* key_mask, int key_mask_ld,
+                              int causal, int B, int H, int Lq, int Lk, int dh, float* dQ, int lddq, float* dK, int lddk,
+                              float* dV, int lddv, int precision, const int* q_live_len, const int* sample_order, skf_stream_t stream);
 /* The second return value of scaled_dot_product_attention (builders/utils.py:105: `return output, attention_weights`):
  * W (B,H,Lq,Lk) = softmax(q.k/sqrt(dh) + mask * -1e9) over the keys, same mask arguments as skf_attention_fwd.  Only the builders
  * front-end calls it, on request (the train step of the reference drops the weights: models/sketchformer.py:140-145); plain fp32

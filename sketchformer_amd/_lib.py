@@ -127,6 +127,9 @@ SIGNATURES = {
     "skf_attention_bwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I,
                                _P, _I, _P, _I, _P, _I, _I, _P]),
     "skf_attention_bwd_rows": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P]),
+    "skf_attention_fwd_ordered": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P]),
+    "skf_attention_bwd_ordered": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P]),
+    "skf_sample_order": (_I, [_P, _I, _I, _P, _I, _I, _I, _P, _P]),
     "skf_attention_weights": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "skf_row_mean": (_I, [_P, _P, C.c_long, _I, _I, _P, _P]),
     "skf_embed_fwd": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _P, _F, _U, _P, _P]),

@@ -67,7 +67,9 @@ __global__ __launch_bounds__(256, MAXT <= 13 ? 4 : 1) void attn_fwd_kernel(AttnP
   // A head is a 64..256-byte slice of every activation row, i.e. half (or less) of each 128-byte line it touches; the
   // other half belongs to the neighbouring head.  XCD-contiguous ids put all heads of a sample on ONE XCD (one L2),
   // consecutively in time, so the neighbour's half is an L2 hit instead of a second HBM fetch of the same line.
-  const int bh = p.xcd_remap ? skf_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x, b = bh / p.H, h = bh % p.H;
+  int bh = p.xcd_remap ? skf_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  if (p.order) { const int k = skf_deal_rank(blockIdx.x); bh = p.order[k / p.H] * p.H + k % p.H; }
+  const int b = bh / p.H, h = bh % p.H;
   const int nkt = (p.Lk + 15) >> 4, nqt = (p.Lq + 15) >> 4;
   const int VP = nkt * 16 + 8;            // pitch of the transposed V image: (VP / 4) mod 4 == 2 keeps the ds_read_b128 of the PV
                                           // operands free of bank conflicts (the four 16-lane groups of the instruction mix lane groups g)
@@ -653,7 +655,14 @@ int check_common(const AttnParams& p, int dh) {
 extern "C" int skf_attention_fwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
                                  const unsigned char* key_mask, int key_mask_ld, int causal, int B, int H, int Lq, int Lk,
                                  int dh, float* O, int ldo, float* stats, int precision, skf_stream_t stream) {
+  return skf_attention_fwd_ordered(Q, ldq, K, ldk, V, ldv, key_mask, key_mask_ld, causal, B, H, Lq, Lk, dh, O, ldo, stats, precision, nullptr, stream);
+}
+
+extern "C" int skf_attention_fwd_ordered(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
+                                         const unsigned char* key_mask, int key_mask_ld, int causal, int B, int H, int Lq, int Lk,
+                                         int dh, float* O, int ldo, float* stats, int precision, const int* sample_order, skf_stream_t stream) {
   AttnParams p{};
+  p.order = ((B * H) & 31) == 0 ? sample_order : nullptr;      // (the deal needs whole rounds of the 32 shader engines; results never depend on it)
   p.Q = Q; p.K = K; p.V = V; p.O = O; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
   p.key_mask = key_mask; p.key_mask_ld = key_mask_ld; p.causal = causal; p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.stats = stats;
   { const char* e = skf_knob("SKF_ATTN_XCD"); p.xcd_remap = !(e && e[0] == '0'); }
@@ -701,8 +710,8 @@ extern "C" int skf_attention_bwd(const float* Q, int ldq, const float* K, int ld
                                  const float* O, int ldo, const float* dO, int lddo, const float* stats,
                                  const unsigned char* key_mask, int key_mask_ld, int causal, int B, int H, int Lq, int Lk,
                                  int dh, float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv, int precision, skf_stream_t stream) {
-  return skf_attention_bwd_rows(Q, ldq, K, ldk, V, ldv, O, ldo, dO, lddo, stats, key_mask, key_mask_ld, causal, B, H, Lq, Lk, dh, dQ, lddq,
-                                dK, lddk, dV, lddv, precision, nullptr, stream);
+  return skf_attention_bwd_ordered(Q, ldq, K, ldk, V, ldv, O, ldo, dO, lddo, stats, key_mask, key_mask_ld, causal, B, H, Lq, Lk, dh, dQ, lddq,
+                                   dK, lddk, dV, lddv, precision, nullptr, nullptr, stream);
 }
 
 extern "C" int skf_attention_bwd_rows(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
@@ -710,9 +719,19 @@ extern "C" int skf_attention_bwd_rows(const float* Q, int ldq, const float* K, i
                                       const unsigned char* key_mask, int key_mask_ld, int causal, int B, int H, int Lq, int Lk,
                                       int dh, float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv, int precision,
                                       const int* q_live_len, skf_stream_t stream) {
+  return skf_attention_bwd_ordered(Q, ldq, K, ldk, V, ldv, O, ldo, dO, lddo, stats, key_mask, key_mask_ld, causal, B, H, Lq, Lk, dh, dQ, lddq,
+                                   dK, lddk, dV, lddv, precision, q_live_len, nullptr, stream);
+}
+
+extern "C" int skf_attention_bwd_ordered(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
+                                         const float* O, int ldo, const float* dO, int lddo, const float* stats,
+                                         const unsigned char* key_mask, int key_mask_ld, int causal, int B, int H, int Lq, int Lk,
+                                         int dh, float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv, int precision,
+                                         const int* q_live_len, const int* sample_order, skf_stream_t stream) {
   const bool two_pass = (precision & SKF_ATTN_TWO_PASS) != 0;
   precision &= ~SKF_ATTN_TWO_PASS;
   AttnParams p{};
+  p.order = ((B * H) & 31) == 0 ? sample_order : nullptr;
   p.q_live = q_live_len;
   p.Q = Q; p.K = K; p.V = V; p.O = const_cast<float*>(O); p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
   p.key_mask = key_mask; p.key_mask_ld = key_mask_ld; p.causal = causal; p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk;

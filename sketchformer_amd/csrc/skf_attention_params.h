@@ -17,6 +17,7 @@ struct AttnParams {
   const float* dO; int lddo;
   float* dQ; float* dK; float* dV;
   int lddq, lddk, lddv;
+  const int* order;               // optional (B): the samples sorted by cost, heaviest first (skf_sample_order): workgroups are dealt over the shader engines (skf_deal_rank)
   const int* q_live;              // optional (B): query rows >= q_live[b] have dO == 0 exactly (skf_target_live_len); one-pass
                                   // backward: their tiles are neither staged nor visited, dQ is stored as zeros
 };

@@ -95,6 +95,14 @@ __device__ __forceinline__ void skf_part_major(int lid, int ngroups, int nparts,
   *w = j / gc;
   *g = chunk * G + j - *w * gc;
 }
+// The other way round: workgroups whose cost is known per SAMPLE (padded batches: one workgroup per (sample, head)).  Given the
+// samples sorted by cost (heaviest first) and numbered k = rank * H + head, workgroup `bid` takes the k that DEALS the sorted list
+// over the 32 shader engines of the chip (bid -> XCD bid % 8, arrival i = bid / 8 in that XCD -> engine i % 4): every engine gets
+// the same mix of lengths, heaviest first.  Needs gridDim.x % 32 == 0 (the caller checks).
+__device__ __forceinline__ int skf_deal_rank(int bid) {
+  const int x = bid & 7, i = bid >> 3;
+  return 32 * (i >> 2) + 4 * x + (i & 3);
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -298,6 +298,7 @@ struct DecAct { size_t x_in, qkv, o1, z1, st1, astats1, out1, q2, kv2, o2, astat
 struct Plan {
   size_t bytes = 0;
   size_t inp, tar, labels, enc_mask, dec_mask;
+  size_t order;            // (B) samples sorted by length, longest first (skf_sample_order): the attention launches deal their workgroups from it
   std::vector<EncAct> enc;
   std::vector<DecAct> dec;
   size_t u, pool_a, emb, pooled, dpooled, cls_logits, cls_probs, pre, logits;
@@ -419,6 +420,7 @@ Plan build_plan(const SkfConfig& c) {
   P.dc_tok = b.take(B * (L + 1) * 8); P.dc_cont = b.take(B * (L + 1) * 5 * f); P.dc_kvnew = b.take(B * 2 * d * f);
   P.dc_dyn = b.take(64);
   P.live_len = b.take(B * sizeof(int));
+  P.order = b.take(B * sizeof(int));
   P.live16 = b.take(skf_row_blocks_bytes(B * (L - 1), 16)); P.live32 = b.take(skf_row_blocks_bytes(B * (L - 1), 32));
   P.bytes = b.off;
   return P;
@@ -463,6 +465,7 @@ struct SkfModel {
   // Live row blocks of the decoder-side backward (skf_row_blocks.hip): set while the decoder layers' gradients are issued,
   // consulted by dense_dgrad / dense_wgrad for problems with exactly `live_rows` rows; null = every row is visited
   const int* live16 = nullptr; const int* live32 = nullptr; int live_rows = 0;
+  const int* order = nullptr;        // this step's samples sorted by length (run_forward), or null
   bool lists_built = false;             // this step's lists are in P.live16 / P.live32 (issued, not necessarily complete)
   std::map<const void*, SideEvent> pending_writers;    // buffers a side-stream dgrad still writes
   std::vector<QueuedWgrad> wq;                         // wgrads of the current layer, not yet issued
@@ -905,6 +908,14 @@ int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s, bool 
     SKF_TRY(skf_padding_mask(inp, Le, B, Le, emask, s));
     SKF_TRY(skf_padding_mask(tar, Le, B, Ld, dmask, s));
   }
+  // samples by length (both masks), longest first: every (sample, head) attention launch of the step deals its workgroups from it
+  static const bool order_off = skf_knob("SKF_ATTN_ORDER") && skf_knob("SKF_ATTN_ORDER")[0] == '0';      // (measurement builds)
+  const int* order = nullptr;
+  if (!order_off && B <= 8192) {
+    SKF_TRY(skf_sample_order(emask, Le, Le, encoder_only ? nullptr : dmask, Ld, Ld, B, M->at<int>(P.order), s));
+    order = M->at<int>(P.order);
+  }
+  M->order = order;
 
   // ---------------- encoder (builders/layers/transformer.py:288-301)
   if (c.continuous)
@@ -920,8 +931,8 @@ int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s, bool 
     float* x = M->at<float>(a.x_in);
     float* qkv = M->at<float>(a.qkv);
     if (!enc_qkv_done) SKF_TRY(dense_fwd(M, w.mha.qkv, x, Me, qkv, 0, s));     // (else: the previous layer's feed-forward launch wrote it)
-    SKF_TRY(skf_attention_fwd(qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, emask, Le, 0, B, H, Le, Le, dh,
-                              M->at<float>(a.o), d, M->at<float>(a.astats), M->cfg.gemm_precision, s));
+    SKF_TRY(skf_attention_fwd_ordered(qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, emask, Le, 0, B, H, Le, Le, dh,
+                                      M->at<float>(a.o), d, M->at<float>(a.astats), M->cfg.gemm_precision, order, s));
     const bool has_next = i + 1 < N;
     SKF_TRY(attn_tail_ffn_fwd(M, w.mha.o, w.ln1, M->at<float>(a.o), x, M->at<float>(a.z1), M->at<float>(a.x1), M->at<float>(a.st1),
                               site_enc(i, 0), M->at<char>(a.img_of), w.f1, w.f2, w.ln2, M->at<float>(a.h), hbits_of(M, a.hbits, Me),
@@ -982,16 +993,16 @@ int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s, bool 
     float* x = M->at<float>(a.x_in);
     float* qkv = M->at<float>(a.qkv);
     if (!dec_qkv_done) SKF_TRY(dense_fwd(M, w.mha1.qkv, x, Md, qkv, 0, s));
-    SKF_TRY(skf_attention_fwd(qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, dmask, Ld, 1, B, H, Ld, Ld, dh,
-                              M->at<float>(a.o1), d, M->at<float>(a.astats1), M->cfg.gemm_precision, s));
+    SKF_TRY(skf_attention_fwd_ordered(qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, dmask, Ld, 1, B, H, Ld, Ld, dh,
+                                      M->at<float>(a.o1), d, M->at<float>(a.astats1), M->cfg.gemm_precision, order, s));
     SKF_TRY(dense_ln_fwd(M, w.mha1.o, M->at<float>(a.o1), Md, x, M->at<float>(a.z1), w.ln1, M->at<float>(a.out1), M->at<float>(a.st1),
                          rate, site_dec(N, i, 0), s));
     float* kv2 = M->at<float>(a.kv2);
     SKF_TRY(dense_fwd(M, w.mha2.q, M->at<float>(a.out1), Md, M->at<float>(a.q2), 0, s));
     if (!kv_done) SKF_TRY(dense_fwd(M, w.mha2.kv, pre, Me, kv2, 0, s));
     else if (i == 0) SKF_HIP(hipStreamWaitEvent(s, kv_done, 0));
-    SKF_TRY(skf_attention_fwd(M->at<float>(a.q2), d, kv2, 2 * d, kv2 + d, 2 * d, cross_mask, Le, 0, B, H, Ld, Le, dh,
-                              M->at<float>(a.o2), d, M->at<float>(a.astats2), M->cfg.gemm_precision, s));
+    SKF_TRY(skf_attention_fwd_ordered(M->at<float>(a.q2), d, kv2, 2 * d, kv2 + d, 2 * d, cross_mask, Le, 0, B, H, Ld, Le, dh,
+                                      M->at<float>(a.o2), d, M->at<float>(a.astats2), M->cfg.gemm_precision, order, s));
     const bool has_next = i + 1 < N;
     SKF_TRY(attn_tail_ffn_fwd(M, w.mha2.o, w.ln2, M->at<float>(a.o2), M->at<float>(a.out1), M->at<float>(a.z2), M->at<float>(a.out2),
                               M->at<float>(a.st2), site_dec(N, i, 1), M->at<char>(a.img_o2f), w.f1, w.f2, w.ln3, M->at<float>(a.h),
@@ -1219,9 +1230,9 @@ int run_backward(SkfModel* M, hipStream_t s) {
     SKF_TRY(before_write(M, dq2, s));
     SKF_TRY(before_write(M, dkv2, s));
     const int* qlive = M->live16 ? M->at<int>(P.live_len) : nullptr;      // decoder query rows behind it have dO == 0
-    SKF_TRY(skf_attention_bwd_rows(M->at<float>(a.q2), d, kv2, 2 * d, kv2 + d, 2 * d, M->at<float>(a.o2), d, dO, d,
-                                   M->at<float>(a.astats2), cross_mask, Le, 0, B, H, Ld, Le, dh, dq2, d, dkv2, 2 * d,
-                                   dkv2 + d, 2 * d, M->cfg.gemm_precision, qlive, s));
+    SKF_TRY(skf_attention_bwd_ordered(M->at<float>(a.q2), d, kv2, 2 * d, kv2 + d, 2 * d, M->at<float>(a.o2), d, dO, d,
+                                      M->at<float>(a.astats2), cross_mask, Le, 0, B, H, Ld, Le, dh, dq2, d, dkv2, 2 * d,
+                                      dkv2 + d, 2 * d, M->cfg.gemm_precision, qlive, M->order, s));
     SKF_TRY(dense_wgrad(M, w.mha2.q, M->at<float>(a.out1), d, dq2, d, Md, s));
     SKF_TRY(dense_dgrad(M, w.mha2.q, dq2, d, Md, G, d, 1, nullptr, 0, s));
     SKF_TRY(dense_wgrad(M, w.mha2.kv, pre, L.E, dkv2, 2 * d, Me, s));
@@ -1235,9 +1246,9 @@ int run_backward(SkfModel* M, hipStream_t s) {
                          site_dec(N, i, 0), s, M->at<char>(a.img_o1)));
     const float* qkv = M->at<float>(a.qkv);
     SKF_TRY(before_write(M, dqkv, s));
-    SKF_TRY(skf_attention_bwd_rows(qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, M->at<float>(a.o1), d, dO, d,
-                                   M->at<float>(a.astats1), dmask, Ld, 1, B, H, Ld, Ld, dh, dqkv, 3 * d, dqkv + d, 3 * d,
-                                   dqkv + 2 * d, 3 * d, M->cfg.gemm_precision, qlive, s));
+    SKF_TRY(skf_attention_bwd_ordered(qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, M->at<float>(a.o1), d, dO, d,
+                                      M->at<float>(a.astats1), dmask, Ld, 1, B, H, Ld, Ld, dh, dqkv, 3 * d, dqkv + d, 3 * d,
+                                      dqkv + 2 * d, 3 * d, M->cfg.gemm_precision, qlive, M->order, s));
     SKF_TRY(dense_wgrad(M, w.mha1.qkv, M->at<float>(a.x_in), d, dqkv, 3 * d, Md, s));
     SKF_TRY(dense_dgrad(M, w.mha1.qkv, dqkv, 3 * d, Md, G2, d, 1, nullptr, 0, s));
     float* t = G; G = G2; G2 = t;
@@ -1332,9 +1343,9 @@ int run_backward(SkfModel* M, hipStream_t s) {
     if (i == 0 && early_tail) SKF_TRY(issue_wgrads(M, s));
     const float* qkv = M->at<float>(a.qkv);
     SKF_TRY(before_write(M, dqkv, s));
-    SKF_TRY(skf_attention_bwd(qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, M->at<float>(a.o), d, dO, d,
-                              M->at<float>(a.astats), emask, Le, 0, B, H, Le, Le, dh, dqkv, 3 * d, dqkv + d, 3 * d,
-                              dqkv + 2 * d, 3 * d, M->cfg.gemm_precision, s));
+    SKF_TRY(skf_attention_bwd_ordered(qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, M->at<float>(a.o), d, dO, d,
+                                      M->at<float>(a.astats), emask, Le, 0, B, H, Le, Le, dh, dqkv, 3 * d, dqkv + d, 3 * d,
+                                      dqkv + 2 * d, 3 * d, M->cfg.gemm_precision, nullptr, M->order, s));
     SKF_TRY(dense_wgrad(M, w.mha.qkv, M->at<float>(a.x_in), d, dqkv, 3 * d, Me, s));
     // last layer of the backward: the weight gradient only needs dqkv, so it goes out BEFORE the input-gradient GEMM - the hop
     // to the side stream and the kernel itself then run under that GEMM and the embedding gradient instead of behind them

@@ -97,7 +97,38 @@ __global__ __launch_bounds__(1024) void row_list_kernel(const int* __restrict__ 
   if (blockIdx.x == 0 && tid == 0) { blocks[0] = nlive; blocks[1] = rows; }
 }
 
+// Samples sorted by the number of unmasked positions of up to two mask matrices (stable, most first): one workgroup; rank by counting
+__global__ __launch_bounds__(1024) void sample_order_kernel(const unsigned char* __restrict__ ma, int lda, int La,
+                                                            const unsigned char* __restrict__ mb, int ldb, int Lb, int B, int* __restrict__ order) {
+  extern __shared__ int key[];                 // [B]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int b = wave; b < B; b += 16) {
+    int n = 0;
+    if (ma) for (int t = lane; t < La; t += 64) n += ma[(size_t)b * lda + t] ? 0 : 1;
+    if (mb) for (int t = lane; t < Lb; t += 64) n += mb[(size_t)b * ldb + t] ? 0 : 1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+    if (lane == 0) key[b] = n;
+  }
+  __syncthreads();
+  for (int b = tid; b < B; b += 1024) {
+    const int k = key[b];
+    int rank = 0;
+    for (int j = 0; j < B; ++j) { const int kj = key[j]; rank += (kj > k || (kj == k && j < b)) ? 1 : 0; }
+    order[rank] = b;
+  }
+}
+
 }  // namespace
+
+extern "C" int skf_sample_order(const unsigned char* mask_a, int lda, int La, const unsigned char* mask_b, int ldb, int Lb, int B, int* order,
+                                skf_stream_t stream) {
+  SKF_CHECK_ARG(order && B > 0 && B <= 8192 && (mask_a || mask_b), "bad argument");
+  SKF_CHECK_ARG((!mask_a || (La > 0 && lda >= La)) && (!mask_b || (Lb > 0 && ldb >= Lb)), "bad mask shape");
+  hipLaunchKernelGGL(sample_order_kernel, dim3(1), dim3(1024), (size_t)B * sizeof(int), (hipStream_t)stream, mask_a, lda, La, mask_b, ldb, Lb, B, order);
+  SKF_LAUNCH_CHECK();
+  return SKF_OK;
+}
 
 extern "C" int skf_target_live_len(const long long* tar, int tar_ld, int B, int Ld, int* live_len, skf_stream_t stream) {
   SKF_CHECK_ARG(tar && live_len && B > 0 && Ld > 0 && tar_ld > Ld, "bad argument");

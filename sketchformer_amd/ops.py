@@ -128,15 +128,26 @@ def gemm(a, b, a_kcontig=True, b_kcontig=False, bias=None, act=0, relu_src=None,
     return out
 
 
-def attention_fwd(q, k, v, num_heads, key_mask=None, causal=False, precision=None):
-    """q (B,Lq,d) k,v (B,Lk,d) views with unit inner stride -> o (B,Lq,d), stats (B,H,Lq,2)."""
+def sample_order(mask_a=None, mask_b=None):
+    """uint8 padding masks (B, La) / (B, Lb), 1 = padded -> int32 (B,): the samples by unmasked positions, most first (skf_sample_order)."""
+    m = mask_a if mask_a is not None else mask_b
+    out = torch.empty(m.shape[0], dtype=torch.int32, device=m.device)
+    _lib.call("skf_sample_order", _p(mask_a), mask_a.stride(0) if mask_a is not None else 0, mask_a.shape[1] if mask_a is not None else 0,
+              _p(mask_b), mask_b.stride(0) if mask_b is not None else 0, mask_b.shape[1] if mask_b is not None else 0, m.shape[0], _p(out),
+              _stream())
+    return out
+
+
+def attention_fwd(q, k, v, num_heads, key_mask=None, causal=False, precision=None, sample_order=None):
+    """q (B,Lq,d) k,v (B,Lk,d) views with unit inner stride -> o (B,Lq,d), stats (B,H,Lq,2).
+    sample_order: optional int32 (B,) from ``sample_order`` - workgroup numbering only, never a result bit."""
     B, Lq, d = q.shape
     Lk = k.shape[1]
     o = torch.empty(B, Lq, d, dtype=torch.float32, device=q.device)
     stats = torch.empty(B, num_heads, Lq, 2, dtype=torch.float32, device=q.device)
-    _lib.call("skf_attention_fwd", _p(q), q.stride(1), _p(k), k.stride(1), _p(v), v.stride(1), _p(key_mask),
+    _lib.call("skf_attention_fwd_ordered", _p(q), q.stride(1), _p(k), k.stride(1), _p(v), v.stride(1), _p(key_mask),
               key_mask.stride(0) if key_mask is not None else 0, int(causal), B, num_heads, Lq, Lk, d // num_heads,
-              _p(o), o.stride(1), _p(stats), _prec(precision), _stream())
+              _p(o), o.stride(1), _p(stats), _prec(precision), _p(sample_order), _stream())
     return o, stats
 
 
@@ -176,7 +187,8 @@ def attention_decode(q, k, v, num_heads, n_keys=None, key_mask=None, key_limit=N
     return o
 
 
-def attention_bwd(q, k, v, o, do, stats, num_heads, key_mask=None, causal=False, precision=None, q_live_len=None, two_pass=False):
+def attention_bwd(q, k, v, o, do, stats, num_heads, key_mask=None, causal=False, precision=None, q_live_len=None, two_pass=False,
+                  sample_order=None):
     """q_live_len: optional int32 (B,) - query rows at or behind it have do == 0 exactly (``target_live_len``).
     two_pass: OR SKF_ATTN_TWO_PASS into the precision argument (the two-pass kernel of skf_attention_bwd2.hip also where the
     dispatch would take the one-pass kernel: head size 16)."""
@@ -185,10 +197,10 @@ def attention_bwd(q, k, v, o, do, stats, num_heads, key_mask=None, causal=False,
     dq = torch.full((B, Lq, d), float("nan"), dtype=torch.float32, device=q.device)
     dk = torch.empty(B, Lk, d, dtype=torch.float32, device=q.device)
     dv = torch.empty(B, Lk, d, dtype=torch.float32, device=q.device)
-    _lib.call("skf_attention_bwd_rows", _p(q), q.stride(1), _p(k), k.stride(1), _p(v), v.stride(1), _p(o), o.stride(1),
+    _lib.call("skf_attention_bwd_ordered", _p(q), q.stride(1), _p(k), k.stride(1), _p(v), v.stride(1), _p(o), o.stride(1),
               _p(do), do.stride(1), _p(stats), _p(key_mask), key_mask.stride(0) if key_mask is not None else 0,
               int(causal), B, num_heads, Lq, Lk, d // num_heads, _p(dq), dq.stride(1), _p(dk), dk.stride(1),
-              _p(dv), dv.stride(1), _prec(precision) | (_lib.ATTN_TWO_PASS if two_pass else 0), _p(q_live_len), _stream())
+              _p(dv), dv.stride(1), _prec(precision) | (_lib.ATTN_TWO_PASS if two_pass else 0), _p(q_live_len), _p(sample_order), _stream())
     return dq, dk, dv
 
 

@@ -493,6 +493,41 @@ def test_attention_backward_random_shapes_masks_and_live_lengths(ops, seed):
             assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_sample_order_and_dealt_attention_workgroups(ops, seed):
+    """skf_sample_order = a stable descending sort of the samples by unmasked positions (one or two masks); the attention launches that
+    deal their (sample, head) workgroups over the shader engines from such a list (B * H a multiple of 32; any permutation will do) return
+    the bits of the plain numbering, forward and backward, dh = 16 (forward + skf_attention_bwd3) and a size the list is ignored for."""
+    rng = np.random.RandomState(2000 + seed)
+    B, H, dh = int(rng.choice([4, 8, 16, 33])), int(rng.choice([8, 4])), 16
+    causal = bool(seed & 1)
+    Lq = int(rng.choice([17, 100, 200]))
+    Lk = Lq if causal else int(rng.choice([33, 128, 200]))
+    d = H * dh
+    la, lb = rng.randint(0, Lk + 1, size=B), rng.randint(0, Lq + 1, size=B)
+    la[rng.randint(B)] = la[rng.randint(B)]                      # ties: the sort is stable
+    ma = np.arange(Lk)[None, :] >= la[:, None]
+    mb = np.arange(Lq)[None, :] >= lb[:, None]
+    ma_d, mb_d = _dev(ma, torch.uint8), _dev(mb, torch.uint8)
+    for a_, b_, key in ((ma_d, mb_d, la + lb), (ma_d, None, la), (None, mb_d, lb)):
+        got = ops.sample_order(a_, b_).cpu().numpy()
+        want = np.argsort(-key, kind="stable")
+        assert np.array_equal(got, want), (got, want)
+    order = ops.sample_order(ma_d, mb_d)
+    perm = torch.as_tensor(rng.permutation(B).astype(np.int32)).cuda()
+    q, k, v, do = (_dev(rng.randn(B, n, d)) for n in (Lq, Lk, Lk, Lq))
+    live = torch.as_tensor(lb.astype(np.int32)).cuda()
+    do = do * (torch.arange(Lq, device="cuda")[None, :, None] < live[:, None, None])
+    o, st = ops.attention_fwd(q, k, v, H, key_mask=ma_d, causal=causal)
+    g = ops.attention_bwd(q, k, v, o, do, st, H, key_mask=ma_d, causal=causal, q_live_len=live)
+    for od in (order, perm):
+        o2, st2 = ops.attention_fwd(q, k, v, H, key_mask=ma_d, causal=causal, sample_order=od)
+        assert torch.equal(o2, o) and torch.equal(st2, st)
+        g2 = ops.attention_bwd(q, k, v, o, do, st, H, key_mask=ma_d, causal=causal, q_live_len=live, sample_order=od)
+        for x, y in zip(g, g2):
+            assert torch.equal(x, y)
+
+
 @pytest.fixture
 def ops_two_pass(ops, monkeypatch):
     """`ops` with attention_bwd asking for the two-pass kernel (SKF_ATTN_TWO_PASS in the precision argument)."""
