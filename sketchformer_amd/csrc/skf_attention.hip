@@ -314,7 +314,9 @@ __global__ __launch_bounds__(256, SKF_ATTN_BWD_WAVES) void attn_bwd_kernel(AttnP
   // A head is a 64..256-byte slice of every activation row, i.e. half (or less) of each 128-byte line it touches; the
   // other half belongs to the neighbouring head.  XCD-contiguous ids put all heads of a sample on ONE XCD (one L2),
   // consecutively in time, so the neighbour's half is an L2 hit instead of a second HBM fetch of the same line.
-  const int bh = p.xcd_remap ? skf_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x, b = bh / p.H, h = bh % p.H;
+  int bh = p.xcd_remap ? skf_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  if (p.order) { const int k = skf_deal_rank(blockIdx.x); bh = p.order[k / p.H] * p.H + k % p.H; }
+  const int b = bh / p.H, h = bh % p.H;
   const int nkt = (p.Lk + 15) >> 4, nqt_all = (p.Lq + 15) >> 4;
   // query tiles behind the sample's last live row have dO == 0: they add nothing to dK / dV and their dQ is zero
   const int nqt = p.q_live ? min(nqt_all, (max(p.q_live[b], 0) + 15) >> 4) : nqt_all;

@@ -466,6 +466,7 @@ struct SkfModel {
   // consulted by dense_dgrad / dense_wgrad for problems with exactly `live_rows` rows; null = every row is visited
   const int* live16 = nullptr; const int* live32 = nullptr; int live_rows = 0;
   const int* order = nullptr;        // this step's samples sorted by length (run_forward), or null
+  hipEvent_t pre_ready = nullptr, masks_ready = nullptr;    // train step: forward_preamble ran on the side stream; the forward waits for the masks before its first attention, for the images behind it
   bool lists_built = false;             // this step's lists are in P.live16 / P.live32 (issued, not necessarily complete)
   std::map<const void*, SideEvent> pending_writers;    // buffers a side-stream dgrad still writes
   std::vector<QueuedWgrad> wq;                         // wgrads of the current layer, not yet issued
@@ -885,6 +886,34 @@ int attn_tail_ffn_fwd(SkfModel* M, const DenseP& o, const LnP& ln_a, const float
   return skf_ffn_block_fwd_f32(&b, s);
 }
 
+// What the forward needs besides its inputs: the pre-split weight images of the row-owner launches (the weights changed in the last
+// optimizer step), the two padding masks, and the samples sorted by length (both masks), longest first - every (sample, head)
+// attention launch of the step deals its workgroups from that list.  None of it is read before the first attention.
+int forward_preamble(SkfModel* M, bool with_backward, bool encoder_only, hipStream_t s, hipEvent_t masks_ready = nullptr) {
+  const SkfConfig& c = M->cfg;
+  const Plan& P = M->plan;
+  const int B = c.batch, Le = c.seq_len, Ld = c.seq_len - 1;
+  unsigned char* emask = M->at<unsigned char>(P.enc_mask);
+  unsigned char* dmask = M->at<unsigned char>(P.dec_mask);
+  if (c.continuous) {
+    SKF_TRY(skf_padding_mask_continuous(M->at<float>(P.inp), Le, B, Le, emask, s));
+    SKF_TRY(skf_padding_mask_continuous(M->at<float>(P.tar), Le, B, Ld, dmask, s));
+  } else {
+    SKF_TRY(skf_padding_mask(M->at<long long>(P.inp), Le, B, Le, emask, s));
+    SKF_TRY(skf_padding_mask(M->at<long long>(P.tar), Le, B, Ld, dmask, s));
+  }
+  static const bool order_off = skf_knob("SKF_ATTN_ORDER") && skf_knob("SKF_ATTN_ORDER")[0] == '0';      // (measurement builds)
+  M->order = nullptr;
+  if (!order_off && B <= 8192) {
+    SKF_TRY(skf_sample_order(emask, Le, Le, encoder_only ? nullptr : dmask, Ld, Ld, B, M->at<int>(P.order), s));
+    M->order = M->at<int>(P.order);
+  }
+  if (masks_ready) SKF_HIP(hipEventRecord(masks_ready, s));      // (the images are only read by the launch BEHIND the first attention)
+  M->ffn_fused = ffn_fused_on(M);
+  if (M->ffn_fused) SKF_TRY(build_ffn_images(M, with_backward, encoder_only, s));
+  return SKF_OK;
+}
+
 int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s, bool encoder_only = false) {
   const SkfConfig& c = M->cfg;
   const Layout& L = M->lay;
@@ -899,23 +928,11 @@ int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s, bool 
 
   const float* inpf = M->at<float>(P.inp);      // continuous mode: (B, L, 5) stroke-5 rows
   const float* tarf = M->at<float>(P.tar);
-  M->ffn_fused = ffn_fused_on(M);
-  if (M->ffn_fused) SKF_TRY(build_ffn_images(M, training && with_loss, encoder_only, s));
-  if (c.continuous) {
-    SKF_TRY(skf_padding_mask_continuous(inpf, Le, B, Le, emask, s));
-    SKF_TRY(skf_padding_mask_continuous(tarf, Le, B, Ld, dmask, s));
-  } else {
-    SKF_TRY(skf_padding_mask(inp, Le, B, Le, emask, s));
-    SKF_TRY(skf_padding_mask(tar, Le, B, Ld, dmask, s));
-  }
-  // samples by length (both masks), longest first: every (sample, head) attention launch of the step deals its workgroups from it
-  static const bool order_off = skf_knob("SKF_ATTN_ORDER") && skf_knob("SKF_ATTN_ORDER")[0] == '0';      // (measurement builds)
-  const int* order = nullptr;
-  if (!order_off && B <= 8192) {
-    SKF_TRY(skf_sample_order(emask, Le, Le, encoder_only ? nullptr : dmask, Ld, Ld, B, M->at<int>(P.order), s));
-    order = M->at<int>(P.order);
-  }
-  M->order = order;
+  // weight images, padding masks, sample order: here, unless the train step already put them on the side stream (issue_embed_sorts)
+  hipEvent_t pre_ready = M->pre_ready, masks_ready = M->masks_ready;
+  M->pre_ready = M->masks_ready = nullptr;
+  if (!pre_ready) SKF_TRY(forward_preamble(M, training && with_loss, encoder_only, s));
+  const int* order = M->order;
 
   // ---------------- encoder (builders/layers/transformer.py:288-301)
   if (c.continuous)
@@ -931,9 +948,11 @@ int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s, bool 
     float* x = M->at<float>(a.x_in);
     float* qkv = M->at<float>(a.qkv);
     if (!enc_qkv_done) SKF_TRY(dense_fwd(M, w.mha.qkv, x, Me, qkv, 0, s));     // (else: the previous layer's feed-forward launch wrote it)
+    if (i == 0 && pre_ready) SKF_HIP(hipStreamWaitEvent(s, masks_ready, 0));    // masks and order were built beside the embedding and this projection
     SKF_TRY(skf_attention_fwd_ordered(qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, emask, Le, 0, B, H, Le, Le, dh,
                                       M->at<float>(a.o), d, M->at<float>(a.astats), M->cfg.gemm_precision, order, s));
     const bool has_next = i + 1 < N;
+    if (i == 0 && pre_ready) SKF_HIP(hipStreamWaitEvent(s, pre_ready, 0));      // ... and the weight images beside the first attention
     SKF_TRY(attn_tail_ffn_fwd(M, w.mha.o, w.ln1, M->at<float>(a.o), x, M->at<float>(a.z1), M->at<float>(a.x1), M->at<float>(a.st1),
                               site_enc(i, 0), M->at<char>(a.img_of), w.f1, w.f2, w.ln2, M->at<float>(a.h), hbits_of(M, a.hbits, Me),
                               M->at<char>(a.img[0]), M->at<float>(a.z2), M->at<float>(a.x2), M->at<float>(a.st2), site_enc(i, 1), Me, rate, s,
@@ -1569,6 +1588,7 @@ int stage_inputs(SkfModel* M, const void* inp, const void* tar, int tar_ld, cons
   const Plan& P = M->plan;
   reset_live_rows(M);
   M->lists_built = false;
+  M->pre_ready = M->masks_ready = nullptr;
   SKF_CHECK_ARG(inp && tar, "null input");
   const size_t row = c.continuous ? (size_t)c.seq_len * 5 * sizeof(float) : (size_t)c.seq_len * 8;     // bytes per sample
   const size_t src_row = c.continuous ? (size_t)tar_ld * 5 * sizeof(float) : (size_t)tar_ld * 8;
@@ -1869,6 +1889,16 @@ int issue_embed_sorts(SkfModel* M, hipStream_t s) {
     SKF_HIP(hipEventRecord(staged, s));
     SKF_HIP(hipStreamWaitEvent(M->side, staged, 0));
     ss = M->side;
+    // first on the side stream: what the forward does not need before its first attention (forward_preamble) - the main stream goes
+    // straight to the embedding and the first q|k|v projection (30 us of one-workgroup and short launches off the critical path)
+    static const bool pre_off = skf_knob("SKF_NO_SIDE_PREAMBLE") && skf_knob("SKF_NO_SIDE_PREAMBLE")[0] == '1';   // (measurement builds)
+    if (!pre_off) {
+      hipEvent_t masks = M->new_event(), ready = M->new_event();
+      SKF_CHECK_ARG(masks && ready, "event allocation failed");
+      SKF_TRY(forward_preamble(M, true, false, ss, masks));
+      SKF_HIP(hipEventRecord(ready, ss));
+      M->masks_ready = masks; M->pre_ready = ready;
+    }
   }
   SKF_TRY(skf_embed_sort(M->at<long long>(P.inp), Le, B, Le, c.vocab_size, M->G(L.enc_emb), d, M->at<char>(P.emb_sort[0]),
                          P.emb_sort_bytes, ss));

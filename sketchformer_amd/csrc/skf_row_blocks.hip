@@ -97,26 +97,66 @@ __global__ __launch_bounds__(1024) void row_list_kernel(const int* __restrict__ 
   if (blockIdx.x == 0 && tid == 0) { blocks[0] = nlive; blocks[1] = rows; }
 }
 
-// Samples sorted by the number of unmasked positions of up to two mask matrices (stable, most first): one workgroup; rank by counting
+// Samples sorted by the number of unmasked positions of up to two mask matrices (stable, most first): one workgroup on the step's
+// critical path, so every load is independent of the others (four mask bytes per request where the rows allow it, the sample's count in
+// LDS by atomic add); then rank by counting.  (First version: a wave per sample with the byte loads of a row behind one another - 17 us.)
+__device__ __forceinline__ void count_unmasked(const unsigned char* __restrict__ m, int ld, int L, int B, int* key, int tid) {
+  if (!m) return;
+  if (ld == L && ((uintptr_t)m & 3) == 0) {          // contiguous rows: the matrix as words, a word may straddle two samples
+    const int total = B * L, n = (total + 3) >> 2;
+    for (int i0 = tid; i0 < n; i0 += 4 * 1024) {
+      unsigned v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {           // four requests in flight per thread
+        const int i = i0 + 1024 * u, t0 = 4 * i;
+        v[u] = 0x01010101u;
+        if (t0 + 3 < total) v[u] = *reinterpret_cast<const unsigned*>(m + t0);
+        else if (t0 < total) v[u] = (unsigned)m[t0] | (t0 + 1 < total ? (unsigned)m[t0 + 1] << 8 : 0x100u) | (t0 + 2 < total ? (unsigned)m[t0 + 2] << 16 : 0x10000u) | 0x1000000u;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t0 = 4 * (i0 + 1024 * u), b = t0 / L, split = (b + 1) * L - t0;       // bytes [0, split) of the word belong to sample b
+        int z0 = 0, z1 = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int z = ((v[u] >> (8 * e)) & 0xffu) == 0u;
+          if (e < split) z0 += z; else z1 += z;
+        }
+        if (z0) atomicAdd(&key[b], z0);
+        if (z1) atomicAdd(&key[b + 1], z1);
+      }
+    }
+  } else {
+    const int n = B * L;
+    for (int i = tid; i < n; i += 1024) {
+      const int b = i / L, t = i - b * L;
+      if (!m[(size_t)b * ld + t]) atomicAdd(&key[b], 1);
+    }
+  }
+}
 __global__ __launch_bounds__(1024) void sample_order_kernel(const unsigned char* __restrict__ ma, int lda, int La,
                                                             const unsigned char* __restrict__ mb, int ldb, int Lb, int B, int* __restrict__ order) {
-  extern __shared__ int key[];                 // [B]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int b = wave; b < B; b += 16) {
-    int n = 0;
-    if (ma) for (int t = lane; t < La; t += 64) n += ma[(size_t)b * lda + t] ? 0 : 1;
-    if (mb) for (int t = lane; t < Lb; t += 64) n += mb[(size_t)b * ldb + t] ? 0 : 1;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
-    if (lane == 0) key[b] = n;
+  extern __shared__ int key[];                 // [B] counts, [B] ranks
+  int* rank = key + B;
+  const int tid = threadIdx.x;
+  for (int b = tid; b < 2 * B; b += 1024) key[b] = 0;
+  __syncthreads();
+  count_unmasked(ma, lda, La, B, key, tid);
+  count_unmasked(mb, ldb, Lb, B, key, tid);
+  __syncthreads();
+  // rank[b] = samples in front of b: `parts` threads per sample share the comparisons
+  const int parts = B >= 1024 ? 1 : 1024 / B, per_pass = 1024 / parts;
+  for (int b0 = 0; b0 < B; b0 += per_pass) {
+    const int b = b0 + tid / parts, part = tid - (tid / parts) * parts;
+    if (tid < per_pass * parts && b < B) {
+      const int k = key[b];
+      int cnt = 0;
+      for (int j = part; j < B; j += parts) { const int kj = key[j]; cnt += (kj > k || (kj == k && j < b)) ? 1 : 0; }
+      if (cnt) atomicAdd(&rank[b], cnt);
+    }
   }
   __syncthreads();
-  for (int b = tid; b < B; b += 1024) {
-    const int k = key[b];
-    int rank = 0;
-    for (int j = 0; j < B; ++j) { const int kj = key[j]; rank += (kj > k || (kj == k && j < b)) ? 1 : 0; }
-    order[rank] = b;
-  }
+  for (int b = tid; b < B; b += 1024) order[rank[b]] = b;
 }
 
 }  // namespace
@@ -125,7 +165,7 @@ extern "C" int skf_sample_order(const unsigned char* mask_a, int lda, int La, co
                                 skf_stream_t stream) {
   SKF_CHECK_ARG(order && B > 0 && B <= 8192 && (mask_a || mask_b), "bad argument");
   SKF_CHECK_ARG((!mask_a || (La > 0 && lda >= La)) && (!mask_b || (Lb > 0 && ldb >= Lb)), "bad mask shape");
-  hipLaunchKernelGGL(sample_order_kernel, dim3(1), dim3(1024), (size_t)B * sizeof(int), (hipStream_t)stream, mask_a, lda, La, mask_b, ldb, Lb, B, order);
+  hipLaunchKernelGGL(sample_order_kernel, dim3(1), dim3(1024), (size_t)2 * B * sizeof(int), (hipStream_t)stream, mask_a, lda, La, mask_b, ldb, Lb, B, order);
   SKF_LAUNCH_CHECK();
   return SKF_OK;
 }

@@ -513,6 +513,8 @@ def test_sample_order_and_dealt_attention_workgroups(ops, seed):
         got = ops.sample_order(a_, b_).cpu().numpy()
         want = np.argsort(-key, kind="stable")
         assert np.array_equal(got, want), (got, want)
+    wide = _dev(np.concatenate([ma, np.zeros((B, 3), bool)], axis=1), torch.uint8)          # rows with a pitch: the byte path
+    assert np.array_equal(ops.sample_order(wide[:, :Lk], None).cpu().numpy(), np.argsort(-la, kind="stable"))
     order = ops.sample_order(ma_d, mb_d)
     perm = torch.as_tensor(rng.permutation(B).astype(np.int32)).cuda()
     q, k, v, do = (_dev(rng.randn(B, n, d)) for n in (Lq, Lk, Lk, Lq))
