@@ -252,9 +252,9 @@ int skf_attention_bwd_rows(const float* Q, int ldq, const float* K, int ldk, con
 /* Padded batches: a (sample, head) workgroup costs what its sample's length makes it cost, and consecutive workgroups of an XCD are
  * handed to its four shader engines in turn and never leave them - so the engine that draws the long samples finishes last.
  * skf_sample_order: order[0..B) = the samples sorted by the number of UNMASKED positions in up to two padding-mask matrices (either may
- * be NULL), most first, stable.  The *_ordered forms take that list (or NULL = the plain numbering) and deal the sorted (sample, head)
- * pairs over the 32 engines, heaviest first; used when B * H is a multiple of 32, ignored otherwise and by the kernels other than the
- * dh = 16 forward / skf_attention_bwd3.  The numbering never changes a result bit.  Measured (B 128, H 8, L 200, 58 % padding): the three
+ * be NULL), most first, stable.  The *_ordered forms take that list (or NULL = the plain numbering) and deal the sorted samples over the
+ * 8 XCDs, heaviest first, the heads of a sample over the engines of its XCD; used when B is a multiple of 8, ignored otherwise and by the
+ * plain fp32 kernels of other head sizes.  The numbering never changes a result bit.  Measured (B 128, H 8, L 200, 58 % padding): the three
  * backward calls of a layer 168 -> 143 us, the forward calls 98 -> 90 us (profiles/r05o_attn_order.txt). */
 int skf_sample_order(const unsigned char* mask_a, int lda, int La, const unsigned char* mask_b, int ldb, int Lb, int B, int* order,
                      skf_stream_t stream);
@@ -480,6 +480,16 @@ int skf_attention_bf16_bwd_rows(const void* Q, int ldq, const void* K, int ldk, 
                                 int key_mask_ld, int causal, int B, int H, int Lq, int Lk, int dh, void* dQ, int lddq, void* dK,
                                 int lddk, void* dV, int lddv, void* workspace, size_t workspace_bytes, const int* q_live_len,
                                 skf_stream_t stream);
+/* the same with the sorted sample list of skf_sample_order (or NULL): the (sample, head) pairs of the list are dealt over the 8 XCDs and,
+ * inside one, over its shader engines (B a multiple of 8, ignored otherwise); a numbering, never a result bit */
+int skf_attention_bf16_fwd_ordered(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const unsigned char* key_mask,
+                                   int key_mask_ld, int causal, int B, int H, int Lq, int Lk, int dh, void* O, int ldo, void* O_lo,
+                                   float* stats, const int* sample_order, skf_stream_t stream);
+int skf_attention_bf16_bwd_ordered(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const void* O, int ldo,
+                                   const void* O_lo, const void* dO, int lddo, const float* stats, const unsigned char* key_mask,
+                                   int key_mask_ld, int causal, int B, int H, int Lq, int Lk, int dh, void* dQ, int lddq, void* dK,
+                                   int lddk, void* dV, int lddv, void* workspace, size_t workspace_bytes, const int* q_live_len,
+                                   const int* sample_order, skf_stream_t stream);
 /* row kernels: the fp32 entries of the same name with bf16 activations (d in {128, 256, 512, 1024}) */
 int skf_embed_fwd_bf16(const long long* tokens, int tok_ld, int B, int L, const float* table, int vocab, int d, const float* pos,
                        void* out, float rate, unsigned site, const void* step_state, skf_stream_t stream);

@@ -185,6 +185,8 @@ SIGNATURES = {
     "skf_attention_bf16_bwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I,
                                     _P, _I, _P, _I, _P, _I, _P, _Z, _P]),
     "skf_attention_bf16_bwd_rows": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _Z, _P, _P]),
+    "skf_attention_bf16_fwd_ordered": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P]),
+    "skf_attention_bf16_bwd_ordered": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _Z, _P, _P, _P]),
     "skf_embed_fwd_bf16": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _P, _F, _U, _P, _P]),
     "skf_embed_bwd_sorted_bf16": (_I, [_P, _I, _I, _P, _I, _I, _P, _F, _U, _P, _P]),
     "skf_layernorm_residual_fwd_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _U, _P, _P]),

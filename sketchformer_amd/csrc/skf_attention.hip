@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256, MAXT <= 13 ? 4 : 1) void attn_fwd_kernel(AttnP
   // other half belongs to the neighbouring head.  XCD-contiguous ids put all heads of a sample on ONE XCD (one L2),
   // consecutively in time, so the neighbour's half is an L2 hit instead of a second HBM fetch of the same line.
   int bh = p.xcd_remap ? skf_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  if (p.order) { const int k = skf_deal_rank(blockIdx.x); bh = p.order[k / p.H] * p.H + k % p.H; }
+  if (p.order) { const int k = skf_deal_rank(blockIdx.x, p.H); bh = p.order[k / p.H] * p.H + k % p.H; }
   const int b = bh / p.H, h = bh % p.H;
   const int nkt = (p.Lk + 15) >> 4, nqt = (p.Lq + 15) >> 4;
   const int VP = nkt * 16 + 8;            // pitch of the transposed V image: (VP / 4) mod 4 == 2 keeps the ds_read_b128 of the PV
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256, SKF_ATTN_BWD_WAVES) void attn_bwd_kernel(AttnP
   // other half belongs to the neighbouring head.  XCD-contiguous ids put all heads of a sample on ONE XCD (one L2),
   // consecutively in time, so the neighbour's half is an L2 hit instead of a second HBM fetch of the same line.
   int bh = p.xcd_remap ? skf_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  if (p.order) { const int k = skf_deal_rank(blockIdx.x); bh = p.order[k / p.H] * p.H + k % p.H; }
+  if (p.order) { const int k = skf_deal_rank(blockIdx.x, p.H); bh = p.order[k / p.H] * p.H + k % p.H; }
   const int b = bh / p.H, h = bh % p.H;
   const int nkt = (p.Lk + 15) >> 4, nqt_all = (p.Lq + 15) >> 4;
   // query tiles behind the sample's last live row have dO == 0: they add nothing to dK / dV and their dQ is zero
@@ -664,7 +664,7 @@ extern "C" int skf_attention_fwd_ordered(const float* Q, int ldq, const float* K
                                          const unsigned char* key_mask, int key_mask_ld, int causal, int B, int H, int Lq, int Lk,
                                          int dh, float* O, int ldo, float* stats, int precision, const int* sample_order, skf_stream_t stream) {
   AttnParams p{};
-  p.order = ((B * H) & 31) == 0 ? sample_order : nullptr;      // (the deal needs whole rounds of the 32 shader engines; results never depend on it)
+  p.order = (B & 7) == 0 ? sample_order : nullptr;      // (the deal needs whole rounds of the 8 XCDs; results never depend on it)
   p.Q = Q; p.K = K; p.V = V; p.O = O; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
   p.key_mask = key_mask; p.key_mask_ld = key_mask_ld; p.causal = causal; p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.stats = stats;
   { const char* e = skf_knob("SKF_ATTN_XCD"); p.xcd_remap = !(e && e[0] == '0'); }
@@ -733,7 +733,7 @@ extern "C" int skf_attention_bwd_ordered(const float* Q, int ldq, const float* K
   const bool two_pass = (precision & SKF_ATTN_TWO_PASS) != 0;
   precision &= ~SKF_ATTN_TWO_PASS;
   AttnParams p{};
-  p.order = ((B * H) & 31) == 0 ? sample_order : nullptr;
+  p.order = (B & 7) == 0 ? sample_order : nullptr;
   p.q_live = q_live_len;
   p.Q = Q; p.K = K; p.V = V; p.O = const_cast<float*>(O); p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
   p.key_mask = key_mask; p.key_mask_ld = key_mask_ld; p.causal = causal; p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk;

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd3_kernel(AttnParams p) {
   // workgroups per CU walking the heads with the second one started late so that one stages while the other multiplies - static
   // head assignment loses more on padded batches (91 vs 71 us) than the offset gains (100 vs 107 us on full-length rows).
   int bh = p.xcd_remap ? skf_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  if (p.order) { const int k = skf_deal_rank(blockIdx.x); bh = p.order[k / p.H] * p.H + k % p.H; }
+  if (p.order) { const int k = skf_deal_rank(blockIdx.x, p.H); bh = p.order[k / p.H] * p.H + k % p.H; }
   const int b = bh / p.H, h = bh % p.H;
 #if SKF_MEASURE     // clock stamps of a few workgroups (tools/attn_bwd3_timeline.py): measurement builds only
   long long* dbg = (p.dbg && lane == 0 && (blockIdx.x % 131) == 0 && blockIdx.x / 131 < 8) ? p.dbg + ((blockIdx.x / 131) * 8 + wave) * 16 : nullptr;

@@ -43,6 +43,7 @@ struct AP {
   skf_bf16* dQ; skf_bf16* dK; skf_bf16* dV; int lddq, lddk, lddv;
   float* delta;                 // (B, H, Lq) rowsum(dO o O): written by the dQ pass, read by the dK/dV pass
   const int* q_live;            // optional (B): query rows >= q_live[b] have dO == 0 exactly (skf_target_live_len) - backward only
+  const int* order;             // optional (B): the samples sorted by length, longest first (skf_sample_order); needs B % 8 == 0 (the entry checks)
   skf_bf16* Olo;                // optional (same shape / pitch as O): O_fp32 - bf16(O), the rounding residual of the output.
                                 // delta = rowsum(dO o O) is subtracted from dP = dO.V^T, which it nearly cancels wherever the
                                 // softmax gradient is small: with O at 8 significand bits the error of delta (2^-9 |delta|)
@@ -135,8 +136,18 @@ __global__ __launch_bounds__(256, 3) void attn_bf16_q_kernel(AP p) {
   // (round 5) the block a workgroup takes is rotated by its (b, h): under the look-ahead mask block nqb-1 visits the most keys, and
   // with 4 blocks per (b, h) numbered in order every such block went to the same shader engine (see skf_part_major; the part-major
   // numbering itself costs this kernel 10 % - measured, profiles/r05n_bf16_attn_dispatch.txt)
-  const int lid = skf_xcd_remap(blockIdx.x, gridDim.x);
-  const int bh = lid / nqb, qb = (lid - bh * nqb + bh + (bh >> 3)) % nqb, b = bh / p.H, h = bh % p.H;
+  // (round 5) with a sorted sample list: the samples of the list are dealt over the 8 XCDs (skf_deal_rank), the m-th (sample, head) pair
+  // of an XCD takes this kernel's blocks in a row - every XCD, and every engine of it, gets the same mix of lengths, longest first
+  int bh, qb;
+  if (p.order) {
+    const int i = blockIdx.x >> 3, m = i / nqb, r = skf_deal_rank((int)(blockIdx.x & 7) + 8 * m, p.H);
+    qb = (i - m * nqb + m + (m >> 3)) % nqb;
+    bh = p.order[r / p.H] * p.H + r % p.H;
+  } else {
+    const int lid = skf_xcd_remap(blockIdx.x, gridDim.x);
+    bh = lid / nqb; qb = (lid - bh * nqb + bh + (bh >> 3)) % nqb;
+  }
+  const int b = bh / p.H, h = bh % p.H;
   const int q0 = qb * 128 + wave * 32, q = q0 + lq;
   const bool qok = q < p.Lq;
   if constexpr (MODE == 1) {
@@ -348,9 +359,16 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kv_kernel(AP p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lk = lane & 31, hi = lane >> 5;
   const int nkb = (p.Lk + 127) >> 7;
-  const int lid = skf_xcd_remap(blockIdx.x, gridDim.x);
   int kbk, bh;
-  skf_part_major(lid, p.B * p.H, nkb, &bh, &kbk);       // key block 0 (never all padding, the most queries under the look-ahead mask) first
+  if (p.order) {       // the sorted (sample, head) pairs dealt over the XCDs (see the forward / dQ kernel), block-major in chunks of 32 inside an XCD
+    int m;
+    skf_part_major((int)(blockIdx.x >> 3), (p.B * p.H) >> 3, nkb, &m, &kbk);
+    const int r = skf_deal_rank((int)(blockIdx.x & 7) + 8 * m, p.H);
+    bh = p.order[r / p.H] * p.H + r % p.H;
+  } else {
+    const int lid = skf_xcd_remap(blockIdx.x, gridDim.x);
+    skf_part_major(lid, p.B * p.H, nkb, &bh, &kbk);     // key block 0 (never all padding, the most queries under the look-ahead mask) first
+  }
   const int b = bh / p.H, h = bh % p.H;
   const int k0 = kbk * 128 + wave * 32, key = k0 + lk;
   const bool kok = key < p.Lk;
@@ -521,7 +539,14 @@ int set_smem(K kfn, size_t bytes) {
 extern "C" int skf_attention_bf16_fwd(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
                                       const unsigned char* key_mask, int key_mask_ld, int causal, int B, int H, int Lq, int Lk,
                                       int dh, void* O, int ldo, void* O_lo, float* stats, skf_stream_t stream) {
+  return skf_attention_bf16_fwd_ordered(Q, ldq, K, ldk, V, ldv, key_mask, key_mask_ld, causal, B, H, Lq, Lk, dh, O, ldo, O_lo, stats, nullptr, stream);
+}
+
+extern "C" int skf_attention_bf16_fwd_ordered(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
+                                              const unsigned char* key_mask, int key_mask_ld, int causal, int B, int H, int Lq, int Lk,
+                                              int dh, void* O, int ldo, void* O_lo, float* stats, const int* sample_order, skf_stream_t stream) {
   AP p{};
+  p.order = (B & 7) == 0 ? sample_order : nullptr;     // whole rounds of the 8 XCDs (a numbering: never a result bit)
   p.Olo = (skf_bf16*)O_lo;
   p.Q = (const skf_bf16*)Q; p.K = (const skf_bf16*)K; p.V = (const skf_bf16*)V; p.O = (skf_bf16*)O;
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.key_mask = key_mask; p.key_mask_ld = key_mask_ld; p.causal = causal;
@@ -547,8 +572,8 @@ extern "C" int skf_attention_bf16_bwd(const void* Q, int ldq, const void* K, int
                                       int key_mask_ld, int causal, int B, int H, int Lq, int Lk, int dh, void* dQ, int lddq,
                                       void* dK, int lddk, void* dV, int lddv, void* workspace, size_t workspace_bytes,
                                       skf_stream_t stream) {
-  return skf_attention_bf16_bwd_rows(Q, ldq, K, ldk, V, ldv, O, ldo, O_lo, dO, lddo, stats, key_mask, key_mask_ld, causal, B, H, Lq, Lk, dh,
-                                     dQ, lddq, dK, lddk, dV, lddv, workspace, workspace_bytes, nullptr, stream);
+  return skf_attention_bf16_bwd_ordered(Q, ldq, K, ldk, V, ldv, O, ldo, O_lo, dO, lddo, stats, key_mask, key_mask_ld, causal, B, H, Lq, Lk, dh,
+                                        dQ, lddq, dK, lddk, dV, lddv, workspace, workspace_bytes, nullptr, nullptr, stream);
 }
 
 extern "C" int skf_attention_bf16_bwd_rows(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const void* O,
@@ -556,8 +581,18 @@ extern "C" int skf_attention_bf16_bwd_rows(const void* Q, int ldq, const void* K
                                            const unsigned char* key_mask, int key_mask_ld, int causal, int B, int H, int Lq, int Lk,
                                            int dh, void* dQ, int lddq, void* dK, int lddk, void* dV, int lddv, void* workspace,
                                            size_t workspace_bytes, const int* q_live_len, skf_stream_t stream) {
+  return skf_attention_bf16_bwd_ordered(Q, ldq, K, ldk, V, ldv, O, ldo, O_lo, dO, lddo, stats, key_mask, key_mask_ld, causal, B, H, Lq, Lk, dh,
+                                        dQ, lddq, dK, lddk, dV, lddv, workspace, workspace_bytes, q_live_len, nullptr, stream);
+}
+
+extern "C" int skf_attention_bf16_bwd_ordered(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const void* O,
+                                              int ldo, const void* O_lo, const void* dO, int lddo, const float* stats,
+                                              const unsigned char* key_mask, int key_mask_ld, int causal, int B, int H, int Lq, int Lk,
+                                              int dh, void* dQ, int lddq, void* dK, int lddk, void* dV, int lddv, void* workspace,
+                                              size_t workspace_bytes, const int* q_live_len, const int* sample_order, skf_stream_t stream) {
   AP p{};
   p.q_live = q_live_len;
+  p.order = (B & 7) == 0 ? sample_order : nullptr;
   p.Q = (const skf_bf16*)Q; p.K = (const skf_bf16*)K; p.V = (const skf_bf16*)V; p.O = (skf_bf16*)const_cast<void*>(O);
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.key_mask = key_mask; p.key_mask_ld = key_mask_ld; p.causal = causal;
   p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.stats = const_cast<float*>(stats);

@@ -96,12 +96,14 @@ __device__ __forceinline__ void skf_part_major(int lid, int ngroups, int nparts,
   *g = chunk * G + j - *w * gc;
 }
 // The other way round: workgroups whose cost is known per SAMPLE (padded batches: one workgroup per (sample, head)).  Given the
-// samples sorted by cost (heaviest first) and numbered k = rank * H + head, workgroup `bid` takes the k that DEALS the sorted list
-// over the 32 shader engines of the chip (bid -> XCD bid % 8, arrival i = bid / 8 in that XCD -> engine i % 4): every engine gets
-// the same mix of lengths, heaviest first.  Needs gridDim.x % 32 == 0 (the caller checks).
-__device__ __forceinline__ int skf_deal_rank(int bid) {
-  const int x = bid & 7, i = bid >> 3;
-  return 32 * (i >> 2) + 4 * x + (i & 3);
+// samples sorted by cost (heaviest first), workgroup `bid` (-> XCD bid % 8, arrival i = bid / 8 in that XCD -> engine i % 4) takes head
+// i % H of the sample with rank (bid % 8) + 8 * (i / H): the sorted list is DEALT over the XCDs, heaviest first, and the heads of a
+// sample stay on one XCD, spread over its engines - every XCD and every engine gets the same mix of lengths, and an XCD reads whole
+// activation rows (its heads' slices side by side: with the heads of a row on eight XCDs each L2 saw one 128-byte slice per KB and the
+// bf16 dQ pass ran 27 % slower).  Returns rank * H + head; needs B % 8 == 0 (the caller checks).
+__device__ __forceinline__ int skf_deal_rank(int bid, int H) {
+  const int x = bid & 7, i = bid >> 3, m = i / H;
+  return (x + 8 * m) * H + (i - m * H);
 }
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -185,6 +185,35 @@ def test_attention_bf16_bwd_live_query_counts_is_exact(lib, causal, Lk):
     assert float(res[1][0][0].float().abs().max()) == 0.0          # sample 0 has no live row at all
 
 
+@pytest.mark.parametrize("causal", [False, True])
+def test_attention_bf16_sorted_sample_list_is_a_numbering(lib, causal):
+    """skf_attention_bf16_{fwd,bwd}_ordered with the list of skf_sample_order (B * H = 256: the deal over XCDs and shader engines is
+    taken) or any permutation: every output bit equals the plain call."""
+    from sketchformer_amd import ops
+    B, H, L, dh = 32, 8, 300, 64
+    d = H * dh
+    rng = np.random.RandomState(31 + causal)
+    Q, _ = _bf(rng.randn(B, L, d)); K, _ = _bf(rng.randn(B, L, d)); V, _ = _bf(rng.randn(B, L, d))
+    lens = rng.randint(1, L + 1, size=B)
+    km = torch.as_tensor(np.arange(L)[None, :] >= lens[:, None]).to(torch.uint8).cuda()
+    live = torch.as_tensor(lens.astype(np.int32)).cuda()
+    dO, _ = _bf(rng.randn(B, L, d) * (np.arange(L)[None, :, None] < lens[:, None, None]))
+    ws = torch.empty(B * H * L, dtype=torch.float32, device="cuda")
+    res = []
+    for od in (None, ops.sample_order(km, None), torch.as_tensor(rng.permutation(B).astype(np.int32)).cuda()):
+        O = torch.empty(B, L, d, dtype=BF, device="cuda"); Olo = torch.empty_like(O)
+        stats = torch.empty(B, H, L, 2, dtype=torch.float32, device="cuda")
+        lib.call("skf_attention_bf16_fwd_ordered", _p(Q), d, _p(K), d, _p(V), d, _p(km), L, int(causal), B, H, L, L, dh, _p(O), d, _p(Olo),
+                 _p(stats), _p(od), _s())
+        dQ, dK, dV = (torch.full((B, L, d), 3.0, dtype=BF, device="cuda") for _ in range(3))
+        lib.call("skf_attention_bf16_bwd_ordered", _p(Q), d, _p(K), d, _p(V), d, _p(O), d, _p(Olo), _p(dO), d, _p(stats), _p(km), L, int(causal),
+                 B, H, L, L, dh, _p(dQ), d, _p(dK), d, _p(dV), d, _p(ws), ws.numel() * 4, _p(live), _p(od), _s())
+        res.append((O, Olo, stats, dQ, dK, dV))
+    for r in res[1:]:
+        for a, b_ in zip(res[0], r):
+            assert torch.equal(a, b_)
+
+
 def test_attention_bf16_fully_padded_sample_is_uniform(lib):
     B, H, L, dh = 2, 2, 130, 64
     d = H * dh

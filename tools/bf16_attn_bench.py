@@ -17,15 +17,18 @@ Q = torch.randn(B, L, d, device="cuda").to(BF); K = torch.randn(B, L, d, device=
 dO = torch.randn(B, L, d, device="cuda").to(BF)
 O = torch.empty_like(Q); Olo = torch.empty_like(Q); stats = torch.empty(B, H, L, 2, device="cuda")
 ws = torch.empty(B * H * L, device="cuda"); dQ = torch.empty_like(Q); dK = torch.empty_like(Q); dV = torch.empty_like(Q)
+from sketchformer_amd import ops
+order = ops.sample_order(km, None)
 for name, mask, causal in (("enc self (pad %.2f)" % km.float().mean().item(), km, 0), ("dec self (causal+pad)", km, 1), ("cross / full (no mask)", None, 0), ("causal, no pad", None, 1)):
+  for od in ((None, order) if mask is not None else (None,)):
     def fwd():
-        _lib.call("skf_attention_bf16_fwd", p(Q), d, p(K), d, p(V), d, p(mask), L if mask is not None else 0, causal, B, H, L, L, dh, p(O), d, p(Olo), p(stats), s())
+        _lib.call("skf_attention_bf16_fwd_ordered", p(Q), d, p(K), d, p(V), d, p(mask), L if mask is not None else 0, causal, B, H, L, L, dh, p(O), d, p(Olo), p(stats), p(od), s())
     def bwd():
-        _lib.call("skf_attention_bf16_bwd", p(Q), d, p(K), d, p(V), d, p(O), d, p(Olo), p(dO), d, p(stats), p(mask), L if mask is not None else 0, causal,
-                  B, H, L, L, dh, p(dQ), d, p(dK), d, p(dV), d, p(ws), ws.numel() * 4, s())
+        _lib.call("skf_attention_bf16_bwd_ordered", p(Q), d, p(K), d, p(V), d, p(O), d, p(Olo), p(dO), d, p(stats), p(mask), L if mask is not None else 0, causal,
+                  B, H, L, L, dh, p(dQ), d, p(dK), d, p(dV), d, p(ws), ws.numel() * 4, None, p(od), s())
     for _ in range(3): fwd(); bwd()
     torch.cuda.synchronize(); lib.skf_profiler_enable(1)
     for _ in range(20): fwd(); bwd()
     torch.cuda.synchronize()
     buf = C.create_string_buffer(1 << 16); lib.skf_profiler_report(buf, len(buf)); lib.skf_profiler_enable(0)
-    print("%-24s" % name, "  ".join("%s %.1f us" % (r["tag"].replace("attn_bf16_", "").replace("<dh64>", ""), r["ms"] / r["count"] * 1e3) for r in json.loads(buf.value.decode())))
+    print("%-24s%-8s" % (name, "sorted" if od is not None else ""), "  ".join("%s %.1f us" % (r["tag"].replace("attn_bf16_", "").replace("<dh64>", ""), r["ms"] / r["count"] * 1e3) for r in json.loads(buf.value.decode())))
