@@ -170,7 +170,10 @@ int skf_ffn_fused_fwd_proj_f32(int M, int d, int dff, const float* x, const void
  *   pre_z = pre_residual + dropout(a . Wo + pre_bias, rate, pre_site);  pre_out = LayerNorm(pre_z; pre_gamma, pre_beta);  pre_stats = (mean, rstd)
  * - the MultiHeadAttention output projection with its residual LayerNorm (builders/layers/transformer.py:186, 216-224 / 262-268), i.e.
  * skf_gemm_ln_residual_f32 - and pre_out is the block's input and residual (pre_image = skf_dense_weight_images(Wo [d][d], transpose 0)).
- * Chained projection (proj_image != NULL): as skf_ffn_fused_fwd_proj_f32.  struct_size = sizeof(SkfFfnBlockFwd). */
+ * Chained projection (proj_image != NULL): as skf_ffn_fused_fwd_proj_f32.  struct_size = sizeof(SkfFfnBlockFwd).
+ * image == NULL (with pre_image and proj_image): NO feed-forward block - the leading stage followed by the projection of ITS LayerNorm
+ * output, proj_out = pre_out . Wp + proj_bias: the decoder's self-attention tail with the cross-attention query projection behind it
+ * (builders/layers/transformer.py:258-262); b1, b2, h, relu_bits_out, gamma, beta, z, out, stats, site are not used. */
 typedef struct SkfFfnBlockFwd {
   uint32_t struct_size; int32_t M, d, dff, precision;
   const float* x; const void* image; const float* b1; const float* b2; float* h; void* relu_bits_out;

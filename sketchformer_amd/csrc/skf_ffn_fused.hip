@@ -79,13 +79,13 @@ size_t image_bytes(int pieces) { return (size_t)2 * pieces * (FD * FF * 2); }
 // The feed-forward pair: image 1 = B1 [128][512] followed by image 2 = B2 [512][128]; forward B1 = W1, B2 = W2; input gradient
 // B1 = W2^T, B2 = W1^T.
 struct DenseImageDesc { const float* src; char* img; int ld, transpose, K, N, block_begin, pad; };
-constexpr int kImageBatch = 64;   // (64 descriptors of 40 bytes: 2.5 KB of kernel arguments; the 58 images of a cfg-2 train step are one launch)
+constexpr int kImageBatch = 80;   // (80 descriptors of 40 bytes: 3.1 KB of kernel arguments; the 66 images of a cfg-2 train step are one launch)
 struct DenseImageBatch { DenseImageDesc d[kImageBatch]; int n; };
 
 template <int P>
 __global__ __launch_bounds__(256) void dense_image_kernel(DenseImageBatch batch) {
   int j = 0;
-  while (j + 1 < batch.n && (int)blockIdx.x >= batch.d[j + 1].block_begin) ++j;       // (wave-uniform, <= 64 steps)
+  while (j + 1 < batch.n && (int)blockIdx.x >= batch.d[j + 1].block_begin) ++j;       // (wave-uniform, <= 80 steps)
   const DenseImageDesc d = batch.d[j];
   const SkfSplitSel sel = skf_split_sel();
   const int t = ((int)blockIdx.x - d.block_begin) * 256 + threadIdx.x;
@@ -211,11 +211,15 @@ __device__ __forceinline__ float ffn_half_wave_sum(float v) {
 // PRE (forward only): the launch STARTS one sublayer earlier, at the attention output a: x1 = LayerNorm(x + dropout(a . Wo + bo)) - the
 // MultiHeadAttention output projection with its residual LayerNorm (builders/layers/transformer.py:186, 216-224) - is formed by one
 // product stage (K = N = 128) and a row epilogue in front of the feed-forward block, whose input and residual it is.
-template <int P, int MODE, bool LNB = false, bool POST = false, bool PRE = false>
-__global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnFusedParams p) {
+// NOFFN (forward, PRE and POST only): the launch is the leading stage followed at once by the chained projection of ITS LayerNorm
+// output - the decoder's self-attention tail with the cross-attention query projection behind it (builders/layers/transformer.py:258-262):
+// no hidden blocks, no second LayerNorm; runs as attn_tail_proj_kernel (a name of its own in profiles).
+template <int P, int MODE, bool LNB, bool POST, bool PRE, bool NOFFN>
+__device__ __forceinline__ void ffn_fused_body(const FfnFusedParams& p) {
   static_assert(!LNB || MODE == 1, "LayerNorm-backward prologue: backward only");
   static_assert(!POST || MODE == 0, "chained projection: forward only");
   static_assert(!PRE || MODE == 0, "leading projection + LayerNorm: forward only");
+  static_assert(!NOFFN || (PRE && POST), "tail + projection: needs both stages");
   extern __shared__ __attribute__((aligned(16))) char smem_f[];
   char* Xp = smem_f;                     // [P][ROWS][256]
   char* Hp = smem_f + P * PLANE;         // [2][P][ROWS][256]
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnFusedParams p) {
   const int st_row = tid >> 5, st_c = tid & 31;            // staging: thread -> (row of the tile, float4 of the row)
   const unsigned st_off = (unsigned)(st_row * RPITCH + (((st_c >> 1) ^ st_row) << 4) + (st_c & 1) * 8);
   const unsigned st_voff = (unsigned)(st_row * p.lda + 4 * st_c) * 4u;
-  if (MODE == 0 && tid < FF / 4) *reinterpret_cast<f32x4*>(B1s + 4 * tid) = *reinterpret_cast<const f32x4*>(p.bias1 + 4 * tid);   // (read behind the staging barrier)
+  if (MODE == 0 && !NOFFN && tid < FF / 4) *reinterpret_cast<f32x4*>(B1s + 4 * tid) = *reinterpret_cast<const f32x4*>(p.bias1 + 4 * tid);   // (read behind the staging barrier)
   float* B3s = B1s + FF;                 // POST: the chained projection's bias [n2 <= 384] (a global load in front of each block's
                                          // first product was a cold miss per block: the chained launch took 34 us for 24 us of projection)
   if (POST && tid >= 128 && tid - 128 < p.n2 / 4) *reinterpret_cast<f32x4*>(B3s + 4 * (tid - 128)) = *reinterpret_cast<const f32x4*>(p.bias3 + 4 * (tid - 128));
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnFusedParams p) {
   const float* bias1_p = B1s + 16 * wave + 4 * g;
   // (s_setprio 1 for the second-dispatched half, which loses the issue arbitration on its SIMD to the older wave and makes waves
   //  0-3 wait 2-4 k cycles at every block barrier, only swaps the roles: measured with stamps, zero-sum)
-  const f32x4 bias2_r = MODE == 0 ? *reinterpret_cast<const f32x4*>(p.bias2 + 16 * wave + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  const f32x4 bias2_r = MODE == 0 && !NOFFN ? *reinterpret_cast<const f32x4*>(p.bias2 + 16 * wave + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // epilogue constants: a half-wave owns a row (32 lanes x 4 columns)
   const int e_half = lane >> 5, e_sub = lane & 31;     // row 2 wave + e_half = tid >> 5 = st_row, float4 e_sub = st_c: the staging map
@@ -284,8 +288,10 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnFusedParams p) {
       thresh = skf_drop_thresh(p.rate);
       inv_keep = 1.0f / (1.0f - p.rate);
     }
-    gm = *reinterpret_cast<const f32x4*>(p.gamma + 4 * e_sub);
-    if constexpr (MODE == 0) bt = *reinterpret_cast<const f32x4*>(p.beta + 4 * e_sub);
+    if constexpr (!NOFFN) {
+      gm = *reinterpret_cast<const f32x4*>(p.gamma + 4 * e_sub);
+      if constexpr (MODE == 0) bt = *reinterpret_cast<const f32x4*>(p.beta + 4 * e_sub);
+    }
   }
   f32x4 ln_dg = (f32x4){0.f, 0.f, 0.f, 0.f}, ln_db = ln_dg;     // LNB: this thread's columns of dgamma / dbeta over its rows
 
@@ -321,7 +327,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnFusedParams p) {
   const int img1_w = wave * (NKS * P * 1024);            // + b * 8 * NKS * P * 1024
   const int img2_w = wave * (16 * P * 1024);             // + b * NKS * P * 1024
   u32x4 w1[NKS][P], w2[NKS][P];
-  if (nsub > 0) load_frags<P>(w1, r_img1, lane16, img1_w, true);
+  if (!NOFFN && nsub > 0) load_frags<P>(w1, r_img1, lane16, img1_w, true);
 #if SKF_FFN_ABLATE & 32
   load_frags<P>(w2, r_img2, lane16, img2_w, true);
 #endif
@@ -480,7 +486,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnFusedParams p) {
 #endif
 
 #pragma unroll 1
-    for (int b = 0; b < NBLK; ++b) {
+    for (int b = 0; b < (NOFFN ? 0 : NBLK); ++b) {
       char* Hb = Hp + (b & 1) * (P * PLANE);
       const f32x4 b1 = MODE == 0 ? *reinterpret_cast<const f32x4*>(bias1_p + HB * b) : (f32x4){0.f, 0.f, 0.f, 0.f};   // (LDS)
       if (b == NBLK - 1) {                      // the next sub-group's rows (all four descriptors: absent tiles read as zeros)
@@ -584,8 +590,13 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnFusedParams p) {
       FFN_STAMP();   // stage 2 issued
     }
 
+    if constexpr (NOFFN) {                      // (no hidden block to hide them under: the next sub-group's rows are requested here)
+      nrt_next = sub_tiles(pos, sub + 1, tn);
+      request_rows(tn, xn);
+    }
     // ---- epilogue: Y through LDS, a half-wave per row
     if constexpr (POST) load_frags<P>(w2, r_img3, lane16, wave * (NKS * P * 1024));   // the chained projection's first operands
+    if constexpr (!NOFFN) {
 #pragma unroll
     for (int rt = 0; rt < NRT; ++rt) *reinterpret_cast<f32x4*>(Yt + (rt * TR + i) * YPITCH + 16 * wave + 4 * g) = y[rt];
     f32x4 xres[NRT];
@@ -614,6 +625,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnFusedParams p) {
         }
       }
     }
+    }   // !NOFFN
     if constexpr (POST) {
       // ---- the chained projection: out2[rows][nb * 128 + 16 wave + 4g ..] = out . B3 + bias3, 128 output columns at a time.
       // Operand registers: w2 for even blocks (free since the last hidden block), w1 for odd ones (it holds the next sub-group's
@@ -651,7 +663,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnFusedParams p) {
         FFN_STAMP();   // (POST) block 1
         if (nb2 > 2) post_block(w2, 2);
         FFN_STAMP();   // (POST) block 2
-        load_frags<P>(w1, r_img1, lane16, img1_w);        // the next sub-group's first operands again
+        if constexpr (!NOFFN) load_frags<P>(w1, r_img1, lane16, img1_w);        // the next sub-group's first operands again
       }
       __syncthreads();                                   // the next sub-group's staging overwrites the planes
     }
@@ -701,6 +713,11 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnFusedParams p) {
     }
   }
 }
+
+template <int P, int MODE, bool LNB = false, bool POST = false, bool PRE = false>
+__global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnFusedParams p) { ffn_fused_body<P, MODE, LNB, POST, PRE, false>(p); }
+template <int P>
+__global__ __launch_bounds__(512, 2) void attn_tail_proj_kernel(FfnFusedParams p) { ffn_fused_body<P, 0, false, true, true, true>(p); }
 
 // ---------------------------------------------------------------- LayerNorm backward + the input gradient of the Dense in front of it
 // The attention sublayers' counterpart of the LNB prologue above: out = LayerNorm(x + dropout(Dense(a))) (the MultiHeadAttention
@@ -911,9 +928,26 @@ int launch_ffn(const FfnFusedParams& p, hipStream_t st) {
   return SKF_OK;
 }
 
+// the self-attention tail with the next projection (NOFFN): a = p.A, x1 = LayerNorm(pre_res + dropout(a . Bp + pre_bias)), out2 = x1 . B3 + bias3
+template <int P>
+int launch_tail_proj(const FfnFusedParams& p, hipStream_t st) {
+  const int grid = ffn_grid(p.M);
+  const size_t smem = (size_t)3 * P * PLANE + (P * PLANE >= ROWS * YPITCH * 4 ? 0 : ROWS * YPITCH * 4) + (FF + 384 + 3 * FD) * sizeof(float);
+  SKF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_tail_proj_kernel<P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  static const std::string tag = std::string("attn_tail_proj<d128,bf16x") + std::to_string(P * (P + 1) / 2) + ">";
+  const double flops = 2.0 * p.M * FD * FD + 2.0 * p.M * FD * p.n2;
+  const double bytes = 4.0 * ((double)p.M * FD * 4 + (double)p.M * p.n2) + 2.0 * P * FD * (FD + p.n2);
+  SkfProfScope ps(st, tag.c_str(), flops, bytes);
+  ps.done(flops, bytes);
+  hipLaunchKernelGGL((attn_tail_proj_kernel<P>), dim3(grid), dim3(512), smem, st, p);
+  SKF_LAUNCH_CHECK();
+  return SKF_OK;
+}
+
 }  // namespace
 
 int skf_ffn_fused_launch(const FfnFusedParams& p, int pieces, int direction, hipStream_t st) {
+  if (direction == 0 && p.pre_img && p.img3 && !p.img1) return pieces == 2 ? launch_tail_proj<2>(p, st) : launch_tail_proj<3>(p, st);
   if (direction == 1 && p.ln_dout) return pieces == 2 ? launch_ffn<2, 1, true>(p, st) : launch_ffn<3, 1, true>(p, st);
   if (direction == 0 && p.pre_img && p.img3) return pieces == 2 ? launch_ffn<2, 0, false, true, true>(p, st) : launch_ffn<3, 0, false, true, true>(p, st);
   if (direction == 0 && p.pre_img) return pieces == 2 ? launch_ffn<2, 0, false, false, true>(p, st) : launch_ffn<3, 0, false, false, true>(p, st);
@@ -1103,16 +1137,22 @@ extern "C" int skf_ffn_fused_fwd_proj_f32(int M, int d, int dff, const float* x,
 
 extern "C" int skf_ffn_block_fwd_f32(const SkfFfnBlockFwd* b, skf_stream_t stream) {
   SKF_CHECK_ARG(b && b->struct_size == sizeof(SkfFfnBlockFwd), "SkfFfnBlockFwd.struct_size does not match this library's include/skf.h");
-  const int rc = ffn_common_checks(b->M, b->d, b->dff, b->precision, b->x, b->image, b->h, b->z);
-  if (rc != SKF_OK) return rc;
-  SKF_CHECK_ARG(b->gamma && b->beta && b->out && b->stats && b->b1 && b->b2, "null bias / LayerNorm operand");
+  const bool tail_only = !b->image;           // no feed-forward block: the leading stage and the projection of ITS LayerNorm output
+  if (tail_only) {
+    SKF_CHECK_ARG(skf_ffn_fused_supported(b->M, b->d, b->dff > 0 ? b->dff : FF, b->precision), "row-owner launches: d = 128 in a split-arithmetic mode only");
+    SKF_CHECK_ARG(b->x && b->pre_image && b->proj_image && ((uintptr_t)b->x & 15) == 0, "without a feed-forward image the launch needs the leading stage and the chained projection");
+  } else {
+    const int rc = ffn_common_checks(b->M, b->d, b->dff, b->precision, b->x, b->image, b->h, b->z);
+    if (rc != SKF_OK) return rc;
+    SKF_CHECK_ARG(b->gamma && b->beta && b->out && b->stats && b->b1 && b->b2, "null bias / LayerNorm operand");
+    SKF_CHECK_ARG((((uintptr_t)b->out | (uintptr_t)b->gamma | (uintptr_t)b->beta | (uintptr_t)b->b1 | (uintptr_t)b->b2) & 15) == 0 &&
+                  (((uintptr_t)b->stats | (uintptr_t)b->relu_bits_out) & 7) == 0, "operands must be 16-byte aligned");
+  }
   SKF_CHECK_ARG(b->rate >= 0.f && b->rate < 1.f && (b->rate == 0.f || b->step_state), "dropout needs 0 <= rate < 1 and the step state");
-  SKF_CHECK_ARG((((uintptr_t)b->out | (uintptr_t)b->gamma | (uintptr_t)b->beta | (uintptr_t)b->b1 | (uintptr_t)b->b2) & 15) == 0 &&
-                (((uintptr_t)b->stats | (uintptr_t)b->relu_bits_out) & 7) == 0, "operands must be 16-byte aligned");
   const int P = b->precision == SKF_PREC_BF16X3 ? 2 : 3;
   FfnFusedParams p{};
   p.A = b->x; p.lda = b->d; p.M = b->M;
-  p.img1 = (const char*)b->image; p.img2 = (const char*)b->image + image_bytes(P) / 2;
+  p.img1 = (const char*)b->image; p.img2 = tail_only ? nullptr : (const char*)b->image + image_bytes(P) / 2;
   p.bias1 = b->b1; p.bias2 = b->b2; p.H = b->h; p.bits_out = (unsigned long long*)b->relu_bits_out;
   p.C = b->z; p.res = b->x; p.gamma = b->gamma; p.beta = b->beta; p.out = b->out; p.stats = b->stats;
   p.rate = b->rate; p.site = b->site; p.state = b->step_state;

@@ -293,7 +293,7 @@ struct Bump {
 };
 
 struct EncAct { size_t x_in, qkv, o, z1, st1, astats, x1, h, z2, st2, x2, hbits, img[2], img_o, img_qkv, img_of; };   // img: pre-split ffn weight images (forward, backward); img_o: Wo^T; img_qkv: this layer's Wqkv (read by the PREVIOUS layer's feed-forward launch)
-struct DecAct { size_t x_in, qkv, o1, z1, st1, astats1, out1, q2, kv2, o2, astats2, z2, st2, out2, h, z3, st3, out3, hbits, img[2], img_o1, img_o2, img_qkv, img_o2f; };
+struct DecAct { size_t x_in, qkv, o1, z1, st1, astats1, out1, q2, kv2, o2, astats2, z2, st2, out2, h, z3, st3, out3, hbits, img[2], img_o1, img_o2, img_qkv, img_o2f, img_o1f, img_q2; };
 
 struct Plan {
   size_t bytes = 0;
@@ -370,6 +370,7 @@ Plan build_plan(const SkfConfig& c) {
     a.img_o1 = b.take(skf_dense_image_bytes((int)d, (int)d, c.gemm_precision)); a.img_o2 = b.take(skf_dense_image_bytes((int)d, (int)d, c.gemm_precision));
     a.img_qkv = b.take(skf_dense_image_bytes((int)d, 3 * (int)d, c.gemm_precision));
     a.img_o2f = b.take(skf_dense_image_bytes((int)d, (int)d, c.gemm_precision));
+    a.img_o1f = b.take(skf_dense_image_bytes((int)d, (int)d, c.gemm_precision)); a.img_q2 = b.take(skf_dense_image_bytes((int)d, (int)d, c.gemm_precision));
     a.out3 = 0;
     P.dec.push_back(a);
   }
@@ -834,6 +835,7 @@ int build_ffn_images(SkfModel* M, bool with_backward, bool encoder_only, hipStre
       ffn(L.dec[i].f1, L.dec[i].f2, P.dec[i].img);
       if (i > 0) one(L.dec[i].mha1.qkv, 0, d, 3 * d, M->at<char>(P.dec[i].img_qkv));
       one(L.dec[i].mha2.o, 0, d, d, M->at<char>(P.dec[i].img_o2f));
+      one(L.dec[i].mha1.o, 0, d, d, M->at<char>(P.dec[i].img_o1f)); one(L.dec[i].mha2.q, 0, d, d, M->at<char>(P.dec[i].img_q2));   // self-attention tail + query projection
       if (with_backward) { one(L.dec[i].mha1.o, 1, d, d, M->at<char>(P.dec[i].img_o1)); one(L.dec[i].mha2.o, 1, d, d, M->at<char>(P.dec[i].img_o2)); }
     }
   return skf_dense_weight_images((int)src.size(), src.data(), ld.data(), tr.data(), K.data(), N.data(), img.data(), c.gemm_precision, s);
@@ -929,9 +931,9 @@ int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s, bool 
   const float* inpf = M->at<float>(P.inp);      // continuous mode: (B, L, 5) stroke-5 rows
   const float* tarf = M->at<float>(P.tar);
   // weight images, padding masks, sample order: here, unless the train step already put them on the side stream (issue_embed_sorts)
-  hipEvent_t pre_ready = M->pre_ready, masks_ready = M->masks_ready;
+  hipEvent_t images_ready = M->pre_ready, masks_ready = M->masks_ready;
   M->pre_ready = M->masks_ready = nullptr;
-  if (!pre_ready) SKF_TRY(forward_preamble(M, training && with_loss, encoder_only, s));
+  if (!images_ready) SKF_TRY(forward_preamble(M, training && with_loss, encoder_only, s));
   const int* order = M->order;
 
   // ---------------- encoder (builders/layers/transformer.py:288-301)
@@ -948,11 +950,11 @@ int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s, bool 
     float* x = M->at<float>(a.x_in);
     float* qkv = M->at<float>(a.qkv);
     if (!enc_qkv_done) SKF_TRY(dense_fwd(M, w.mha.qkv, x, Me, qkv, 0, s));     // (else: the previous layer's feed-forward launch wrote it)
-    if (i == 0 && pre_ready) SKF_HIP(hipStreamWaitEvent(s, masks_ready, 0));    // masks and order were built beside the embedding and this projection
+    if (i == 0 && images_ready) SKF_HIP(hipStreamWaitEvent(s, masks_ready, 0));    // masks and order were built beside the embedding and this projection
     SKF_TRY(skf_attention_fwd_ordered(qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, emask, Le, 0, B, H, Le, Le, dh,
                                       M->at<float>(a.o), d, M->at<float>(a.astats), M->cfg.gemm_precision, order, s));
     const bool has_next = i + 1 < N;
-    if (i == 0 && pre_ready) SKF_HIP(hipStreamWaitEvent(s, pre_ready, 0));      // ... and the weight images beside the first attention
+    if (i == 0 && images_ready) SKF_HIP(hipStreamWaitEvent(s, images_ready, 0));      // ... and the weight images beside the first attention
     SKF_TRY(attn_tail_ffn_fwd(M, w.mha.o, w.ln1, M->at<float>(a.o), x, M->at<float>(a.z1), M->at<float>(a.x1), M->at<float>(a.st1),
                               site_enc(i, 0), M->at<char>(a.img_of), w.f1, w.f2, w.ln2, M->at<float>(a.h), hbits_of(M, a.hbits, Me),
                               M->at<char>(a.img[0]), M->at<float>(a.z2), M->at<float>(a.x2), M->at<float>(a.st2), site_enc(i, 1), Me, rate, s,
@@ -994,15 +996,22 @@ int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s, bool 
   const unsigned char* cross_mask = c.blind_decoder_mask ? nullptr : emask;
   // The cross-attention K|V projections of ALL decoder layers only depend on pre_decoder: on the eager path they run
   // on the side stream under the first layer's self-attention block (one event pair) instead of on the critical path.
-  hipEvent_t kv_done = nullptr;
+  // (round 5: the first layer's cross-attention waits for ITS projection only - it used to wait for all of them, 45 us with the main
+  //  stream idle at cfg 2 - the second layer's for the rest)
+  hipEvent_t kv_done = nullptr, kv_first = nullptr;
   if (M->side) {
     M->next_event = 0;
-    hipEvent_t pre_ready = M->new_event();
+    hipEvent_t dec_in_ready = M->new_event();
     kv_done = M->new_event();
-    SKF_CHECK_ARG(pre_ready && kv_done, "event allocation failed");
-    SKF_HIP(hipEventRecord(pre_ready, s));
-    SKF_HIP(hipStreamWaitEvent(M->side, pre_ready, 0));
-    for (int i = 0; i < N; ++i) SKF_TRY(dense_fwd(M, L.dec[i].mha2.kv, pre, Me, M->at<float>(P.dec[i].kv2), 0, M->side));
+    static const bool wait_all = skf_knob("SKF_KV_WAIT_ALL") && skf_knob("SKF_KV_WAIT_ALL")[0] == '1';      // (measurement builds)
+    kv_first = N > 1 && !wait_all ? M->new_event() : kv_done;
+    SKF_CHECK_ARG(dec_in_ready && kv_done && kv_first, "event allocation failed");
+    SKF_HIP(hipEventRecord(dec_in_ready, s));
+    SKF_HIP(hipStreamWaitEvent(M->side, dec_in_ready, 0));
+    for (int i = 0; i < N; ++i) {
+      SKF_TRY(dense_fwd(M, L.dec[i].mha2.kv, pre, Me, M->at<float>(P.dec[i].kv2), 0, M->side));
+      if (i == 0 && kv_first != kv_done) SKF_HIP(hipEventRecord(kv_first, M->side));
+    }
     SKF_HIP(hipEventRecord(kv_done, M->side));
   }
   bool dec_qkv_done = false;
@@ -1014,12 +1023,28 @@ int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s, bool 
     if (!dec_qkv_done) SKF_TRY(dense_fwd(M, w.mha1.qkv, x, Md, qkv, 0, s));
     SKF_TRY(skf_attention_fwd_ordered(qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, dmask, Ld, 1, B, H, Ld, Ld, dh,
                                       M->at<float>(a.o1), d, M->at<float>(a.astats1), M->cfg.gemm_precision, order, s));
-    SKF_TRY(dense_ln_fwd(M, w.mha1.o, M->at<float>(a.o1), Md, x, M->at<float>(a.z1), w.ln1, M->at<float>(a.out1), M->at<float>(a.st1),
-                         rate, site_dec(N, i, 0), s));
+    // out1 = LayerNorm(x + dropout(o1 . Wo + bo)) and q2 = out1 . Wq + bq: one row-owner launch where that kernel runs
+    // (skf_ffn_block_fwd_f32 without a feed-forward image), else the fused Dense + LayerNorm launch and the projection launch
+    static const bool tail_off = skf_knob("SKF_NO_TAIL_PROJ") && skf_knob("SKF_NO_TAIL_PROJ")[0] == '1';   // (measurement builds only)
+    const bool tail_proj = M->ffn_fused && !tail_off && w.mha1.o.in == d && w.mha1.o.out == d && w.mha2.q.in == d && w.mha2.q.out == d &&
+                           w.mha2.q.ld == d && w.ln1.b == w.ln1.g + (size_t)d;
+    if (tail_proj) {
+      SkfFfnBlockFwd tb{};
+      tb.struct_size = sizeof(SkfFfnBlockFwd); tb.M = Md; tb.d = d; tb.dff = c.dff; tb.precision = c.gemm_precision;
+      tb.x = M->at<float>(a.o1); tb.rate = rate; tb.step_state = M->state;
+      tb.pre_image = M->at<char>(a.img_o1f); tb.pre_bias = M->P(w.mha1.o.b); tb.pre_residual = x; tb.pre_gamma = M->P(w.ln1.g); tb.pre_beta = M->P(w.ln1.b);
+      tb.pre_z = M->at<float>(a.z1); tb.pre_out = M->at<float>(a.out1); tb.pre_stats = M->at<float>(a.st1); tb.pre_site = site_dec(N, i, 0);
+      tb.proj_image = M->at<char>(a.img_q2); tb.proj_bias = M->P(w.mha2.q.b); tb.proj_out = M->at<float>(a.q2); tb.proj_n = d;
+      SKF_TRY(skf_ffn_block_fwd_f32(&tb, s));
+    } else {
+      SKF_TRY(dense_ln_fwd(M, w.mha1.o, M->at<float>(a.o1), Md, x, M->at<float>(a.z1), w.ln1, M->at<float>(a.out1), M->at<float>(a.st1),
+                           rate, site_dec(N, i, 0), s));
+      SKF_TRY(dense_fwd(M, w.mha2.q, M->at<float>(a.out1), Md, M->at<float>(a.q2), 0, s));
+    }
     float* kv2 = M->at<float>(a.kv2);
-    SKF_TRY(dense_fwd(M, w.mha2.q, M->at<float>(a.out1), Md, M->at<float>(a.q2), 0, s));
     if (!kv_done) SKF_TRY(dense_fwd(M, w.mha2.kv, pre, Me, kv2, 0, s));
-    else if (i == 0) SKF_HIP(hipStreamWaitEvent(s, kv_done, 0));
+    else if (i == 0) SKF_HIP(hipStreamWaitEvent(s, kv_first, 0));
+    else if (i == 1) SKF_HIP(hipStreamWaitEvent(s, kv_done, 0));
     SKF_TRY(skf_attention_fwd_ordered(M->at<float>(a.q2), d, kv2, 2 * d, kv2 + d, 2 * d, cross_mask, Le, 0, B, H, Ld, Le, dh,
                                       M->at<float>(a.o2), d, M->at<float>(a.astats2), M->cfg.gemm_precision, order, s));
     const bool has_next = i + 1 < N;

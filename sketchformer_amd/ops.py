@@ -340,6 +340,23 @@ def ffn_block_fwd(a, residual, pre, image, b1, b2, gamma, beta, dff, rate=0.0, p
     return r
 
 
+def attn_tail_proj(a, residual, pre, proj, rate=0.0, pre_site=0, state=None, precision=None):
+    """skf_ffn_block_fwd_f32 without a feed-forward image: z1 = residual + dropout(a.Wo + bo), x1 = LayerNorm(z1), proj_out = x1.Wp + bp in
+    one launch (pre = (image of Wo, bo, gamma, beta), proj = (image of Wp, bp)) -> dict(z1, x1, stats1, proj_out)."""
+    _f32(a, "a")
+    M, d = a.shape
+    e = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=a.device)  # noqa: E731
+    r = {"z1": e(M, d), "x1": e(M, d), "stats1": e(M, 2), "proj_out": e(M, proj[1].numel())}
+    pimg, pbias, pg, pb = pre
+    P = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    blk = _lib.SkfFfnBlockFwd(struct_size=C.sizeof(_lib.SkfFfnBlockFwd), M=M, d=d, dff=4 * d, precision=_prec(precision), x=P(a), rate=rate,
+                              step_state=P(state), pre_image=P(pimg), pre_bias=P(pbias), pre_residual=P(residual), pre_gamma=P(pg), pre_beta=P(pb),
+                              pre_z=P(r["z1"]), pre_out=P(r["x1"]), pre_stats=P(r["stats1"]), pre_site=pre_site, proj_image=P(proj[0]),
+                              proj_bias=P(proj[1]), proj_out=P(r["proj_out"]), proj_n=proj[1].numel())
+    _lib.call("skf_ffn_block_fwd_f32", C.byref(blk), _stream())
+    return r
+
+
 def ffn_fused_bwd(dy, image_t, bits, dff, dx=None, row_blocks=None, precision=None):
     """One launch: dh = (dy.W2^T) o relu'(h), dx (+)= dh.W1^T -> dh, dx (accumulated into `dx` when given)."""
     _f32(dy, "dy")

@@ -1124,6 +1124,43 @@ def test_ffn_block_forward_from_attention_output(ops, rows, n2, rate):
         assert (r["x1"] - o1).abs().max().item() <= 2e-5 * max(1.0, o1.abs().max().item())
 
 
+@pytest.mark.parametrize("rows,n2,rate", [(25472, 128, 0.1), (1031, 128, 0.0), (7, 128, 0.1), (4000, 384, 0.1)])
+def test_attention_tail_with_the_next_projection(ops, rows, n2, rate):
+    """skf_ffn_block_fwd_f32 without a feed-forward image (round 5): the decoder's self-attention tail x1 = LayerNorm(x + dropout(a.Wo + bo))
+    and the cross-attention query projection q = x1.Wq + bq (builders/layers/transformer.py:258-262) in one row-owner launch - against
+    the oracle, against the two launches it replaces, and with the leading stage's outputs bit-equal to the full block's."""
+    d = 128
+    rng = np.random.RandomState(rows + n2 + 11)
+    a, x = rng.randn(rows, d), rng.randn(rows, d)
+    wo, bo = rng.randn(d, d) / np.sqrt(d), 0.1 * rng.randn(d)
+    wp, bp = rng.randn(d, n2) / np.sqrt(d), 0.1 * rng.randn(n2)
+    g1, be1 = 1 + 0.1 * rng.randn(d), 0.1 * rng.randn(d)
+    st = ops.new_step_state("cuda", iterations=3)
+    ops.step_prologue(st, seed=5)
+    key = ops.read_step_state(st)["drop_key"]
+    k1 = ops.dropout_keep_mask(key, 4, rate, rows * d).reshape(rows, d) if rate > 0 else np.ones((rows, d), bool)
+    z1 = x + oracle.dropout_fwd(a @ wo + bo, k1, rate)
+    x1, _ = oracle.layernorm_fwd(z1, g1, be1)
+    A, X, WO, BO, WP, BP, G1, BE1 = (_dev(v) for v in (a, x, wo, bo, wp, bp, g1, be1))
+    pre = (ops.dense_weight_image(WO, transpose=False), BO, G1, BE1)
+    r = ops.attn_tail_proj(A, X, pre, (ops.dense_weight_image(WP, transpose=False), BP), rate=rate, pre_site=4, state=st)
+    _close(r["z1"], z1, name="z1")
+    _close(r["x1"], x1, name="x1")
+    _close(r["stats1"][:, 0], z1.mean(-1), name="mean1")
+    _close(r["proj_out"], x1 @ wp + bp, rtol=3e-5, name="projection")
+    # the two launches it replaces
+    o1, zz1, _ = ops.gemm_ln_residual(A, WO, BO, X, G1, BE1, rate=rate, site=4, state=st, precision=6)
+    ref = ops.gemm(r["x1"], WP, bias=BP)
+    assert (r["z1"] - zz1).abs().max().item() <= 2e-6 * max(1.0, zz1.abs().max().item())
+    assert (r["x1"] - o1).abs().max().item() <= 2e-5 * max(1.0, o1.abs().max().item())
+    assert (r["proj_out"] - ref).abs().max().item() <= 4e-6 * max(1.0, ref.abs().max().item())
+    # the same leading stage inside the full block
+    w1, w2 = _dev(rng.randn(d, 512) / np.sqrt(d)), _dev(rng.randn(512, d) / np.sqrt(512))
+    img, = ops.ffn_weight_images([(w1, w2)], transpose=False)
+    full = ops.ffn_block_fwd(A, X, pre, img, _dev(np.zeros(512)), _dev(np.zeros(d)), G1, BE1, 512, rate=rate, pre_site=4, site=9, state=st)
+    assert torch.equal(full["z1"], r["z1"]) and torch.equal(full["x1"], r["x1"]) and torch.equal(full["stats1"], r["stats1"])
+
+
 def test_ffn_fused_refuses_other_shapes(ops):
     lib = ops._lib.load()
     assert lib.skf_ffn_fused_supported(25600, 128, 512, 6) == 1
