@@ -309,7 +309,9 @@ struct Plan {
   // Buffers that weight-gradient GEMMs read (dY operands).  Two sets, alternating by layer: the wgrads of a layer are
   // issued together on the side stream at the end of that layer, so their operands must stay untouched until the
   // layer after next starts (every cross-stream event costs ~5 us of dead time on the main stream).
-  struct GradSet { size_t dy[3], dh, dq2, dkv2, dqkv; } gs[2];
+  struct GradSet { size_t dy[3], dh, dq2, dkv2, dqkv; };
+  std::vector<GradSet> gs;        // gradient buffers of the backward, n_gs sets in rotation (one per layer where memory allows: see plan())
+  int n_gs = 2;
   size_t gemm_ws, gemm_ws_bytes, small_ws, small_ws_bytes;
   size_t emb_sort[2] = {0, 0}, emb_sort_bytes = 0;         // token positions sorted by id (encoder, decoder): skf_embed_sort
   size_t slab_arena, slab_arena_bytes, descs, n_wgrads;   // deferred split-K reduction (eager path)
@@ -382,7 +384,18 @@ Plan build_plan(const SkfConfig& c) {
   P.gA = b.take(Me * d * f); P.gB = b.take(Me * d * f); P.gC = b.take(Me * d * f);
   P.dqkv = b.take(Me * 3 * d * f); P.dh = b.take(Me * F * f); P.do_ = b.take(Me * d * f);
   P.dpre = b.take(Me * E * f); P.dkv2 = b.take(Me * 2 * d * f); P.dq2 = b.take(Md * d * f); P.demb = b.take(B * E * f);
-  for (int k = 0; k < 2; ++k) {
+  // A layer's weight gradients (side stream) read its dy / dh / dq|k|v buffers long after the main stream has moved on, so the buffers
+  // rotate.  With two sets the main stream waits for the group of two layers ago in front of every layer - finished long since, but a
+  // wait in the queue costs the waiting stream ~6 us whether or not it has to wait (tools/wait_cost.py).  One set per layer: no buffer
+  // is written twice in a step and those waits are gone (cfg 2: 8 x 170 MB); above 8 GB the sets fall back to two.
+  {
+    const size_t per_set = (3 * Me * d + Me * F + Md * d + Me * 2 * d + Me * 3 * d) * f;
+    static const bool two_sets = skf_knob("SKF_TWO_GRAD_SETS") && skf_knob("SKF_TWO_GRAD_SETS")[0] == '1';      // (measurement builds)
+    const size_t layers = (size_t)c.num_layers * (do_recon(c) ? 2 : 1);
+    P.n_gs = (two_sets || per_set * layers > ((size_t)8 << 30) || layers < 2) ? 2 : (int)layers;
+    P.gs.resize(P.n_gs);
+  }
+  for (int k = 0; k < P.n_gs; ++k) {
     for (int j = 0; j < 3; ++j) P.gs[k].dy[j] = b.take(Me * d * f);
     P.gs[k].dh = k == 0 ? P.dh : b.take(Me * F * f);
     P.gs[k].dq2 = k == 0 ? P.dq2 : b.take(Md * d * f);
@@ -1261,7 +1274,7 @@ int run_backward(SkfModel* M, hipStream_t s) {
   for (int i = N - 1; i >= 0; --i, ++layer_no) {
     const DecLayerP& w = L.dec[i];
     const DecAct& a = P.dec[i];
-    const Plan::GradSet& gs = P.gs[layer_no & 1];
+    const Plan::GradSet& gs = P.gs[layer_no % P.n_gs];
     float* dy3 = M->at<float>(gs.dy[0]); float* dy2 = M->at<float>(gs.dy[1]); float* dy1 = M->at<float>(gs.dy[2]);
     float* dqkv = M->at<float>(gs.dqkv); float* dkv2 = M->at<float>(gs.dkv2); float* dq2 = M->at<float>(gs.dq2);
     // out3 = LN3(out2 + drop(ffn(out2)))
@@ -1373,7 +1386,7 @@ int run_backward(SkfModel* M, hipStream_t s) {
   for (int i = N - 1; i >= 0; --i, ++layer_no) {
     const EncLayerP& w = L.enc[i];
     const EncAct& a = P.enc[i];
-    const Plan::GradSet& gs = P.gs[layer_no & 1];
+    const Plan::GradSet& gs = P.gs[layer_no % P.n_gs];
     float* dy2 = M->at<float>(gs.dy[0]); float* dy1 = M->at<float>(gs.dy[1]);
     float* dqkv = M->at<float>(gs.dqkv);
     SKF_TRY(ffn_ln_bwd(M, w.ln2, w.f1, w.f2, G, M->at<float>(a.z2), M->at<float>(a.st2), M->at<float>(a.x1), M->at<float>(a.h), dy2,

@@ -1,7 +1,10 @@
 #!/usr/bin/env python
-"""What a cross-stream wait costs the WAITING stream: N kernels of ~25 us on stream A (the host runs ahead), a short kernel + event record
-on stream B per iteration; with / without A waiting for that event in front of its kernel.  The event is complete long before A gets
-there (B's kernels depend on nothing), so the difference is what the wait itself costs A."""
+"""What cross-stream synchronisation costs a stream whose kernels run back to back: N kernels of ~25 us on stream A (the host runs
+ahead) and a short kernel on stream B per iteration, with
+  wait   : A waits (hipStreamWaitEvent) for an event B recorded - complete long before A gets there
+  record : A records an event that B waits for (A itself never waits)
+  both   : both of the above per iteration
+The difference to `none` is what the packet costs stream A."""
 import time
 import torch
 
@@ -11,24 +14,26 @@ y = torch.zeros(1 << 10, device="cuda")
 N = 400
 
 
-def run(wait, every=1):
+def run(mode):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(N):
-        ev = None
         with torch.cuda.stream(b):
             y.add_(1.0)
-            if i % every == 0:
+            if mode in ("wait", "both"):
                 ev = torch.cuda.Event(); ev.record(b)
         with torch.cuda.stream(a):
-            if wait and ev is not None:
+            if mode in ("wait", "both"):
                 a.wait_event(ev)
             x.add_(1.0)
+            if mode in ("record", "both"):
+                e2 = torch.cuda.Event(); e2.record(a)
+                b.wait_event(e2)
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / N * 1e6
 
 
+run("none")
 for _ in range(2):
-    print("no wait            %.2f us per iteration" % run(False), flush=True)
-    print("wait every kernel  %.2f us per iteration" % run(True), flush=True)
-    print("wait every 4th     %.2f us per iteration" % run(True, 4), flush=True)
+    for mode in ("none", "wait", "record", "both"):
+        print("%-7s %.2f us per iteration" % (mode, run(mode)), flush=True)
