@@ -214,6 +214,13 @@ int skf_layernorm_bwd_dgrad_f32(int M, int d, const float* dout, const float* z,
                                 float rate, unsigned site, const void* step_state, const void* image_t, float* dz, float* dy,
                                 float* da, float* ln_partials, size_t ln_partials_bytes, const int* row_blocks,
                                 int row_block_rows, int precision, skf_stream_t stream);
+/* the same with a LEADING product: the gradient of `out` is dout + lead_a[M,d] . Wl^T (lead_image_t = the transposed image of Wl [d][d]) -
+ * the input gradient of a Dense that reads `out` (the decoder's cross-attention query projection, builders/layers/transformer.py:258-262),
+ * formed in the launch instead of being accumulated into dout by a GEMM launch of its own; lead_a == NULL: skf_layernorm_bwd_dgrad_f32 */
+int skf_layernorm_bwd_dgrad_lead_f32(int M, int d, const float* dout, const float* lead_a, const void* lead_image_t, const float* z,
+                                     const float* stats, const float* gamma, float rate, unsigned site, const void* step_state,
+                                     const void* image_t, float* dz, float* dy, float* da, float* ln_partials, size_t ln_partials_bytes,
+                                     const int* row_blocks, int row_block_rows, int precision, skf_stream_t stream);
 int skf_gemm_wgrad_partial_rows(int M, int N, int K, const float* A, int lda, const float* B, int ldb, int splits,
                                 int with_bias_grad, float* slab, size_t slab_bytes, int* splits_used_host, int precision,
                                 const int* row_blocks, int row_block_rows, skf_stream_t stream);

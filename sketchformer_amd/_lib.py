@@ -114,6 +114,7 @@ SIGNATURES = {
     "skf_layernorm_bwd_dgrad_supported": (_I, [_I, _I, _I]),
     "skf_layernorm_bwd_dgrad_partials": (_I, [_I]),
     "skf_layernorm_bwd_dgrad_f32": (_I, [_I, _I, _P, _P, _P, _P, _F, _U, _P, _P, _P, _P, _P, _P, _Z, _P, _I, _I, _P]),
+    "skf_layernorm_bwd_dgrad_lead_f32": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _F, _U, _P, _P, _P, _P, _P, _P, _Z, _P, _I, _I, _P]),
     "skf_ffn_fused_fwd_proj_f32": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _U, _P, _P, _P, _I, _P, _I, _P]),
     "skf_ffn_block_fwd_f32": (_I, [C.POINTER(SkfFfnBlockFwd), _P]),
     "skf_target_live_len": (_I, [_P, _I, _I, _I, _P, _P]),

@@ -732,12 +732,17 @@ struct LnDgradParams {
   float* part;
   int M; float rate; unsigned site; const void* state;
   const int* row_blocks;
+  // LEAD: the gradient of the LayerNorm output is dout + lead_a . Wl^T (lead_img = the transposed image of Wl [128][128]): the input
+  // gradient of a Dense that consumes the LayerNorm output (the cross-attention query projection behind the decoder's self-attention
+  // sublayer, builders/layers/transformer.py:258-262) formed in the same launch instead of accumulated into dout by one of its own
+  const float* lead_a; const char* lead_img;
 };
 
-template <int P>
+template <int P, bool LEAD>
 __global__ __launch_bounds__(512, 2) void ln_bwd_dgrad_kernel(LnDgradParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_f[];
   char* Xp = smem_f;                     // [P][ROWS][256]
+  float* Yt = reinterpret_cast<float*>(smem_f + P * PLANE);     // LEAD: the leading product's rows [ROWS][YPITCH]
   constexpr int TILE = TR * RPITCH;
   const SkfSplitSel sel = skf_split_sel();
   const int tid = threadIdx.x, lane = tid & 63;
@@ -778,11 +783,17 @@ __global__ __launch_bounds__(512, 2) void ln_bwd_dgrad_kernel(LnDgradParams p) {
   const __amdgpu_buffer_rsrc_t r_DZ = __builtin_amdgcn_make_buffer_rsrc(p.dz, 0, row_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_DY = __builtin_amdgcn_make_buffer_rsrc(p.dy, 0, row_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_C = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, row_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_L = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(LEAD ? p.lead_a : p.dout), 0, LEAD ? row_bytes : 0, 0x00020000);
 
   u32x4 w[NKS][P];
   if (nsub > 0) load_frags<P>(w, __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.img), 0, P * FD * FD * 2, 0x00020000), (unsigned)lane * 16u, wave * (NKS * P * 1024));
+  u32x4 wl[LEAD ? NKS : 1][P];
+  if constexpr (LEAD) {
+    if (nsub > 0) load_frags<P>(wl, __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.lead_img), 0, P * FD * FD * 2, 0x00020000), (unsigned)lane * 16u, wave * (NKS * P * 1024));
+  }
 
   f32x4 xn[MAXRT], zn[MAXRT];
+  f32x4 an[LEAD ? MAXRT : 1];
   u32x2 sn[MAXRT];
   int tn[MAXRT];
   auto sub_tiles = [&](int pos0, int sub_i, int (&t)[MAXRT]) -> int {
@@ -796,6 +807,7 @@ __global__ __launch_bounds__(512, 2) void ln_bwd_dgrad_kernel(LnDgradParams p) {
 #pragma unroll
     for (int rt = 0; rt < MAXRT; ++rt) {
       const unsigned voff = tn[rt] < ntiles ? st_voff + (unsigned)tn[rt] * (unsigned)(TR * FD * 4) : OOB;
+      if constexpr (LEAD) an[rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_L, voff, 0, 0));
       xn[rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_D, voff, 0, 0));
       zn[rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_Z, voff, 0, 0));
       sn[rt] = __builtin_amdgcn_raw_buffer_load_b64(r_S, tn[rt] < ntiles ? (unsigned)(tn[rt] * TR + st_row) * 8u : OOB, 0, 0);
@@ -810,12 +822,40 @@ __global__ __launch_bounds__(512, 2) void ln_bwd_dgrad_kernel(LnDgradParams p) {
 #pragma unroll
     for (int rt = 0; rt < MAXRT; ++rt) tl[rt] = tn[rt];
     pos += nrt;
+    if constexpr (LEAD) {
+      // ---- the leading product: rows of lead_a -> planes -> y = lead_a . Wl^T (a wave's 16 columns) -> the Y tile
+#pragma unroll
+      for (int rt = 0; rt < MAXRT; ++rt) {
+        unsigned lo[P], hi[P];
+        skf_split2<P>(an[rt][0], an[rt][1], lo, sel);
+        skf_split2<P>(an[rt][2], an[rt][3], hi, sel);
+#pragma unroll
+        for (int q = 0; q < P; ++q) *reinterpret_cast<u32x2*>(Xp + q * PLANE + rt * TILE + st_off) = (u32x2){lo[q], hi[q]};
+      }
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < MAXRT; ++t) {
+        if (t < nrt) {
+          FfnFrags<P> fr;
+          load_half<P>(Xp + t * TILE, a_off, fr.f[0], 0);
+          load_half<P>(Xp + t * TILE, a_off, fr.f[1], 1);
+          f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+          int c = 0;
+          half_products<P>(wl, fr.f[0], 0, acc0, acc1, c);
+          half_products<P>(wl, fr.f[1], 1, acc0, acc1, c);
+          *reinterpret_cast<f32x4*>(Yt + (t * TR + i) * YPITCH + 16 * wave + 4 * g) = acc0 + acc1;
+        }
+      }
+      __syncthreads();                          // the Y tile is complete, the planes are free for dy
+    }
     // ---- LayerNorm backward of this thread's float4 of row (tile rt, st_row) (ln_bwd_v4_kernel's arithmetic) on the way to LDS
 #pragma unroll
     for (int rt = 0; rt < MAXRT; ++rt) {
       typedef float f32x2_t __attribute__((ext_vector_type(2)));
       const f32x2_t ms = __builtin_bit_cast(f32x2_t, sn[rt]);
-      const f32x4 dv = xn[rt], zv = zn[rt];
+      f32x4 dv = xn[rt];
+      if constexpr (LEAD) { if (rt < nrt) dv += *reinterpret_cast<const f32x4*>(Yt + (rt * TR + st_row) * YPITCH + 4 * st_c); }
+      const f32x4 zv = zn[rt];
       const f32x4 xh = (zv - ms[0]) * ms[1], gg = dv * gm;
       ln_dg += dv * xh; ln_db += dv;
       const float s1 = ffn_half_wave_sum((gg[0] + gg[1]) + (gg[2] + gg[3])) * (1.0f / FD);
@@ -1089,7 +1129,16 @@ extern "C" int skf_layernorm_bwd_dgrad_f32(int M, int d, const float* dout, cons
                                            float rate, unsigned site, const void* step_state, const void* image_t, float* dz, float* dy,
                                            float* da, float* ln_partials, size_t ln_partials_bytes, const int* row_blocks,
                                            int row_block_rows, int precision, skf_stream_t stream) {
+  return skf_layernorm_bwd_dgrad_lead_f32(M, d, dout, nullptr, nullptr, z, stats, gamma, rate, site, step_state, image_t, dz, dy, da, ln_partials,
+                                          ln_partials_bytes, row_blocks, row_block_rows, precision, stream);
+}
+
+extern "C" int skf_layernorm_bwd_dgrad_lead_f32(int M, int d, const float* dout, const float* lead_a, const void* lead_image_t, const float* z,
+                                                const float* stats, const float* gamma, float rate, unsigned site, const void* step_state,
+                                                const void* image_t, float* dz, float* dy, float* da, float* ln_partials, size_t ln_partials_bytes,
+                                                const int* row_blocks, int row_block_rows, int precision, skf_stream_t stream) {
   SKF_CHECK_ARG(skf_layernorm_bwd_dgrad_supported(M, d, precision), "LayerNorm backward + input gradient: d = 128 in a split-arithmetic mode only");
+  SKF_CHECK_ARG(!lead_a == !lead_image_t && (((uintptr_t)lead_a | (uintptr_t)lead_image_t) & 15) == 0, "leading product: rows and the transposed image together, 16-byte aligned");
   SKF_CHECK_ARG(dout && z && stats && gamma && image_t && dz && dy && da && ln_partials, "null operand");
   SKF_CHECK_ARG((((uintptr_t)dout | (uintptr_t)z | (uintptr_t)gamma | (uintptr_t)image_t | (uintptr_t)dz | (uintptr_t)dy | (uintptr_t)da |
                   (uintptr_t)ln_partials) & 15) == 0 && ((uintptr_t)stats & 7) == 0, "operands must be 16-byte aligned");
@@ -1100,15 +1149,24 @@ extern "C" int skf_layernorm_bwd_dgrad_f32(int M, int d, const float* dout, cons
   LnDgradParams p{};
   p.dout = dout; p.z = z; p.stats = stats; p.gamma = gamma; p.dz = dz; p.dy = dy; p.C = da; p.img = (const char*)image_t;
   p.part = ln_partials; p.M = M; p.rate = rate; p.site = site; p.state = step_state; p.row_blocks = row_blocks;
+  p.lead_a = lead_a; p.lead_img = (const char*)lead_image_t;
   const int grid = ffn_grid(M);
-  const size_t smem = (size_t)P * PLANE;
+  const bool lead = lead_a != nullptr;
+  const size_t smem = (size_t)P * PLANE + (lead ? (size_t)ROWS * YPITCH * sizeof(float) : 0);
   hipStream_t st = (hipStream_t)stream;
   static const std::string tag2 = "ln_bwd_dgrad<d128,bf16x3>", tag3 = "ln_bwd_dgrad<d128,bf16x6>";
   const double live = skf_prof_list_fraction(row_blocks);
-  SkfProfScope ps(st, (P == 2 ? tag2 : tag3).c_str(), 2.0 * M * FD * FD, 4.0 * 5.0 * M * FD);
-  ps.done(2.0 * M * FD * FD * live, 4.0 * 5.0 * M * FD * live);
-  if (P == 2) hipLaunchKernelGGL(ln_bwd_dgrad_kernel<2>, dim3(grid), dim3(512), smem, st, p);
-  else hipLaunchKernelGGL(ln_bwd_dgrad_kernel<3>, dim3(grid), dim3(512), smem, st, p);
+  const double nprod = lead ? 2.0 : 1.0, nrows = lead ? 6.0 : 5.0;
+  SkfProfScope ps(st, (P == 2 ? tag2 : tag3).c_str(), nprod * 2.0 * M * FD * FD, 4.0 * nrows * M * FD);
+  ps.done(nprod * 2.0 * M * FD * FD * live, 4.0 * nrows * M * FD * live);
+#define SKF_LN_DGRAD_GO(PV, LV)                                                                                                                  \
+  {                                                                                                                                              \
+    SKF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_dgrad_kernel<PV, LV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+    hipLaunchKernelGGL((ln_bwd_dgrad_kernel<PV, LV>), dim3(grid), dim3(512), smem, st, p);                                                       \
+  }
+  if (P == 2) { if (lead) SKF_LN_DGRAD_GO(2, true) else SKF_LN_DGRAD_GO(2, false) }
+  else { if (lead) SKF_LN_DGRAD_GO(3, true) else SKF_LN_DGRAD_GO(3, false) }
+#undef SKF_LN_DGRAD_GO
   SKF_LAUNCH_CHECK();
   return SKF_OK;
 }

@@ -293,7 +293,7 @@ struct Bump {
 };
 
 struct EncAct { size_t x_in, qkv, o, z1, st1, astats, x1, h, z2, st2, x2, hbits, img[2], img_o, img_qkv, img_of; };   // img: pre-split ffn weight images (forward, backward); img_o: Wo^T; img_qkv: this layer's Wqkv (read by the PREVIOUS layer's feed-forward launch)
-struct DecAct { size_t x_in, qkv, o1, z1, st1, astats1, out1, q2, kv2, o2, astats2, z2, st2, out2, h, z3, st3, out3, hbits, img[2], img_o1, img_o2, img_qkv, img_o2f, img_o1f, img_q2; };
+struct DecAct { size_t x_in, qkv, o1, z1, st1, astats1, out1, q2, kv2, o2, astats2, z2, st2, out2, h, z3, st3, out3, hbits, img[2], img_o1, img_o2, img_qkv, img_o2f, img_o1f, img_q2, img_q2t; };
 
 struct Plan {
   size_t bytes = 0;
@@ -373,6 +373,7 @@ Plan build_plan(const SkfConfig& c) {
     a.img_qkv = b.take(skf_dense_image_bytes((int)d, 3 * (int)d, c.gemm_precision));
     a.img_o2f = b.take(skf_dense_image_bytes((int)d, (int)d, c.gemm_precision));
     a.img_o1f = b.take(skf_dense_image_bytes((int)d, (int)d, c.gemm_precision)); a.img_q2 = b.take(skf_dense_image_bytes((int)d, (int)d, c.gemm_precision));
+    a.img_q2t = b.take(skf_dense_image_bytes((int)d, (int)d, c.gemm_precision));
     a.out3 = 0;
     P.dec.push_back(a);
   }
@@ -850,6 +851,7 @@ int build_ffn_images(SkfModel* M, bool with_backward, bool encoder_only, hipStre
       one(L.dec[i].mha2.o, 0, d, d, M->at<char>(P.dec[i].img_o2f));
       one(L.dec[i].mha1.o, 0, d, d, M->at<char>(P.dec[i].img_o1f)); one(L.dec[i].mha2.q, 0, d, d, M->at<char>(P.dec[i].img_q2));   // self-attention tail + query projection
       if (with_backward) { one(L.dec[i].mha1.o, 1, d, d, M->at<char>(P.dec[i].img_o1)); one(L.dec[i].mha2.o, 1, d, d, M->at<char>(P.dec[i].img_o2)); }
+      if (with_backward) one(L.dec[i].mha2.q, 1, d, d, M->at<char>(P.dec[i].img_q2t));      // its input gradient rides in the self-attention sublayer's LayerNorm launch
     }
   return skf_dense_weight_images((int)src.size(), src.data(), ld.data(), tr.data(), K.data(), N.data(), img.data(), c.gemm_precision, s);
 }
@@ -1190,8 +1192,19 @@ int ffn_ln_bwd(SkfModel* M, const LnP& ln, const DenseP& f1, const DenseP& f2, c
 
 // The backward of an attention sublayer's tail, out = LayerNorm(x + dropout(o_proj(a))): LayerNorm backward + the projection's
 // input gradient in one launch (skf_layernorm_bwd_dgrad_f32) where it exists, else the two launches.  The weight gradient is queued.
+// lead_a / lead_w / lead_image_t (optional): the gradient of the LayerNorm output is dout + lead_a . lead_w^T - one launch where the fused
+// kernel takes it (*lead_done = true), else the caller's accumulating GEMM has to run first (*lead_done = false, nothing done yet)
+bool ln_oproj_bwd_takes_lead(SkfModel* M, const LnP& ln, const DenseP& o, const DenseP& lead_w, int rows) {
+  const Plan& P = M->plan;
+  const int d = M->cfg.d_model;
+  static const bool off = (skf_knob("SKF_NO_LN_DGRAD") && skf_knob("SKF_NO_LN_DGRAD")[0] == '1') || (skf_knob("SKF_NO_LN_LEAD") && skf_knob("SKF_NO_LN_LEAD")[0] == '1');
+  const size_t pbytes = (size_t)skf_layernorm_bwd_dgrad_partials(rows) * 2 * d * sizeof(float);
+  return !off && M->ffn_fused && M->side && ln.b == ln.g + (size_t)d && pbytes <= P.ln_part_stride && o.in == d && o.out == d &&
+         lead_w.in == d && lead_w.out == d && skf_layernorm_bwd_dgrad_supported(rows, d, M->cfg.gemm_precision);
+}
 int ln_oproj_bwd(SkfModel* M, const LnP& ln, const DenseP& o, const float* dout, const float* z, const float* st, const float* a_in,
-                 float* dz, float* dy, float* da, int rows, float rate, unsigned site, hipStream_t s, const void* image_t) {
+                 float* dz, float* dy, float* da, int rows, float rate, unsigned site, hipStream_t s, const void* image_t,
+                 const float* lead_a = nullptr, const void* lead_image_t = nullptr) {
   const Plan& P = M->plan;
   const int d = M->cfg.d_model;
   static const bool off = skf_knob("SKF_NO_LN_DGRAD") && skf_knob("SKF_NO_LN_DGRAD")[0] == '1';   // (measurement builds only)
@@ -1208,8 +1221,8 @@ int ln_oproj_bwd(SkfModel* M, const LnP& ln, const DenseP& o, const float* dout,
   SKF_TRY(before_write(M, dy, s));
   SKF_TRY(before_write(M, da, s));
   const int* blocks = (M->live16 && rows == M->live_rows) ? M->live16 : nullptr;
-  SKF_TRY(skf_layernorm_bwd_dgrad_f32(rows, d, dout, z, st, M->P(ln.g), rate, site, M->state, image_t, dz, dy, da, part, pbytes, blocks,
-                                      blocks ? 16 : 0, M->cfg.gemm_precision, s));
+  SKF_TRY(skf_layernorm_bwd_dgrad_lead_f32(rows, d, dout, lead_a, lead_image_t, z, st, M->P(ln.g), rate, site, M->state, image_t, dz, dy, da, part,
+                                           pbytes, blocks, blocks ? 16 : 0, M->cfg.gemm_precision, s));
   SKF_TRY(ln_partials_desc(M, ln, part, skf_layernorm_bwd_dgrad_partials(rows)));
   return dense_wgrad(M, o, a_in, d, dy, d, rows, s);
 }
@@ -1291,7 +1304,9 @@ int run_backward(SkfModel* M, hipStream_t s) {
                                       M->at<float>(a.astats2), cross_mask, Le, 0, B, H, Ld, Le, dh, dq2, d, dkv2, 2 * d,
                                       dkv2 + d, 2 * d, M->cfg.gemm_precision, qlive, M->order, s));
     SKF_TRY(dense_wgrad(M, w.mha2.q, M->at<float>(a.out1), d, dq2, d, Md, s));
-    SKF_TRY(dense_dgrad(M, w.mha2.q, dq2, d, Md, G, d, 1, nullptr, 0, s));
+    // d(out1) += dq2 . Wq^T: inside the LayerNorm-backward launch of the self-attention sublayer below where that kernel takes it
+    const bool lead = ln_oproj_bwd_takes_lead(M, w.ln1, w.mha1.o, w.mha2.q, Md);
+    if (!lead) SKF_TRY(dense_dgrad(M, w.mha2.q, dq2, d, Md, G, d, 1, nullptr, 0, s));
     SKF_TRY(dense_wgrad(M, w.mha2.kv, pre, L.E, dkv2, 2 * d, Me, s));
     // (the last layer of the loop runs it on the main stream: its reader follows too soon to gain anything)
     if (i == 0) {
@@ -1300,7 +1315,7 @@ int run_backward(SkfModel* M, hipStream_t s) {
     } else SKF_TRY(dense_dgrad_deferred(M, w.mha2.kv, dkv2, 2 * d, Me, dpre, L.E, i != N - 1, s));
     // out1 = LN1(x + drop(mha1(x,x,x)))
     SKF_TRY(ln_oproj_bwd(M, w.ln1, w.mha1.o, G, M->at<float>(a.z1), M->at<float>(a.st1), M->at<float>(a.o1), G2, dy1, dO, Md, rate,
-                         site_dec(N, i, 0), s, M->at<char>(a.img_o1)));
+                         site_dec(N, i, 0), s, M->at<char>(a.img_o1), lead ? dq2 : nullptr, lead ? M->at<char>(a.img_q2t) : nullptr));
     const float* qkv = M->at<float>(a.qkv);
     SKF_TRY(before_write(M, dqkv, s));
     SKF_TRY(skf_attention_bwd_ordered(qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, M->at<float>(a.o1), d, dO, d,

@@ -400,15 +400,17 @@ def dense_weight_image(w, transpose, precision=None):
     return img
 
 
-def layernorm_bwd_dgrad(dout, z, stats, gamma, image_t, rate=0.0, site=0, state=None, row_blocks=None, precision=None):
-    """One launch: dz = LayerNorm'(dout), dy = dropout'(dz), da = dy . W^T -> dz, dy, da, dgamma, dbeta (skf_layernorm_bwd_dgrad_f32)."""
+def layernorm_bwd_dgrad(dout, z, stats, gamma, image_t, rate=0.0, site=0, state=None, row_blocks=None, precision=None, lead=None):
+    """One launch: dz = LayerNorm'(dout), dy = dropout'(dz), da = dy . W^T -> dz, dy, da, dgamma, dbeta (skf_layernorm_bwd_dgrad_f32).
+    lead = (rows a [M, d], transposed image of Wl): the LayerNorm output's gradient is dout + a . Wl^T (skf_layernorm_bwd_dgrad_lead_f32)."""
     _f32(dout, "dout")
     M, d = dout.shape
     n = _lib.load().skf_layernorm_bwd_dgrad_partials(M)
     part = torch.empty(n, 2, d, dtype=torch.float32, device=dout.device)
     dz, dy, da = torch.empty_like(dout), torch.empty_like(dout), torch.empty_like(dout)
-    _lib.call("skf_layernorm_bwd_dgrad_f32", M, d, _p(dout), _p(z), _p(stats), _p(gamma), rate, site, _p(state), _p(image_t), _p(dz), _p(dy),
-              _p(da), _p(part), part.numel() * 4, _p(row_blocks), 16 if row_blocks is not None else 0, _prec(precision), _stream())
+    la, li = lead if lead is not None else (None, None)
+    _lib.call("skf_layernorm_bwd_dgrad_lead_f32", M, d, _p(dout), _p(la), _p(li), _p(z), _p(stats), _p(gamma), rate, site, _p(state), _p(image_t),
+              _p(dz), _p(dy), _p(da), _p(part), part.numel() * 4, _p(row_blocks), 16 if row_blocks is not None else 0, _prec(precision), _stream())
     g = part.sum(0)
     return dz, dy, da, g[0], g[1]
 

@@ -1048,6 +1048,50 @@ def test_layernorm_bwd_dgrad_one_launch(ops, rows, listed, rate):
         assert (gda - rda).abs().max().item() <= 4e-6 * max(1.0, rda.abs().max().item())
 
 
+@pytest.mark.parametrize("rows,listed,rate", [(25472, True, 0.1), (25600, False, 0.1), (1031, False, 0.0), (7, False, 0.1)])
+def test_layernorm_bwd_dgrad_with_a_leading_product(ops, rows, listed, rate):
+    """skf_layernorm_bwd_dgrad_lead_f32 (round 5): the gradient of the LayerNorm output is dout + a . Wl^T - the decoder's cross-attention
+    query projection's input gradient formed inside the self-attention sublayer's LayerNorm-backward launch
+    (builders/layers/transformer.py:258-262) - against the oracle and against the accumulating GEMM launch followed by the plain launch."""
+    d = 128
+    rng = np.random.RandomState(rows + 17)
+    z = rng.randn(rows, d) * 1.5 + 0.3
+    w, wl = rng.randn(d, d) / np.sqrt(d), rng.randn(d, d) / np.sqrt(d)
+    gamma, beta = 1 + 0.1 * rng.randn(d), 0.1 * rng.randn(d)
+    dout, a = rng.randn(rows, d), rng.randn(rows, d)
+    blocks = None
+    if listed:
+        Ld = 199
+        B = rows // Ld
+        live = rng.randint(0, Ld + 1, size=B).astype(np.int32)
+        live[0] = 0; live[-1] = Ld
+        for b in range(B):
+            dout[b * Ld + live[b]:(b + 1) * Ld] = 0.0
+            a[b * Ld + live[b]:(b + 1) * Ld] = 0.0
+        blocks = ops.row_blocks(_dev(live, torch.int32), Ld, 16)
+    st = ops.new_step_state("cuda", iterations=3)
+    ops.step_prologue(st, seed=5)
+    keep = np.ones((rows, d), bool)
+    if rate > 0:
+        keep = ops.dropout_keep_mask(ops.read_step_state(st)["drop_key"], 6, rate, rows * d).reshape(rows, d)
+    Z, W, WL, G, A, DOUT = _dev(z), _dev(w), _dev(wl), _dev(gamma), _dev(a), _dev(dout)
+    z32 = Z.cpu().numpy().astype(np.float64)
+    _, cache = oracle.layernorm_fwd(z32, gamma, beta)
+    stats = _dev(np.stack([z32.mean(-1), 1.0 / np.sqrt(z32.var(-1) + 1e-6)], -1))
+    dz, dg, db = oracle.layernorm_bwd(dout + a @ wl.T, cache)
+    dy = dz * keep / (1.0 - rate)
+    da = dy @ w.T
+    img, limg = ops.dense_weight_image(W, transpose=True), ops.dense_weight_image(WL, transpose=True)
+    got = ops.layernorm_bwd_dgrad(DOUT, Z, stats, G, img, rate=rate, site=6, state=st, row_blocks=blocks, lead=(A, limg))
+    for g_, w_, n in zip(got, (dz, dy, da, dg, db), ("dz", "dy", "da", "dgamma", "dbeta")):
+        _close(g_, w_, rtol=6e-5, name=n)
+    # the two launches it replaces: dout += a . Wl^T (accumulating input-gradient GEMM), then the plain launch
+    acc = ops.gemm(A, WL, a_kcontig=True, b_kcontig=True, out=DOUT.clone(), accumulate=True)
+    ref = ops.layernorm_bwd_dgrad(acc, Z, stats, G, img, rate=rate, site=6, state=st, row_blocks=blocks)
+    for g_, r_, n in zip(got[:3], ref[:3], ("dz", "dy", "da")):
+        assert (g_ - r_).abs().max().item() <= 8e-6 * max(1.0, r_.abs().max().item()), n
+
+
 @pytest.mark.parametrize("rows,n2", [(25600, 384), (25472, 128), (1031, 384), (7, 128)])
 def test_ffn_fused_forward_with_chained_projection(ops, rows, n2):
     """The forward launch going on to the next layer's q|k|v (N = 384) / query (N = 128) projection of its LayerNorm output."""
