@@ -675,13 +675,19 @@ def main():
         # the same step replayed from hipGraphs: `hip_graph_mode` = the two-stream step captured (use_graph = 2, round 5: the side stream
         # is forked / joined inside the capture, its launches become parallel branches; bit-equal to the eager step),
         # `one_stream_ms_per_step` inside it = the single-stream capture of rounds 1-4.  The eager step stays the default.
+        # (each capture mode in a process of its own: hipGraphLaunch of a multi-branch graph has crashed inside the HIP runtime -
+        #  hip::Graph::UpdateStreams - in processes that had built and destroyed many models before; a child cannot take the line down)
         try:
             rec = {}
             for mode, key in ((2, "ms_per_step"), (1, "one_stream_ms_per_step")):
-                engg = engine.TrainEngine(engine.make_config(use_graph=mode, **cfg_kwargs), init_seed=0)
-                e1 = timed(engg, x, y, args.steps, 5)
-                del engg
-                rec[key] = 1e3 * e1 / args.steps
+                cmd = [sys.executable, os.path.abspath(__file__), "--graph", str(mode), "--steps", str(args.steps), "--warmup", "5", "--batch", str(B),
+                       "--workload", args.workload, "--no-extras", "--no-cpu-baseline", "--no-profile"]
+                env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+                child = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300, check=False)
+                lines = [ln for ln in child.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+                if child.returncode != 0 or not lines:
+                    raise RuntimeError("use_graph=%d child exited with %d" % (mode, child.returncode))
+                rec[key] = float(json.loads(lines[-1])["ms_per_step"])
             rec["value"] = B * L / (rec["ms_per_step"] * 1e-3)
             rec["step_mfma_frac"] = f_step / (rec["ms_per_step"] * 1e-3) / (peak * 1e12)
             out["hip_graph_mode"] = rec

@@ -559,7 +559,9 @@ typedef struct SkfConfig {
   float beta1, beta2, eps;
   uint32_t seed;
   int32_t use_graph; /* 0: eager launches, weight gradients on a side stream; 1: the step captured into hipGraphs on ONE stream and replayed;
-                      * 2: the two-stream step captured (the side stream is forked / joined inside the capture; the first step runs eagerly) */
+                      * 2: the two-stream step captured (the side stream is forked / joined inside the capture; the first step runs eagerly).
+                      * Experimental: in long-lived processes that had created and destroyed many models, launching this multi-branch graph
+                      * has crashed inside the HIP runtime of ROCm 7.0 (hip::Graph::UpdateStreams); the default is 0 and is also the fastest */
   int32_t optimizer; /* 0 = Keras Adam (beta1, beta2, eps above), 1 = Keras SGD with momentum (models/sketchformer.py:120-126) */
   float momentum;
   int32_t class_buffer_layers; /* Dense(lowerdim, relu) + Dropout(class_dropout) layers before classify (models/sketchformer.py:44-45,101-104) */
