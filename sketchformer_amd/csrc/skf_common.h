@@ -73,6 +73,19 @@ double skf_prof_attention_fraction(const unsigned char* key_mask, int mask_ld, i
 
 static inline int skf_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// "Once per DEVICE" guard for hipFuncSetAttribute (the attribute belongs to the (function, device) pair; one process may drive
+// several GPUs): `static SkfOncePerDevice once; if (once.first()) set the attribute`.  A benign race sets it twice.
+struct SkfOncePerDevice {
+  unsigned long long done = 0;
+  bool first() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;      // unknown device: always set
+    if ((done >> dev) & 1ull) return false;
+    done |= 1ull << dev;
+    return true;
+  }
+};
+
 // ---------------------------------------------------------------- device
 // Bijective XCD-aware remap of a 1-D grid: block b runs on XCD b % 8 (observed dispatch order), so giving
 // every XCD a CONTIGUOUS range of logical ids keeps workgroups that share operand panels on one L2.

@@ -411,11 +411,10 @@ int skf_gemm_wgrad_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, i
     // and would halve the register budget the pipelined splits need
     const int nwg = q.tiles_m * q.tiles_n * splits;
     const size_t smem_x = (size_t)4 * (4096 + 64) * sizeof(float);
-    static bool attr_x = false;
-    if (!attr_x) {
+    static SkfOncePerDevice attr_x;
+    if (attr_x.first()) {
       SKF_HIP(hipFuncSetAttribute((const void*)wgrad_x_kernel<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_x));
       SKF_HIP(hipFuncSetAttribute((const void*)wgrad_x_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_x));
-      attr_x = true;
     }
     const double live = skf_prof_list_fraction(q.row_blocks);      // contraction over the live 32-row blocks only
     SkfProfScope ps(st, prec == 3 ? "wgrad<64x64,bf16x3>" : "wgrad<64x64,bf16x6>", 2.0 * p.M * p.N * p.K, 4.0 * (double)p.K * (p.M + p.N));
@@ -463,11 +462,10 @@ int skf_gemm_wgrad_group_dispatch(const GemmParams* ps, const int* splits, int n
   grp.start[n] = cursor;
   *handled = 1;
   const size_t smem_x = (size_t)4 * (4096 + 64) * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
+  static SkfOncePerDevice attr;
+  if (attr.first()) {
     SKF_HIP(hipFuncSetAttribute((const void*)wgrad_x_group_kernel<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_x));
     SKF_HIP(hipFuncSetAttribute((const void*)wgrad_x_group_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_x));
-    attr = true;
   }
   SkfProfScope ps_(st, prec == 3 ? "wgrad_group<64x64,bf16x3>" : "wgrad_group<64x64,bf16x6>", flops, bytes);
   ps_.done(flops_done, bytes_done);

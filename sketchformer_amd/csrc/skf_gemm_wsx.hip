@@ -611,11 +611,10 @@ int launch_wsx(const GemmParams& p, int b_kc, hipStream_t st) {
   q.xcd_remap = xcd_env ? xcd_env[0] == '1' : (groups > 1 && (K >= 384 || groups >= 3));
 #define SKF_WSX_LAUNCH(BKC, EX)                                                                                    \
   do {                                                                                                             \
-    static bool attr_done = false;                                                                                 \
-    if (!attr_done) {                                                                                              \
+    static SkfOncePerDevice attr_done;                                                                             \
+    if (attr_done.first()) {                                                                                       \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wsx_kernel<K, NB, P, BKC, EX, false, false, KS>),  \
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                                  \
-      attr_done = true;                                                                                            \
     }                                                                                                              \
     hipLaunchKernelGGL((gemm_wsx_kernel<K, NB, P, BKC, EX, false, false, KS>), grid, block, smem, st, q, groups, workers); \
   } while (0)
@@ -623,10 +622,9 @@ int launch_wsx(const GemmParams& p, int b_kc, hipStream_t st) {
     if (q.ln_out) {            // residual + dropout + LayerNorm epilogue (skf_gemm_ln_residual_f32 checked the shape)
       if (groups != 1 || extra || q.row_blocks || b_kc || q.act != 0) { skf_set_error("gemm_wsx: LayerNorm epilogue on an unsupported launch"); return SKF_EUNSUPPORTED; }
       const size_t smem_ln = smem + (size_t)2 * TR * 4 * 2 * sizeof(float);
-      static bool attr_ln = false;
-      if (!attr_ln) {
+      static SkfOncePerDevice attr_ln;
+      if (attr_ln.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wsx_kernel<K, NB, P, false, 0, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_ln);
-        attr_ln = true;
       }
       hipLaunchKernelGGL((gemm_wsx_kernel<K, NB, P, false, 0, false, true>), grid, block, smem_ln, st, q, groups, workers);
       SKF_LAUNCH_CHECK();
@@ -635,11 +633,10 @@ int launch_wsx(const GemmParams& p, int b_kc, hipStream_t st) {
   }
   if constexpr (K == 512 && NB == 1) {
     if (q.k_valid > 0) {       // masked last slice of a long contraction (dgrad form only: skf_gemm_ws_dispatch)
-      static bool attr_m[2] = {false, false};
-      if (!attr_m[extra ? 1 : 0]) {
+      static SkfOncePerDevice attr_m[2];
+      if (attr_m[extra ? 1 : 0].first()) {
         if (extra) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wsx_kernel<K, NB, P, true, 3, true, false, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wsx_kernel<K, NB, P, true, 0, true, false, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_m[extra ? 1 : 0] = true;
       }
       if (extra) hipLaunchKernelGGL((gemm_wsx_kernel<K, NB, P, true, 3, true, false, KS>), grid, block, smem, st, q, groups, workers);
       else hipLaunchKernelGGL((gemm_wsx_kernel<K, NB, P, true, 0, true, false, KS>), grid, block, smem, st, q, groups, workers);
