@@ -200,7 +200,10 @@ __global__ __launch_bounds__(256, MAXT <= 13 ? 4 : 1) void attn_fwd_kernel(AttnP
     float4 qf[NC];
     attn_u32x4 qb1, qb2, qb3;             // SPLIT: B operands [q0|q1], [q0|q0], [q1|q2]
     if constexpr (SPLIT) {
-      const float4 qa = qcur[0], qc = qcur[1];
+      // (round 5) the query rows carry the softmax scale log2(e)/sqrt(dh) into the split, like skf_attention_bwd3.hip's: one multiply per
+      // query element instead of one per score, and the same split operands as the backward kernel forms
+      const float4 qa = make_float4(qcur[0].x * c2, qcur[0].y * c2, qcur[0].z * c2, qcur[0].w * c2);
+      const float4 qc = make_float4(qcur[1].x * c2, qcur[1].y * c2, qcur[1].z * c2, qcur[1].w * c2);
       unsigned d0[3], d1[3], d2[3], d3[3];
       skf_split2<3>(qa.x, qa.y, d0, sel); skf_split2<3>(qa.z, qa.w, d1, sel);
       skf_split2<3>(qc.x, qc.y, d2, sel); skf_split2<3>(qc.z, qc.w, d3, sel);
@@ -244,13 +247,13 @@ __global__ __launch_bounds__(256, MAXT <= 13 ? 4 : 1) void attn_fwd_kernel(AttnP
           for (int r = 0; r < 4; ++r) {
             const int key = kt * 16 + g * 4 + r;
             const float m = fminf(mr[r], (p.causal && key > qrow) ? -1e9f : 0.f);   // one -1e9, never two
-            const float v = m < 0.f ? m : acc[r] * c2;
+            const float v = m < 0.f ? m : (SPLIT ? acc[r] : acc[r] * c2);
             s[kt][r] = v;
             mx = fmaxf(mx, v);
           }
         } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { s[kt][r] = acc[r] * c2; mx = fmaxf(mx, s[kt][r]); }
+          for (int r = 0; r < 4; ++r) { s[kt][r] = SPLIT ? acc[r] : acc[r] * c2; mx = fmaxf(mx, s[kt][r]); }
         }
       }
     }
