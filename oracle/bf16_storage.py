@@ -19,8 +19,19 @@ import numpy as np
 from . import sketchformer_oracle as so
 
 
+# Error model of an fp32 evaluation (tests/test_gpu_bf16_model.py, tools/bf16_rounding_noise.py): (numpy Generator, rel) multiplies every
+# value by 1 + rel * N(0, 1) BEFORE it is rounded to bf16 - what a different fp32 accumulation order does to a value that is about to
+# be stored.  A value within that distance of a rounding boundary then lands on the other side (a 2^-9 step), and where a later
+# difference cancels to 1e-4 of its terms (dS = P o (dP - delta) in the upper encoder layers of a padded batch) that step is amplified.
+NOISE = None
+
+
 def rbf(x):
     """round to nearest-even bf16, returned as float64 (skf_f2bf / v_cvt_pk_bf16_f32)"""
+    if NOISE is not None:
+        rng, rel = NOISE
+        x = np.asarray(x, dtype=np.float64)
+        x = x * (1.0 + rel * rng.standard_normal(x.shape))
     f = np.ascontiguousarray(x, dtype=np.float32)
     u = f.view(np.uint32)
     r = ((u >> 16) & 1) + 0x7FFF
