@@ -921,7 +921,7 @@ int forward_preamble(SkfModel* M, bool with_backward, bool encoder_only, hipStre
   }
   static const bool order_off = skf_knob("SKF_ATTN_ORDER") && skf_knob("SKF_ATTN_ORDER")[0] == '0';      // (measurement builds)
   M->order = nullptr;
-  if (!order_off && B <= 8192) {
+  if (!order_off && B <= 4096) {
     SKF_TRY(skf_sample_order(emask, Le, Le, encoder_only ? nullptr : dmask, Ld, Ld, B, M->at<int>(P.order), s));
     M->order = M->at<int>(P.order);
   }

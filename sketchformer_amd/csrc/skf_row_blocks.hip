@@ -163,7 +163,7 @@ __global__ __launch_bounds__(1024) void sample_order_kernel(const unsigned char*
 
 extern "C" int skf_sample_order(const unsigned char* mask_a, int lda, int La, const unsigned char* mask_b, int ldb, int Lb, int B, int* order,
                                 skf_stream_t stream) {
-  SKF_CHECK_ARG(order && B > 0 && B <= 8192 && (mask_a || mask_b), "bad argument");
+  SKF_CHECK_ARG(order && B > 0 && B <= 4096 && (mask_a || mask_b), "bad argument (B <= 4096: the counts and ranks of a batch sit in 32 KB of LDS)");
   SKF_CHECK_ARG((!mask_a || (La > 0 && lda >= La)) && (!mask_b || (Lb > 0 && ldb >= Lb)), "bad mask shape");
   hipLaunchKernelGGL(sample_order_kernel, dim3(1), dim3(1024), (size_t)2 * B * sizeof(int), (hipStream_t)stream, mask_a, lda, La, mask_b, ldb, Lb, B, order);
   SKF_LAUNCH_CHECK();

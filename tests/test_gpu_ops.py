@@ -515,6 +515,9 @@ def test_sample_order_and_dealt_attention_workgroups(ops, seed):
         assert np.array_equal(got, want), (got, want)
     wide = _dev(np.concatenate([ma, np.zeros((B, 3), bool)], axis=1), torch.uint8)          # rows with a pitch: the byte path
     assert np.array_equal(ops.sample_order(wide[:, :Lk], None).cpu().numpy(), np.argsort(-la, kind="stable"))
+    if seed == 0:       # more samples than threads per pass of the rank phase, rows that are not a multiple of four bytes
+        big = rng.randint(0, 2, size=(3000, 37)).astype(bool)
+        assert np.array_equal(ops.sample_order(_dev(big, torch.uint8), None).cpu().numpy(), np.argsort(-(~big).sum(1), kind="stable"))
     order = ops.sample_order(ma_d, mb_d)
     perm = torch.as_tensor(rng.permutation(B).astype(np.int32)).cuda()
     q, k, v, do = (_dev(rng.randn(B, n, d)) for n in (Lq, Lk, Lk, Lq))
