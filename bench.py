@@ -607,6 +607,8 @@ def main():
     cfg_kwargs = dict(batch=B, seq_len=L, d_model=d, num_heads=8, dff=dff, num_layers=N, vocab_size=None if cont else V,
                       n_classes=CN, lowerdim=U, dropout_rate=0.1, seed=1234 + rank, continuous=cont, act_dtype=w["act"])
     eng = engine.TrainEngine(engine.make_config(use_graph=args.graph, **cfg_kwargs), init_seed=0, process_group=pg)
+    if args.graph == 2:        # the two-stream capture is opt-in (include/skf.h: SKF_MODEL_TWO_STREAM_GRAPH); this leg runs in a child process
+        eng.set_flags(_lib.MODEL_TWO_STREAM_GRAPH)
     eng.dp_mode = args.allreduce
     xs, ys = make_batch(synthetic, w, B, rank, args.full_length)
     x = torch.from_numpy(xs).cuda()

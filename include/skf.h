@@ -264,7 +264,9 @@ int skf_attention_bwd_rows(const float* Q, int ldq, const float* K, int ldk, con
  * skf_sample_order: order[0..B) = the samples sorted by the number of UNMASKED positions in up to two padding-mask matrices (either may
  * be NULL), most first, stable (B <= 4096).  The *_ordered forms take that list (or NULL = the plain numbering) and deal the sorted samples over the
  * 8 XCDs, heaviest first, the heads of a sample over the engines of its XCD; used when B is a multiple of 8, ignored otherwise and by the
- * plain fp32 kernels of other head sizes.  The numbering never changes a result bit.  Measured (B 128, H 8, L 200, 58 % padding): the three
+ * plain fp32 kernels of other head sizes.  The numbering never changes a result bit.  sample_order must be a PERMUTATION of [0, B) in device
+ * memory (what skf_sample_order writes); the kernels do not verify it - entries are clamped into [0, B), so a malformed list cannot touch
+ * memory outside the tensors, but it computes some samples twice and leaves the outputs of others unwritten.  Measured (B 128, H 8, L 200, 58 % padding): the three
  * backward calls of a layer 168 -> 143 us, the forward calls 98 -> 90 us (profiles/r05o_attn_order.txt). */
 int skf_sample_order(const unsigned char* mask_a, int lda, int La, const unsigned char* mask_b, int ldb, int Lb, int B, int* order,
                      skf_stream_t stream);
@@ -281,6 +283,15 @@ int skf_attention_bwd_ordered(const float* Q, int ldq, const float* K, int ldk, 
  * kernel, any dh <= 128, Lq, Lk <= 1024. */
 int skf_attention_weights(const float* Q, int ldq, const float* K, int ldk, const unsigned char* key_mask, int key_mask_ld,
                           int causal, int B, int H, int Lq, int Lk, int dh, float* W, skf_stream_t stream);
+/* builders/utils.py:71-105 scaled_dot_product_attention with ANY float mask broadcastable to (B,H,Lq,Lk) (`:96-97`:
+ * `scaled_attention_logits += (mask * -1e9)` - the mask is ADDED, a fractional value lowers a logit, it does not remove the key).
+ * mask may be NULL; mask_stride_b / _h / _q are ELEMENT strides of the sample / head / query axes (0 = broadcast), the key axis has
+ * unit stride.  O (B,Lq,H*dh) with row stride ldo; W = the (B,H,Lq,Lk) weights or NULL.  Plain fp32 kernel of skf_generic.hip (one
+ * wave per query row: correct, not fast) - the padding and padding + look-ahead masks the model builds go to skf_attention_fwd as
+ * bytes; the front-end (builders.utils.scaled_dot_product_attention) routes every other mask here instead of refusing it. */
+int skf_attention_fwd_float_mask(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* mask,
+                                 long mask_stride_b, long mask_stride_h, long mask_stride_q, int B, int H, int Lq, int Lk, int dh,
+                                 float* O, int ldo, float* W, skf_stream_t stream);
 /* Row means behind LossManager.add_mean_loss / add_mae_loss / add_mse_loss (builders/losses.py:68-75; tf.keras.losses.MAE / MSE
  * reduce the LAST axis): out[r] = mean_c a[r][c] (mode 0), mean_c |a - b| (mode 1), mean_c (a - b)^2 (mode 2); a, b (rows, cols)
  * contiguous. */
@@ -559,9 +570,10 @@ typedef struct SkfConfig {
   float beta1, beta2, eps;
   uint32_t seed;
   int32_t use_graph; /* 0: eager launches, weight gradients on a side stream; 1: the step captured into hipGraphs on ONE stream and replayed;
-                      * 2: the two-stream step captured (the side stream is forked / joined inside the capture; the first step runs eagerly).
-                      * Experimental: in long-lived processes that had created and destroyed many models, launching this multi-branch graph
-                      * has crashed inside the HIP runtime of ROCm 7.0 (hip::Graph::UpdateStreams); the default is 0 and is also the fastest */
+                      * 2: the two-stream step captured (the side stream is forked / joined inside the capture; the first step runs eagerly) -
+                      * only with SKF_MODEL_TWO_STREAM_GRAPH set through skf_model_set_flags, otherwise mode 2 issues the same launches
+                      * eagerly (bit-equal results): hipGraphLaunch of a multi-branch graph can crash inside the HIP runtime, see the flag.
+                      * The default is 0 and is also the fastest */
   int32_t optimizer; /* 0 = Keras Adam (beta1, beta2, eps above), 1 = Keras SGD with momentum (models/sketchformer.py:120-126) */
   float momentum;
   int32_t class_buffer_layers; /* Dense(lowerdim, relu) + Dropout(class_dropout) layers before classify (models/sketchformer.py:44-45,101-104) */
@@ -602,6 +614,14 @@ void skf_model_destroy(SkfModel* m);
 /* SKF_MODEL_FFN_LAUNCHES: the feed-forward blocks of the step run as separate Dense / LayerNorm launches instead of the one launch
  * per direction of skf_ffn_fused_fwd_f32 / _bwd_f32 (same arithmetic, the sums in a different order): cross-check and A/B. */
 #define SKF_MODEL_FFN_LAUNCHES 2u
+/* SKF_MODEL_TWO_STREAM_GRAPH: opt-in for SkfConfig.use_graph = 2.  Root cause of the crash recorded in profiles/r05y_two_stream_graph_crash.txt
+ * (round 6, from the disassembly of the runtime that ships with torch 2.10+rocm7.0): hip::Graph::UpdateStreams walks the graph exec's internal
+ * stream vector WITHOUT a bound while it skips entries that share a hardware queue with the launch stream - one aliasing stream and it
+ * dereferences whatever lies behind the vector.  Streams are dealt over a small pool of hardware queues in creation order, so a process
+ * that has created "the wrong number" of streams before (models built and destroyed, other libraries) faults at the first replay.  Not a
+ * lifetime bug of this library: tools/micro/graph_parallel_stream_alias.hip reproduces it with plain HIP calls.  Set the flag only in a
+ * process whose stream history you control (the test and bench.py use a child process). */
+#define SKF_MODEL_TWO_STREAM_GRAPH 4u
 int skf_model_set_flags(SkfModel* m, uint32_t flags);
 /* params/grads/adam_m/adam_v: skf_model_param_floats floats each; pos: (max_pos, d_model) table
  * (builders/utils.py:17-32, computed by the host in float64 like the reference);

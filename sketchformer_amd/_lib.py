@@ -33,6 +33,7 @@ class SkfError(RuntimeError):
 ATTN_TWO_PASS = 0x100                                 # SKF_ATTN_TWO_PASS
 MODEL_DECODE_LAYERWISE = 1                            # SKF_MODEL_DECODE_LAYERWISE
 MODEL_FFN_LAUNCHES = 2                                # SKF_MODEL_FFN_LAUNCHES: feed-forward blocks as separate launches
+MODEL_TWO_STREAM_GRAPH = 4                            # SKF_MODEL_TWO_STREAM_GRAPH: opt-in for use_graph = 2 (HIP runtime fault, see skf.h)
 
 
 class SkfConfig(C.Structure):
@@ -132,6 +133,7 @@ SIGNATURES = {
     "skf_attention_bwd_ordered": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P]),
     "skf_sample_order": (_I, [_P, _I, _I, _P, _I, _I, _I, _P, _P]),
     "skf_attention_weights": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "skf_attention_fwd_float_mask": (_I, [_P, _I, _P, _I, _P, _I, _P, C.c_long, C.c_long, C.c_long, _I, _I, _I, _I, _I, _P, _I, _P, _P]),
     "skf_row_mean": (_I, [_P, _P, C.c_long, _I, _I, _P, _P]),
     "skf_embed_fwd": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _P, _F, _U, _P, _P]),
     "skf_embed_bwd": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _F, _U, _P, _P]),

@@ -37,10 +37,17 @@ def create_masks(inp, tar):
 
 
 def _decode_mask(mask, B, Lq, Lk):
-    """A reference-style float mask -> (key padding bytes or None, causal flag) understood by the fused kernel."""
+    """A reference-style float mask -> (key padding bytes or None, causal flag) understood by the fused kernel, or None when the
+    mask is neither a padding mask nor padding + look-ahead (fractional values, per-head or per-query patterns): those take the
+    float-mask kernel, which ADDS mask * -1e9 like builders/utils.py:96-97."""
     if mask is None:
         return None, False
-    m = torch.broadcast_to(torch.as_tensor(mask), (B, 1, Lq, Lk))[:, 0] != 0      # (B,Lq,Lk) bool
+    mask = torch.as_tensor(mask)
+    if mask.dim() == 4 and mask.shape[1] != 1:
+        return None
+    if not bool(((mask == 0) | (mask == 1)).all()):
+        return None
+    m = torch.broadcast_to(mask, (B, 1, Lq, Lk))[:, 0] != 0                       # (B,Lq,Lk) bool
     key = m[:, -1, :]                                                             # last query row: no look-ahead term
     la = torch.triu(torch.ones(Lq, Lk, dtype=torch.bool, device=m.device), diagonal=1) if Lq == Lk else None
     if torch.equal(m, key[:, None, :].expand(B, Lq, Lk)):
@@ -48,7 +55,7 @@ def _decode_mask(mask, B, Lq, Lk):
     elif la is not None and torch.equal(m, key[:, None, :] | la[None]):
         causal = True
     else:
-        raise NotImplementedError("only padding masks and padding+look-ahead masks are supported by the fused kernel")
+        return None
     km = key.to(torch.uint8).contiguous() if bool(key.any()) else None
     return km, causal
 
@@ -65,12 +72,16 @@ def scaled_dot_product_attention(q, k, v, mask, return_weights=None):
     the weights are materialised on request only (see RETURN_ATTENTION_WEIGHTS)."""
     B, H, Lq, dh = q.shape
     Lk = k.shape[2]
-    km, causal = _decode_mask(mask, B, Lq, Lk)
+    dec = _decode_mask(mask, B, Lq, Lk)
 
     def flat(x):
         return x.permute(0, 2, 1, 3).reshape(B, x.shape[2], H * dh).contiguous()
     qf, kf = flat(q), flat(k)
-    o, _ = ops.attention_fwd(qf, kf, flat(v), H, key_mask=km, causal=causal)
     want = RETURN_ATTENTION_WEIGHTS if return_weights is None else return_weights
+    if dec is None:         # any other float mask (builders/utils.py:96-97 adds mask * -1e9 whatever it holds): the generic kernel
+        o, w = ops.attention_fwd_float_mask(qf, kf, flat(v), H, mask=mask, return_weights=want)
+        return o.view(B, Lq, H, dh).permute(0, 2, 1, 3), w
+    km, causal = dec
+    o, _ = ops.attention_fwd(qf, kf, flat(v), H, key_mask=km, causal=causal)
     w = ops.attention_weights(qf, kf, H, key_mask=km, causal=causal) if want else None
     return o.view(B, Lq, H, dh).permute(0, 2, 1, 3), w

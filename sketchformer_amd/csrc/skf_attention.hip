@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256, MAXT <= 13 ? 4 : 1) void attn_fwd_kernel(AttnP
   // other half belongs to the neighbouring head.  XCD-contiguous ids put all heads of a sample on ONE XCD (one L2),
   // consecutively in time, so the neighbour's half is an L2 hit instead of a second HBM fetch of the same line.
   int bh = p.xcd_remap ? skf_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  if (p.order) { const int k = skf_deal_rank(blockIdx.x, p.H); bh = p.order[k / p.H] * p.H + k % p.H; }
+  if (p.order) { const int k = skf_deal_rank(blockIdx.x, p.H); bh = min(max(p.order[k / p.H], 0), p.B - 1) * p.H + k % p.H; }   // (clamped: a list that is no permutation must not leave the tensors)
   const int b = bh / p.H, h = bh % p.H;
   const int nkt = (p.Lk + 15) >> 4, nqt = (p.Lq + 15) >> 4;
   const int VP = nkt * 16 + 8;            // pitch of the transposed V image: (VP / 4) mod 4 == 2 keeps the ds_read_b128 of the PV
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256, SKF_ATTN_BWD_WAVES) void attn_bwd_kernel(AttnP
   // other half belongs to the neighbouring head.  XCD-contiguous ids put all heads of a sample on ONE XCD (one L2),
   // consecutively in time, so the neighbour's half is an L2 hit instead of a second HBM fetch of the same line.
   int bh = p.xcd_remap ? skf_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  if (p.order) { const int k = skf_deal_rank(blockIdx.x, p.H); bh = p.order[k / p.H] * p.H + k % p.H; }
+  if (p.order) { const int k = skf_deal_rank(blockIdx.x, p.H); bh = min(max(p.order[k / p.H], 0), p.B - 1) * p.H + k % p.H; }   // (clamped: a list that is no permutation must not leave the tensors)
   const int b = bh / p.H, h = bh % p.H;
   const int nkt = (p.Lk + 15) >> 4, nqt_all = (p.Lq + 15) >> 4;
   // query tiles behind the sample's last live row have dO == 0: they add nothing to dK / dV and their dQ is zero

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256, NC == 1 ? 4 : 2) void attn_bwd2_kernel(AttnPar
   constexpr int RP = 32 * NC, DH = 16 * NC;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int bh = p.xcd_remap ? skf_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  if (p.order) { const int k = skf_deal_rank(blockIdx.x, p.H); bh = p.order[k / p.H] * p.H + k % p.H; }
+  if (p.order) { const int k = skf_deal_rank(blockIdx.x, p.H); bh = min(max(p.order[k / p.H], 0), p.B - 1) * p.H + k % p.H; }   // (clamped: a list that is no permutation must not leave the tensors)
   const int b = bh / p.H, h = bh % p.H;
   const int nkt = (p.Lk + 15) >> 4, nqt = (p.Lq + 15) >> 4;
   const int R = (nkt > nqt ? nkt : nqt) * 16;

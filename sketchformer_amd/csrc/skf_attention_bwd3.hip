@@ -144,7 +144,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd3_kernel(AttnParams p) {
   // workgroups per CU walking the heads with the second one started late so that one stages while the other multiplies - static
   // head assignment loses more on padded batches (91 vs 71 us) than the offset gains (100 vs 107 us on full-length rows).
   int bh = p.xcd_remap ? skf_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  if (p.order) { const int k = skf_deal_rank(blockIdx.x, p.H); bh = p.order[k / p.H] * p.H + k % p.H; }
+  if (p.order) { const int k = skf_deal_rank(blockIdx.x, p.H); bh = min(max(p.order[k / p.H], 0), p.B - 1) * p.H + k % p.H; }   // (clamped: a list that is no permutation must not leave the tensors)
   const int b = bh / p.H, h = bh % p.H;
 #if SKF_MEASURE     // clock stamps of a few workgroups (tools/attn_bwd3_timeline.py): measurement builds only
   long long* dbg = (p.dbg && lane == 0 && (blockIdx.x % 131) == 0 && blockIdx.x / 131 < 8) ? p.dbg + ((blockIdx.x / 131) * 8 + wave) * 16 : nullptr;
@@ -244,7 +244,9 @@ __global__ __launch_bounds__(512, 4) void attn_bwd3_kernel(AttnParams p) {
       __builtin_amdgcn_sched_barrier(0);
       put_planes(sbase + G_OFF, row, c4, scaled(gv[u], ri), sel);
       __builtin_amdgcn_sched_barrier(0);
-      if (c4 == 0) { SKF_LDS(float, sbase + NMX_OFF + row * 4) = -sv[u].x; SKF_LDS(float, sbase + NDL_OFF + row * 4) = -dl * ri; }
+      // rows past Lq of the last live tile: seed -inf, so that exp2 gives exactly 0 on the masked and the unmasked path alike (with the
+      // clamped row's -max as the seed, exp2(0 - max) overflowed for max < -128 and inf * 0 put NaN into the whole key tile's dK / dV)
+      if (c4 == 0) { SKF_LDS(float, sbase + NMX_OFF + row * 4) = qok ? -sv[u].x : -INFINITY; SKF_LDS(float, sbase + NDL_OFF + row * 4) = qok ? -dl * ri : 0.f; }
     } else if (qok) {             // dead query tiles: dQ = 0
       *reinterpret_cast<float4*>(p.dQ + (size_t)(b * p.Lq + row) * p.lddq + h * 16 + c4) = make_float4(0.f, 0.f, 0.f, 0.f);
     }

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256, 3) void attn_bf16_q_kernel(AP p) {
   if (p.order) {
     const int i = blockIdx.x >> 3, m = i / nqb, r = skf_deal_rank((int)(blockIdx.x & 7) + 8 * m, p.H);
     qb = (i - m * nqb + m + (m >> 3)) % nqb;
-    bh = p.order[r / p.H] * p.H + r % p.H;
+    bh = min(max(p.order[r / p.H], 0), p.B - 1) * p.H + r % p.H;
   } else {
     const int lid = skf_xcd_remap(blockIdx.x, gridDim.x);
     bh = lid / nqb; qb = (lid - bh * nqb + bh + (bh >> 3)) % nqb;
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kv_kernel(AP p) {
     int m;
     skf_part_major((int)(blockIdx.x >> 3), (p.B * p.H) >> 3, nkb, &m, &kbk);
     const int r = skf_deal_rank((int)(blockIdx.x & 7) + 8 * m, p.H);
-    bh = p.order[r / p.H] * p.H + r % p.H;
+    bh = min(max(p.order[r / p.H], 0), p.B - 1) * p.H + r % p.H;
   } else {
     const int lid = skf_xcd_remap(blockIdx.x, gridDim.x);
     skf_part_major(lid, p.B * p.H, nkb, &bh, &kbk);     // key block 0 (never all padding, the most queries under the look-ahead mask) first

@@ -74,15 +74,23 @@ double skf_prof_attention_fraction(const unsigned char* key_mask, int mask_ld, i
 static inline int skf_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // "Once per DEVICE" guard for hipFuncSetAttribute (the attribute belongs to the (function, device) pair; one process may drive
-// several GPUs): `static SkfOncePerDevice once; if (once.first()) set the attribute`.  A benign race sets it twice.
+// several GPUs, one host thread each):
+//     static SkfOncePerDevice once;  if (once.needed()) { SKF_HIP(hipFuncSetAttribute(...)); once.mark(); }
+// The bit is set AFTER the attribute call succeeded (a second host thread on the same device either sees the bit and finds the
+// attribute applied, or sets the attribute again itself - idempotent) and with an atomic OR (threads of different devices share the word).
 struct SkfOncePerDevice {
   unsigned long long done = 0;
-  bool first() {
+  static int device() {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;      // unknown device: always set
-    if ((done >> dev) & 1ull) return false;
-    done |= 1ull << dev;
-    return true;
+    return (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) ? dev : -1;
+  }
+  bool needed() const {
+    const int dev = device();
+    return dev < 0 || !((__atomic_load_n(&done, __ATOMIC_ACQUIRE) >> dev) & 1ull);      // unknown device: always set
+  }
+  void mark() {
+    const int dev = device();
+    if (dev >= 0) __atomic_fetch_or(&done, 1ull << dev, __ATOMIC_RELEASE);
   }
 };
 

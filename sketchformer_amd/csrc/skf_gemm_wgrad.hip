@@ -20,6 +20,9 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+#ifndef SKF_WGRAD_OCC
+#define SKF_WGRAD_OCC 1  // workgroups per CU of the split-arithmetic kernels (2: the one-register-set loop below)
+#endif
 constexpr int UN = 4;    // 4-row steps per unrolled iteration (per wave): 16 rows
 #ifndef SKF_WGRAD_PIPE
 #define SKF_WGRAD_PIPE 0 // 1: software-pipelined split-arithmetic step (see wgrad_x_body) - measured SLOWER, kept as a build-time experiment
@@ -316,6 +319,55 @@ __device__ __forceinline__ void wgrad_x_body(const GemmParams& p, const int bid,
     if (it + 1 >= niter) break;
     pstep(it + 1, yb1, xa1, xa0, axB, axA);
   }
+#elif SKF_WGRAD_OCC == 2
+  // Two workgroups per CU (<= 256 registers): ONE register set of operand rows.  The X rows of step it + 1 are requested as soon as
+  // this step's X columns are split (the rows die with the split), the dY rows behind the split of the last dY column; the loads fly
+  // under the step's MFMAs and under the other workgroup's wave on the same SIMD, whose prologue / epilogue (first-load latency, LDS
+  // reduction, slab store) this wave covers in turn.
+  auto rows_of = [&](int it, int& r0, int& r1) {
+    if (blk) {
+      const int e = eb + NW * it + wave;
+      r0 = e < ee ? blk[2 + e] * 32 : p.K; r1 = min(p.K, r0 + 32);
+    } else {
+      r0 = kb + RI * it + 32 * wave; r1 = ke;
+    }
+  };
+  load_step(0, xa0, yb0);
+  for (int it = 0; it < niter; ++it) {
+    int r0, r1;
+    rows_of(it + 1, r0, r1);                         // past the end: empty descriptor, zeros
+    const __amdgpu_buffer_rsrc_t rx = wg_rows_rsrc(p.A, p.lda, r0, r1);
+    const __amdgpu_buffer_rsrc_t ry = wg_rows_rsrc(p.B, p.ldb, r0, r1);
+    u32x4 ax[4][P];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wg_split_col<P>(xa0, e, ax[e], sel);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xa0[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xo[j], 0, 0));
+    if (do_colsum) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) csum += yb0[j];
+    }
+    u32x4 by[4][P];
+    wg_split_col<P>(yb0, 0, by[0], sel);
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      if (f < 3) wg_split_col<P>(yb0, f + 1, by[f + 1], sel);
+      if (f == 3) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) yb0[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, yo[j], 0, 0));
+      }
+#pragma unroll
+      for (int d = P - 1; d >= 0; --d)
+#pragma unroll
+        for (int qa = 0; qa <= d; ++qa)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc[e][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ax[e][qa]),
+                                                                __builtin_bit_cast(bf16x8, by[f][d - qa]), acc[e][f], 0, 0, 0);
+    }
+  }
 #else
   load_step(0, xa0, yb0);
   for (int it = 0; it < niter; it += 2) {
@@ -367,7 +419,7 @@ __device__ __forceinline__ void wgrad_x_body(const GemmParams& p, const int bid,
 }
 
 template <int P, int NW>
-__global__ __launch_bounds__(64 * NW, 1) void wgrad_x_kernel(GemmParams p) {   // grids are ~one workgroup per CU: registers before occupancy
+__global__ __launch_bounds__(64 * NW, SKF_WGRAD_OCC) void wgrad_x_kernel(GemmParams p) {   // grids are ~one workgroup per CU: registers before occupancy
   extern __shared__ __attribute__((aligned(16))) float smem[];   // [NW waves][64][64] + [NW][64] column sums
   wgrad_x_body<P, NW>(p, blockIdx.x, gridDim.x, smem);
 }
@@ -377,7 +429,7 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_x_kernel(GemmParams p) {   /
 constexpr int kWgradGroupMax = 8;
 struct WgradGroup { int n; int start[kWgradGroupMax + 1]; int nblocks[kWgradGroupMax]; GemmParams p[kWgradGroupMax]; };
 template <int P, int NW>
-__global__ __launch_bounds__(64 * NW, 1) void wgrad_x_group_kernel(WgradGroup grp) {
+__global__ __launch_bounds__(64 * NW, SKF_WGRAD_OCC) void wgrad_x_group_kernel(WgradGroup grp) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int gi = 0;
   while (gi + 1 < grp.n && (int)blockIdx.x >= grp.start[gi + 1]) ++gi;       // wave-uniform scan of a short table
@@ -412,9 +464,10 @@ int skf_gemm_wgrad_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, i
     const int nwg = q.tiles_m * q.tiles_n * splits;
     const size_t smem_x = (size_t)4 * (4096 + 64) * sizeof(float);
     static SkfOncePerDevice attr_x;
-    if (attr_x.first()) {
+    if (attr_x.needed()) {
       SKF_HIP(hipFuncSetAttribute((const void*)wgrad_x_kernel<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_x));
       SKF_HIP(hipFuncSetAttribute((const void*)wgrad_x_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_x));
+      attr_x.mark();
     }
     const double live = skf_prof_list_fraction(q.row_blocks);      // contraction over the live 32-row blocks only
     SkfProfScope ps(st, prec == 3 ? "wgrad<64x64,bf16x3>" : "wgrad<64x64,bf16x6>", 2.0 * p.M * p.N * p.K, 4.0 * (double)p.K * (p.M + p.N));
@@ -463,9 +516,10 @@ int skf_gemm_wgrad_group_dispatch(const GemmParams* ps, const int* splits, int n
   *handled = 1;
   const size_t smem_x = (size_t)4 * (4096 + 64) * sizeof(float);
   static SkfOncePerDevice attr;
-  if (attr.first()) {
+  if (attr.needed()) {
     SKF_HIP(hipFuncSetAttribute((const void*)wgrad_x_group_kernel<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_x));
     SKF_HIP(hipFuncSetAttribute((const void*)wgrad_x_group_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_x));
+    attr.mark();
   }
   SkfProfScope ps_(st, prec == 3 ? "wgrad_group<64x64,bf16x3>" : "wgrad_group<64x64,bf16x6>", flops, bytes);
   ps_.done(flops_done, bytes_done);

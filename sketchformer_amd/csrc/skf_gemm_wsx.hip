@@ -612,9 +612,10 @@ int launch_wsx(const GemmParams& p, int b_kc, hipStream_t st) {
 #define SKF_WSX_LAUNCH(BKC, EX)                                                                                    \
   do {                                                                                                             \
     static SkfOncePerDevice attr_done;                                                                             \
-    if (attr_done.first()) {                                                                                       \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wsx_kernel<K, NB, P, BKC, EX, false, false, KS>),  \
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                                  \
+    if (attr_done.needed()) {                                                                                       \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wsx_kernel<K, NB, P, BKC, EX, false, false, KS>),  \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess)                \
+        attr_done.mark();                     /* (a failed call shows up as the launch error below) */              \
     }                                                                                                              \
     hipLaunchKernelGGL((gemm_wsx_kernel<K, NB, P, BKC, EX, false, false, KS>), grid, block, smem, st, q, groups, workers); \
   } while (0)
@@ -623,8 +624,9 @@ int launch_wsx(const GemmParams& p, int b_kc, hipStream_t st) {
       if (groups != 1 || extra || q.row_blocks || b_kc || q.act != 0) { skf_set_error("gemm_wsx: LayerNorm epilogue on an unsupported launch"); return SKF_EUNSUPPORTED; }
       const size_t smem_ln = smem + (size_t)2 * TR * 4 * 2 * sizeof(float);
       static SkfOncePerDevice attr_ln;
-      if (attr_ln.first()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wsx_kernel<K, NB, P, false, 0, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_ln);
+      if (attr_ln.needed()) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wsx_kernel<K, NB, P, false, 0, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_ln) == hipSuccess)
+          attr_ln.mark();
       }
       hipLaunchKernelGGL((gemm_wsx_kernel<K, NB, P, false, 0, false, true>), grid, block, smem_ln, st, q, groups, workers);
       SKF_LAUNCH_CHECK();
@@ -634,9 +636,10 @@ int launch_wsx(const GemmParams& p, int b_kc, hipStream_t st) {
   if constexpr (K == 512 && NB == 1) {
     if (q.k_valid > 0) {       // masked last slice of a long contraction (dgrad form only: skf_gemm_ws_dispatch)
       static SkfOncePerDevice attr_m[2];
-      if (attr_m[extra ? 1 : 0].first()) {
-        if (extra) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wsx_kernel<K, NB, P, true, 3, true, false, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wsx_kernel<K, NB, P, true, 0, true, false, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (attr_m[extra ? 1 : 0].needed()) {
+        const hipError_t ea = extra ? hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wsx_kernel<K, NB, P, true, 3, true, false, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)
+                                    : hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wsx_kernel<K, NB, P, true, 0, true, false, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (ea == hipSuccess) attr_m[extra ? 1 : 0].mark();
       }
       if (extra) hipLaunchKernelGGL((gemm_wsx_kernel<K, NB, P, true, 3, true, false, KS>), grid, block, smem, st, q, groups, workers);
       else hipLaunchKernelGGL((gemm_wsx_kernel<K, NB, P, true, 0, true, false, KS>), grid, block, smem, st, q, groups, workers);

@@ -241,6 +241,65 @@ __global__ __launch_bounds__(256) void attn_weights_any_kernel(AttnParams p, int
   }
 }
 
+// scaled_dot_product_attention with an ARBITRARY float mask (builders/utils.py:90-105): logits = q.k / sqrt(dh) + mask * -1e9 - the mask is
+// ADDED (a value of 0.5 lowers a logit by 5e8, it does not remove the key), broadcast over any of (sample, head, query) through zero
+// strides.  One wave per (sample, head, query): softmax over the keys, O = weights . V, optionally the weights.  The padding / look-ahead
+// masks the model itself builds never come here (the MFMA kernels take them as bytes); this is the reference's signature for everything else.
+__global__ __launch_bounds__(256) void attn_fwd_fmask_kernel(AttnParams p, int DH, const float* __restrict__ mask, long ms_b, long ms_h, long ms_q,
+                                                             float* __restrict__ W) {
+  __shared__ float qs[4][kMaxDh];
+  __shared__ float ws[4][64 * kMaxKeysPerLane];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row_ = blockIdx.x * 4 + wave;
+  const bool active = row_ < p.B * p.H * p.Lq;
+  const int row = active ? row_ : 0;
+  const int q = row % p.Lq, bh = row / p.Lq, h = bh % p.H, b = bh / p.H;
+  const float sq = sqrtf((float)DH);
+  const float* qp = p.Q + (size_t)(b * p.Lq + q) * p.ldq + h * DH;
+  for (int d = lane; d < DH; d += 64) qs[wave][d] = qp[d];
+  __syncthreads();
+  const float* mrow = mask ? mask + b * ms_b + h * ms_h + q * ms_q : nullptr;
+  float s[kMaxKeysPerLane];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < kMaxKeysPerLane; ++j) {
+    const int key = lane + 64 * j;
+    s[j] = -INFINITY;
+    if (key < p.Lk) {
+      const float* kp = p.K + (size_t)(b * p.Lk + key) * p.ldk + h * DH;
+      float dot = 0.f;
+      for (int d = 0; d < DH; ++d) dot += qs[wave][d] * kp[d];
+      s[j] = dot / sq;                                   // (divide after the matmul, then add: builders/utils.py:92-97)
+      if (mrow) s[j] += mrow[key] * -1e9f;
+      mx = fmaxf(mx, s[j]);
+    }
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < kMaxKeysPerLane; ++j) {
+    s[j] = lane + 64 * j < p.Lk ? __expf(s[j] - mx) : 0.f;
+    sum += s[j];
+  }
+  sum = wave_sum(sum);
+  const float rinv = 1.0f / sum;
+#pragma unroll
+  for (int j = 0; j < kMaxKeysPerLane; ++j) {
+    const int key = lane + 64 * j;
+    if (key < p.Lk) {
+      ws[wave][key] = s[j] * rinv;
+      if (W && active) W[(size_t)row * p.Lk + key] = s[j] * rinv;
+    }
+  }
+  __syncthreads();
+  float* op = p.O + (size_t)(b * p.Lq + q) * p.ldo + h * DH;
+  for (int d = lane; d < DH; d += 64) {
+    float acc = 0.f;
+    for (int key = 0; key < p.Lk; ++key) acc += ws[wave][key] * p.V[(size_t)(b * p.Lk + key) * p.ldv + h * DH + d];
+    if (active) op[d] = acc;
+  }
+}
+
 // Row reductions behind LossManager.add_mae_loss / add_mse_loss / add_mean_loss (builders/losses.py:68-75): out[r] = mean over the
 // last axis of |a - b| (mode 1), (a - b)^2 (mode 2) or a (mode 0, b ignored).  One wave per row.
 __global__ __launch_bounds__(256) void row_mean_kernel(const float* __restrict__ a, const float* __restrict__ b, long rows, int cols, int mode,
@@ -392,6 +451,23 @@ extern "C" int skf_attention_weights(const float* Q, int ldq, const float* K, in
   p.Q = Q; p.K = K; p.ldq = ldq; p.ldk = ldk; p.key_mask = key_mask; p.key_mask_ld = key_mask_ld; p.causal = causal;
   p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk;
   hipLaunchKernelGGL(attn_weights_any_kernel, dim3(skf_cdiv((long)B * H * Lq, 4)), dim3(256), 0, (hipStream_t)stream, p, dh, W);
+  SKF_LAUNCH_CHECK();
+  return SKF_OK;
+}
+
+extern "C" int skf_attention_fwd_float_mask(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* mask,
+                                            long mask_stride_b, long mask_stride_h, long mask_stride_q, int B, int H, int Lq, int Lk, int dh,
+                                            float* O, int ldo, float* W, skf_stream_t stream) {
+  SKF_CHECK_ARG(Q && K && V && O, "null operand");
+  SKF_CHECK_ARG(B > 0 && H > 0 && Lq > 0 && Lk > 0, "empty problem");
+  SKF_CHECK_ARG(skf_attention_any_supported(dh, Lq, Lk), "head size > 128 or sequence > 1024");
+  SKF_CHECK_ARG(mask_stride_b >= 0 && mask_stride_h >= 0 && mask_stride_q >= 0, "mask strides are element counts >= 0 (0 = broadcast)");
+  AttnParams p{};
+  p.Q = Q; p.K = K; p.V = V; p.O = O; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
+  p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk;
+  SkfProfScope ps((hipStream_t)stream, "attn_fwd<float mask>", 4.0 * B * H * (double)Lq * Lk * dh, 4.0 * B * H * dh * (2.0 * Lq + 2.0 * Lk));
+  hipLaunchKernelGGL(attn_fwd_fmask_kernel, dim3(skf_cdiv((long)B * H * Lq, 4)), dim3(256), 0, (hipStream_t)stream, p, dh, mask, mask_stride_b,
+                     mask_stride_h, mask_stride_q, W);
   SKF_LAUNCH_CHECK();
   return SKF_OK;
 }

@@ -1671,6 +1671,12 @@ int stage_inputs(SkfModel* M, const void* inp, const void* tar, int tar_ld, cons
 template <typename F>
 int capture_or_run(SkfModel* M, hipGraphExec_t* exec, hipStream_t s, F body) {
   if (!M->cfg.use_graph) return body();
+  // use_graph = 2 replays a MULTI-BRANCH graph, and hipGraphLaunch of such a graph reads past the end of the exec's stream vector in the
+  // HIP runtime whenever one of the exec's internal streams shares a hardware queue with the launch stream (hip::Graph::UpdateStreams:
+  // root cause and reproducer in tools/micro/graph_parallel_stream_alias.hip).  Whether that happens depends on how many streams the
+  // PROCESS created before, so the mode needs the caller's explicit SKF_MODEL_TWO_STREAM_GRAPH; without it the same launches go out
+  // eagerly on the two streams (bit-equal results, and the faster form anyway).
+  if (M->cfg.use_graph == 2 && !(M->flags & SKF_MODEL_TWO_STREAM_GRAPH)) return body();
   const bool two_stream = M->side != nullptr && exec == &M->g_fb;
   if (two_stream && !M->descs_uploaded) return body();
   if (!*exec) {
@@ -1710,7 +1716,7 @@ extern "C" size_t skf_config_size(void) { return sizeof(SkfConfig); }
 
 extern "C" int skf_model_set_flags(SkfModel* M, uint32_t flags) {
   SKF_CHECK_ARG(M, "null model");
-  SKF_CHECK_ARG((flags & ~(SKF_MODEL_DECODE_LAYERWISE | SKF_MODEL_FFN_LAUNCHES)) == 0, "unknown flag bits");
+  SKF_CHECK_ARG((flags & ~(SKF_MODEL_DECODE_LAYERWISE | SKF_MODEL_FFN_LAUNCHES | SKF_MODEL_TWO_STREAM_GRAPH)) == 0, "unknown flag bits");
   // SKF_MODEL_FFN_LAUNCHES changes the launch sequence of the step, hence the split counts of the LayerNorm partials and the
   // reduction descriptors that were built (and uploaded once) by the first step, and the captured step graphs: drop them like
   // skf_model_bind does, so that the next step rebuilds its descriptors / re-captures with the new sequence.

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(1024) void row_list_kernel(const int* __restrict__ 
 // LDS by atomic add); then rank by counting.  (First version: a wave per sample with the byte loads of a row behind one another - 17 us.)
 __device__ __forceinline__ void count_unmasked(const unsigned char* __restrict__ m, int ld, int L, int B, int* key, int tid) {
   if (!m) return;
-  if (ld == L && ((uintptr_t)m & 3) == 0) {          // contiguous rows: the matrix as words, a word may straddle two samples
+  if (ld == L && L >= 4 && ((uintptr_t)m & 3) == 0) {  // contiguous rows: the matrix as words, a word may straddle two samples (L >= 4: never three)
     const int total = B * L, n = (total + 3) >> 2;
     for (int i0 = tid; i0 < n; i0 += 4 * 1024) {
       unsigned v[4];

@@ -1224,9 +1224,10 @@ extern "C" int skf_embed_sort(const long long* tokens, int tok_ld, int B, int L,
   const bool per_wave = vocab <= kEmbOrderedVocab;      // 16 histograms fit in LDS; otherwise one table and a one-wave scatter
   const size_t smem = ((size_t)3 * vocab + 1 + (per_wave ? (size_t)16 * vocab : 0)) * sizeof(int);
   static SkfOncePerDevice attr_done;
-  if (attr_done.first()) {
+  if (attr_done.needed()) {
     SKF_HIP(hipFuncSetAttribute((const void*)embed_sort_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (3 * 12288 + 1) * 4));
     SKF_HIP(hipFuncSetAttribute((const void*)embed_sort_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (19 * kEmbOrderedVocab + 1) * 4));
+    attr_done.mark();
   }
   SkfProfScope ps((hipStream_t)stream, "embed_sort", 0.0, 12.0 * rows);
   if (per_wave)

@@ -161,6 +161,29 @@ def attention_weights(q, k, num_heads, key_mask=None, causal=False):
     return w
 
 
+def attention_fwd_float_mask(q, k, v, num_heads, mask=None, return_weights=False):
+    """softmax(q.k/sqrt(dh) + mask * -1e9) . v for ANY float mask broadcastable to (B,H,Lq,Lk) (builders/utils.py:90-105);
+    q (B,Lq,d), k/v (B,Lk,d) views -> (o (B,Lq,d), weights (B,H,Lq,Lk) or None).  skf_attention_fwd_float_mask."""
+    B, Lq, d = q.shape
+    Lk = k.shape[1]
+    o = torch.empty(B, Lq, d, dtype=torch.float32, device=q.device)
+    w = torch.empty(B, num_heads, Lq, Lk, dtype=torch.float32, device=q.device) if return_weights else None
+    sb = sh = sq = 0
+    if mask is not None:
+        mask = torch.as_tensor(mask, device=q.device).detach().to(torch.float32)
+        while mask.dim() < 4:
+            mask = mask[None]
+        if mask.stride(-1) != 1 and mask.shape[-1] != 1:
+            mask = mask.contiguous()
+        mask = torch.broadcast_to(mask, (B, num_heads, Lq, Lk))
+        if mask.stride(-1) != 1:                 # a broadcast key axis: materialise (the kernel wants unit stride there)
+            mask = mask.contiguous()
+        sb, sh, sq = mask.stride(0), mask.stride(1), mask.stride(2)
+    _lib.call("skf_attention_fwd_float_mask", _p(q), q.stride(1), _p(k), k.stride(1), _p(v), v.stride(1), _p(mask), sb, sh, sq,
+              B, num_heads, Lq, Lk, d // num_heads, _p(o), o.stride(1), _p(w), _stream())
+    return o, w
+
+
 def row_mean(a, b=None, mode=0):
     """mean over the last axis of a (mode 0), |a - b| (1) or (a - b)^2 (2) -> a.shape[:-1]  (skf_row_mean)"""
     a = torch.as_tensor(a).detach().to(device="cuda", dtype=torch.float32).contiguous()

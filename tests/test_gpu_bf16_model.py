@@ -115,7 +115,10 @@ def test_bf16_losses_and_all_gradients(name, B, rate, lengths):
     # Against float64 the bars are the storage precision of the path (small model 1.7e-2, cfg-5 dimensions 5.1e-2 (B = 2) ... 7.6e-2
     # (B = 8, 83 % padding, encoder/layer7/mha/wq)); the error MODEL that accounts for them tensor by tensor sits below, at the comparison
     # with the bf16-storage restatement.
-    assert worst[0] < (6e-2 if name == "small" else 1e-1), worst
+    # (round 6, ADVICE: the float64 bar is 6e-2 again for every case but the one whose measured distance is above it - cfg-5 dimensions,
+    #  B = 8 at the bench's 83 % padding: 7.6e-2, profiles/r04_cfg5_parity_B8.txt; full-length 3.0e-2, B = 2 5.1e-2, small model 1.7e-2)
+    padded_cfg5 = name == "cfg5" and lengths == "bench"
+    assert worst[0] < (1e-1 if padded_cfg5 and B == 8 else 6e-2), worst
     assert np.median(list(rel.values())) < 1.5e-2
     assert np.isfinite(eng.grads.cpu().numpy()).all()
     # ---- the tight check: the same step restated with bf16 rounding at the product's storage points (oracle/bf16_storage.py:
@@ -164,21 +167,33 @@ def test_bf16_losses_and_all_gradients(name, B, rate, lengths):
     # padded batch: max|dQ| there is 1e-7 against 1e-3 for dV) the step is amplified.  That evaluation moves the SAME tensors by the SAME
     # amounts as the device is away from the plain restatement (cfg-5 dimensions, B = 8, 83 % padding: encoder/layer7/mha/wq 7.4e-2 ...
     # 9.2e-2 over three noise draws against the device's 9.4e-2; device / noise over the 50 tensors above 5e-3: median 0.81, max 1.14):
-    # the distance IS the rounding-boundary noise of the storage scheme, not a term of the kernels.  Every tensor must stay below
-    # max(1.5e-2, 3 x its own noise figure); a kernel that leaves the arithmetic moves tensors the noise does not.
-    bf16_storage.NOISE = (np.random.default_rng(1), 2.0 ** -24)
-    try:
-        _, _, Gn = bf16_storage.loss_and_grads(P, ocfg, x, x, y, drops, relu_masks=dev_masks)
-    finally:
-        bf16_storage.NOISE = None
-    noise = {k: np.abs(Gn[k] - G16[k]).max() / max(np.abs(G16[k]).max(), floor16) for k in rel16}
-    ratio = {k: rel16[k] / max(noise[k], 5e-3) for k in rel16}
-    wk = max(ratio, key=ratio.get)
-    print("[bf16 %s] rounding-noise model: worst noise %.3e (%s); device / max(noise, 5e-3): worst %.2f (%s: device %.3e, noise %.3e)"
-          % (name, max(noise.values()), max(noise, key=noise.get), ratio[wk], wk, rel16[wk], noise[wk]))
-    for k in rel16:
-        assert rel16[k] < max(1.5e-2, 3.0 * noise[k]), (k, rel16[k], noise[k])
-    assert worst16[0] < 2e-1                                   # (a cap on top of the model: nothing is allowed to be THAT noisy)
+    # the distance IS the rounding-boundary noise of the storage scheme, not a term of the kernels.  On the padded cfg-5 cases every
+    # tensor must stay below max(1.5e-2, 1.5 x its noise figure, maximum of three draws); a kernel that leaves the arithmetic moves
+    # tensors the noise does not.
+    # Round 6: the error model is the bar ONLY where it is needed - cfg-5 dimensions on a padded batch - and there it is
+    # the maximum over three noise draws with a multiplier of 1.5 (a single draw x 3 let a regression in the high-cancellation tensors
+    # pass with up to 20 % error); the small model and the full-length case keep the absolute bars of round 4.
+    if name == "small":
+        assert worst16[0] < 2.5e-2, worst16
+    elif lengths == "full":
+        assert worst16[0] < 5e-2 and len(above) <= len(rel16) // 25, (worst16, len(above), len(rel16))
+    else:
+        noise = {k: 0.0 for k in rel16}
+        for draw in range(3):
+            bf16_storage.NOISE = (np.random.default_rng(1 + draw), 2.0 ** -24)
+            try:
+                _, _, Gn = bf16_storage.loss_and_grads(P, ocfg, x, x, y, drops, relu_masks=dev_masks)
+            finally:
+                bf16_storage.NOISE = None
+            for k in rel16:
+                noise[k] = max(noise[k], np.abs(Gn[k] - G16[k]).max() / max(np.abs(G16[k]).max(), floor16))
+        ratio = {k: rel16[k] / max(noise[k], 5e-3) for k in rel16}
+        wk = max(ratio, key=ratio.get)
+        print("[bf16 %s] rounding-noise model (max of 3 draws): worst noise %.3e (%s); device / max(noise, 5e-3): worst %.2f (%s: device "
+              "%.3e, noise %.3e)" % (name, max(noise.values()), max(noise, key=noise.get), ratio[wk], wk, rel16[wk], noise[wk]))
+        for k in rel16:
+            assert rel16[k] < max(1.5e-2, 1.5 * noise[k]), (k, rel16[k], noise[k])
+        assert worst16[0] < 1e-1 and len(above) <= len(rel16) // 10, (worst16, len(above), len(rel16))
     assert st["relu_overrides"] <= st["relu_units"] // 200
 
 

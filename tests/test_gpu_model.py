@@ -840,20 +840,24 @@ _TWO_STREAM_CAPTURE = r"""
 import sys
 import numpy as np, torch
 sys.path.insert(0, %r)
-from sketchformer_amd import engine, synthetic
+from sketchformer_amd import engine, synthetic, _lib
 B, L = 16, 56
 kw = dict(batch=B, seq_len=L, d_model=128, num_heads=8, dff=512, num_layers=2, vocab_size=1004, n_classes=345, lowerdim=64,
           dropout_rate=0.1, seed=7)
 batches = [synthetic.token_batch(B, L, 1004, 345, seed=60 + i) for i in range(4)]
 got = {}
 for mode in (0, 2):
-    eng = engine.TrainEngine(engine.make_config(use_graph=mode, **kw), init_seed=1)
-    for x, y in batches:
-        eng.train_step(x, y)
-    torch.cuda.synchronize()
-    got[mode] = (eng.params.clone(), eng.step_metrics()["total_loss"])
-assert np.isfinite(got[2][1]) and got[0][1] == got[2][1], (got[0][1], got[2][1])
-assert torch.equal(got[0][0], got[2][0])
+    for flag in ((0, _lib.MODEL_TWO_STREAM_GRAPH) if mode == 2 else (0,)):     # mode 2 without the opt-in flag: the eager launches
+        eng = engine.TrainEngine(engine.make_config(use_graph=mode, **kw), init_seed=1)
+        eng.set_flags(flag)
+        for x, y in batches:
+            eng.train_step(x, y)
+        torch.cuda.synchronize()
+        got[(mode, flag)] = (eng.params.clone(), eng.step_metrics()["total_loss"])
+for key in ((2, 0), (2, _lib.MODEL_TWO_STREAM_GRAPH)):
+    assert np.isfinite(got[key][1]) and got[(0, 0)][1] == got[key][1], (key, got[(0, 0)][1], got[key][1])
+    assert torch.equal(got[(0, 0)][0], got[key][0]), key
+got[2] = got[(2, _lib.MODEL_TWO_STREAM_GRAPH)]
 print("TWO_STREAM_CAPTURE_OK", got[2][1])
 """
 
@@ -865,7 +869,10 @@ def test_two_stream_graph_capture_is_bit_equal_to_the_eager_step():
     use_graph = 1, takes other launch forms and only agrees to rounding).
     In a process of its own: launching the multi-branch graph has crashed INSIDE the HIP runtime (hip::Graph::UpdateStreams, below
     hipGraphLaunch; rocgdb backtrace in profiles/r05y_two_stream_graph_crash.txt) when the process had built and destroyed the models of
-    tests/test_gpu_bf16_model.py and of this file before - never in a fresh process, never with the eager step or the single-stream capture."""
+    tests/test_gpu_bf16_model.py and of this file before - never in a fresh process, never with the eager step or the single-stream capture.
+    Round 6 root cause (include/skf.h at SKF_MODEL_TWO_STREAM_GRAPH, tools/micro/graph_parallel_stream_alias.hip): the runtime walks the
+    exec's stream vector without a bound when one of its streams shares a hardware queue with the launch stream, which depends on the
+    process's stream history.  The mode therefore needs the opt-in flag; without it use_graph = 2 issues the eager launches (checked here)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -136,9 +136,17 @@ def test_builders_front_ends_against_oracle():
     want, _, _ = oracle.sdpa_fwd(q, k, v, oc.astype(np.float64))
     got, w = builders.utils.scaled_dot_product_attention(*(torch.as_tensor(t, dtype=torch.float32).cuda() for t in (q, k, v)), comb_m)
     assert w is None and np.abs(got.cpu().numpy() - want).max() < 1e-5
-    with pytest.raises(NotImplementedError):
-        builders.utils.scaled_dot_product_attention(*(torch.as_tensor(t, dtype=torch.float32).cuda() for t in (q, k, v)),
-                                                    torch.rand(B, 1, L - 1, L - 1).cuda().round())
+    # any OTHER float mask (builders/utils.py:96-97 adds mask * -1e9 whatever the mask holds): a random 0/1 pattern per query, a
+    # fractional mask (a logit lowered, not removed: 1e-9 * -1e9 = -1), a per-head mask, a per-key row broadcast over the queries
+    qkv32 = [torch.as_tensor(t, dtype=torch.float32).cuda() for t in (q, k, v)]
+    Lq = L - 1
+    for mk in (np.round(rng.rand(B, 1, Lq, Lq)), rng.rand(B, 1, Lq, Lq) * 4e-9, np.round(rng.rand(B, H, Lq, Lq) * 0.7),
+               rng.rand(1, 1, 1, Lq) * 2e-9, np.round(rng.rand(1, H, 1, Lq))):
+        mk = mk.astype(np.float32)
+        want_o, want_a, _ = oracle.sdpa_fwd(q, k, v, mk.astype(np.float64))
+        got_o, got_a = builders.utils.scaled_dot_product_attention(*qkv32, torch.as_tensor(mk).cuda(), return_weights=True)
+        assert got_o.shape == (B, H, Lq, dh) and got_a.shape == (B, H, Lq, Lq)
+        assert np.abs(got_o.cpu().numpy() - want_o).max() < 1e-5 and np.abs(got_a.cpu().numpy() - want_a).max() < 1e-6, mk.shape
     # LossManager / MetricManager
     lm = builders.losses.LossManager()
     lm.add_reconstruction_loss("recon", weight=0.5)
