@@ -1,6 +1,7 @@
 // Shared device/host helpers for the sketchformer_amd HIP kernels (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include "../../include/skf.h"
@@ -72,6 +73,23 @@ double skf_prof_attention_fraction(const unsigned char* key_mask, int mask_ld, i
                                    const int* q_live, int qtile, int ktile);
 
 static inline int skf_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// An event that means "everything this stream was given so far is complete" costs the stream ~5 us as a packet of its own
+// (hipEventRecord) and ~1.3 us attached to the kernel launch in front of it as that command's completion signal (hipExtLaunchKernelGGL's
+// stop event; tools/micro/event_cost.hip, profiles/r06c_event_cost.txt: 25.4 vs 21.7 us per iteration against 20.4 without any event).
+// A caller that is about to record such an event behind a launcher's LAST kernel parks it in skf_tls_stop_event first; a launcher built
+// with SKF_LAUNCH_TAIL attaches it and clears the slot (a launcher that is not leaves it: the caller then records the event as before).
+extern thread_local hipEvent_t skf_tls_stop_event;
+#define SKF_LAUNCH_TAIL(kernel, grid, block, smem, stream, ...)                                        \
+  do {                                                                                                 \
+    hipEvent_t ev__ = skf_tls_stop_event;                                                              \
+    if (ev__) {                                                                                        \
+      skf_tls_stop_event = nullptr;                                                                    \
+      hipExtLaunchKernelGGL(kernel, grid, block, smem, stream, nullptr, ev__, 0, __VA_ARGS__);         \
+    } else {                                                                                           \
+      hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);                              \
+    }                                                                                                  \
+  } while (0)
 
 // "Once per DEVICE" guard for hipFuncSetAttribute (the attribute belongs to the (function, device) pair; one process may drive
 // several GPUs, one host thread each):

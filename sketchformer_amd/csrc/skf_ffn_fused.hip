@@ -963,7 +963,7 @@ int launch_ffn(const FfnFusedParams& p, hipStream_t st) {
   const double bytes = 4.0 * ((double)p.M * FD * (MODE == 0 ? 4 : 3) + (double)p.M * FF + (POST ? (double)p.M * p.n2 : 0.0) + (PRE ? 4.0 * p.M * FD : 0.0)) + 2.0 * image_bytes(P) / 2;
   SkfProfScope ps(st, tag.c_str(), flops, bytes);
   ps.done(flops * live, bytes * live);
-  hipLaunchKernelGGL((ffn_fused_kernel<P, MODE, LNB, POST, PRE>), dim3(grid), dim3(512), smem, st, p);
+  SKF_LAUNCH_TAIL((ffn_fused_kernel<P, MODE, LNB, POST, PRE>), dim3(grid), dim3(512), smem, st, p);
   SKF_LAUNCH_CHECK();
   return SKF_OK;
 }

@@ -140,6 +140,20 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // column e of eight row vectors -> P operands of 8 bf16
 template <int P>
 __device__ __forceinline__ void wg_split_col(const f32x4 (&rows)[8], int e, u32x4 (&out)[P], const SkfSplitSel& sel) {
+#ifdef SKF_WG_ABLATE_SPLIT   // diagnostics (wrong results): what operand PLANES handed over by the producers would leave of the split -
+  // 1: one v_perm per pair and plane (row-major bf16 planes transposed in registers), 2: nothing (operand-ordered planes)
+#pragma unroll
+  for (int q = 0; q < P; ++q) {
+#if SKF_WG_ABLATE_SPLIT == 1
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+      out[q][d] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, rows[2 * d + 1][(e + q) & 3]), __builtin_bit_cast(unsigned, rows[2 * d][(e + q) & 3]), 0x07060302u);
+#else
+    out[q] = __builtin_bit_cast(u32x4, rows[(2 * e + q) & 7]);
+#endif
+  }
+  return;
+#endif
 #pragma unroll
   for (int d = 0; d < 4; ++d) {
     unsigned pc[P];

@@ -346,12 +346,14 @@ int skf_gemm_ws_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, hipS
   // accumulating into C - only without an epilogue that must see the complete sum (activation, relu mask)
   const bool single = p.K == 128 || p.K == 256 || p.K == 384 || p.K == 512;
   const bool chain = !single && p.K > 512 && p.K <= 2048 && (p.K & 127) == 0 && p.act == 0 && !p.relu_src;
-  // Input-gradient form with any K % 4 == 0 up to 2048 (the logits layer: K = vocabulary = 1004), split arithmetic only: 512-deep
+  // Input-gradient form with any K % 4 == 0 (the logits layer: K = vocabulary = 1004 / 10004), split arithmetic only: 512-deep
   // slices, the last one masked (GemmParams::k_valid).  SKF_NO_MASKED_CHAIN=1 keeps such shapes on the generic kernel.
   static const bool masked_off = skf_knob("SKF_NO_MASKED_CHAIN") && skf_knob("SKF_NO_MASKED_CHAIN")[0] == '1';
   const bool fits32m = (double)p.M * p.lda * 4 < 2147483648.0 && (double)p.M * p.ldc * 4 < 2147483648.0;
+  // (round 6: up to 16384 - the grid tokenizer's vocabulary of 10004 is twenty 512-deep launches, ~0.45 ms instead of ONE 0.85-ms launch of
+  //  the generic fp32-MFMA kernel; every launch after the first re-reads and rewrites the 13 MB of C)
   const bool chain_masked = !single && !chain && !masked_off && b_kcontig && p.precision != SKF_PREC_F32 && fits32m && p.K > 512 &&
-                            p.K <= 2048 && (p.K & 3) == 0 && p.act == 0 && !p.relu_src && !p.relu_bits_in && !p.relu_bits_out && !p.bias;
+                            p.K <= 16384 && (p.K & 3) == 0 && p.act == 0 && !p.relu_src && !p.relu_bits_in && !p.relu_bits_out && !p.bias;
   if (!single && !chain && !chain_masked) return SKF_OK;
   if ((p.N & 3) || (p.lda & 3) || (p.ldc & 3) || ((uintptr_t)p.A & 15) || ((uintptr_t)p.C & 15)) return SKF_OK;
   if (b_kcontig && ((p.ldb & 3) || ((uintptr_t)p.B & 15))) return SKF_OK;

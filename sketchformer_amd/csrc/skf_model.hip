@@ -15,6 +15,7 @@
 
 // ------------------------------------------------------------------ error plumbing
 static thread_local char g_err[512] = "";
+thread_local hipEvent_t skf_tls_stop_event = nullptr;      // skf_common.h: an event for the next SKF_LAUNCH_TAIL launch of this thread
 void skf_set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -572,8 +573,17 @@ int dense_wgrad_on(SkfModel* M, const DenseP& w, const float* x, int ldx, const 
   return skf_gemm_f32(0, 0, w.in, w.out, rows, x, ldx, dy, lddy, M->G(w.w), w.ld, nullptr, 0, nullptr, 0, 0, splits,
                       M->G(w.b), 0, M->at<char>(M->plan.gemm_ws), M->plan.gemm_ws_bytes, M->cfg.gemm_precision, s);
 }
-int issue_wgrads(SkfModel* M, hipStream_t s);
-int issue_held_wgrads(SkfModel* M, hipStream_t s);
+int issue_wgrads(SkfModel* M, hipStream_t s, hipEvent_t ready_recorded = nullptr);
+int issue_held_wgrads(SkfModel* M, hipStream_t s, hipEvent_t ready_recorded = nullptr);
+// The "main stream has reached this point" event of a held weight-gradient group as the COMPLETION SIGNAL of the launch in front of it
+// (skf_common.h: SKF_LAUNCH_TAIL) instead of a packet of its own: park_ready() before the launcher, take_ready() behind it - the
+// event when the launcher attached it, null when it did not (or nothing is held / the step is being captured).
+hipEvent_t park_ready(SkfModel* M);
+hipEvent_t take_ready(hipEvent_t parked) {
+  const bool attached = parked && skf_tls_stop_event == nullptr;
+  skf_tls_stop_event = nullptr;
+  return attached ? parked : nullptr;
+}
 // Main-stream kernels that overwrite `buf` must first wait for the side-stream wgrad that still reads it
 // (a wgrad that is still queued is issued first; with the alternating gradient-buffer sets this is the rare case).
 int before_write(SkfModel* M, const void* buf, hipStream_t s) {
@@ -618,12 +628,19 @@ int before_read(SkfModel* M, const void* buf, hipStream_t s) {
 // stream, the block on the main stream - they ran one after the other (134 + 136 us where 45 + 100 were expected, per layer).  So a
 // layer's group is HELD at the end of the layer and goes out right behind the next layer's first launch: it then runs beside the
 // LayerNorm / projection / attention kernels of that layer, which share CUs with it well.
-int issue_held_wgrads(SkfModel* M, hipStream_t s) {
+hipEvent_t park_ready(SkfModel* M) {
+  static const bool off = skf_knob("SKF_NO_STOP_EVENTS") && skf_knob("SKF_NO_STOP_EVENTS")[0] == '1';   // (measurement builds only)
+  if (off || M->wq_held.empty() || !M->side || g_capturing) return nullptr;
+  hipEvent_t e = M->new_event();
+  skf_tls_stop_event = e;
+  return e;
+}
+int issue_held_wgrads(SkfModel* M, hipStream_t s, hipEvent_t ready_recorded) {
   if (M->wq_held.empty()) return SKF_OK;
   std::vector<SkfModel::QueuedWgrad> cur;
   cur.swap(M->wq);
   M->wq.swap(M->wq_held);
-  const int rc = issue_wgrads(M, s);
+  const int rc = issue_wgrads(M, s, ready_recorded);
   M->wq.swap(cur);
   return rc;
 }
@@ -632,7 +649,7 @@ int hold_wgrads(SkfModel* M, hipStream_t s) {
   M->wq_held.swap(M->wq);
   return SKF_OK;
 }
-int issue_wgrads(SkfModel* M, hipStream_t s) {
+int issue_wgrads(SkfModel* M, hipStream_t s, hipEvent_t ready_recorded) {
   if (!M->wq_held.empty()) {                                   // the held group first, as a group of its own
     std::vector<SkfModel::QueuedWgrad> cur;
     cur.swap(M->wq);
@@ -644,9 +661,9 @@ int issue_wgrads(SkfModel* M, hipStream_t s) {
   if (M->wq.empty()) return SKF_OK;
   std::vector<SkfModel::QueuedWgrad> group;
   group.swap(M->wq);
-  hipEvent_t ready = M->new_event(), done = M->new_event();
+  hipEvent_t ready = ready_recorded ? ready_recorded : M->new_event(), done = M->new_event();
   SKF_CHECK_ARG(ready && done, "event allocation failed");
-  SKF_HIP(hipEventRecord(ready, s));
+  if (!ready_recorded) SKF_HIP(hipEventRecord(ready, s));     // (else: already the completion signal of the launch in front of this call)
   SKF_HIP(hipStreamWaitEvent(M->side, ready, 0));
   // deferred input gradients first, with their own completion event: their reader must not wait for the weight gradients
   hipEvent_t dgrad_done = nullptr;
@@ -1110,9 +1127,12 @@ int ffn_bwd(SkfModel* M, const DenseP& f1, const DenseP& f2, const float* x_in, 
     SKF_TRY(before_write(M, dh, s));
     SKF_TRY(before_write(M, dx_acc, s));
     const int* blocks = (M->live16 && rows == M->live_rows) ? M->live16 : nullptr;
-    SKF_TRY(skf_ffn_fused_bwd_f32(rows, M->cfg.d_model, M->cfg.dff, dy, image_t, hbits, dh, dx_acc, 1, blocks, blocks ? 16 : 0,
-                                  M->cfg.gemm_precision, s));
-    SKF_TRY(issue_held_wgrads(M, s));
+    hipEvent_t parked = park_ready(M);
+    const int rc = skf_ffn_fused_bwd_f32(rows, M->cfg.d_model, M->cfg.dff, dy, image_t, hbits, dh, dx_acc, 1, blocks, blocks ? 16 : 0,
+                                         M->cfg.gemm_precision, s);
+    const hipEvent_t ready = take_ready(parked);
+    SKF_TRY(rc);
+    SKF_TRY(issue_held_wgrads(M, s, ready));
     return dense_wgrad(M, f1, x_in, f1.in, dh, f1.out, rows, s);
   }
   SKF_TRY(dense_wgrad(M, f2, h, f2.in, dy, f2.out, rows, s));
@@ -1182,10 +1202,13 @@ int ffn_ln_bwd(SkfModel* M, const LnP& ln, const DenseP& f1, const DenseP& f2, c
   SKF_TRY(before_write(M, dh, s));
   SKF_TRY(before_write(M, dx, s));
   const int* blocks = (M->live16 && rows == M->live_rows) ? M->live16 : nullptr;
-  SKF_TRY(skf_ffn_fused_bwd_ln_f32(rows, d, M->cfg.dff, dout, z, st, M->P(ln.g), rate, site, M->state, image_t, hbits, dy, dh, dx, part,
-                                   pbytes, blocks, blocks ? 16 : 0, M->cfg.gemm_precision, s));
+  hipEvent_t parked = park_ready(M);
+  const int rc = skf_ffn_fused_bwd_ln_f32(rows, d, M->cfg.dff, dout, z, st, M->P(ln.g), rate, site, M->state, image_t, hbits, dy, dh, dx, part,
+                                          pbytes, blocks, blocks ? 16 : 0, M->cfg.gemm_precision, s);
+  const hipEvent_t ready = take_ready(parked);
+  SKF_TRY(rc);
   SKF_TRY(ln_partials_desc(M, ln, part, skf_ffn_fused_ln_partials(rows)));
-  SKF_TRY(issue_held_wgrads(M, s));      // the previous layer's weight gradients: behind this launch (see hold_wgrads)
+  SKF_TRY(issue_held_wgrads(M, s, ready));      // the previous layer's weight gradients: behind this launch (see hold_wgrads)
   SKF_TRY(dense_wgrad(M, f2, h, f2.in, dy, f2.out, rows, s));
   return dense_wgrad(M, f1, x_in, f1.in, dh, f1.out, rows, s);
 }

@@ -746,6 +746,7 @@ _WSX_CASES = [
     (128, 128, "dgrad", ""), (128, 128, "dgrad", "acc"), (128, 384, "dgrad", ""), (128, 384, "dgrad", "acc"), (128, 256, "dgrad", "acc"),
     (512, 128, "dgrad", "bits"), (512, 128, "dgrad", "relu_src"), (128, 512, "dgrad", ""), (128, 512, "dgrad", "acc"),
     (128, 1004, "dgrad", ""), (128, 1004, "dgrad", "list"), (128, 128, "dgrad", "list"), (128, 384, "dgrad", "list_acc"),
+    (128, 10004, "dgrad", ""), (128, 10004, "dgrad", "list"),        # cfg2grid logits input gradient: twenty chained 512-deep launches (round 6)
     (512, 128, "dgrad", "bits_list"), (128, 512, "dgrad", "list_acc"),
     # cfg 3 (d = 256, dff = 1024): K = 256 one column per lane (KS = 1 for N > 128), chained 512-deep launches for K = 768 / 1024
     (256, 256, "fwd", ""), (768, 256, "fwd", ""), (512, 256, "fwd", ""), (1024, 256, "fwd", "relu_bits_out"), (256, 1024, "fwd", ""),
