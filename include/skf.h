@@ -617,10 +617,12 @@ void skf_model_destroy(SkfModel* m);
 /* SKF_MODEL_TWO_STREAM_GRAPH: opt-in for SkfConfig.use_graph = 2.  Root cause of the crash recorded in profiles/r05y_two_stream_graph_crash.txt
  * (round 6, from the disassembly of the runtime that ships with torch 2.10+rocm7.0): hip::Graph::UpdateStreams walks the graph exec's internal
  * stream vector WITHOUT a bound while it skips entries that share a hardware queue with the launch stream - one aliasing stream and it
- * dereferences whatever lies behind the vector.  Streams are dealt over a small pool of hardware queues in creation order, so a process
- * that has created "the wrong number" of streams before (models built and destroyed, other libraries) faults at the first replay.  Not a
- * lifetime bug of this library: tools/micro/graph_parallel_stream_alias.hip reproduces it with plain HIP calls.  Set the flag only in a
- * process whose stream history you control (the test and bench.py use a child process). */
+ * dereferences whatever lies behind the vector.  Which streams compare equal is decided inside the runtime, so a process
+ * whose runtime state makes an internal stream of the exec compare equal to the launch stream faults at a replay.  Nothing this library
+ * creates or destroys is read on that path.  tools/micro/graph_parallel_stream_alias.hip tries to provoke it with plain HIP calls
+ * (stream counts, build / replay / destroy cycles, leaked execs, stream 0): none of its 72 cases faults (profiles/r06b_graph_alias.txt) -
+ * the trigger needs the history of the process that showed it (pytest over two test files) and was not isolated.  Set the flag only in
+ * a process of its own (the test and bench.py use a child process). */
 #define SKF_MODEL_TWO_STREAM_GRAPH 4u
 int skf_model_set_flags(SkfModel* m, uint32_t flags);
 /* params/grads/adam_m/adam_v: skf_model_param_floats floats each; pos: (max_pos, d_model) table

@@ -1695,10 +1695,10 @@ template <typename F>
 int capture_or_run(SkfModel* M, hipGraphExec_t* exec, hipStream_t s, F body) {
   if (!M->cfg.use_graph) return body();
   // use_graph = 2 replays a MULTI-BRANCH graph, and hipGraphLaunch of such a graph reads past the end of the exec's stream vector in the
-  // HIP runtime whenever one of the exec's internal streams shares a hardware queue with the launch stream (hip::Graph::UpdateStreams:
-  // root cause and reproducer in tools/micro/graph_parallel_stream_alias.hip).  Whether that happens depends on how many streams the
-  // PROCESS created before, so the mode needs the caller's explicit SKF_MODEL_TWO_STREAM_GRAPH; without it the same launches go out
-  // eagerly on the two streams (bit-equal results, and the faster form anyway).
+  // HIP runtime whenever one of the exec's internal streams compares equal to the launch stream (hip::Graph::UpdateStreams: analysis in
+  // include/skf.h at SKF_MODEL_TWO_STREAM_GRAPH, DESIGN.md section 6 "Round 6").  Whether that happens is decided by the runtime's state
+  // in the PROCESS, so the mode needs the caller's explicit SKF_MODEL_TWO_STREAM_GRAPH; without it the same launches go out eagerly on
+  // the two streams (bit-equal results, and the faster form anyway).
   if (M->cfg.use_graph == 2 && !(M->flags & SKF_MODEL_TWO_STREAM_GRAPH)) return body();
   const bool two_stream = M->side != nullptr && exec == &M->g_fb;
   if (two_stream && !M->descs_uploaded) return body();

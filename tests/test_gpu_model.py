@@ -870,9 +870,10 @@ def test_two_stream_graph_capture_is_bit_equal_to_the_eager_step():
     In a process of its own: launching the multi-branch graph has crashed INSIDE the HIP runtime (hip::Graph::UpdateStreams, below
     hipGraphLaunch; rocgdb backtrace in profiles/r05y_two_stream_graph_crash.txt) when the process had built and destroyed the models of
     tests/test_gpu_bf16_model.py and of this file before - never in a fresh process, never with the eager step or the single-stream capture.
-    Round 6 root cause (include/skf.h at SKF_MODEL_TWO_STREAM_GRAPH, tools/micro/graph_parallel_stream_alias.hip): the runtime walks the
-    exec's stream vector without a bound when one of its streams shares a hardware queue with the launch stream, which depends on the
-    process's stream history.  The mode therefore needs the opt-in flag; without it use_graph = 2 issues the eager launches (checked here)."""
+    Round 6 (include/skf.h at SKF_MODEL_TWO_STREAM_GRAPH): in the runtime's disassembly the loop over the exec's stream vector has no bound
+    when one of its streams compares equal to the launch stream - nothing of libskf is on that path; a plain-HIP reproducer
+    (tools/micro/graph_parallel_stream_alias.hip) did not trigger it.  The mode therefore needs the opt-in flag; without it use_graph = 2
+    issues the eager launches (checked here)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

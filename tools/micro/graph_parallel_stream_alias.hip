@@ -1,14 +1,16 @@
-// Reproducer for the SIGSEGV below hipGraphLaunch of a MULTI-BRANCH graph (profiles/r05y_two_stream_graph_crash.txt), without libskf.
+// Attempted reproducer for the SIGSEGV below hipGraphLaunch of a MULTI-BRANCH graph (profiles/r05y_two_stream_graph_crash.txt), without libskf.
 //
 // Disassembly of hip::Graph::UpdateStreams(hip::Stream* launch, const std::vector<hip::Stream*>& parallel) in the libamdhip64.so that
 // ships with torch 2.10+rocm7.0 (function at .text+0xaed90, fault at +0xb1 = the load of parallel[i]->field_0x1a8):
 //     streams_.resize(max_streams_);  streams_[0] = launch;
 //     for (i = 0, k = 1; k < streams_.size(); ++i)                     // <- i is NOT bounded by parallel.size()
 //       if (queue_of(parallel[i]) != queue_of(launch)) streams_[k++] = parallel[i];
-// An internal stream of the graph exec that sits on the SAME hardware queue as the launch stream is skipped, and the loop then reads
-// past the end of the exec's stream vector.  Streams are dealt over a small pool of hardware queues in creation order, so whether the
-// exec's stream aliases the launch stream depends on how many streams the process created before - which is why the crash only showed
-// after the models of two test files had been built and destroyed in one process.
+// An internal stream of the graph exec that compares equal to the launch stream (same underlying queue object) is skipped, and the
+// loop then reads past the end of the exec's stream vector.  Hypothesis tested here: streams are dealt over a small pool of hardware
+// queues in creation order, so the number of streams a process created before decides whether the exec's stream aliases the launch
+// stream.  RESULT (profiles/r06b_graph_alias.txt, both HIP runtimes of the image): none of the 72 cases below faults - the hypothesis
+// about the trigger is not confirmed; the unbounded loop is in the disassembly either way, and the crash of
+// profiles/r05y_two_stream_graph_crash.txt has only ever been seen in the pytest process that ran two test files.
 //
 // Each case runs in a forked child (the parent never touches HIP): `pre` dummy streams are created and used, then a two-branch graph
 // is captured on a launch stream (fork to a side stream through an event, join back), instantiated and launched.
