@@ -634,6 +634,10 @@ int skf_model_bind(SkfModel* m, float* params, float* grads, float* adam_m, floa
  * stroke-5 rows when cfg.continuous; tar has row stride tar_ld (in sequence positions), its first L-1 positions feed the decoder. */
 int skf_model_forward(SkfModel* m, const void* inp, const void* tar, int tar_ld, int training,
                       skf_stream_t stream);
+/* Every call that takes inp / tar / labels copies them into the model's workspace first (one launch on `stream`) and records the model's
+ * "inputs staged" event behind that copy.  A caller that passes DEVICE tensors which it will overwrite for the next batch makes the
+ * stream that overwrites them wait here - the step itself is not waited for, and nothing has to be cloned in front of the call. */
+int skf_model_wait_inputs_staged(SkfModel* m, skf_stream_t stream);
 /* model_trainer minus apply_gradients: forward, losses, metrics, backward into `grads`. labels (B,1) int64. */
 int skf_model_forward_backward(SkfModel* m, const void* inp, const void* tar, int tar_ld,
                                const long long* labels, skf_stream_t stream);

@@ -214,6 +214,7 @@ SIGNATURES = {
     "skf_model_destroy": (None, [_P]),
     "skf_model_bind": (_I, [_P, _P, _P, _P, _P, _P, _P, _Z, _P, _P]),
     "skf_model_forward": (_I, [_P, _P, _P, _I, _I, _P]),
+    "skf_model_wait_inputs_staged": (_I, [_P, _P]),
     "skf_model_forward_backward": (_I, [_P, _P, _P, _I, _P, _P]),
     "skf_model_grad_buckets": (_I, [_P, _I, C.POINTER(_Z), C.POINTER(_Z)]),
     "skf_model_wait_grad_bucket": (_I, [_P, _I, _P]),

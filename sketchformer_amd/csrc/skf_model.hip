@@ -467,6 +467,8 @@ struct SkfModel {
   // weight-gradient GEMMs run on a side stream, off the dgrad critical path
   hipStream_t side = nullptr;
   hipEvent_t fork_event = nullptr, join_event = nullptr;      // use_graph = 2: the side stream's entry into / exit from the capture
+  hipEvent_t inputs_staged = nullptr;                         // recorded behind the staging copies of every call (skf_model_wait_inputs_staged)
+  bool inputs_staged_valid = false;
   std::vector<hipEvent_t> events;
   size_t next_event = 0;
   // Side-stream events carry a sequence number (their record order on the in-order side stream): once the main stream has
@@ -1687,6 +1689,23 @@ int stage_inputs(SkfModel* M, const void* inp, const void* tar, int tar_ld, cons
   return SKF_OK;
 }
 
+// The staging copies with the model's `inputs_staged` event behind them: a caller that hands over DEVICE tensors it will refill in place
+// makes its own stream wait for that event (skf_model_wait_inputs_staged) instead of cloning the tensors in front of every call - the
+// clones were two copy kernels on the caller's stream that the step then waited for, ~19 us of idle GPU at the head of every step.
+// The event rides on the staging launch as its completion signal where there is one (SKF_LAUNCH_TAIL), else it is recorded.
+template <typename F>
+int stage_with_event(SkfModel* M, hipStream_t s, F stage) {
+  if (!M->inputs_staged) SKF_HIP(hipEventCreateWithFlags(&M->inputs_staged, hipEventDisableTiming));
+  skf_tls_stop_event = M->inputs_staged;
+  const int rc = stage();
+  const bool attached = skf_tls_stop_event == nullptr;
+  skf_tls_stop_event = nullptr;
+  SKF_TRY(rc);
+  if (!attached) SKF_HIP(hipEventRecord(M->inputs_staged, s));
+  M->inputs_staged_valid = true;
+  return SKF_OK;
+}
+
 // use_graph = 1: the step is captured on ONE stream (no side stream exists).  use_graph = 2 (round 5): the two-stream step is captured -
 // the side stream joins the capture through an event recorded on the capturing stream (fork) and is joined back before the capture
 // ends, so the weight-gradient groups / embedding sorts / K|V projections become parallel branches of the graph.  The first call runs
@@ -1896,6 +1915,7 @@ extern "C" void skf_model_destroy(SkfModel* m) {
   if (m->g_dec) (void)hipGraphExecDestroy(m->g_dec);
   for (hipEvent_t e : m->events) (void)hipEventDestroy(e);
   for (int i = 0; i < 2; ++i) if (m->bucket_ready[i]) (void)hipEventDestroy(m->bucket_ready[i]);
+  if (m->inputs_staged) (void)hipEventDestroy(m->inputs_staged);
   if (m->fork_event) (void)hipEventDestroy(m->fork_event);
   if (m->join_event) (void)hipEventDestroy(m->join_event);
   if (m->side) (void)hipStreamDestroy(m->side);
@@ -1922,11 +1942,11 @@ extern "C" int skf_model_forward(SkfModel* m, const void* inp, const void* tar, 
   SKF_CHECK_ARG(m && m->ws, "model not bound");
   hipStream_t s = (hipStream_t)stream;
   if (m->bf16) {
-    SKF_TRY(stage_inputs16(m, inp, tar, tar_ld, nullptr, s));
+    SKF_TRY(stage_with_event(m, s, [&]() { return stage_inputs16(m, inp, tar, tar_ld, nullptr, s); }));
     if (training) SKF_TRY(prologue(m, s));
     return run_forward16(m, training != 0, false, s);
   }
-  SKF_TRY(stage_inputs(m, inp, tar, tar_ld, nullptr, s));
+  SKF_TRY(stage_with_event(m, s, [&]() { return stage_inputs(m, inp, tar, tar_ld, nullptr, s); }));
   if (training) SKF_TRY(prologue(m, s));
   return run_forward(m, training != 0, false, s);
 }
@@ -1935,10 +1955,10 @@ extern "C" int skf_model_encode(SkfModel* m, const void* inp, skf_stream_t strea
   SKF_CHECK_ARG(m && m->ws, "model not bound");
   hipStream_t s = (hipStream_t)stream;
   if (m->bf16) {
-    SKF_TRY(stage_inputs16(m, inp, inp, m->cfg.seq_len, nullptr, s));
+    SKF_TRY(stage_with_event(m, s, [&]() { return stage_inputs16(m, inp, inp, m->cfg.seq_len, nullptr, s); }));
     return run_forward16(m, false, false, s, true);
   }
-  SKF_TRY(stage_inputs(m, inp, inp, m->cfg.seq_len, nullptr, s));
+  SKF_TRY(stage_with_event(m, s, [&]() { return stage_inputs(m, inp, inp, m->cfg.seq_len, nullptr, s); }));
   return run_forward(m, false, false, s, true);
 }
 
@@ -1966,9 +1986,14 @@ int issue_embed_sorts(SkfModel* M, hipStream_t s) {
   const int B = c.batch, Le = c.seq_len, Ld = c.seq_len - 1, d = c.d_model;
   hipStream_t ss = s;
   if (M->side && do_recon(c)) {
-    hipEvent_t staged = M->new_event();
-    SKF_CHECK_ARG(staged, "event allocation failed");
-    SKF_HIP(hipEventRecord(staged, s));
+    // (the staged inputs are all the side stream's first launches read: it waits for the staging launch's own completion signal,
+    //  no packet of its own on the main stream)
+    hipEvent_t staged = (M->inputs_staged && M->inputs_staged_valid && !g_capturing) ? M->inputs_staged : nullptr;
+    if (!staged) {
+      staged = M->new_event();
+      SKF_CHECK_ARG(staged, "event allocation failed");
+      SKF_HIP(hipEventRecord(staged, s));
+    }
     SKF_HIP(hipStreamWaitEvent(M->side, staged, 0));
     ss = M->side;
     // first on the side stream: what the forward does not need before its first attention (forward_preamble) - the main stream goes
@@ -1996,7 +2021,7 @@ extern "C" int skf_model_forward_backward(SkfModel* m, const void* inp, const vo
   SKF_CHECK_ARG(labels, "null labels");
   hipStream_t s = (hipStream_t)stream;
   if (m->bf16) {
-    SKF_TRY(stage_inputs16(m, inp, tar, tar_ld, labels, s));
+    SKF_TRY(stage_with_event(m, s, [&]() { return stage_inputs16(m, inp, tar, tar_ld, labels, s); }));
     return capture_or_run(m, &m->g_fb, s, [&]() -> int {
       SKF_TRY(prologue(m, s));
       SKF_TRY(issue_embed_sorts16(m, s));
@@ -2004,13 +2029,20 @@ extern "C" int skf_model_forward_backward(SkfModel* m, const void* inp, const vo
       return run_backward16(m, s);
     });
   }
-  SKF_TRY(stage_inputs(m, inp, tar, tar_ld, labels, s));
+  SKF_TRY(stage_with_event(m, s, [&]() { return stage_inputs(m, inp, tar, tar_ld, labels, s); }));
   return capture_or_run(m, &m->g_fb, s, [&]() -> int {
     SKF_TRY(prologue(m, s));
     SKF_TRY(issue_embed_sorts(m, s));
     SKF_TRY(run_forward(m, true, true, s));
     return run_backward(m, s);
   });
+}
+
+extern "C" int skf_model_wait_inputs_staged(SkfModel* m, skf_stream_t stream) {
+  SKF_CHECK_ARG(m, "null model");
+  SKF_CHECK_ARG(m->inputs_staged && m->inputs_staged_valid, "no call has staged inputs yet");
+  SKF_HIP(hipStreamWaitEvent((hipStream_t)stream, m->inputs_staged, 0));
+  return SKF_OK;
 }
 
 extern "C" int skf_model_apply_gradients(SkfModel* m, float grad_scale, skf_stream_t stream) {

@@ -1177,7 +1177,7 @@ int skf_stage_inputs_launch(const void* inp, void* dinp, const void* tar, void* 
   if ((double)(row + copy) * batch / 4 + 2.0 * batch >= 2147483648.0) return SKF_EUNSUPPORTED;
   const int total = (int)((row + copy) / 4) * batch + 2 * batch;
   int grid = skf_cdiv(total, 256); if (grid > 512) grid = 512;
-  hipLaunchKernelGGL(stage_inputs_kernel, dim3(grid), dim3(256), 0, st, (const unsigned*)inp, (unsigned*)dinp, (const unsigned*)tar,
+  SKF_LAUNCH_TAIL(stage_inputs_kernel, dim3(grid), dim3(256), 0, st, (const unsigned*)inp, (unsigned*)dinp, (const unsigned*)tar,
                      (unsigned*)dtar, (int)(row / 4), (int)(src_row / 4), (int)(copy / 4), batch, (const unsigned*)labels, (unsigned*)dlabels);
   SKF_LAUNCH_CHECK();
   return SKF_OK;

@@ -9,6 +9,7 @@ fp32 gradient buffer is summed with ONE all-reduce (RCCL over xGMI on GPUs) and
 the 1/world_size scale is fused into the Adam sweep.
 """
 import ctypes as C
+import os
 import math
 
 import numpy as np
@@ -252,13 +253,14 @@ class TrainEngine:
             t = t.to(torch.int64)
         return self._own(t, t.to(self.device, non_blocking=True).contiguous())
 
-    @staticmethod
-    def _own(given, staged):
+    _clone_inputs = True
+
+    def _own(self, given, staged):
         """The step reads its inputs asynchronously on the engine's stream and no longer makes the caller's stream wait for it
         (_publish): a device tensor the caller passes in - and may refill IN PLACE for the next batch - is therefore copied here,
         on the caller's stream (the hand-over of _enter orders the step behind the copy).  Host inputs already became fresh device
         copies.  ~2 us of copy kernels on the caller's stream, nothing on the engine's."""
-        if torch.is_tensor(given) and given.is_cuda and staged.data_ptr() == given.data_ptr():
+        if self._clone_inputs and torch.is_tensor(given) and given.is_cuda and staged.data_ptr() == given.data_ptr():
             return staged.clone()
         return staged
 
@@ -350,17 +352,26 @@ class TrainEngine:
         return res if self.cfg.continuous else res.astype(np.int32)
 
     def _stage(self, inp, tar, labels):
-        """caller-side arguments -> device tensors (enqueued on the CALLER's stream: must precede _enter)"""
-        inp = self._dev_input(inp)
-        tar = inp if tar is None else self._dev_input(tar)
-        labels = self._dev_tokens(labels, self.cfg.n_classes if self.cfg.do_classification and self.cfg.lowerdim else None,
-                                  "class label")
+        """caller-side arguments -> device tensors (enqueued on the CALLER's stream: must precede _enter).  Device tensors of the
+        caller are NOT cloned here (round 6): the library copies them into its workspace first thing on the engine's stream and
+        _forward_backward_staged makes the caller's stream wait for exactly that copy (skf_model_wait_inputs_staged) - the two
+        clone kernels per step sat on the caller's stream in front of the hand-over, ~19 us of idle GPU at the head of every step."""
+        self._clone_inputs = os.environ.get("SKF_CLONE_INPUTS") == "1"      # (A/B knob of the Python layer: the round-5 behaviour)
+        try:
+            inp = self._dev_input(inp)
+            tar = inp if tar is None else self._dev_input(tar)
+            labels = self._dev_tokens(labels, self.cfg.n_classes if self.cfg.do_classification and self.cfg.lowerdim else None,
+                                      "class label")
+        finally:
+            self._clone_inputs = True
         return inp, tar, labels
 
     def _forward_backward_staged(self, inp, tar, labels):
         self._hold(inp, tar, labels)
         _lib.call("skf_model_forward_backward", self.handle, self._p(inp), self._p(tar), self._ld(tar), self._p(labels),
                   self._stream())
+        # the caller may refill its device tensors as soon as the staging copy has read them: its stream waits for that copy only
+        _lib.call("skf_model_wait_inputs_staged", self.handle, torch.cuda.current_stream(self.device).cuda_stream)
 
     def forward_backward(self, inp, tar, labels):
         staged = self._stage(inp, tar, labels)

@@ -683,6 +683,32 @@ def test_two_stream_step_is_deterministic_in_every_model_structure(over):
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
+def test_device_inputs_may_be_refilled_in_place_right_after_the_call(use_graph):
+    """train_step on DEVICE tensors returns before the step has run; the caller's next action may be to refill the same tensors with
+    the next batch (a prefetching loader does exactly that).  The step must see the batch it was given: the library copies its inputs
+    into the workspace first thing and the caller's stream waits for that copy only (skf_model_wait_inputs_staged) - it no longer
+    clones the tensors.  Two engines from one seed: one is handed fresh tensors per step, the other ONE pair of tensors that is
+    overwritten (with the next batch, then with garbage) immediately after every call; parameters bit-equal after 6 steps."""
+    from sketchformer_amd import engine
+    B, L = 32, 64
+    kw = dict(batch=B, seq_len=L, d_model=128, num_heads=8, dff=512, num_layers=2, vocab_size=1004, n_classes=345, lowerdim=64,
+              dropout_rate=0.1, seed=11, use_graph=use_graph)
+    a, b = (engine.TrainEngine(engine.make_config(**kw), init_seed=5) for _ in range(2))
+    batches = [synthetic.token_batch(B, L, 1004, 345, seed=300 + i) for i in range(6)]
+    xd = torch.zeros(B, L, dtype=torch.int64, device="cuda")
+    yd = torch.zeros(B, 1, dtype=torch.int64, device="cuda")
+    big = torch.empty(1 << 26, device="cuda")
+    for x, y in batches:
+        a.train_step(torch.as_tensor(x).cuda(), torch.as_tensor(y).cuda().view(B, 1))
+        xd.copy_(torch.as_tensor(x), non_blocking=False); yd.copy_(torch.as_tensor(y).view(B, 1))
+        big.normal_()                                  # keeps the device busy so that the step below starts late
+        b.train_step(xd, yd)
+        xd.fill_(777); yd.fill_(3)                     # garbage lands in the caller's tensors while the step is still queued
+    torch.cuda.synchronize()
+    assert torch.equal(a.params, b.params) and torch.equal(a.adam_m, b.adam_m)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
 def test_benchmarked_step_is_run_to_run_deterministic(use_graph):
     """Two engines from one seed take the same 40 batches at the benchmarked size (cfg 2, B = 128, dropout 0.1): parameters and both Adam
     moments bit-equal afterwards.  The eager step runs weight gradients, deferred input gradients and the sorts on a side stream; a missing
