@@ -39,8 +39,13 @@ extern "C" int skf_device_info(char* name_host, size_t name_len, int* n_devices_
 }
 
 // ------------------------------------------------------------------ launch profiler
+int skf_pool_bwd_partials(float* u_inout_dpre, const float* Vw, const float* x, const float* a, const float* demb, int B, int L, int U, int d,
+                          float* dx, float* dV_part, hipStream_t s);
+int skf_expander_bwd_partials(const float* dpre, const float* emb, const float* w, int B, int L, int d, float* demb, int demb_accumulate,
+                              float* p1, float* p2, hipStream_t s);
 int skf_stage_inputs_launch(const void* inp, void* dinp, const void* tar, void* dtar, size_t row, size_t src_row, size_t copy, int batch,
-                            const void* labels, void* dlabels, hipStream_t st);   // skf_rowops.hip
+                            const void* labels, void* dlabels, hipStream_t st, unsigned char* emask = nullptr, unsigned char* dmask = nullptr,
+                            int mask_L = 0);   // skf_rowops.hip
 namespace {
 struct ProfRec { const char* tag; double flops, bytes, flops_done, bytes_done; hipEvent_t e0, e1; };
 bool g_prof_on = false;
@@ -317,6 +322,7 @@ struct Plan {
   size_t emb_sort[2] = {0, 0}, emb_sort_bytes = 0;         // token positions sorted by id (encoder, decoder): skf_embed_sort
   size_t slab_arena, slab_arena_bytes, descs, n_wgrads;   // deferred split-K reduction (eager path)
   size_t ln_part, ln_part_stride;                          // per-LayerNorm dgamma|dbeta partials [5N][g][2d], reduced in the same batch
+  size_t bott_part = 0;                                    // expander / pooling gradient partials (see build_plan)
   // KV-cached greedy decode (inference): per-layer self-attention K|V cache (B, L, 2d) + one-row-per-sample step buffers
   std::vector<size_t> dc_cache;
   size_t dc_x[2], dc_q, dc_o, dc_z, dc_out1, dc_out2, dc_h, dc_logits, dc_stats, dc_mask, dc_flags, dc_limit;
@@ -413,7 +419,10 @@ Plan build_plan(const SkfConfig& c) {
     mx(wgrad_ws((int)E, c.n_classes, B)); mx(wgrad_ws(U, c.n_classes, B)); mx(wgrad_ws(d, U, B)); mx(wgrad_ws((int)E, U, B)); mx(wgrad_ws(U, U, B));
   }
   P.gemm_ws_bytes = g; P.gemm_ws = b.take(g);
-  P.n_wgrads = 4 + 11 * (size_t)c.num_layers + (size_t)c.class_buffer_layers + 5 * (size_t)c.num_layers;   // + one entry per LayerNorm
+  P.n_wgrads = 4 + 11 * (size_t)c.num_layers + (size_t)c.class_buffer_layers + 5 * (size_t)c.num_layers + 3;   // + one entry per LayerNorm + expander (2) / pooling (1) partials
+  // per-sample partials of the expander's kernel / bias gradients [2][B][L] and of the pooling scorer's V gradient [B][Ua]: column
+  // sums in the batched reduction instead of three one-workgroup launches on the main stream between the decoder and encoder backward
+  P.bott_part = b.take((2 * B * L + B * 4096) * f);
   P.ln_part_stride = (skf_layernorm_bwd_workspace_bytes((int)Me, (int)d) + 255) & ~(size_t)255;
   P.ln_part = b.take(5 * (size_t)c.num_layers * P.ln_part_stride);
   P.slab_arena_bytes = P.n_wgrads * ((g + 255) & ~(size_t)255);
@@ -453,6 +462,7 @@ struct SkfModel {
   uint32_t flags = 0;                // skf_model_set_flags
   bool no_ln_fuse = false, no_relu_bits = false;   // a fused entry answered SKF_EUNSUPPORTED once: this model takes the general pair
   bool ffn_fused = false;            // the feed-forward blocks run as one launch per direction (skf_ffn_fused.hip); set per forward
+  bool masks_staged = false;         // the padding masks of this call were written by its staging launch (stage_inputs)
   Layout lay;
   Plan plan;
   Plan16 p16;                        // bf16 path (cfg.act_dtype == SKF_ACT_BF16): its own workspace plan
@@ -575,7 +585,7 @@ int dense_wgrad_on(SkfModel* M, const DenseP& w, const float* x, int ldx, const 
   return skf_gemm_f32(0, 0, w.in, w.out, rows, x, ldx, dy, lddy, M->G(w.w), w.ld, nullptr, 0, nullptr, 0, 0, splits,
                       M->G(w.b), 0, M->at<char>(M->plan.gemm_ws), M->plan.gemm_ws_bytes, M->cfg.gemm_precision, s);
 }
-int issue_wgrads(SkfModel* M, hipStream_t s, hipEvent_t ready_recorded = nullptr);
+int issue_wgrads(SkfModel* M, hipStream_t s, hipEvent_t ready_recorded = nullptr, bool on_main = false);
 int issue_held_wgrads(SkfModel* M, hipStream_t s, hipEvent_t ready_recorded = nullptr);
 // The "main stream has reached this point" event of a held weight-gradient group as the COMPLETION SIGNAL of the launch in front of it
 // (skf_common.h: SKF_LAUNCH_TAIL) instead of a packet of its own: park_ready() before the launcher, take_ready() behind it - the
@@ -651,7 +661,9 @@ int hold_wgrads(SkfModel* M, hipStream_t s) {
   M->wq_held.swap(M->wq);
   return SKF_OK;
 }
-int issue_wgrads(SkfModel* M, hipStream_t s, hipEvent_t ready_recorded) {
+// on_main: the queued group runs on the MAIN stream, in place (no events, no hop) - for the one weight gradient at the very end of
+// the backward that the side stream would finish last (see run_backward)
+int issue_wgrads(SkfModel* M, hipStream_t s, hipEvent_t ready_recorded, bool on_main) {
   if (!M->wq_held.empty()) {                                   // the held group first, as a group of its own
     std::vector<SkfModel::QueuedWgrad> cur;
     cur.swap(M->wq);
@@ -663,18 +675,22 @@ int issue_wgrads(SkfModel* M, hipStream_t s, hipEvent_t ready_recorded) {
   if (M->wq.empty()) return SKF_OK;
   std::vector<SkfModel::QueuedWgrad> group;
   group.swap(M->wq);
-  hipEvent_t ready = ready_recorded ? ready_recorded : M->new_event(), done = M->new_event();
-  SKF_CHECK_ARG(ready && done, "event allocation failed");
-  if (!ready_recorded) SKF_HIP(hipEventRecord(ready, s));     // (else: already the completion signal of the launch in front of this call)
-  SKF_HIP(hipStreamWaitEvent(M->side, ready, 0));
+  hipStream_t ws = on_main ? s : M->side;                      // the stream the group runs on
+  hipEvent_t ready = nullptr, done = nullptr;
+  if (!on_main) {
+    ready = ready_recorded ? ready_recorded : M->new_event(); done = M->new_event();
+    SKF_CHECK_ARG(ready && done, "event allocation failed");
+    if (!ready_recorded) SKF_HIP(hipEventRecord(ready, s));   // (else: already the completion signal of the launch in front of this call)
+    SKF_HIP(hipStreamWaitEvent(M->side, ready, 0));
+  }
   // deferred input gradients first, with their own completion event: their reader must not wait for the weight gradients
   hipEvent_t dgrad_done = nullptr;
   for (const auto& q : group) {
     if (q.kind != 1) continue;
     const DenseP& w = q.w;
     SKF_TRY(skf_gemm_f32(1, 1, q.rows, w.in, w.out, q.dy, q.lddy, M->P(w.w), w.ld, q.dx, q.lddx, nullptr, 0, nullptr, 0,
-                         q.accumulate, 1, nullptr, 0, nullptr, 0, M->cfg.gemm_precision, M->side));
-    if (!dgrad_done) { dgrad_done = M->new_event(); SKF_CHECK_ARG(dgrad_done, "event allocation failed"); }
+                         q.accumulate, 1, nullptr, 0, nullptr, 0, M->cfg.gemm_precision, ws));
+    if (!dgrad_done && !on_main) { dgrad_done = M->new_event(); SKF_CHECK_ARG(dgrad_done, "event allocation failed"); }
   }
   long dgrad_seq = 0;
   if (dgrad_done) { SKF_HIP(hipEventRecord(dgrad_done, M->side)); dgrad_seq = ++M->side_seq; }
@@ -687,7 +703,7 @@ int issue_wgrads(SkfModel* M, hipStream_t s, hipEvent_t ready_recorded) {
     if (q.kind == 1) continue;
     if ((double)w.in * w.out * q.rows <= 33554432.0) {
       // batch-sized problems (classifier, class buffers, SelfAttnV2 projection): one small-GEMM launch, no split-K slab
-      SKF_TRY(dense_wgrad_on(M, w, q.x, q.ldx, q.dy, q.lddy, q.rows, M->side));
+      SKF_TRY(dense_wgrad_on(M, w, q.x, q.ldx, q.dy, q.lddy, q.rows, ws));
       continue;
     }
     const int splits = skf_gemm_default_splits(w.in, w.out, q.rows);
@@ -707,7 +723,7 @@ int issue_wgrads(SkfModel* M, hipStream_t s, hipEvent_t ready_recorded) {
   const size_t gmax = small ? 8 : 1;
   for (size_t b0 = 0; b0 < probs.size(); b0 += gmax) {
     const int nb = (int)std::min<size_t>(gmax, probs.size() - b0);
-    SKF_TRY(skf_gemm_wgrad_partial_group(probs.data() + b0, nb, M->cfg.gemm_precision, M->side));
+    SKF_TRY(skf_gemm_wgrad_partial_group(probs.data() + b0, nb, M->cfg.gemm_precision, ws));
   }
   for (size_t i = 0; i < probs.size(); ++i) {
     const DenseP& w = prob_q[i]->w;
@@ -722,6 +738,8 @@ int issue_wgrads(SkfModel* M, hipStream_t s, hipEvent_t ready_recorded) {
     M->reduce_blocks += skf_splitk_reduce_blocks(w.in, w.out);
     M->desc_cursor += 1;
   }
+  M->side_used = true;                                         // (the slabs are reduced by the batched launch either way)
+  if (on_main) return SKF_OK;                                  // same stream as every later reader / writer of the operands: nothing to track
   SKF_HIP(hipEventRecord(done, M->side));
   const long done_seq = ++M->side_seq;
   for (const auto& q : group) {
@@ -729,7 +747,6 @@ int issue_wgrads(SkfModel* M, hipStream_t s, hipEvent_t ready_recorded) {
     if (q.x) M->pending_readers[q.x] = SkfModel::SideEvent{done, done_seq};
     if (q.kind == 1) M->pending_writers[q.dx] = SkfModel::SideEvent{dgrad_done, dgrad_seq};
   }
-  M->side_used = true;
   return SKF_OK;
 }
 // Reduce the split-K partials of the wgrads issued since the last flush (one batched launch on the side stream) and
@@ -931,7 +948,9 @@ int forward_preamble(SkfModel* M, bool with_backward, bool encoder_only, hipStre
   const int B = c.batch, Le = c.seq_len, Ld = c.seq_len - 1;
   unsigned char* emask = M->at<unsigned char>(P.enc_mask);
   unsigned char* dmask = M->at<unsigned char>(P.dec_mask);
-  if (c.continuous) {
+  if (M->masks_staged) {
+    // (written by the staging launch of this call)
+  } else if (c.continuous) {
     SKF_TRY(skf_padding_mask_continuous(M->at<float>(P.inp), Le, B, Le, emask, s));
     SKF_TRY(skf_padding_mask_continuous(M->at<float>(P.tar), Le, B, Ld, dmask, s));
   } else {
@@ -1162,6 +1181,23 @@ int ln_partials_desc(SkfModel* M, const LnP& ln, const float* part, int splits) 
   return SKF_OK;
 }
 
+// column sums of per-sample partials part[splits][n] -> C[n] in the batched reduction (a "slab" of `splits` splits of a 1 x n matrix)
+int colsum_desc(SkfModel* M, const float* part, int splits, int n, float* C) {
+  SKF_CHECK_ARG(M->desc_cursor < M->plan.n_wgrads, "reduction descriptor table exhausted");
+  SkfReduceDesc r;
+  r.slab = part; r.C = C; r.bias_grad = nullptr; r.splits = splits; r.M = 1; r.N = n;
+  r.ldc = n; r.block_begin = M->reduce_blocks; r.pad = 0;
+  if (!M->descs_uploaded) M->descs.push_back(r);
+  else {
+    const SkfReduceDesc& o = M->descs[M->desc_cursor];
+    SKF_CHECK_ARG(o.slab == r.slab && o.C == r.C && o.splits == r.splits && o.block_begin == r.block_begin, "reduction sequence changed between steps");
+  }
+  M->reduce_blocks += skf_splitk_reduce_blocks(1, n);
+  M->desc_cursor += 1;
+  M->side_used = true;
+  return SKF_OK;
+}
+
 int ln_bwd(SkfModel* M, const LnP& ln, const float* dout, const float* z, const float* st, float* dz, float* dy,
            int rows, float rate, unsigned site, hipStream_t s) {
   const Plan& P = M->plan;
@@ -1375,7 +1411,16 @@ int run_backward(SkfModel* M, hipStream_t s) {
   const int E = L.E, Ua = L.Ua, U = c.lowerdim, NB = c.class_buffer_layers;
   if (bott) {
     // expander, classifier
-    if (recon)
+    static const bool part_off = skf_knob("SKF_NO_BOTT_PARTIALS") && skf_knob("SKF_NO_BOTT_PARTIALS")[0] == '1';   // (measurement builds only)
+    const bool defer_sums = !part_off && M->side && Ua <= 4096;      // (wherever the batched reduction runs: the eager step and its two-stream capture)
+    float* xp1 = M->at<float>(P.bott_part);
+    float* xp2 = xp1 + (size_t)B * Le;
+    float* pvp = xp2 + (size_t)B * Le;
+    if (recon && defer_sums) {
+      SKF_TRY(skf_expander_bwd_partials(dpre, M->at<float>(P.emb), M->P(L.exp_w), B, Le, E, demb, 0, xp1, xp2, s));
+      SKF_TRY(colsum_desc(M, xp1, B, Le, M->G(L.exp_w)));
+      SKF_TRY(colsum_desc(M, xp2, B, Le, M->G(L.exp_b)));
+    } else if (recon)
       SKF_TRY(skf_expander_bwd(dpre, M->at<float>(P.emb), M->P(L.exp_w), B, Le, E, demb, 0, M->G(L.exp_w), M->G(L.exp_b),
                                M->at<char>(P.small_ws), P.small_ws_bytes, s));
     const int acc_emb = recon ? 1 : 0;        // without a decoder the class head is the only source of d(embedding)
@@ -1413,6 +1458,10 @@ int run_backward(SkfModel* M, hipStream_t s) {
       dpool = M->at<float>(P.dpooled);
     }
     SKF_TRY(before_write(M, G, s));
+    if (defer_sums) {
+      SKF_TRY(skf_pool_bwd_partials(M->at<float>(P.u), M->P(L.bott_v), enc_out, M->at<float>(P.pool_a), dpool, B, Le, Ua, d, G, pvp, s));
+      SKF_TRY(colsum_desc(M, pvp, B, Ua, M->G(L.bott_v)));
+    } else
     SKF_TRY(skf_pool_bwd(M->at<float>(P.u), M->P(L.bott_v), enc_out, M->at<float>(P.pool_a), dpool, B, Le, Ua, d,
                          G, M->G(L.bott_v), M->at<char>(P.small_ws), P.small_ws_bytes, s));
     SKF_TRY(dense_wgrad(M, L.bott_w, enc_out, d, M->at<float>(P.u), Ua, Me, s));
@@ -1445,8 +1494,13 @@ int run_backward(SkfModel* M, hipStream_t s) {
                                       dqkv + 2 * d, 3 * d, M->cfg.gemm_precision, nullptr, M->order, s));
     SKF_TRY(dense_wgrad(M, w.mha.qkv, M->at<float>(a.x_in), d, dqkv, 3 * d, Me, s));
     // last layer of the backward: the weight gradient only needs dqkv, so it goes out BEFORE the input-gradient GEMM - the hop
-    // to the side stream and the kernel itself then run under that GEMM and the embedding gradient instead of behind them
-    if (i == 0 && early_tail) SKF_TRY(issue_wgrads(M, s));
+    // to the side stream and the kernel itself then run under that GEMM and the embedding gradient instead of behind them.
+    // Round 6: it runs on the MAIN stream.  The side stream still has this layer's feed-forward and output-projection gradients
+    // queued behind the held group of the layer above and finished ~20 us AFTER the main stream's last kernel
+    // (profiles/r06h_timeline.txt: 34 us of idle main stream in front of the final reduction); with the 18-us q|k|v gradient in line
+    // here both streams end together and the final reduction starts without waiting for a hop.
+    static const bool tail_main = !(skf_knob("SKF_TAIL_WGRAD_SIDE") && skf_knob("SKF_TAIL_WGRAD_SIDE")[0] == '1');   // (measurement builds only)
+    if (i == 0 && early_tail) SKF_TRY(issue_wgrads(M, s, nullptr, tail_main && M->wq_held.empty()));
     SKF_TRY(dense_dgrad(M, w.mha.qkv, dqkv, 3 * d, Me, G, d, 1, nullptr, 0, s));
     static const bool hold_off_e = skf_knob("SKF_NO_WGRAD_HOLD") && skf_knob("SKF_NO_WGRAD_HOLD")[0] == '1';
     if (M->ffn_fused && i > 0 && !hold_off_e) SKF_TRY(hold_wgrads(M, s));
@@ -1667,14 +1721,20 @@ int stage_inputs(SkfModel* M, const void* inp, const void* tar, int tar_ld, cons
   reset_live_rows(M);
   M->lists_built = false;
   M->pre_ready = M->masks_ready = nullptr;
+  M->masks_staged = false;
   SKF_CHECK_ARG(inp && tar, "null input");
   const size_t row = c.continuous ? (size_t)c.seq_len * 5 * sizeof(float) : (size_t)c.seq_len * 8;     // bytes per sample
   const size_t src_row = c.continuous ? (size_t)tar_ld * 5 * sizeof(float) : (size_t)tar_ld * 8;
   // one launch for the three copies (skf_rowops.hip); operands that are not 4-byte aligned take the copy engine below
   static const bool stage_off = skf_knob("SKF_NO_STAGE_KERNEL") && skf_knob("SKF_NO_STAGE_KERNEL")[0] == '1';   // (measurement builds only)
   if (!stage_off) {
+    // token mode: the two padding masks are written by the same launch (forward_preamble then skips its mask launches)
+    static const bool mask_off = skf_knob("SKF_NO_STAGED_MASKS") && skf_knob("SKF_NO_STAGED_MASKS")[0] == '1';   // (measurement builds only)
+    const bool masks = !c.continuous && !mask_off && tar_ld >= c.seq_len;
     const int rc = skf_stage_inputs_launch(inp, M->at<char>(P.inp), tar, M->at<char>(P.tar), row, src_row, row < src_row ? row : src_row, c.batch,
-                                           labels, M->at<char>(P.labels), s);
+                                           labels, M->at<char>(P.labels), s, masks ? M->at<unsigned char>(P.enc_mask) : nullptr,
+                                           masks ? M->at<unsigned char>(P.dec_mask) : nullptr, masks ? c.seq_len : 0);
+    if (rc == SKF_OK) M->masks_staged = masks;
     if (rc != SKF_EUNSUPPORTED) return rc;
   }
   SKF_HIP(hipMemcpyAsync(M->at<char>(P.inp), inp, row * c.batch, hipMemcpyDeviceToDevice, s));

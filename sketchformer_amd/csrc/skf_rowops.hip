@@ -6,6 +6,10 @@
 #include "skf_common.h"
 #include "skf_bf16.h"
 
+int skf_pool_bwd_partials(float* u_inout_dpre, const float* Vw, const float* x, const float* a, const float* demb, int B, int L, int U, int d,
+                          float* dx, float* dV_part, hipStream_t s);
+int skf_expander_bwd_partials(const float* dpre, const float* emb, const float* w, int B, int L, int d, float* demb, int demb_accumulate,
+                              float* p1, float* p2, hipStream_t s);
 namespace {
 
 // two consecutive activation values as fp32 (the bf16 path reuses the sorted embedding gradient kernel)
@@ -1159,26 +1163,42 @@ extern "C" int skf_padding_mask(const long long* tokens, int tok_ld, int B, int 
 
 // The three input copies of a step (inputs, targets with their own pitch, labels or zeros) as ONE launch instead of three
 // copy-engine kernels (6 us each, back to back at the head of every step); 4-byte words, internal to the library (skf_model.hip).
+// mask_L > 0 (token mode: 8-byte ids): the two padding masks of builders/utils.py:35-43 ride along - emask[b][t] = inp[b][t] == 0 (t < mask_L),
+// dmask[b][t] = tar[b][t] == 0 (t < mask_L - 1): the side stream's sample ordering no longer waits for two mask launches of its own
 __global__ void stage_inputs_kernel(const unsigned* __restrict__ inp, unsigned* __restrict__ dinp, const unsigned* __restrict__ tar,
                                     unsigned* __restrict__ dtar, int row_w, int src_row_w, int copy_w, int batch,
-                                    const unsigned* __restrict__ labels, unsigned* __restrict__ dlabels) {
+                                    const unsigned* __restrict__ labels, unsigned* __restrict__ dlabels,
+                                    unsigned char* __restrict__ emask, unsigned char* __restrict__ dmask, int mask_L) {
   const int n_inp = row_w * batch, n_tar = copy_w * batch, n_lab = 2 * batch;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_inp + n_tar + n_lab; e += gridDim.x * blockDim.x) {
+  const int n_em = mask_L * batch, n_dm = (mask_L > 0 ? mask_L - 1 : 0) * batch;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_inp + n_tar + n_lab + n_em + n_dm; e += gridDim.x * blockDim.x) {
     if (e < n_inp) dinp[e] = inp[e];
     else if (e < n_inp + n_tar) { const int t = e - n_inp, b = t / copy_w, w = t % copy_w; dtar[(size_t)b * row_w + w] = tar[(size_t)b * src_row_w + w]; }
-    else { const int t = e - n_inp - n_tar; dlabels[t] = labels ? labels[t] : 0u; }
+    else if (e < n_inp + n_tar + n_lab) { const int t = e - n_inp - n_tar; dlabels[t] = labels ? labels[t] : 0u; }
+    else if (e < n_inp + n_tar + n_lab + n_em) {
+      const int t = e - n_inp - n_tar - n_lab, b = t / mask_L, k = t % mask_L;
+      const size_t w = (size_t)b * row_w + 2 * k;
+      emask[t] = (inp[w] | inp[w + 1]) == 0u ? 1 : 0;
+    } else {
+      const int t = e - n_inp - n_tar - n_lab - n_em, b = t / (mask_L - 1), k = t % (mask_L - 1);
+      const size_t w = (size_t)b * src_row_w + 2 * k;
+      dmask[t] = (tar[w] | tar[w + 1]) == 0u ? 1 : 0;
+    }
   }
 }
 // row / src_row / copy in bytes (multiples of 4); returns SKF_EUNSUPPORTED when an operand is not 4-byte aligned (caller copies)
 int skf_stage_inputs_launch(const void* inp, void* dinp, const void* tar, void* dtar, size_t row, size_t src_row, size_t copy, int batch,
-                            const void* labels, void* dlabels, hipStream_t st) {
+                            const void* labels, void* dlabels, hipStream_t st, unsigned char* emask, unsigned char* dmask, int mask_L) {
   if (((uintptr_t)inp | (uintptr_t)dinp | (uintptr_t)tar | (uintptr_t)dtar | (uintptr_t)labels | (uintptr_t)dlabels | row | src_row | copy) & 3)
     return SKF_EUNSUPPORTED;
-  if ((double)(row + copy) * batch / 4 + 2.0 * batch >= 2147483648.0) return SKF_EUNSUPPORTED;
-  const int total = (int)((row + copy) / 4) * batch + 2 * batch;
+  if ((double)(row + copy) * batch / 4 + 2.0 * batch + 2.0 * mask_L * batch >= 2147483648.0) return SKF_EUNSUPPORTED;
+  // the masks read whole 8-byte ids: mask_L of them per row of inp, mask_L - 1 per row of tar
+  if (mask_L > 0 && (!emask || !dmask || (size_t)mask_L * 8 > row || (size_t)(mask_L - 1) * 8 > src_row)) mask_L = 0;
+  const int total = (int)((row + copy) / 4) * batch + 2 * batch + (mask_L > 0 ? (2 * mask_L - 1) * batch : 0);
   int grid = skf_cdiv(total, 256); if (grid > 512) grid = 512;
   SKF_LAUNCH_TAIL(stage_inputs_kernel, dim3(grid), dim3(256), 0, st, (const unsigned*)inp, (unsigned*)dinp, (const unsigned*)tar,
-                     (unsigned*)dtar, (int)(row / 4), (int)(src_row / 4), (int)(copy / 4), batch, (const unsigned*)labels, (unsigned*)dlabels);
+                     (unsigned*)dtar, (int)(row / 4), (int)(src_row / 4), (int)(copy / 4), batch, (const unsigned*)labels, (unsigned*)dlabels,
+                     emask, dmask, mask_L);
   SKF_LAUNCH_CHECK();
   return SKF_OK;
 }
@@ -1423,10 +1443,18 @@ extern "C" int skf_pool_bwd(float* u_inout_dpre, const float* Vw, const float* x
   SKF_CHECK_ARG(workspace && workspace_bytes >= (size_t)B * U * sizeof(float), "workspace too small");
   hipStream_t s = (hipStream_t)stream;
   float* part = (float*)workspace;
+  const int rc = skf_pool_bwd_partials(u_inout_dpre, Vw, x, a, demb, B, L, U, d, dx, part, s);
+  if (rc != SKF_OK) return rc;
+  hipLaunchKernelGGL(colsum_kernel, dim3(skf_cdiv(U, 64)), dim3(1024), 0, s, part, B, U, U, dV, 0);
+  SKF_LAUNCH_CHECK();
+  return SKF_OK;
+}
+// internal (skf_model.hip): the launch without the column sum - dV_part[B][U] is left for a batched reduction (a "slab" of B splits of a 1 x U matrix)
+int skf_pool_bwd_partials(float* u_inout_dpre, const float* Vw, const float* x, const float* a, const float* demb, int B, int L, int U, int d,
+                          float* dx, float* dV_part, hipStream_t s) {
   SkfProfScope ps(s, "pool_bwd", 0.0, 8.0 * B * L * (U + d));
   SKF_CHECK_ARG(L <= 1024 && (U & 3) == 0 && (d & 3) == 0 && d <= 4096 && U <= 4096, "pool: need L <= 1024, U % 4 == d % 4 == 0, U,d <= 4096");
-  hipLaunchKernelGGL(pool_bwd_kernel, dim3(B), dim3(1024), (4096 + d + 2 * L + 16) * sizeof(float), s, u_inout_dpre, Vw, x, a, demb, L, U, d, dx, part);
-  hipLaunchKernelGGL(colsum_kernel, dim3(skf_cdiv(U, 64)), dim3(1024), 0, s, part, B, U, U, dV, 0);
+  hipLaunchKernelGGL(pool_bwd_kernel, dim3(B), dim3(1024), (4096 + d + 2 * L + 16) * sizeof(float), s, u_inout_dpre, Vw, x, a, demb, L, U, d, dx, dV_part);
   SKF_LAUNCH_CHECK();
   return SKF_OK;
 }
@@ -1450,6 +1478,16 @@ extern "C" int skf_expander_bwd(const float* dpre, const float* emb, const float
   hipStream_t s = (hipStream_t)stream;
   float* p1 = (float*)workspace;
   float* p2 = p1 + (size_t)B * L;
+  const int rc = skf_expander_bwd_partials(dpre, emb, w, B, L, d, demb, demb_accumulate, p1, p2, s);
+  if (rc != SKF_OK) return rc;
+  hipLaunchKernelGGL(colsum_kernel, dim3(skf_cdiv(L, 64)), dim3(1024), 0, s, p1, B, L, L, dw, 0);
+  hipLaunchKernelGGL(colsum_kernel, dim3(skf_cdiv(L, 64)), dim3(1024), 0, s, p2, B, L, L, dbias, 0);
+  SKF_LAUNCH_CHECK();
+  return SKF_OK;
+}
+// internal (skf_model.hip): the launch without the two column sums - p1 / p2 [B][L] (dw / dbias partials) are left for a batched reduction
+int skf_expander_bwd_partials(const float* dpre, const float* emb, const float* w, int B, int L, int d, float* demb, int demb_accumulate,
+                              float* p1, float* p2, hipStream_t s) {
   SkfProfScope ps(s, "expander_bwd", 0.0, 8.0 * B * L * d);
   switch (d) {
     case 64:  hipLaunchKernelGGL(expander_bwd_kernel<1>, dim3(B), dim3(1024), 0, s, dpre, emb, w, L, demb, demb_accumulate, p1, p2); break;
@@ -1458,8 +1496,6 @@ extern "C" int skf_expander_bwd(const float* dpre, const float* emb, const float
     case 512: hipLaunchKernelGGL(expander_bwd_kernel<8>, dim3(B), dim3(1024), 0, s, dpre, emb, w, L, demb, demb_accumulate, p1, p2); break;
     default: { const int rc = skf_expander_bwd_any(dpre, emb, w, B, L, d, demb, demb_accumulate, p1, p2, s); if (rc) return rc; }   // skf_generic.hip
   }
-  hipLaunchKernelGGL(colsum_kernel, dim3(skf_cdiv(L, 64)), dim3(1024), 0, s, p1, B, L, L, dw, 0);
-  hipLaunchKernelGGL(colsum_kernel, dim3(skf_cdiv(L, 64)), dim3(1024), 0, s, p2, B, L, L, dbias, 0);
   SKF_LAUNCH_CHECK();
   return SKF_OK;
 }
