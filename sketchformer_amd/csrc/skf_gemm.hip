@@ -428,7 +428,7 @@ extern "C" int skf_splitk_reduce_blocks(int M, int N) { return (int)((((size_t)M
 extern "C" int skf_splitk_reduce_batch(const SkfReduceDesc* descs_dev, int ndesc, int total_blocks, skf_stream_t stream) {
   SKF_CHECK_ARG(descs_dev && ndesc > 0 && total_blocks > 0, "bad argument");
   SkfProfScope ps((hipStream_t)stream, "splitk_reduce_batch", 0.0, 0.0);
-  hipLaunchKernelGGL(splitk_reduce_batch_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, ndesc);
+  SKF_LAUNCH_TAIL(splitk_reduce_batch_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, ndesc);
   SKF_LAUNCH_CHECK();
   return SKF_OK;
 }

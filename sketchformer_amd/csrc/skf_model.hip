@@ -463,6 +463,7 @@ struct SkfModel {
   bool no_ln_fuse = false, no_relu_bits = false;   // a fused entry answered SKF_EUNSUPPORTED once: this model takes the general pair
   bool ffn_fused = false;            // the feed-forward blocks run as one launch per direction (skf_ffn_fused.hip); set per forward
   bool masks_staged = false;         // the padding masks of this call were written by its staging launch (stage_inputs)
+  hipEvent_t last_ready = nullptr;   // ffn_ln_bwd: the event attached to its fused launch (valid until the caller's next main-stream launch)
   Layout lay;
   Plan plan;
   Plan16 p16;                        // bf16 path (cfg.act_dtype == SKF_ACT_BF16): its own workspace plan
@@ -755,6 +756,7 @@ int flush_wgrads(SkfModel* M, hipStream_t s, int bucket, bool final, bool issue_
   if (issue_queued) SKF_TRY(issue_wgrads(M, s));      // (false: reduce what has been issued; queued / held groups stay where they are)
   const size_t begin = M->phase_desc_begin, end = M->desc_cursor;
   hipStream_t ready_on = s;
+  bool bucket_recorded = false;
   if (M->side && M->side_used && end > begin) {
     if (!M->descs_uploaded) {      // the launch sequence is fixed: descriptors are built and uploaded once (first step)
       SKF_HIP(hipMemcpy(M->at<SkfReduceDesc>(M->plan.descs) + begin, M->descs.data() + begin,
@@ -771,7 +773,13 @@ int flush_wgrads(SkfModel* M, hipStream_t s, int bucket, bool final, bool issue_
       SKF_CHECK_ARG(e, "event allocation failed");
       SKF_HIP(hipEventRecord(e, M->side));
       SKF_HIP(hipStreamWaitEvent(s, e, 0));
-      SKF_TRY(skf_splitk_reduce_batch(M->at<SkfReduceDesc>(M->plan.descs) + begin, (int)(end - begin), M->reduce_blocks, s));
+      // the bucket-ready event rides on the reduction launch as its completion signal (skf_common.h: SKF_LAUNCH_TAIL)
+      hipEvent_t br = (bucket >= 0 && !g_capturing) ? M->bucket_ready[bucket] : nullptr;
+      skf_tls_stop_event = br;
+      const int rc = skf_splitk_reduce_batch(M->at<SkfReduceDesc>(M->plan.descs) + begin, (int)(end - begin), M->reduce_blocks, s);
+      bucket_recorded = br && skf_tls_stop_event == nullptr;
+      skf_tls_stop_event = nullptr;
+      SKF_TRY(rc);
       ready_on = s;
     } else {
     hipEvent_t em = M->new_event();
@@ -789,7 +797,7 @@ int flush_wgrads(SkfModel* M, hipStream_t s, int bucket, bool final, bool issue_
     }
     }
   }
-  if (bucket >= 0 && M->bucket_ready[bucket]) SKF_HIP(hipEventRecord(M->bucket_ready[bucket], ready_on));   // bucket < 0: an intermediate reduction
+  if (bucket >= 0 && M->bucket_ready[bucket] && !bucket_recorded) SKF_HIP(hipEventRecord(M->bucket_ready[bucket], ready_on));   // bucket < 0: an intermediate reduction
   M->phase_desc_begin = end;
   M->reduce_blocks = 0;                 // block numbering of the next batch starts again at 0
   if (final) {
@@ -1228,6 +1236,7 @@ int ffn_ln_bwd(SkfModel* M, const LnP& ln, const DenseP& f1, const DenseP& f2, c
                const void* hbits, const void* image_t) {
   const Plan& P = M->plan;
   const int d = M->cfg.d_model;
+  M->last_ready = nullptr;
   static const bool ln_off = skf_knob("SKF_NO_FFN_LN_BWD") && skf_knob("SKF_NO_FFN_LN_BWD")[0] == '1';   // (measurement builds only)
   const size_t pbytes = (size_t)skf_ffn_fused_ln_partials(rows) * 2 * d * sizeof(float);
   if (ln_off || !M->ffn_fused || !M->side || ln.b != ln.g + (size_t)d || pbytes > P.ln_part_stride) {
@@ -1246,6 +1255,7 @@ int ffn_ln_bwd(SkfModel* M, const LnP& ln, const DenseP& f1, const DenseP& f2, c
   const hipEvent_t ready = take_ready(parked);
   SKF_TRY(rc);
   SKF_TRY(ln_partials_desc(M, ln, part, skf_ffn_fused_ln_partials(rows)));
+  M->last_ready = ready;                        // (nothing else reaches the main stream before this function returns: the caller may reuse it)
   SKF_TRY(issue_held_wgrads(M, s, ready));      // the previous layer's weight gradients: behind this launch (see hold_wgrads)
   SKF_TRY(dense_wgrad(M, f2, h, f2.in, dy, f2.out, rows, s));
   return dense_wgrad(M, f1, x_in, f1.in, dh, f1.out, rows, s);
@@ -1483,7 +1493,9 @@ int run_backward(SkfModel* M, hipStream_t s) {
     // last layer of the backward: nothing is left on the main stream to hide a whole layer's weight gradients behind
     // (only the embedding gradient follows), so they go out per sublayer - the step's tail before Adam is one wgrad, not four
     static const bool early_tail = !skf_knob("SKF_NO_EARLY_TAIL");
-    if (i == 0 && early_tail) SKF_TRY(issue_wgrads(M, s));
+    // (the fused launch's completion signal already served the held group as its "main stream is here" event: this group shares it)
+    if (i == 0 && early_tail) SKF_TRY(issue_wgrads(M, s, M->last_ready));
+    M->last_ready = nullptr;
     SKF_TRY(ln_oproj_bwd(M, w.ln1, w.mha.o, G2, M->at<float>(a.z1), M->at<float>(a.st1), M->at<float>(a.o), G, dy1, dO, Me, rate,
                          site_enc(i, 0), s, M->at<char>(a.img_o)));
     if (i == 0 && early_tail) SKF_TRY(issue_wgrads(M, s));
