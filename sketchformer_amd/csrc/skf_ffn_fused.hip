@@ -1162,7 +1162,7 @@ extern "C" int skf_layernorm_bwd_dgrad_lead_f32(int M, int d, const float* dout,
 #define SKF_LN_DGRAD_GO(PV, LV)                                                                                                                  \
   {                                                                                                                                              \
     SKF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_dgrad_kernel<PV, LV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-    hipLaunchKernelGGL((ln_bwd_dgrad_kernel<PV, LV>), dim3(grid), dim3(512), smem, st, p);                                                       \
+    SKF_LAUNCH_TAIL((ln_bwd_dgrad_kernel<PV, LV>), dim3(grid), dim3(512), smem, st, p);                                                          \
   }
   if (P == 2) { if (lead) SKF_LN_DGRAD_GO(2, true) else SKF_LN_DGRAD_GO(2, false) }
   else { if (lead) SKF_LN_DGRAD_GO(3, true) else SKF_LN_DGRAD_GO(3, false) }

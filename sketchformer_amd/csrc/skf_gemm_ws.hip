@@ -361,8 +361,12 @@ int skf_gemm_ws_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, hipS
   if (p.relu_src && ((p.ld_relu & 3) || ((uintptr_t)p.relu_src & 15))) return SKF_OK;
   *handled = 1;
   if (single) return ws_launch_one(p, b_kcontig, st);
+  // a chain of launches: an event parked for "the launch" (skf_common.h: SKF_LAUNCH_TAIL) belongs to the LAST one
+  const hipEvent_t tail_event = skf_tls_stop_event;
+  skf_tls_stop_event = nullptr;
   if (chain_masked) {
     for (int k0 = 0; k0 < p.K; k0 += 512) {
+      if (k0 + 512 >= p.K) skf_tls_stop_event = tail_event;
       GemmParams q = p;
       q.K = 512;
       q.A = p.A + k0;
@@ -376,6 +380,7 @@ int skf_gemm_ws_dispatch(const GemmParams& p, int a_kcontig, int b_kcontig, hipS
   }
   for (int k0 = 0; k0 < p.K;) {
     const int left = p.K - k0, kc = left >= 512 ? 512 : left;       // left is a multiple of 128 below 512: 128 / 256 / 384
+    if (k0 + kc >= p.K) skf_tls_stop_event = tail_event;
     GemmParams q = p;
     q.K = kc;
     q.A = p.A + k0;

@@ -617,7 +617,7 @@ int launch_wsx(const GemmParams& p, int b_kc, hipStream_t st) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess)                \
         attr_done.mark();                     /* (a failed call shows up as the launch error below) */              \
     }                                                                                                              \
-    hipLaunchKernelGGL((gemm_wsx_kernel<K, NB, P, BKC, EX, false, false, KS>), grid, block, smem, st, q, groups, workers); \
+    SKF_LAUNCH_TAIL((gemm_wsx_kernel<K, NB, P, BKC, EX, false, false, KS>), grid, block, smem, st, q, groups, workers); \
   } while (0)
   if constexpr (K == 128 && NB == 2 && KS == 1) {
     if (q.ln_out) {            // residual + dropout + LayerNorm epilogue (skf_gemm_ln_residual_f32 checked the shape)
@@ -628,7 +628,7 @@ int launch_wsx(const GemmParams& p, int b_kc, hipStream_t st) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wsx_kernel<K, NB, P, false, 0, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_ln) == hipSuccess)
           attr_ln.mark();
       }
-      hipLaunchKernelGGL((gemm_wsx_kernel<K, NB, P, false, 0, false, true>), grid, block, smem_ln, st, q, groups, workers);
+      SKF_LAUNCH_TAIL((gemm_wsx_kernel<K, NB, P, false, 0, false, true>), grid, block, smem_ln, st, q, groups, workers);
       SKF_LAUNCH_CHECK();
       return SKF_OK;
     }
@@ -641,8 +641,8 @@ int launch_wsx(const GemmParams& p, int b_kc, hipStream_t st) {
                                     : hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wsx_kernel<K, NB, P, true, 0, true, false, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (ea == hipSuccess) attr_m[extra ? 1 : 0].mark();
       }
-      if (extra) hipLaunchKernelGGL((gemm_wsx_kernel<K, NB, P, true, 3, true, false, KS>), grid, block, smem, st, q, groups, workers);
-      else hipLaunchKernelGGL((gemm_wsx_kernel<K, NB, P, true, 0, true, false, KS>), grid, block, smem, st, q, groups, workers);
+      if (extra) SKF_LAUNCH_TAIL((gemm_wsx_kernel<K, NB, P, true, 3, true, false, KS>), grid, block, smem, st, q, groups, workers);
+      else SKF_LAUNCH_TAIL((gemm_wsx_kernel<K, NB, P, true, 0, true, false, KS>), grid, block, smem, st, q, groups, workers);
       SKF_LAUNCH_CHECK();
       return SKF_OK;
     }

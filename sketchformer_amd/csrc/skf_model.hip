@@ -14,6 +14,23 @@
 #include "skf_decode_fused.h"
 
 // ------------------------------------------------------------------ error plumbing
+#if SKF_MEASURE
+// measurement builds: SKF_EVLOG=1 lists every event record / stream wait of the THIRD train step with its source line and stream
+// (tools: which packets still sit on the main stream between two kernels)
+static hipStream_t g_evlog_main = nullptr;
+static int g_evlog_step = 0;
+static inline bool evlog_on() { static const bool on = skf_knob("SKF_EVLOG") != nullptr; return on && g_evlog_step == 3; }
+static inline hipError_t skf_logged_record(hipEvent_t e, hipStream_t st, int line) {
+  if (evlog_on()) fprintf(stderr, "EVLOG record line %d on %s\n", line, st == g_evlog_main ? "MAIN" : "side");
+  return hipEventRecord(e, st);
+}
+static inline hipError_t skf_logged_wait(hipStream_t st, hipEvent_t e, unsigned f, int line) {
+  if (evlog_on()) fprintf(stderr, "EVLOG wait   line %d on %s\n", line, st == g_evlog_main ? "MAIN" : "side");
+  return hipStreamWaitEvent(st, e, f);
+}
+#define hipEventRecord(e, st) skf_logged_record(e, st, __LINE__)
+#define hipStreamWaitEvent(st, e, f) skf_logged_wait(st, e, f, __LINE__)
+#endif
 static thread_local char g_err[512] = "";
 thread_local hipEvent_t skf_tls_stop_event = nullptr;      // skf_common.h: an event for the next SKF_LAUNCH_TAIL launch of this thread
 void skf_set_error(const char* fmt, ...) {
@@ -648,6 +665,20 @@ hipEvent_t park_ready(SkfModel* M) {
   skf_tls_stop_event = e;
   return e;
 }
+// the same for a group that is issued right behind ONE call's last launch (no held group needed): a fresh event, or null
+hipEvent_t park_fresh(SkfModel* M) {
+  static const bool off = skf_knob("SKF_NO_STOP_EVENTS") && skf_knob("SKF_NO_STOP_EVENTS")[0] == '1';   // (measurement builds only)
+  if (off || !M->side || g_capturing) return nullptr;
+  hipEvent_t e = M->new_event();
+  skf_tls_stop_event = e;
+  return e;
+}
+// side-stream launches must never pick up an event that is parked for the main stream's next launch
+struct ParkedEventGuard {
+  hipEvent_t saved;
+  ParkedEventGuard() : saved(skf_tls_stop_event) { skf_tls_stop_event = nullptr; }
+  ~ParkedEventGuard() { skf_tls_stop_event = saved; }
+};
 int issue_held_wgrads(SkfModel* M, hipStream_t s, hipEvent_t ready_recorded) {
   if (M->wq_held.empty()) return SKF_OK;
   std::vector<SkfModel::QueuedWgrad> cur;
@@ -665,6 +696,7 @@ int hold_wgrads(SkfModel* M, hipStream_t s) {
 // on_main: the queued group runs on the MAIN stream, in place (no events, no hop) - for the one weight gradient at the very end of
 // the backward that the side stream would finish last (see run_backward)
 int issue_wgrads(SkfModel* M, hipStream_t s, hipEvent_t ready_recorded, bool on_main) {
+  ParkedEventGuard guard;                                      // (this function may run INSIDE a parked call: before_write)
   if (!M->wq_held.empty()) {                                   // the held group first, as a group of its own
     std::vector<SkfModel::QueuedWgrad> cur;
     cur.swap(M->wq);
@@ -1351,9 +1383,13 @@ int run_backward(SkfModel* M, hipStream_t s) {
   // output layer: logits buffer now holds dlogits
   const float* dlog = M->at<float>(P.logits);
   SKF_TRY(dense_wgrad(M, L.out, M->at<float>(P.dec[N - 1].out3), d, dlog, L.out.out, Md, s));
-  SKF_TRY(dense_dgrad(M, L.out, dlog, L.out.out, Md, G, d, 0, nullptr, 0, s));
-
-  SKF_TRY(issue_wgrads(M, s));
+  {
+    hipEvent_t parked = park_fresh(M);       // the group's "main stream is here" event rides on the input-gradient launch (the last of its chain)
+    const int rc = dense_dgrad(M, L.out, dlog, L.out.out, Md, G, d, 0, nullptr, 0, s);
+    const hipEvent_t ready = take_ready(parked);
+    SKF_TRY(rc);
+    SKF_TRY(issue_wgrads(M, s, ready));
+  }
   const unsigned char* cross_mask = c.blind_decoder_mask ? nullptr : emask;
   for (int i = N - 1; i >= 0; --i, ++layer_no) {
     const DecLayerP& w = L.dec[i];
@@ -1393,12 +1429,16 @@ int run_backward(SkfModel* M, hipStream_t s) {
                                       M->at<float>(a.astats1), dmask, Ld, 1, B, H, Ld, Ld, dh, dqkv, 3 * d, dqkv + d, 3 * d,
                                       dqkv + 2 * d, 3 * d, M->cfg.gemm_precision, qlive, M->order, s));
     SKF_TRY(dense_wgrad(M, w.mha1.qkv, M->at<float>(a.x_in), d, dqkv, 3 * d, Md, s));
-    SKF_TRY(dense_dgrad(M, w.mha1.qkv, dqkv, 3 * d, Md, G2, d, 1, nullptr, 0, s));
-    float* t = G; G = G2; G2 = t;
     // the 8 weight gradients of this layer: one event pair - held until the next layer's fused feed-forward launch is queued
     static const bool hold_off = skf_knob("SKF_NO_WGRAD_HOLD") && skf_knob("SKF_NO_WGRAD_HOLD")[0] == '1';   // (measurement builds only)
-    if (M->ffn_fused && i > 0 && !hold_off) SKF_TRY(hold_wgrads(M, s));
-    else SKF_TRY(issue_wgrads(M, s));
+    const bool hold = M->ffn_fused && i > 0 && !hold_off;
+    hipEvent_t parked = hold ? nullptr : park_fresh(M);         // not held: the group's event rides on this layer's last launch
+    const int rc_dg = dense_dgrad(M, w.mha1.qkv, dqkv, 3 * d, Md, G2, d, 1, nullptr, 0, s);
+    const hipEvent_t ready = take_ready(parked);
+    SKF_TRY(rc_dg);
+    float* t = G; G = G2; G2 = t;
+    if (hold) SKF_TRY(hold_wgrads(M, s));
+    else SKF_TRY(issue_wgrads(M, s, ready));
   }
   M->live16 = M->live32 = nullptr; M->live_rows = 0;
   // decoder embedding
@@ -1419,6 +1459,7 @@ int run_backward(SkfModel* M, hipStream_t s) {
   SKF_TRY(before_read(M, dpre, s));     // the deferred K/V-projection input gradients (side stream) are complete
   }   // recon
   const int E = L.E, Ua = L.Ua, U = c.lowerdim, NB = c.class_buffer_layers;
+  hipEvent_t bott_ready = nullptr;
   if (bott) {
     // expander, classifier
     static const bool part_off = skf_knob("SKF_NO_BOTT_PARTIALS") && skf_knob("SKF_NO_BOTT_PARTIALS")[0] == '1';   // (measurement builds only)
@@ -1475,13 +1516,16 @@ int run_backward(SkfModel* M, hipStream_t s) {
     SKF_TRY(skf_pool_bwd(M->at<float>(P.u), M->P(L.bott_v), enc_out, M->at<float>(P.pool_a), dpool, B, Le, Ua, d,
                          G, M->G(L.bott_v), M->at<char>(P.small_ws), P.small_ws_bytes, s));
     SKF_TRY(dense_wgrad(M, L.bott_w, enc_out, d, M->at<float>(P.u), Ua, Me, s));
-    SKF_TRY(dense_dgrad(M, L.bott_w, M->at<float>(P.u), Ua, Me, G, d, 1, nullptr, 0, s));
+    hipEvent_t parked = park_fresh(M);
+    const int rc_dg = dense_dgrad(M, L.bott_w, M->at<float>(P.u), Ua, Me, G, d, 1, nullptr, 0, s);
+    bott_ready = take_ready(parked);
+    SKF_TRY(rc_dg);
   } else {
     // no bottleneck: d(enc_output) is what the cross-attention K/V projections of all decoder layers sent back
     float* spare = (G == M->at<float>(P.gA)) ? M->at<float>(P.gB) : M->at<float>(P.gA);
     G = dpre; G2 = spare;
   }
-  SKF_TRY(issue_wgrads(M, s));            // expander / classifier / bottleneck group
+  SKF_TRY(issue_wgrads(M, s, bott_ready));            // expander / classifier / bottleneck group
   for (int i = N - 1; i >= 0; --i, ++layer_no) {
     const EncLayerP& w = L.enc[i];
     const EncAct& a = P.enc[i];
@@ -1496,9 +1540,14 @@ int run_backward(SkfModel* M, hipStream_t s) {
     // (the fused launch's completion signal already served the held group as its "main stream is here" event: this group shares it)
     if (i == 0 && early_tail) SKF_TRY(issue_wgrads(M, s, M->last_ready));
     M->last_ready = nullptr;
-    SKF_TRY(ln_oproj_bwd(M, w.ln1, w.mha.o, G2, M->at<float>(a.z1), M->at<float>(a.st1), M->at<float>(a.o), G, dy1, dO, Me, rate,
-                         site_enc(i, 0), s, M->at<char>(a.img_o)));
-    if (i == 0 && early_tail) SKF_TRY(issue_wgrads(M, s));
+    {
+      hipEvent_t parked = (i == 0 && early_tail) ? park_fresh(M) : nullptr;
+      const int rc_ln = ln_oproj_bwd(M, w.ln1, w.mha.o, G2, M->at<float>(a.z1), M->at<float>(a.st1), M->at<float>(a.o), G, dy1, dO, Me, rate,
+                                     site_enc(i, 0), s, M->at<char>(a.img_o));
+      const hipEvent_t ready = take_ready(parked);
+      SKF_TRY(rc_ln);
+      if (i == 0 && early_tail) SKF_TRY(issue_wgrads(M, s, ready));
+    }
     const float* qkv = M->at<float>(a.qkv);
     SKF_TRY(before_write(M, dqkv, s));
     SKF_TRY(skf_attention_bwd_ordered(qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, M->at<float>(a.o), d, dO, d,
@@ -2092,6 +2141,9 @@ extern "C" int skf_model_forward_backward(SkfModel* m, const void* inp, const vo
   SKF_CHECK_ARG(m && m->ws, "model not bound");
   SKF_CHECK_ARG(labels, "null labels");
   hipStream_t s = (hipStream_t)stream;
+#if SKF_MEASURE
+  g_evlog_main = s; ++g_evlog_step;
+#endif
   if (m->bf16) {
     SKF_TRY(stage_with_event(m, s, [&]() { return stage_inputs16(m, inp, tar, tar_ld, labels, s); }));
     return capture_or_run(m, &m->g_fb, s, [&]() -> int {

@@ -1273,10 +1273,10 @@ static int embed_bwd_sorted_launch(const void* ws, int B, int L, const void* dx,
   SkfProfScope ps((hipStream_t)stream, dx_bf16 ? "embed_bwd_sorted_bf16" : "embed_bwd_sorted", 0.0,
                   (dx_bf16 ? 2.0 : 4.0) * rows * d + 4.0 * (double)vocab * d);
   if (dx_bf16)
-    hipLaunchKernelGGL(embed_bwd_sorted_kernel<skf_bf16>, dim3((unsigned)maxc), dim3(256), (size_t)3 * d * sizeof(float), (hipStream_t)stream,
+    SKF_LAUNCH_TAIL(embed_bwd_sorted_kernel<skf_bf16>, dim3((unsigned)maxc), dim3(256), (size_t)3 * d * sizeof(float), (hipStream_t)stream,
                        hdr, chunks, order, (const skf_bf16*)dx, d, dtable, rate, site, (const SkfStepState*)step_state, w.partial, w.done);
   else
-    hipLaunchKernelGGL(embed_bwd_sorted_kernel<float>, dim3((unsigned)maxc), dim3(256), (size_t)3 * d * sizeof(float), (hipStream_t)stream,
+    SKF_LAUNCH_TAIL(embed_bwd_sorted_kernel<float>, dim3((unsigned)maxc), dim3(256), (size_t)3 * d * sizeof(float), (hipStream_t)stream,
                        hdr, chunks, order, (const float*)dx, d, dtable, rate, site, (const SkfStepState*)step_state, w.partial, w.done);
   SKF_LAUNCH_CHECK();
   return SKF_OK;
