@@ -784,7 +784,7 @@ int issue_wgrads(SkfModel* M, hipStream_t s, hipEvent_t ready_recorded, bool on_
 }
 // Reduce the split-K partials of the wgrads issued since the last flush (one batched launch on the side stream) and
 // mark gradient bucket `bucket` complete.  final = the main stream waits for the side stream (before the optimizer).
-int flush_wgrads(SkfModel* M, hipStream_t s, int bucket, bool final, bool issue_queued = true) {
+int flush_wgrads(SkfModel* M, hipStream_t s, int bucket, bool final, bool issue_queued = true, hipEvent_t main_here = nullptr) {
   if (issue_queued) SKF_TRY(issue_wgrads(M, s));      // (false: reduce what has been issued; queued / held groups stay where they are)
   const size_t begin = M->phase_desc_begin, end = M->desc_cursor;
   hipStream_t ready_on = s;
@@ -814,9 +814,9 @@ int flush_wgrads(SkfModel* M, hipStream_t s, int bucket, bool final, bool issue_
       SKF_TRY(rc);
       ready_on = s;
     } else {
-    hipEvent_t em = M->new_event();
+    hipEvent_t em = main_here ? main_here : M->new_event();      // (main_here: already the completion signal of the main stream's last launch)
     SKF_CHECK_ARG(em, "event allocation failed");
-    SKF_HIP(hipEventRecord(em, s));
+    if (!main_here) SKF_HIP(hipEventRecord(em, s));
     SKF_HIP(hipStreamWaitEvent(M->side, em, 0));
     SKF_TRY(skf_splitk_reduce_batch(M->at<SkfReduceDesc>(M->plan.descs) + begin, (int)(end - begin), M->reduce_blocks, M->side));
     ready_on = M->side;
@@ -1075,8 +1075,22 @@ int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s, bool 
   }
   // pre_decoder: the expanded embedding, or the encoder output itself when there is no bottleneck (:172-176)
   float* pre = bott ? M->at<float>(P.pre) : enc_out;
-  if (recon && bott)
-    SKF_TRY(skf_expander_fwd(M->at<float>(P.emb), M->P(L.exp_w), M->P(L.exp_b), B, Le, E, pre, s));
+  // pre_decoder is all the side stream's cross-attention K|V projections wait for: their event rides on the expander launch
+  // (the event pool restarts here: the step's earlier events - masks, images - were waited for in front of the first encoder layer)
+  hipEvent_t dec_in_ready = nullptr;
+  bool dec_in_recorded = false;
+  if (recon && M->side) {
+    M->next_event = 0;
+    dec_in_ready = M->new_event();
+    SKF_CHECK_ARG(dec_in_ready, "event allocation failed");
+  }
+  if (recon && bott) {
+    if (dec_in_ready && !g_capturing) skf_tls_stop_event = dec_in_ready;
+    const int rc_ex = skf_expander_fwd(M->at<float>(P.emb), M->P(L.exp_w), M->P(L.exp_b), B, Le, E, pre, s);
+    dec_in_recorded = dec_in_ready && !g_capturing && skf_tls_stop_event == nullptr;
+    skf_tls_stop_event = nullptr;
+    SKF_TRY(rc_ex);
+  }
 
   // ---------------- decoder (builders/layers/transformer.py:325-344)
   if (recon) {
@@ -1093,13 +1107,11 @@ int run_forward(SkfModel* M, bool training, bool with_loss, hipStream_t s, bool 
   //  stream idle at cfg 2 - the second layer's for the rest)
   hipEvent_t kv_done = nullptr, kv_first = nullptr;
   if (M->side) {
-    M->next_event = 0;
-    hipEvent_t dec_in_ready = M->new_event();
     kv_done = M->new_event();
     static const bool wait_all = skf_knob("SKF_KV_WAIT_ALL") && skf_knob("SKF_KV_WAIT_ALL")[0] == '1';      // (measurement builds)
     kv_first = N > 1 && !wait_all ? M->new_event() : kv_done;
     SKF_CHECK_ARG(dec_in_ready && kv_done && kv_first, "event allocation failed");
-    SKF_HIP(hipEventRecord(dec_in_ready, s));
+    if (!dec_in_recorded) SKF_HIP(hipEventRecord(dec_in_ready, s));
     SKF_HIP(hipStreamWaitEvent(M->side, dec_in_ready, 0));
     for (int i = 0; i < N; ++i) {
       SKF_TRY(dense_fwd(M, L.dec[i].mha2.kv, pre, Me, M->at<float>(P.dec[i].kv2), 0, M->side));
@@ -1441,21 +1453,25 @@ int run_backward(SkfModel* M, hipStream_t s) {
     else SKF_TRY(issue_wgrads(M, s, ready));
   }
   M->live16 = M->live32 = nullptr; M->live_rows = 0;
+  hipEvent_t dec_emb_done = nullptr;
   // decoder embedding
   if (c.continuous) {
     SKF_TRY(skf_embed_continuous_bwd(M->at<float>(P.tar), Le, B, Ld, G, d, M->G(L.dec_embd.w), M->G(L.dec_embd.b), rate,
                                      site_dec_embed(N), M->state, M->at<char>(P.small_ws), P.small_ws_bytes, s));
   } else {
     if (P.emb_sort_bytes) {
-      SKF_TRY(skf_embed_bwd_sorted(M->at<char>(P.emb_sort[1]), B, Ld, G, c.vocab_size, d, M->G(L.dec_emb), rate, site_dec_embed(N),
-                                   M->state, s));
+      hipEvent_t parked = M->n_buckets == 2 ? park_fresh(M) : nullptr;      // the bucket's reduction (side stream) waits for this launch's own signal
+      const int rc_e = skf_embed_bwd_sorted(M->at<char>(P.emb_sort[1]), B, Ld, G, c.vocab_size, d, M->G(L.dec_emb), rate, site_dec_embed(N),
+                                            M->state, s);
+      dec_emb_done = take_ready(parked);
+      SKF_TRY(rc_e);
     } else {
       SKF_HIP(hipMemsetAsync(M->G(L.dec_emb), 0, (size_t)c.vocab_size * d * sizeof(float), s));
       SKF_TRY(skf_embed_bwd(tar, Le, B, Ld, G, c.vocab_size, d, M->G(L.dec_emb), rate, site_dec_embed(N), M->state, s));
     }
   }
   // every gradient of [decoder embedding .. output layer] is issued: first bucket of the flat buffer
-  if (M->n_buckets == 2) SKF_TRY(flush_wgrads(M, s, 0, false));
+  if (M->n_buckets == 2) SKF_TRY(flush_wgrads(M, s, 0, false, true, dec_emb_done));
   SKF_TRY(before_read(M, dpre, s));     // the deferred K/V-projection input gradients (side stream) are complete
   }   // recon
   const int E = L.E, Ua = L.Ua, U = c.lowerdim, NB = c.class_buffer_layers;

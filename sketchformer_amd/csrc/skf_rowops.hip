@@ -1465,7 +1465,7 @@ extern "C" int skf_expander_fwd(const float* emb, const float* w, const float* b
   const size_t total = (size_t)B * L * d;
   int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
   SkfProfScope ps((hipStream_t)stream, "expander_fwd", 0.0, 4.0 * total);
-  hipLaunchKernelGGL(expander_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, emb, w, bias, B, L, d, pre);
+  SKF_LAUNCH_TAIL(expander_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, emb, w, bias, B, L, d, pre);
   SKF_LAUNCH_CHECK();
   return SKF_OK;
 }
