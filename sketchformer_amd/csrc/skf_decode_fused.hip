@@ -193,7 +193,7 @@ template <int DH>
 __global__ __launch_bounds__(NT) void decode_position_kernel(SkfDecodeFused p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, b = blockIdx.x;
-  const int d = p.d, F = p.F;
+  const int d = p.d;
   float* xs = lds;                 // [d]  layer input
   float* o1 = xs + d;              // [d]  after LN1
   float* o2 = o1 + d;              // [d]  after LN2
