@@ -682,6 +682,24 @@ def test_two_stream_step_is_deterministic_in_every_model_structure(over):
     assert np.isfinite(a.params.cpu().numpy()).all()
 
 
+def test_inputs_staged_event_and_model_flags_reject_misuse():
+    """skf_model_wait_inputs_staged before any call has staged inputs, and skf_model_set_flags with an unknown bit, fail loudly
+    (SKF_EINVAL with a message); the three defined flag bits are accepted together."""
+    from sketchformer_amd import engine, _lib
+    eng = engine.TrainEngine(engine.make_config(batch=4, seq_len=24, d_model=64, num_heads=4, dff=128, num_layers=1, vocab_size=52,
+                                                n_classes=7, lowerdim=32, use_graph=False), init_seed=0)
+    with pytest.raises(_lib.SkfError):
+        _lib.call("skf_model_wait_inputs_staged", eng.handle, torch.cuda.current_stream().cuda_stream)
+    with pytest.raises(_lib.SkfError):
+        eng.set_flags(8)
+    eng.set_flags(_lib.MODEL_DECODE_LAYERWISE | _lib.MODEL_FFN_LAUNCHES | _lib.MODEL_TWO_STREAM_GRAPH)
+    eng.set_flags(0)
+    x, y = synthetic.token_batch(4, 24, 52, 7, seed=0)
+    eng.train_step(x, y)
+    _lib.call("skf_model_wait_inputs_staged", eng.handle, torch.cuda.current_stream().cuda_stream)     # now there is a staging copy to wait for
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_device_inputs_may_be_refilled_in_place_right_after_the_call(use_graph):
     """train_step on DEVICE tensors returns before the step has run; the caller's next action may be to refill the same tensors with
