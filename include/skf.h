@@ -616,8 +616,9 @@ void skf_model_destroy(SkfModel* m);
 #define SKF_MODEL_FFN_LAUNCHES 2u
 /* SKF_MODEL_TWO_STREAM_GRAPH: opt-in for SkfConfig.use_graph = 2.  Root cause of the crash recorded in profiles/r05y_two_stream_graph_crash.txt
  * (round 6, from the disassembly of the runtime that ships with torch 2.10+rocm7.0): hip::Graph::UpdateStreams walks the graph exec's internal
- * stream vector WITHOUT a bound while it skips entries that share a hardware queue with the launch stream - one aliasing stream and it
- * dereferences whatever lies behind the vector.  Which streams compare equal is decided inside the runtime, so a process
+ * stream vector WITHOUT a bound while it skips entries that compare equal to the launch stream (the comparison is a virtual call on a
+ * member object of the two streams - which object, the binary does not say) - one such entry and it dereferences whatever lies behind
+ * the vector.  Which streams compare equal is decided inside the runtime, so a process
  * whose runtime state makes an internal stream of the exec compare equal to the launch stream faults at a replay.  Nothing this library
  * creates or destroys is read on that path.  tools/micro/graph_parallel_stream_alias.hip tries to provoke it with plain HIP calls
  * (stream counts, build / replay / destroy cycles, leaked execs, stream 0): none of its 72 cases faults (profiles/r06b_graph_alias.txt) -
