@@ -21,6 +21,9 @@ __global__ void stream_add(float* p, size_t n, float v) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] += v;
 }
 
+__global__ void set_word(int* w, int v) { *w = v; }
+__global__ void copy_word(const int* w, int* out) { *out = *w; }
+
 int main() {
   const size_t n = (size_t)1 << 24;                  // 64 MB read + write: ~25 us
   float *x, *y;
@@ -61,6 +64,23 @@ int main() {
       const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / N;
       printf("%-12s %7.2f us per iteration\n", names[mode], us);
     }
-  // correctness of the attached events: B's kernel must see A's kernel complete.  A writes a counter, B copies it.
-  return 0;
+  // correctness of the launch-attached stop event: B's kernel i must see A's kernel i complete.  A's kernel i sets a word to i (after
+  // a long streaming pass, so that an unordered B would run first), B's kernel i copies the word into slot i.
+  int* word; int* seen;
+  CK(hipMalloc(&word, 4)); CK(hipMalloc(&seen, N * 4));
+  CK(hipMemset(word, 0xff, 4)); CK(hipMemset(seen, 0xff, N * 4));
+  CK(hipDeviceSynchronize());
+  for (int i = 0; i < N; ++i) {
+    hipLaunchKernelGGL(stream_add, dim3(2048), dim3(256), 0, A, x, n, 1.f);
+    hipExtLaunchKernelGGL(set_word, dim3(1), dim3(1), 0, A, nullptr, ev[i], 0, word, i);
+    CK(hipStreamWaitEvent(B, ev[i], 0));
+    hipLaunchKernelGGL(copy_word, dim3(1), dim3(1), 0, B, word, seen + i);
+  }
+  CK(hipDeviceSynchronize());
+  std::vector<int> h(N);
+  CK(hipMemcpy(h.data(), seen, N * 4, hipMemcpyDeviceToHost));
+  int early = 0;
+  for (int i = 0; i < N; ++i) early += h[i] < i;
+  printf("stop-event ordering: %d of %d consumer kernels ran before their producer had finished (must be 0)\n", early, N);
+  return early != 0;
 }
