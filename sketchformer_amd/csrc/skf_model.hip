@@ -56,6 +56,8 @@ extern "C" int skf_device_info(char* name_host, size_t name_len, int* n_devices_
 }
 
 // ------------------------------------------------------------------ launch profiler
+int skf_adam_step_launch(float* w, const float* g, float* m, float* v, size_t n, void* step_state, float grad_scale, float beta1, float beta2,
+                         float eps, int advance, hipStream_t stream);
 int skf_pool_bwd_partials(float* u_inout_dpre, const float* Vw, const float* x, const float* a, const float* demb, int B, int L, int U, int d,
                           float* dx, float* dV_part, hipStream_t s);
 int skf_expander_bwd_partials(const float* dpre, const float* emb, const float* w, int B, int L, int d, float* demb, int demb_accumulate,
@@ -2193,9 +2195,8 @@ extern "C" int skf_model_apply_gradients(SkfModel* m, float grad_scale, skf_stre
   return capture_or_run(m, &m->g_opt, s, [&]() -> int {
     if (m->cfg.optimizer == 1)   // tf.keras.optimizers.SGD(lr_schedule, momentum) - the Adam m buffer is the velocity slot
       SKF_TRY(skf_sgd_momentum_step(m->params, m->grads, m->m, m->lay.total, m->state, grad_scale, m->cfg.momentum, s));
-    else
-      SKF_TRY(skf_adam_step(m->params, m->grads, m->m, m->v, m->lay.total, m->state, grad_scale, m->cfg.beta1,
-                            m->cfg.beta2, m->cfg.eps, s));
+    else      // (the Adam sweep of a whole step also advances optimizer.iterations: one launch instead of two)
+      return skf_adam_step_launch(m->params, m->grads, m->m, m->v, m->lay.total, m->state, grad_scale, m->cfg.beta1, m->cfg.beta2, m->cfg.eps, 1, s);
     return skf_step_epilogue(m->state, s);
   });
 }

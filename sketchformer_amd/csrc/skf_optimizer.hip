@@ -42,11 +42,15 @@ __global__ void step_epilogue_kernel(SkfStepState* st) {
   if (threadIdx.x == 0 && blockIdx.x == 0) st->iterations += 1;
 }
 
+// ADVANCE: the sweep also closes the step (optimizer.iterations += 1, what step_epilogue_kernel does as a launch of its own):
+// one thread adds to `iterations`, a field no thread of this kernel reads (they read alpha)
+template <bool ADVANCE>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, size_t n,
-                                                   const SkfStepState* __restrict__ st, float grad_scale,
+                                                   SkfStepState* st, float grad_scale,
                                                    float one_minus_b1, float one_minus_b2, float eps) {
   const float alpha = st->alpha;
+  if (ADVANCE && blockIdx.x == 0 && threadIdx.x == 0) st->iterations += 1;
   const size_t n4 = n >> 2;
   const size_t stride = (size_t)gridDim.x * 256;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
@@ -126,16 +130,25 @@ extern "C" int skf_step_epilogue(void* step_state, skf_stream_t stream) {
   return SKF_OK;
 }
 
-extern "C" int skf_adam_step(float* w, const float* g, float* m, float* v, size_t n, const void* step_state,
-                             float grad_scale, float beta1, float beta2, float eps, skf_stream_t stream) {
+// internal (skf_model.hip): advance != 0 = the sweep of a whole step, which also performs skf_step_epilogue's increment
+int skf_adam_step_launch(float* w, const float* g, float* m, float* v, size_t n, void* step_state, float grad_scale, float beta1, float beta2,
+                         float eps, int advance, hipStream_t stream) {
   SKF_CHECK_ARG(w && g && m && v && step_state, "null operand");
   SKF_CHECK_ARG((((uintptr_t)w | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "buffers must be 16-byte aligned");
   size_t blocks = ((n >> 2) + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
-  SkfProfScope ps((hipStream_t)stream, "adam", 0.0, 28.0 * n);
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, g, m, v, n,
-                     (const SkfStepState*)step_state, grad_scale, 1.0f - beta1, 1.0f - beta2, eps);
+  SkfProfScope ps(stream, "adam", 0.0, 28.0 * n);
+  if (advance)
+    hipLaunchKernelGGL(adam_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, w, g, m, v, n, (SkfStepState*)step_state, grad_scale,
+                       1.0f - beta1, 1.0f - beta2, eps);
+  else
+    hipLaunchKernelGGL(adam_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, w, g, m, v, n, (SkfStepState*)step_state, grad_scale,
+                       1.0f - beta1, 1.0f - beta2, eps);
   SKF_LAUNCH_CHECK();
   return SKF_OK;
+}
+extern "C" int skf_adam_step(float* w, const float* g, float* m, float* v, size_t n, const void* step_state,
+                             float grad_scale, float beta1, float beta2, float eps, skf_stream_t stream) {
+  return skf_adam_step_launch(w, g, m, v, n, const_cast<void*>(step_state), grad_scale, beta1, beta2, eps, 0, (hipStream_t)stream);
 }
